@@ -1,0 +1,93 @@
+"""ctypes binding of libadamvs_hip.so (C ABI: include/adamvs_hip.h).
+
+The library is loaded AFTER `import torch` so that its libamdhip64 dependency
+binds to the HIP runtime torch already mapped (one runtime per process).
+There is no fallback: if the library is missing or a call fails this raises.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported before the library is loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadamvs_hip.so")
+
+c_f = ctypes.c_void_p          # device pointer to float
+c_i = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_st = ctypes.c_void_p         # hipStream_t
+
+
+class FuseWeights(ctypes.Structure):
+    """adamvs_fuse_weights"""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "conv1", "gates1", "gates1_b", "cand1", "cand1_b", "conv2", "gates2", "gates2_b",
+        "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w")]
+
+
+class StageDesc(ctypes.Structure):
+    """adamvs_stage_desc"""
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w")]
+
+
+# name -> (restype, argtypes); every symbol include/adamvs_hip.h declares
+SIGNATURES = {
+    "adamvs_version": (c_i, []),
+    "adamvs_last_error_string": (ctypes.c_char_p, []),
+    "adamvs_relative_transforms": (c_i, [c_f, c_f, c_i, c_i, c_st]),
+    "adamvs_pack_features": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_unpack_features": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_depth_range_samples_uniform": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_depth_range_samples_window": (c_i, [c_f, ctypes.c_float, c_f, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_depth_regression": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_homo_warp": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_pair_similarity": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_cost_reg_net_2d_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "adamvs_cost_reg_net_2d": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_softmax_max_regress": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_aggregate_conv1": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_slice_reg_step_scratch_bytes": (c_sz, [c_i, c_i, c_i]),
+    "adamvs_slice_reg_step": (c_i, [c_f, c_f, c_f, ctypes.POINTER(FuseWeights), c_f, c_i, c_i, c_i, c_i, c_i,
+                                    ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_depth_stage_workspace_bytes": (c_sz, [ctypes.POINTER(StageDesc)]),
+    "adamvs_depth_stage_forward": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(FuseWeights),
+                                         c_f, c_f, c_f, c_f, ctypes.c_void_p, c_sz, c_st]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class AdaMVSHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdaMVSHipError(
+            "libadamvs_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "-- there is no CPU fallback for the Ada-MVS hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.adamvs_version()
+    if v != ABI_VERSION:
+        raise AdaMVSHipError("libadamvs_hip.so ABI version %d, host expects %d: rebuild" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Map the C status code to an exception (0 ok, <0 argument error, >0 hipError_t)."""
+    if rc == 0:
+        return
+    msg = load().adamvs_last_error_string().decode("utf-8", "replace")
+    kind = "invalid argument" if rc < 0 else "HIP error %d" % rc
+    raise AdaMVSHipError("%s failed (%s): %s" % (what, kind, msg))

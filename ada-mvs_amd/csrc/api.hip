@@ -1,0 +1,149 @@
+// C-ABI glue: error plumbing, the one-step op and the whole-stage driver
+// (InferDepthNet0.forward, reference models/adamvs.py:433-533).
+#include <stdarg.h>
+
+#include "../../include/adamvs_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace adamvs {
+
+thread_local char g_last_error[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static_assert(sizeof(FuseWeights) == sizeof(adamvs_fuse_weights), "adamvs_fuse_weights layout");
+
+static size_t align_up(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats: 256-byte slots
+
+struct StageCarve {
+  size_t c1, h1, rh1, u1, c2, h2, rh2, u2, vol, sim, score, creg, total;   // offsets in floats
+};
+
+static StageCarve carve(const adamvs_stage_desc& s) {
+  StageCarve c;
+  size_t hw = (size_t)s.h * s.w, hw4 = (size_t)(s.h / 2) * (s.w / 2);
+  size_t HW = s.in_up ? 4 * hw : hw;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += align_up(n); return r; };
+  c.c1 = take((size_t)s.D * s.B * hw * 8);
+  c.h1 = take((size_t)s.B * hw * 8);
+  c.rh1 = take((size_t)s.B * hw * 8);
+  c.u1 = take((size_t)s.B * hw * 8);
+  c.c2 = take((size_t)s.B * hw4 * 16);
+  c.h2 = take((size_t)s.B * hw4 * 16);
+  c.rh2 = take((size_t)s.B * hw4 * 16);
+  c.u2 = take((size_t)s.B * hw4 * 16);
+  c.vol = take((size_t)s.B * s.D * HW);
+  c.sim = c.score = c.creg = o;
+  if (s.first_stage) {
+    size_t F = (size_t)s.S * s.B * hw * s.D;
+    c.sim = take(F);
+    c.score = take(F);
+    c.creg = take(3 * F);
+  }
+  c.total = o;
+  return c;
+}
+
+static int check_desc(const adamvs_stage_desc* d) {
+  ADAMVS_CHECK_ARG(d, "stage: null descriptor");
+  ADAMVS_CHECK_ARG(d->B > 0 && d->S > 0 && d->D > 1 && d->h > 1 && d->w > 1, "stage: bad shape (B=%d S=%d D=%d h=%d w=%d)",
+                   d->B, d->S, d->D, d->h, d->w);
+  ADAMVS_CHECK_ARG(d->C == 8 || d->C == 16 || d->C == 32, "stage: C=%d unsupported (8, 16 or 32)", d->C);
+  ADAMVS_CHECK_ARG((d->h % 2) == 0 && (d->w % 2) == 0, "stage: h=%d w=%d must be even", d->h, d->w);
+  ADAMVS_CHECK_ARG((size_t)d->B * d->D <= 65535, "stage: B*D=%d exceeds the grid z limit", d->B * d->D);
+  if (d->first_stage) {
+    ADAMVS_CHECK_ARG(costreg_depth_supported(d->D), "stage: D=%d unsupported by CostRegNet2D (16,32,48,64,96,128,192,256)", d->D);
+    ADAMVS_CHECK_ARG((d->h % 8) == 0 && (d->w % 8) == 0, "stage: first stage needs h=%d w=%d multiples of 8", d->h, d->w);
+  } else {
+    ADAMVS_CHECK_ARG(d->prev_h > 0 && d->prev_w > 0, "stage: prev_h/prev_w missing");
+  }
+  return 0;
+}
+
+}  // namespace adamvs
+
+using namespace adamvs;
+
+extern "C" int adamvs_version(void) { return ADAMVS_ABI_VERSION; }
+extern "C" const char* adamvs_last_error_string(void) { return g_last_error; }
+
+extern "C" size_t adamvs_slice_reg_step_scratch_bytes(int B, int h, int w) {
+  size_t hw = (size_t)h * w, hw4 = (size_t)(h / 2) * (w / 2);
+  return (3 * align_up((size_t)B * hw * 8) + 3 * align_up((size_t)B * hw4 * 16)) * sizeof(float);
+}
+
+extern "C" int adamvs_slice_reg_step(const float* cost, float* state1, float* state2, const adamvs_fuse_weights* weights,
+                                     float* reg_cost, int B, int C, int h, int w, int in_up, void* scratch,
+                                     size_t scratch_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(cost && state1 && state2 && weights && reg_cost && scratch, "slice_reg_step: null pointer");
+  ADAMVS_CHECK_ARG(B > 0 && h > 1 && w > 1 && (h % 2) == 0 && (w % 2) == 0, "slice_reg_step: bad shape (B=%d h=%d w=%d, even sizes)", B, h, w);
+  ADAMVS_CHECK_ARG(C == 8 || C == 16 || C == 32, "slice_reg_step: C=%d unsupported (8, 16 or 32)", C);
+  ADAMVS_CHECK_ARG(scratch_bytes >= adamvs_slice_reg_step_scratch_bytes(B, h, w), "slice_reg_step: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  size_t n1 = align_up((size_t)B * h * w * 8), n2 = align_up((size_t)B * (h / 2) * (w / 2) * 16);
+  float* s = (float*)scratch;
+  float* c1 = s;
+  StepBuffers sb{state1, s + n1, s + 2 * n1, s + 3 * n1, state2, s + 3 * n1 + n2, s + 3 * n1 + 2 * n2};
+  FuseWeights fw;
+  memcpy(&fw, weights, sizeof(fw));
+  int rc = launch_conv1(cost, fw.conv1, c1, B, C, h, w, st);
+  if (rc) return rc;
+  return launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, st);
+}
+
+extern "C" size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc) {
+  if (check_desc(desc)) return 0;
+  return carve(*desc).total * sizeof(float);
+}
+
+extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt,
+                                          const float* planes, const float* prev_conf, const float* w_reg,
+                                          const adamvs_fuse_weights* w_fuse, float* view_weight, float* pair_depth,
+                                          float* depth, float* confidence, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  const adamvs_stage_desc& s = *desc;
+  ADAMVS_CHECK_ARG(feat && rt && planes && w_fuse && view_weight && depth && confidence && workspace, "stage: null pointer");
+  ADAMVS_CHECK_ARG(!s.first_stage || (w_reg && pair_depth), "stage: first stage needs w_reg and pair_depth");
+  ADAMVS_CHECK_ARG(s.first_stage || prev_conf, "stage: later stages need prev_conf");
+  StageCarve c = carve(s);
+  ADAMVS_CHECK_ARG(workspace_bytes >= c.total * sizeof(float), "stage: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                   c.total * sizeof(float));
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  FuseWeights fw;
+  memcpy(&fw, w_fuse, sizeof(fw));
+
+  // -- view weights: scored by CostRegNet2D (stage 1) or resampled from the previous stage
+  if (s.first_stage) {
+    if ((rc = adamvs_pair_similarity(feat, rt, planes, ws + c.sim, s.B, s.S, s.C, s.D, s.h, s.w, stream))) return rc;
+    if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, st))) return rc;
+    if ((rc = launch_softmax_regress(ws + c.score, planes, view_weight, pair_depth, s.S, s.B, s.D, s.h, s.w, st))) return rc;
+  } else {
+    if ((rc = adamvs_resize_bilinear(prev_conf, view_weight, s.S * s.B, s.prev_h, s.prev_w, s.h, s.w, stream))) return rc;
+  }
+
+  // -- weighted aggregation + conv1 for every hypothesis (state-independent)
+  if ((rc = launch_aggregate_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, s.B, s.S, s.C, s.D, s.h, s.w, st)))
+    return rc;
+
+  // -- recurrence over hypotheses
+  hipError_t e = hipMemsetAsync(ws + c.h1, 0, (size_t)s.B * s.h * s.w * 8 * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(ws + c.h2, 0, (size_t)s.B * (s.h / 2) * (s.w / 2) * 16 * sizeof(float), st);
+  if (e != hipSuccess) return set_error((int)e, "stage: hipMemsetAsync: %s", hipGetErrorString(e));
+  StepBuffers sb{ws + c.h1, ws + c.rh1, ws + c.u1, ws + c.c2, ws + c.h2, ws + c.rh2, ws + c.u2};
+  const size_t c1_stride = (size_t)s.B * s.h * s.w * 8;
+  for (int d = 0; d < s.D; ++d) {
+    if ((rc = launch_slice_step(ws + c.c1 + d * c1_stride, fw, sb, ws + c.vol, s.B, s.h, s.w, s.D, d, s.in_up, st))) return rc;
+  }
+  return launch_soft_argmin(ws + c.vol, planes, depth, confidence, s.B, s.D, s.h, s.w, s.in_up, st);
+}

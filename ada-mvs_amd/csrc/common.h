@@ -1,0 +1,43 @@
+// Shared helpers for the gfx950 kernels of the Ada-MVS depth-inference path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace adamvs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (thread-local: DataParallel calls forward from one thread per device)
+extern thread_local char g_last_error[512];
+int set_error(int code, const char* fmt, ...);
+
+#define ADAMVS_CHECK_ARG(cond, ...) \
+  do { if (!(cond)) return ::adamvs::set_error(-1, __VA_ARGS__); } while (0)
+
+#define ADAMVS_CHECK_LAUNCH(name) \
+  do { hipError_t e_ = hipGetLastError(); \
+       if (e_ != hipSuccess) return ::adamvs::set_error((int)e_, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------
+// D[16 x 16] += A[16 x 4] . B[4 x 16], exact fp32 (v_mfma_f32_16x16x4_f32).
+// lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; result reg r = D[4*(l>>4)+r][l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// Uniform (scalar-cache) view of read-only parameters.
+typedef const float __attribute__((address_space(4))) cfloat;
+__device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)p; }
+
+// LDS plane pitch (in floats) >= n with plane % 32 == 16: with channel planes
+// that far apart the two 16-lane halves of a 32-lane LDS group (k = 0/1 of an
+// MFMA B fragment) hit disjoint banks.
+__host__ __device__ constexpr int plane_pitch16(int n) { return ((n + 15) / 32) * 32 + 16; }
+
+}  // namespace adamvs

@@ -1,0 +1,45 @@
+// 3x3 convolution of small-channel maps on the fp32 matrix cores.
+//
+// All the small convolutions of SliceCostRegNetRED (reference
+// models/adamvs.py:400-424, models/module.py:5-52) are evaluated as
+//     D[cout 16][pixel 16] += W_tap[cout 16][cin 4] . X_tap[cin 4][pixel 16]
+// with v_mfma_f32_16x16x4_f32 (exact fp32).  A wave owns a run of 16
+// consecutive output pixels of one row; weights sit in VGPRs as A fragments
+// (packed on the host in fragment order), inputs are read from a planar LDS
+// tile [cin][row][col] as B fragments.
+#pragma once
+#include "common.h"
+
+namespace adamvs {
+
+// Load NT x 9 x KC A-fragments; host layout [nt][tap][kc][64 lanes].
+template <int NT, int KC>
+__device__ __forceinline__ void load_wfrag(float (&wf)[NT][9][KC], const float* __restrict__ wpk, int lane) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) wf[nt][t][kc] = wpk[((nt * 9 + t) * KC + kc) * 64 + lane];
+}
+
+// One run of 16 output pixels.  `xb` = LDS tile + q*PLANE + p*STRIDE (lane's
+// own k-row and pixel); (row, col) = output coordinates inside the tile; the
+// tile origin is input coordinate (out_row0*STRIDE - 1, out_col0*STRIDE - 1).
+template <int NT, int KC, int STRIDE, int PLANE, int PITCH>
+__device__ __forceinline__ void conv3x3_run(f32x4 (&acc)[NT], const float (&wf)[NT][9][KC], const float* xb, int row,
+                                            int col) {
+  const float* x0 = xb + (row * STRIDE) * PITCH + col * STRIDE;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        float bv = x0[(4 * kc) * PLANE + ky * PITCH + kx];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[nt][ky * 3 + kx][kc], bv, acc[nt]);
+      }
+}
+
+}  // namespace adamvs

@@ -1,0 +1,287 @@
+// CostRegNet2D: the depth-as-channel 2D hourglass that scores each source view
+// in stage 1 (reference models/adamvs.py:198-238, blocks models/module.py:254-261),
+// and the per-pixel softmax / max / expectation that turns its scores into a view
+// weight and a pair depth (reference models/adamvs.py:481-486, module.py:617-625).
+//
+// Every layer is a D->D 3x3 convolution: an implicit GEMM with K = 9*D on the fp32
+// matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).  Activations are channel-last
+// [N][h*w][D]; rows of the MFMA tile are output channels, columns are 16
+// consecutive output pixels of one row, so a lane ends up with 4 consecutive
+// channels of one pixel (one 16-byte store).  Weights are pre-packed on the host in
+// A-fragment order with the eval-mode BatchNorm scale folded in and stream
+// straight from L2 into VGPRs (each wave owns different output channels, so
+// there is nothing to share through LDS); activations go through a planar LDS
+// tile shared by the block's four waves.
+#include "common.h"
+#include "kernels.h"
+
+namespace adamvs {
+
+struct ConvDDArgs {
+  const float* in;     // [N][hi*wi][D]
+  const float* wpk;    // [9][D/4][D/16][64]
+  const float* bias;   // [D]
+  const float* skip;   // [N][ho*wo][D] or null; added after the ReLU (adamvs.py:234-236)
+  float* out;          // [N][ho*wo][D]
+  int D, hi, wi, ho, wo, relu;
+};
+
+enum { CONV_S1 = 0, CONV_S2 = 1, CONV_T2 = 2 };
+
+template <int MODE> struct TileGeom;
+template <> struct TileGeom<CONV_S1> { static constexpr int LR = 10, LC = 18, PLANE = plane_pitch16(10 * 18); };
+template <> struct TileGeom<CONV_S2> { static constexpr int LR = 17, LC = 33, PLANE = (17 * 33) | 1; };
+template <> struct TileGeom<CONV_T2> { static constexpr int LR = 9, LC = 17, PLANE = plane_pitch16(9 * 17); };
+
+constexpr int KB = 8;     // input channels per LDS chunk (2 MFMA k-steps)
+
+// Block = 8 rows x 16 columns of output positions x all D output channels.
+// Waves: WM along output channels (MT tiles of 16 each), WN = 4/WM along rows.
+// PY/PX: output parity class, CONV_T2 only (ConvTranspose2d k3 s2 p1 op1).
+template <int MT, int WM, int MODE, int PY, int PX>
+__device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
+  using TG = TileGeom<MODE>;
+  constexpr int LR = TG::LR, LC = TG::LC, PLANE = TG::PLANE;
+  constexpr int WN = 4 / WM, NTR = 8 / WN;
+  constexpr int STR = (MODE == CONV_S2) ? 2 : 1;
+  constexpr int NTY = (MODE == CONV_T2) ? 1 + PY : 3;
+  constexpr int NTX = (MODE == CONV_T2) ? 1 + PX : 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int p = lane & 15, q = lane >> 4;
+  const int D = a.D, KCT = D / 4, NTILES = D / 16;
+  const int r0 = by * 8, c0 = bx * 16;                       // block origin (output rows/cols, or input i/j for T2)
+  const int iy0 = (MODE == CONV_T2) ? r0 : r0 * STR - 1;
+  const int ix0 = (MODE == CONV_T2) ? c0 : c0 * STR - 1;
+  const float* inb = a.in + (size_t)n * a.hi * a.wi * D;
+
+  f32x4 acc[MT][NTR];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < NTR; ++r) acc[mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* xb = lds + q * PLANE + (wn * NTR * STR) * LC + p * STR;
+  for (int ch = 0; ch < D; ch += KB) {
+    // A fragments of this chunk: [tap][kc][mt]
+    float wf[NTY * NTX][KB / 4][MT];
+#pragma unroll
+    for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < NTX; ++tx) {
+        const int ky = (MODE == CONV_T2) ? (PY ? (ty ? 0 : 2) : 1) : ty;
+        const int kx = (MODE == CONV_T2) ? (PX ? (tx ? 0 : 2) : 1) : tx;
+#pragma unroll
+        for (int kc = 0; kc < KB / 4; ++kc)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            wf[ty * NTX + tx][kc][mt] =
+                a.wpk[((size_t)((ky * 3 + kx) * KCT + ch / 4 + kc) * NTILES + wm * MT + mt) * 64 + lane];
+      }
+    __syncthreads();                    // previous chunk's readers are done
+    for (int i = tid; i < LR * LC * (KB / 4); i += 256) {
+      int g = i % (KB / 4), pp = i / (KB / 4);
+      int r = pp / LC, c = pp % LC;
+      int iy = iy0 + r, ix = ix0 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) v = *(const f32x4*)(inb + ((size_t)iy * a.wi + ix) * D + ch + 4 * g);
+      float* dl = lds + (4 * g) * PLANE + r * LC + c;
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < NTX; ++tx)
+#pragma unroll
+        for (int kc = 0; kc < KB / 4; ++kc) {
+          float bv[NTR];
+#pragma unroll
+          for (int r = 0; r < NTR; ++r) bv[r] = xb[(4 * kc) * PLANE + (r * STR + ty) * LC + tx];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < NTR; ++r) acc[mt][r] = mfma16(wf[ty * NTX + tx][kc][mt], bv[r], acc[mt][r]);
+        }
+  }
+
+  // epilogue: lane owns channels co4..co4+3 of the pixel in column p
+#pragma unroll
+  for (int r = 0; r < NTR; ++r) {
+    int row = r0 + wn * NTR + r, col = c0 + p;
+    int oy = (MODE == CONV_T2) ? 2 * row + PY : row;
+    int ox = (MODE == CONV_T2) ? 2 * col + PX : col;
+    bool valid = (MODE == CONV_T2) ? (row < a.hi && col < a.wi) : (oy < a.ho && ox < a.wo);
+    if (!valid) continue;
+    size_t opix = ((size_t)n * a.ho + oy) * a.wo + ox;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int co4 = (wm * MT + mt) * 16 + 4 * q;
+      f32x4 v = acc[mt][r] + *(const f32x4*)(a.bias + co4);
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (a.skip) v += *(const f32x4*)(a.skip + opix * D + co4);
+      *(f32x4*)(a.out + opix * D + co4) = v;
+    }
+  }
+}
+
+// grid: (ceil(cols/16), ceil(rows/8), N [*4 classes for CONV_T2]); block 256
+template <int MT, int WM, int MODE>
+__global__ __launch_bounds__(256) void k_conv_dd(ConvDDArgs a) {
+  __shared__ float lds[KB * TileGeom<MODE>::PLANE];
+  if (MODE == CONV_T2) {
+    int n = blockIdx.z >> 2, cls = blockIdx.z & 3;
+    switch (cls) {        // block-uniform
+      case 0: conv_dd_body<MT, WM, MODE, 0, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      case 1: conv_dd_body<MT, WM, MODE, 0, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      case 2: conv_dd_body<MT, WM, MODE, 1, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      default: conv_dd_body<MT, WM, MODE, 1, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
+    }
+  } else {
+    conv_dd_body<MT, WM, MODE, 0, 0>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+  }
+}
+
+template <int MT, int WM>
+static int launch_conv_dd_cfg(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
+  if (mode == CONV_S1)
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S1>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
+  else if (mode == CONV_S2)
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S2>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_T2>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N * 4), dim3(256), 0, st, a);
+  ADAMVS_CHECK_LAUNCH("conv_dd");
+  return 0;
+}
+
+bool costreg_depth_supported(int D) {
+  return D == 16 || D == 32 || D == 48 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256;
+}
+
+static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
+  switch (a.D) {
+    case 16: return launch_conv_dd_cfg<1, 1>(a, N, mode, st);
+    case 32: return launch_conv_dd_cfg<2, 1>(a, N, mode, st);
+    case 48: return launch_conv_dd_cfg<3, 1>(a, N, mode, st);
+    case 64: return launch_conv_dd_cfg<4, 1>(a, N, mode, st);
+    case 96: return launch_conv_dd_cfg<3, 2>(a, N, mode, st);
+    case 128: return launch_conv_dd_cfg<4, 2>(a, N, mode, st);
+    case 192: return launch_conv_dd_cfg<3, 4>(a, N, mode, st);
+    case 256: return launch_conv_dd_cfg<4, 4>(a, N, mode, st);
+  }
+  return set_error(-1, "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", a.D);
+}
+
+// ---------------------------------------------------------------------------
+// softmax over D, max probability, expectation of depth.  16 lanes per pixel.
+// score [N=S*B][hw][D] (n = s*B + b), planes [B][D][hw] -> vw, pd [S*B][hw].
+__global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict__ score, const float* __restrict__ planes,
+                                                         float* __restrict__ vw, float* __restrict__ pd, int B, int D, int hw,
+                                                         size_t npix) {
+  size_t gp = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
+  const bool live = gp < npix;
+  size_t pix = live ? gp : npix - 1;
+  size_t n = pix / hw, pp = pix % hw;
+  size_t b = n % B;
+  const float* sc = score + pix * D;
+  const float* pl = planes + b * D * hw + pp;
+  float m = -INFINITY;
+  for (int d = 4 * l; d < D; d += 64) {
+    f32x4 v = *(const f32x4*)(sc + d);
+    m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float se = 0.f, sd = 0.f;
+  for (int d = 4 * l; d < D; d += 64) {
+    f32x4 v = *(const f32x4*)(sc + d);
+    float e0 = __expf(v.x - m), e1 = __expf(v.y - m), e2 = __expf(v.z - m), e3 = __expf(v.w - m);
+    se += (e0 + e1) + (e2 + e3);
+    sd += e0 * pl[(size_t)d * hw] + e1 * pl[(size_t)(d + 1) * hw] + e2 * pl[(size_t)(d + 2) * hw] + e3 * pl[(size_t)(d + 3) * hw];
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { se += __shfl_xor(se, o, 64); sd += __shfl_xor(sd, o, 64); }
+  if (live && l == 0) {
+    vw[pix] = 1.0f / se;          // max_d softmax = exp(max - max) / sum
+    pd[pix] = sd / se;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Layer plan.  Packed weights: 11 layers x (9*D*D fragment floats + D bias floats), in the order
+// conv0..conv6, conv7, conv9, conv11, prob.  Workspace: 3 * N*h*w*D floats.
+int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
+                           hipStream_t st) {
+  const size_t F = (size_t)N * h * w * D;
+  const size_t LW = (size_t)9 * D * D + D;
+  float* conv0 = ws;                  // F
+  float* t1 = conv0 + F;              // F/4
+  float* conv2 = t1 + F / 4;          // F/4
+  float* t3 = conv2 + F / 4;          // F/16
+  float* conv4 = t3 + F / 16;         // F/16
+  float* t5 = conv4 + F / 16;         // F/64
+  float* t6 = t5 + F / 64;            // F/64
+  float* x7 = t6 + F / 64;            // F/16
+  float* x9 = x7 + F / 16;            // F/4
+  float* x11 = x9 + F / 4;            // F
+  const int h2 = h / 2, w2 = w / 2, h4 = h / 4, w4 = w / 4, h8 = h / 8, w8 = w / 8;
+  struct L { const float* in; float* out; const float* skip; int hi, wi, ho, wo, mode, relu; };
+  const L plan[11] = {
+      {x, conv0, nullptr, h, w, h, w, CONV_S1, 1},
+      {conv0, t1, nullptr, h, w, h2, w2, CONV_S2, 1},
+      {t1, conv2, nullptr, h2, w2, h2, w2, CONV_S1, 1},
+      {conv2, t3, nullptr, h2, w2, h4, w4, CONV_S2, 1},
+      {t3, conv4, nullptr, h4, w4, h4, w4, CONV_S1, 1},
+      {conv4, t5, nullptr, h4, w4, h8, w8, CONV_S2, 1},
+      {t5, t6, nullptr, h8, w8, h8, w8, CONV_S1, 1},
+      {t6, x7, conv4, h8, w8, h4, w4, CONV_T2, 1},
+      {x7, x9, conv2, h4, w4, h2, w2, CONV_T2, 1},
+      {x9, x11, conv0, h2, w2, h, w, CONV_T2, 1},
+      {x11, score, nullptr, h, w, h, w, CONV_S1, 0},
+  };
+  for (int i = 0; i < 11; ++i) {
+    const float* wl = wpk + (size_t)i * LW;
+    ConvDDArgs a{plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, D,
+                 plan[i].hi, plan[i].wi, plan[i].ho, plan[i].wo, plan[i].relu};
+    int rc = launch_conv_dd(a, N, plan[i].mode, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int launch_softmax_regress(const float* score, const float* planes, float* vw, float* pd, int S, int B, int D, int h, int w,
+                           hipStream_t st) {
+  size_t npix = (size_t)S * B * h * w;
+  hipLaunchKernelGGL(k_softmax_regress, dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, st, score, planes, vw, pd, B, D,
+                     h * w, npix);
+  ADAMVS_CHECK_LAUNCH("softmax_regress");
+  return 0;
+}
+
+}  // namespace adamvs
+
+using namespace adamvs;
+
+extern "C" size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, int w) {
+  return (size_t)3 * N * h * w * D * sizeof(float);
+}
+
+extern "C" int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N, int D, int h, int w,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(x && wpk && score && workspace && N > 0 && h > 0 && w > 0, "cost_reg_net_2d: bad arguments");
+  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
+  ADAMVS_CHECK_ARG((h % 8) == 0 && (w % 8) == 0, "cost_reg_net_2d: h=%d w=%d must be multiples of 8 (three stride-2 levels)", h, w);
+  ADAMVS_CHECK_ARG(workspace_bytes >= adamvs_cost_reg_net_2d_workspace_bytes(N, D, h, w),
+                   "cost_reg_net_2d: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                   adamvs_cost_reg_net_2d_workspace_bytes(N, D, h, w));
+  ADAMVS_CHECK_ARG((size_t)N * 4 <= 65535, "cost_reg_net_2d: N=%d exceeds the grid z limit", N);
+  return launch_cost_reg_net_2d(x, wpk, (float*)workspace, score, N, D, h, w, (hipStream_t)stream);
+}
+
+extern "C" int adamvs_softmax_max_regress(const float* score, const float* planes, float* view_weight, float* pair_depth,
+                                          int S, int B, int D, int h, int w, void* stream) {
+  ADAMVS_CHECK_ARG(score && planes && view_weight && pair_depth && S > 0 && B > 0 && D > 0 && (D % 4) == 0 && h > 0 && w > 0,
+                   "softmax_max_regress: bad arguments (D=%d must be a multiple of 4)", D);
+  return launch_softmax_regress(score, planes, view_weight, pair_depth, S, B, D, h, w, (hipStream_t)stream);
+}

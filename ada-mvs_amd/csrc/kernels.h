@@ -1,0 +1,36 @@
+// Launchers shared between the kernel translation units and the C-ABI glue.
+#pragma once
+#include "common.h"
+
+namespace adamvs {
+
+struct FuseWeights {          // mirrors adamvs_fuse_weights in include/adamvs_hip.h
+  const float* conv1;         // [1][9][C/4][64]
+  const float* gates1; const float* gates1_b;   // [1][9][4][64], [16]
+  const float* cand1;  const float* cand1_b;    // [1][9][4][64], [16]
+  const float* conv2;                           // [1][9][2][64]
+  const float* gates2; const float* gates2_b;   // [2][9][8][64], [32]
+  const float* cand2;  const float* cand2_b;    // [1][9][8][64], [16]
+  const float* upconv1; const float* upconv1_b; // [1][9][4][64], [16]
+  const float* final_w;                         // [73]
+};
+
+struct StepBuffers {          // all channel-last
+  float* h1; float* rh1; float* u1;              // [B][hw][8]
+  float* c2; float* h2; float* rh2; float* u2;   // [B][hw/4][16]
+};
+
+int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, hipStream_t st);
+int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers& sb, float* vol, int B, int h, int w, int D,
+                      int d, int in_up, hipStream_t st);
+int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,
+                       int in_up, hipStream_t st);
+int launch_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+                           float* c1, int B, int S, int C, int D, int h, int w, hipStream_t st);
+int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
+                           hipStream_t st);
+int launch_softmax_regress(const float* score, const float* planes, float* vw, float* pd, int S, int B, int D, int h, int w,
+                           hipStream_t st);
+bool costreg_depth_supported(int D);
+
+}  // namespace adamvs

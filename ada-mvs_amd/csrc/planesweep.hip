@@ -1,0 +1,175 @@
+// Plane-sweep kernels (gfx950).
+//
+//   k_pair_similarity   pass A of InferDepthNet0.forward, reference
+//                       models/adamvs.py:464-478: per source view, per
+//                       hypothesis d: sim[d] = mean_c(ref[c] * warp_d(src)[c])
+//   k_aggregate_conv1   pass B, reference models/adamvs.py:495-512 + the first
+//                       layer of SliceCostRegNetRED (adamvs.py:416):
+//                       sim[c] = sum_v w_v warp_v[c] ref[c] / (1e-5 + sum_v w_v),
+//                       c1 = ReLU(conv1(sim)); evaluated for EVERY hypothesis
+//                       of the stage in one launch (it does not depend on the
+//                       recurrent state), sim never leaves the CU.
+//
+// Feature maps are channel-last [view][B][h*w][C]; a bilinear tap of one
+// pixel is one contiguous C*4-byte line, fetched by C/4 neighbouring lanes as
+// one float4 each; the per-pixel channel reduction is a wavefront shuffle tree.
+#include "common.h"
+#include "kernels.h"
+#include "conv_frag.h"
+#include "warp_math.h"
+
+namespace adamvs {
+
+// ---------------------------------------------------------------------------
+// grid: (pixel groups, S, B); block 256.  sim [S][B][hw][D] (channel-last in d).
+template <int C>
+__global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict__ feat, const float* __restrict__ rt,
+                                                         const float* __restrict__ planes, float* __restrict__ sim,
+                                                         int B, int S, int D, int h, int w) {
+  constexpr int G = C / 4;          // lanes per pixel
+  constexpr int PPB = 256 / G;      // pixels per block
+  const int hw = h * w;
+  const int tid = threadIdx.x;
+  const int g = tid % G;
+  const int pix = blockIdx.x * PPB + tid / G;
+  const int s = blockIdx.y, b = blockIdx.z;
+  const bool live = pix < hw;
+  const int pc = live ? pix : hw - 1;
+  const int y = pc / w, x = pc % w;
+  const float* ref = feat + ((size_t)b * hw + pc) * C + 4 * g;                 // view 0
+  const float* src = feat + ((size_t)(s + 1) * B + b) * (size_t)hw * C;
+  const float* rtp = rt + ((size_t)b * S + s) * 12;
+  float r[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) r[i] = rtp[i];
+  const f32x4 ref4 = *(const f32x4*)ref;
+  const float* pl = planes + (size_t)b * D * hw + pc;
+  float* out = sim + (((size_t)s * B + b) * hw + pc) * D;
+  float keep = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float depth = pl[(size_t)d * hw];
+    WarpTaps tp = warp_taps(r, (float)x, (float)y, depth, h, w);
+    f32x4 v = gather4(src, C, 4 * g, tp);
+    f32x4 m = v * ref4;
+    float part = (m.x + m.y) + (m.z + m.w);
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) part += __shfl_xor(part, o, 64);
+    float val = part * (1.0f / (float)C);
+    if ((d % G) == g) keep = val;
+    if ((d % G) == G - 1 || d == D - 1) {       // flush a group of G hypotheses: G lanes x 4 B contiguous
+      int dd = d - (d % G) + g;
+      if (live && dd <= d) out[dd] = keep;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// grid: (ceil(w/32), ceil(h/TR), B*D); block 256.
+// c1 [D][B][hw][8]; view weights vw [S][B][hw]; w1pk = conv1 A-fragments [1][9][C/4][64].
+template <int C, int TR>
+__global__ __launch_bounds__(256) void k_aggregate_conv1(const float* __restrict__ feat, const float* __restrict__ rt,
+                                                         const float* __restrict__ planes, const float* __restrict__ vw,
+                                                         const float* __restrict__ w1pk, float* __restrict__ c1,
+                                                         int B, int S, int D, int h, int w) {
+  constexpr int G = C / 4, KC = C / 4;
+  constexpr int LR = TR + 2, LC = 34;
+  constexpr int PLANE = plane_pitch16(LR * LC);
+  extern __shared__ float lds[];      // [C][PLANE]
+  const int hw = h * w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z / D, d = blockIdx.z % D;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * TR;
+
+  float wf[1][9][KC];
+  load_wfrag<1, KC>(wf, w1pk, lane);
+
+  const float* refb = feat + (size_t)b * hw * C;
+  const float* pl = planes + ((size_t)b * D + d) * hw;
+  for (int i = tid; i < LR * LC * G; i += 256) {
+    int g = i % G, pp = i / G;
+    int ry = pp / LC, rx = pp % LC;
+    int y = y0 - 1 + ry, x = x0 - 1 + rx;
+    f32x4 simv = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < h && x >= 0 && x < w) {
+      int pix = y * w + x;
+      float depth = pl[pix];
+      f32x4 ref4 = *(const f32x4*)(refb + (size_t)pix * C + 4 * g);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      float wsum = 1e-5f;                                            // adamvs.py:497
+      for (int s = 0; s < S; ++s) {
+        float wv = vw[((size_t)s * B + b) * hw + pix];
+        WarpTaps tp = warp_taps(rt + ((size_t)b * S + s) * 12, (float)x, (float)y, depth, h, w);
+        f32x4 v = gather4(feat + ((size_t)(s + 1) * B + b) * (size_t)hw * C, C, 4 * g, tp);
+        acc += (v * ref4) * wv;                                      // adamvs.py:504-508
+        wsum += wv;
+      }
+      simv = acc / wsum;                                             // adamvs.py:512
+    }
+    float* dl = lds + (4 * g) * PLANE + ry * LC + rx;
+    dl[0] = simv.x; dl[PLANE] = simv.y; dl[2 * PLANE] = simv.z; dl[3 * PLANE] = simv.w;
+  }
+  __syncthreads();
+
+  const int p = lane & 15, q = lane >> 4;
+  const float* xb = lds + q * PLANE + p;
+  float* c1b = c1 + ((size_t)d * B + b) * (size_t)hw * 8;
+  for (int run = wave; run < TR * 2; run += 4) {
+    int row = run >> 1, col = (run & 1) * 16;
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    conv3x3_run<1, KC, 1, PLANE, LC>(acc, wf, xb, row, col);
+    int y = y0 + row, x = x0 + col + p;
+    if (q < 2 && y < h && x < w) {
+      f32x4 o = acc[0];
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      *(f32x4*)(c1b + ((size_t)y * w + x) * 8 + 4 * q) = o;
+    }
+  }
+}
+
+}  // namespace adamvs
+
+using namespace adamvs;
+
+extern "C" int adamvs_pair_similarity(const float* feat, const float* rt, const float* planes, float* sim, int B, int S,
+                                      int C, int D, int h, int w, void* stream) {
+  ADAMVS_CHECK_ARG(feat && rt && planes && sim && B > 0 && S > 0 && D > 0 && h > 1 && w > 1,
+                   "pair_similarity: bad arguments (B=%d S=%d D=%d h=%d w=%d)", B, S, D, h, w);
+  ADAMVS_CHECK_ARG(C == 8 || C == 16 || C == 32, "pair_similarity: C=%d unsupported (8, 16 or 32)", C);
+  int hw = h * w;
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 32)
+    hipLaunchKernelGGL((k_pair_similarity<32>), dim3(cdiv(hw, 32), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w);
+  else if (C == 16)
+    hipLaunchKernelGGL((k_pair_similarity<16>), dim3(cdiv(hw, 64), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w);
+  else
+    hipLaunchKernelGGL((k_pair_similarity<8>), dim3(cdiv(hw, 128), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w);
+  ADAMVS_CHECK_LAUNCH("pair_similarity");
+  return 0;
+}
+
+namespace adamvs {
+int launch_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+                           float* c1, int B, int S, int C, int D, int h, int w, hipStream_t st) {
+  constexpr int TR = 8;
+  dim3 grid(cdiv(w, 32), cdiv(h, TR), B * D);
+  size_t lds = (size_t)C * plane_pitch16((TR + 2) * 34) * sizeof(float);
+  if (C == 32)
+    hipLaunchKernelGGL((k_aggregate_conv1<32, TR>), grid, dim3(256), lds, st, feat, rt, planes, vw, w1pk, c1, B, S, D, h, w);
+  else if (C == 16)
+    hipLaunchKernelGGL((k_aggregate_conv1<16, TR>), grid, dim3(256), lds, st, feat, rt, planes, vw, w1pk, c1, B, S, D, h, w);
+  else if (C == 8)
+    hipLaunchKernelGGL((k_aggregate_conv1<8, TR>), grid, dim3(256), lds, st, feat, rt, planes, vw, w1pk, c1, B, S, D, h, w);
+  else
+    return set_error(-1, "aggregate_conv1: C=%d unsupported (8, 16 or 32)", C);
+  ADAMVS_CHECK_LAUNCH("aggregate_conv1");
+  return 0;
+}
+}  // namespace adamvs
+
+extern "C" int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* view_weight,
+                                      const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, void* stream) {
+  ADAMVS_CHECK_ARG(feat && rt && planes && view_weight && w1pk && c1 && B > 0 && S > 0 && D > 0 && h > 1 && w > 1,
+                   "aggregate_conv1: bad arguments");
+  ADAMVS_CHECK_ARG((size_t)B * D <= 65535, "aggregate_conv1: B*D=%d exceeds the grid z limit", B * D);
+  return launch_aggregate_conv1(feat, rt, planes, view_weight, w1pk, c1, B, S, C, D, h, w, (hipStream_t)stream);
+}

@@ -1,0 +1,55 @@
+// Plane-induced homography + bilinear tap set, shared by every kernel that
+// warps source features (reference models/module.py:549-566).
+//
+//   X = (R.[x,y,1]^T) . d + t ;  (u,v) = (X0/X2, X1/X2)
+//   sample at pixel coordinates (u,v): grid_sample(bilinear, padding zeros,
+//   align_corners=True) applied to the reference's normalised grid lands on
+//   exactly these pixel coordinates.  Taps outside [0,w-1]x[0,h-1] add 0.
+#pragma once
+#include "common.h"
+
+namespace adamvs {
+
+struct WarpTaps {
+  float w00, w01, w10, w11;   // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1); 0 when the tap is out of range
+  int o00, o01, o10, o11;     // pixel offsets y*w+x (0 when out of range)
+};
+
+__device__ __forceinline__ WarpTaps warp_taps(const float* __restrict__ rt, float x, float y, float d, int h, int w) {
+  // rot_xyz = R.[x,y,1]; rot_depth_xyz = rot_xyz * d; proj_xyz = + t   (module.py:549-552)
+  float a0 = rt[0] * x + rt[1] * y + rt[2];
+  float a1 = rt[3] * x + rt[4] * y + rt[5];
+  float a2 = rt[6] * x + rt[7] * y + rt[8];
+  float X0 = a0 * d + rt[9];
+  float X1 = a1 * d + rt[10];
+  float X2 = a2 * d + rt[11];
+  float u = X0 / X2;
+  float v = X1 / X2;
+  WarpTaps t;
+  t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+  t.o00 = t.o01 = t.o10 = t.o11 = 0;
+  // fully outside (or NaN/inf from X2 ~ 0): every tap is padding
+  if (!(u > -1.0f && u < (float)w && v > -1.0f && v < (float)h)) return t;
+  float fx0 = floorf(u), fy0 = floorf(v);
+  int x0 = (int)fx0, y0 = (int)fy0;
+  float lx = u - fx0, ly = v - fy0;
+  bool vx0 = x0 >= 0, vx1 = x0 + 1 <= w - 1;
+  bool vy0 = y0 >= 0, vy1 = y0 + 1 <= h - 1;
+  if (vy0 && vx0) { t.w00 = (1.f - lx) * (1.f - ly); t.o00 = y0 * w + x0; }
+  if (vy0 && vx1) { t.w01 = lx * (1.f - ly);         t.o01 = y0 * w + x0 + 1; }
+  if (vy1 && vx0) { t.w10 = (1.f - lx) * ly;         t.o10 = (y0 + 1) * w + x0; }
+  if (vy1 && vx1) { t.w11 = lx * ly;                 t.o11 = (y0 + 1) * w + x0 + 1; }
+  return t;
+}
+
+// 4 channels of a channel-last feature map [hw][C] gathered with a tap set.
+__device__ __forceinline__ f32x4 gather4(const float* __restrict__ fea, int C, int c0, const WarpTaps& t) {
+  const float* base = fea + c0;
+  f32x4 a = *(const f32x4*)(base + (size_t)t.o00 * C);
+  f32x4 b = *(const f32x4*)(base + (size_t)t.o01 * C);
+  f32x4 c = *(const f32x4*)(base + (size_t)t.o10 * C);
+  f32x4 d = *(const f32x4*)(base + (size_t)t.o11 * C);
+  return a * t.w00 + b * t.w01 + c * t.w10 + d * t.w11;
+}
+
+}  // namespace adamvs

@@ -1,0 +1,207 @@
+"""Thin PyTorch-tensor wrappers over the C ABI (include/adamvs_hip.h).
+
+PyTorch is used for device memory and the current stream only; every
+computation below happens in libadamvs_hip.so.  All functions require CUDA
+(ROCm) fp32 tensors and raise otherwise -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FuseWeights, StageDesc, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.AdaMVSHipError("%s must be a GPU tensor: the Ada-MVS hot path has no CPU fallback" % name)
+    if t.dtype != torch.float32:
+        raise _lib.AdaMVSHipError("%s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def relative_transforms(proj):
+    """proj [B,V,4,4] -> rt [B,V-1,12]   (module.py:539-541)"""
+    proj = _dev(proj, "proj")
+    B, V = proj.shape[:2]
+    rt = torch.empty(B, V - 1, 12, device=proj.device, dtype=torch.float32)
+    check(_lib.load().adamvs_relative_transforms(_p(proj), _p(rt), B, V, _stream()), "relative_transforms")
+    return rt
+
+
+def pack_features(x, out=None):
+    """[N,C,h,w] -> channel-last [N,h*w,C]"""
+    x = _dev(x, "features")
+    N, C, h, w = x.shape
+    if out is None:
+        out = torch.empty(N, h * w, C, device=x.device, dtype=torch.float32)
+    check(_lib.load().adamvs_pack_features(_p(x), _p(out), N, C, h, w, _stream()), "pack_features")
+    return out
+
+
+def unpack_features(x, h, w):
+    """channel-last [N,h*w,C] -> [N,C,h,w]"""
+    x = _dev(x, "features")
+    N, hw, C = x.shape
+    out = torch.empty(N, C, h, w, device=x.device, dtype=torch.float32)
+    check(_lib.load().adamvs_unpack_features(_p(x), _p(out), N, C, h, w, _stream()), "unpack_features")
+    return out
+
+
+def depth_range_samples(cur_depth, ndepth, depth_interval_pixel, shape):
+    """get_depth_range_samples (module.py:646-663) -> [B,D,h,w]"""
+    cur_depth = _dev(cur_depth, "cur_depth")
+    B, h, w = shape
+    out = torch.empty(B, ndepth, h, w, device=cur_depth.device, dtype=torch.float32)
+    lib = _lib.load()
+    if cur_depth.dim() == 2:
+        if cur_depth.shape[1] != 2:        # the reference reads [:,0] and [:,-1] only
+            cur_depth = torch.stack((cur_depth[:, 0], cur_depth[:, -1]), 1).contiguous()
+        check(lib.adamvs_depth_range_samples_uniform(_p(cur_depth), _p(out), B, ndepth, h, w, _stream()),
+              "depth_range_samples_uniform")
+    else:
+        if tuple(cur_depth.shape) != (B, h, w):
+            raise _lib.AdaMVSHipError("cur_depth:%s, input shape:%s" % (tuple(cur_depth.shape), shape))
+        check(lib.adamvs_depth_range_samples_window(_p(cur_depth), float(depth_interval_pixel), _p(out), B, ndepth, h, w,
+                                                    _stream()), "depth_range_samples_window")
+    return out
+
+
+def resize_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) for [N,1,h,w] / [N,h,w]"""
+    x = _dev(x, "x")
+    hi, wi = x.shape[-2:]
+    ho, wo = size
+    N = x.numel() // (hi * wi)
+    out = torch.empty(x.shape[:-2] + (ho, wo), device=x.device, dtype=torch.float32)
+    check(_lib.load().adamvs_resize_bilinear(_p(x), _p(out), N, hi, wi, ho, wo, _stream()), "resize_bilinear")
+    return out
+
+
+def depth_regression(p, depth_values):
+    """module.py:617-625"""
+    p = _dev(p, "p")
+    depth_values = _dev(depth_values, "depth_values")
+    B, D, h, w = p.shape
+    out = torch.empty(B, h, w, device=p.device, dtype=torch.float32)
+    hd, wd = (0, 0) if depth_values.dim() <= 2 else depth_values.shape[2:]
+    check(_lib.load().adamvs_depth_regression(_p(p), _p(depth_values), _p(out), B, D, h, w, hd, wd, _stream()),
+          "depth_regression")
+    return out
+
+
+def homo_warp(src_fea, rt, depth_values):
+    """homo_warping_float body (module.py:543-566): src [B,C,h,w], rt [B,12], depth [B,Nd,h,w] -> [B,C,Nd,h,w]"""
+    src_fea = _dev(src_fea, "src_fea")
+    rt = _dev(rt, "rt")
+    depth_values = _dev(depth_values, "depth_values")
+    B, C, h, w = src_fea.shape
+    Nd = depth_values.shape[1]
+    out = torch.empty(B, C, Nd, h, w, device=src_fea.device, dtype=torch.float32)
+    check(_lib.load().adamvs_homo_warp(_p(src_fea), _p(rt), _p(depth_values), _p(out), B, C, Nd, h, w, _stream()), "homo_warp")
+    return out
+
+
+def pair_similarity(feat, rt, planes, B, S, C, D, h, w):
+    """feat [V*B,hw,C] (view-major), rt [B,S,12], planes [B,D,h,w] -> sim [S*B,hw,D]"""
+    sim = torch.empty(S * B, h * w, D, device=feat.device, dtype=torch.float32)
+    check(_lib.load().adamvs_pair_similarity(_p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")), _p(sim),
+                                             B, S, C, D, h, w, _stream()), "pair_similarity")
+    return sim
+
+
+def cost_reg_net_2d(x_cl, wpk, h, w):
+    """x_cl [N,hw,D] channel-last -> score [N,hw,D]   (adamvs.py:229-238)"""
+    x_cl = _dev(x_cl, "x")
+    N, hw, D = x_cl.shape
+    lib = _lib.load()
+    nbytes = lib.adamvs_cost_reg_net_2d_workspace_bytes(N, D, h, w)
+    ws = torch.empty(nbytes // 4, device=x_cl.device, dtype=torch.float32)
+    score = torch.empty_like(x_cl)
+    check(lib.adamvs_cost_reg_net_2d(_p(x_cl), _p(wpk), _p(score), N, D, h, w, _p(ws), nbytes, _stream()), "cost_reg_net_2d")
+    return score
+
+
+def softmax_max_regress(score, planes, S, B, D, h, w):
+    vw = torch.empty(S, B, h, w, device=score.device, dtype=torch.float32)
+    pd = torch.empty(S, B, h, w, device=score.device, dtype=torch.float32)
+    check(_lib.load().adamvs_softmax_max_regress(_p(_dev(score, "score")), _p(_dev(planes, "planes")), _p(vw), _p(pd),
+                                                 S, B, D, h, w, _stream()), "softmax_max_regress")
+    return vw, pd
+
+
+def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w):
+    c1 = torch.empty(D, B, h * w, 8, device=feat.device, dtype=torch.float32)
+    check(_lib.load().adamvs_aggregate_conv1(_p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")),
+                                             _p(_dev(view_weight, "view_weight")), _p(w1pk), _p(c1), B, S, C, D, h, w,
+                                             _stream()), "aggregate_conv1")
+    return c1
+
+
+class PackedFuse:
+    """Device copy of a packed SliceCostRegNetRED + its adamvs_fuse_weights struct."""
+
+    def __init__(self, flat, offsets, device):
+        self.buf = flat.to(device)
+        base = self.buf.data_ptr()
+        self.struct = FuseWeights(**{f: base + 4 * o for f, o in offsets.items()})
+
+    def ptr(self):
+        return ctypes.byref(self.struct)
+
+    def field(self, name):
+        return ctypes.c_void_p(getattr(self.struct, name))
+
+
+def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up):
+    """SliceCostRegNetRED.forward on channel-last maps; states updated in place. -> reg [B,1,Ho,Wo]"""
+    lib = _lib.load()
+    Ho, Wo = (2 * h, 2 * w) if in_up else (h, w)
+    reg = torch.empty(B, 1, Ho, Wo, device=cost_cl.device, dtype=torch.float32)
+    nbytes = lib.adamvs_slice_reg_step_scratch_bytes(B, h, w)
+    scratch = torch.empty(nbytes // 4, device=cost_cl.device, dtype=torch.float32)
+    check(lib.adamvs_slice_reg_step(_p(_dev(cost_cl, "cost")), _p(state1), _p(state2), fuse.ptr(), _p(reg), B, C, h, w,
+                                    int(in_up), _p(scratch), nbytes, _stream()), "slice_reg_step")
+    return reg
+
+
+def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0)):
+    return StageDesc(B, S, C, h, w, D, int(in_up), int(first_stage), int(prev_hw[0]), int(prev_hw[1]))
+
+
+def depth_stage_workspace_bytes(desc):
+    n = _lib.load().adamvs_depth_stage_workspace_bytes(ctypes.byref(desc))
+    if n == 0:
+        check(-1, "depth_stage_workspace_bytes")
+    return n
+
+
+def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspace=None):
+    """InferDepthNet0.forward (adamvs.py:433-533).  Returns (view_weight [S,B,h,w], pair_depth or None,
+    depth [B,Ho,Wo], confidence [B,Ho,Wo])."""
+    dev = feat.device
+    B, S, h, w = desc.B, desc.S, desc.h, desc.w
+    Ho, Wo = (2 * h, 2 * w) if desc.in_up else (h, w)
+    nbytes = depth_stage_workspace_bytes(desc)
+    if workspace is None or workspace.numel() * 4 < nbytes:
+        workspace = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+    vw = torch.empty(S, B, h, w, device=dev, dtype=torch.float32)
+    pd = torch.empty(S, B, h, w, device=dev, dtype=torch.float32) if desc.first_stage else None
+    depth = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
+    conf = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
+    null = ctypes.c_void_p(0)
+    check(_lib.load().adamvs_depth_stage_forward(
+        ctypes.byref(desc), _p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")),
+        _p(_dev(prev_conf, "prev_conf")) if prev_conf is not None else null,
+        _p(w_reg) if w_reg is not None else null, fuse.ptr(),
+        _p(vw), _p(pd) if pd is not None else null, _p(depth), _p(conf), _p(workspace), nbytes, _stream()),
+        "depth_stage_forward")
+    return vw, pd, depth, conf

@@ -1,0 +1,261 @@
+"""Drop-in `Infer_AdaMVSNet` for MI355X: the constructor, forward() signature,
+output dict and state-dict keys of reference models/adamvs.py:537-620, with the
+depth-inference hot path (reference models/adamvs.py:426-533 and the functions
+it calls in models/module.py) running in libadamvs_hip.so.
+
+    from models.adamvs import Infer_AdaMVSNet          # with ada-mvs_amd/ on sys.path
+    model = Infer_AdaMVSNet(num_depth, ndepths, depth_intervals_ratio, share_cr, cr_base_chs)
+    model = nn.DataParallel(model).cuda(); model.load_state_dict(ckpt["model"]); model.eval()
+    out = model(imgs, proj_matrices, depth_values)     # out["depth"], out["photometric_confidence"], ...
+
+FeatureNet0 (upstream of the hot path) stays on PyTorch/MIOpen.  There is no
+CPU fallback: CPU tensors, or a missing library, raise.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip_ops, packing
+from .._lib import AdaMVSHipError
+from .module import Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse
+
+STAGE_SCALE = {"stage1": 4, "stage2": 2, "stage3": 1}
+
+
+def _pooled_context(in_ch, out_ch, pool):
+    return nn.Sequential(nn.AvgPool2d((pool, pool), stride=(pool, pool)),
+                         Conv2d(in_ch, out_ch, 1, stride=1, padding=0, dilation=1))
+
+
+class FeatureNet0(nn.Module):
+    """2D U-Net with pooled-context branches, three output scales (C = 32/16/8 at 1/4, 1/2, 1/1);
+    reference models/adamvs.py:49-152.  Plain PyTorch: not part of the hand-written path."""
+
+    def __init__(self, base_channels, num_stage=3, stride=4):
+        super().__init__()
+        c = base_channels
+        self.stride, self.base_channels, self.num_stage = stride, c, num_stage
+        self.conv0 = nn.Sequential(Conv2d(3, c, 3, 1, padding=1), Conv2d(c, c, 3, 1, padding=1))
+        self.conv1 = nn.Sequential(Conv2d(c, 2 * c, 5, stride=2, padding=2), Conv2d(2 * c, 2 * c, 3, 1, padding=1),
+                                   Conv2d(2 * c, 2 * c, 3, 1, padding=1))
+        self.conv2 = nn.Sequential(Conv2d(2 * c, 4 * c, 5, stride=2, padding=2), Conv2d(4 * c, 4 * c, 3, 1, padding=1),
+                                   Conv2d(4 * c, 4 * c, 3, 1, padding=1))
+        self.branch1_1 = _pooled_context(4 * c, 2 * c, 4)
+        self.branch1_2 = _pooled_context(4 * c, 2 * c, 8)
+        self.out1 = nn.Conv2d(8 * c, 4 * c, 1, bias=False)
+        self.deconv1 = DeConv2dFuse(4 * c, 2 * c, 3)
+        self.deconv2 = DeConv2dFuse(2 * c, c, 3)
+        self.branch2_1 = _pooled_context(2 * c, c, 4)
+        self.branch2_2 = _pooled_context(2 * c, c, 8)
+        self.branch3_1 = _pooled_context(c, c // 2, 4)
+        self.branch3_2 = _pooled_context(c, c // 2, 8)
+        self.out2 = nn.Conv2d(4 * c, 2 * c, 1, bias=False)
+        self.out3 = nn.Conv2d(2 * c, c, 1, bias=False)
+        self.out_channels = [4 * c, 2 * c, c]
+
+    @staticmethod
+    def _with_context(feat, branch_a, branch_b):
+        size = feat.shape[2:]
+        a = F.interpolate(branch_a(feat), size=size, mode="bilinear", align_corners=False)
+        b = F.interpolate(branch_b(feat), size=size, mode="bilinear", align_corners=False)
+        return torch.cat((a, b, feat), 1)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1(c0)
+        c2 = self.conv2(c1)
+        out = {"stage1": self.out1(self._with_context(c2, self.branch1_1, self.branch1_2))}
+        f = self.deconv1(c1, c2)
+        out["stage2"] = self.out2(self._with_context(f, self.branch2_1, self.branch2_2))
+        f = self.deconv2(c0, f)
+        out["stage3"] = self.out3(self._with_context(f, self.branch3_1, self.branch3_2))
+        return out
+
+
+class CostRegNet2D(nn.Module):
+    """Depth-as-channel 2D hourglass (reference models/adamvs.py:198-238); forward = adamvs_cost_reg_net_2d."""
+
+    def __init__(self, in_channels, base_channels=8):
+        super().__init__()
+        d = in_channels
+        for i, stride in enumerate((1, 2, 1, 2, 1, 2, 1)):
+            setattr(self, "conv%d" % i, ConvBnReLU(d, d, stride=stride))
+        for i in (7, 9, 11):
+            setattr(self, "conv%d" % i, nn.Sequential(
+                nn.ConvTranspose2d(d, d, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                nn.BatchNorm2d(d), nn.ReLU(inplace=True)))
+        self.prob = nn.Conv2d(d, d, 3, stride=1, padding=1)
+        self._packed = None
+
+    def packed(self, device):
+        if self._packed is None or self._packed.device != device:
+            self._packed = packing.pack_cost_reg_net_2d(self.state_dict(), "").to(device)
+        return self._packed
+
+    def forward(self, x):
+        N, D, h, w = x.shape
+        score = hip_ops.cost_reg_net_2d(hip_ops.pack_features(x), self.packed(x.device), h, w)
+        return hip_ops.unpack_features(score, h, w)
+
+
+class SliceCostRegNetRED(nn.Module):
+    """One recurrent regularisation step (reference models/adamvs.py:400-424); forward = adamvs_slice_reg_step."""
+
+    def __init__(self, in_channels, up=True, base_channels=8):
+        super().__init__()
+        c = base_channels
+        self.base_channels, self.in_channels, self.up = c, in_channels, up
+        self.conv1 = ConvReLU(in_channels, c, 3, 1, 1)
+        self.conv_gru1 = ConvGRUCell(c, c, 3)
+        self.conv2 = ConvReLU(c, 2 * c, 3, 2, 1)
+        self.conv_gru2 = ConvGRUCell(2 * c, 2 * c, 3)
+        self.upconv1 = nn.ConvTranspose2d(2 * c, c, kernel_size=3, stride=2, padding=1, output_padding=1)
+        if up:
+            self.upconv2d = nn.ConvTranspose2d(c, 1, kernel_size=3, stride=2, padding=1, output_padding=1)
+        else:
+            self.upconv2d = nn.Conv2d(c, 1, kernel_size=3, stride=1, padding=1)
+        self._packed = None
+
+    def packed(self, device):
+        if self.base_channels != 8:
+            raise AdaMVSHipError("SliceCostRegNetRED: the reference hard-codes 8/16 GRU widths (adamvs.py:448-449)")
+        if self._packed is None or self._packed.buf.device != device:
+            flat, offsets = packing.pack_slice_reg_net(self.state_dict(), "")
+            self._packed = hip_ops.PackedFuse(flat, offsets, device)
+        return self._packed
+
+    def forward(self, cost, state1, state2):
+        B, C, h, w = cost.shape
+        s1 = hip_ops.pack_features(state1)
+        s2 = hip_ops.pack_features(state2)
+        reg = hip_ops.slice_reg_step(hip_ops.pack_features(cost), s1, s2, self.packed(cost.device), B, C, h, w, self.up)
+        return reg, hip_ops.unpack_features(s1, h, w), hip_ops.unpack_features(s2, h // 2, w // 2)
+
+
+def _drop_packed(module):
+    for m in module.modules():
+        if hasattr(m, "_packed"):
+            m._packed = None
+
+
+class InferDepthNet0(nn.Module):
+    """One cascade stage (reference models/adamvs.py:426-533) = adamvs_depth_stage_forward."""
+
+    def __init__(self, in_depths, in_channels, in_up=True, base_channels=8):
+        super().__init__()
+        self.in_up = in_up
+        self.reg = CostRegNet2D(in_depths, base_channels)
+        self.reg_fuse = SliceCostRegNetRED(in_channels, in_up, base_channels)
+        self.mirror_list_lengths = True        # pair_confidence carries the reference's S*D duplicate entries (quirk Q1)
+        self._workspace = None
+
+    def _apply(self, fn, *a, **k):             # .cuda()/.to(): repack on next use
+        _drop_packed(self)
+        self._workspace = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        _drop_packed(self)
+        return super()._load_from_state_dict(*a, **k)
+
+    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf):
+        """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w];
+        prev_conf None (stage 1) or [S,B,hp,wp].  -> (view_weight [S,B,h,w], pair_depth|None, depth, conf)"""
+        S = feat_cl.shape[0] // B - 1
+        D = depth_values.shape[1]
+        first = prev_conf is None
+        prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
+        desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw)
+        need = hip_ops.depth_stage_workspace_bytes(desc) // 4
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != feat_cl.device:
+            self._workspace = torch.empty(need, device=feat_cl.device, dtype=torch.float32)
+        dev = feat_cl.device
+        w_reg = self.reg.packed(dev) if first else None
+        return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev),
+                                           self._workspace)
+
+    def forward(self, features, proj_matrices, depth_values, num_depth, confidence_map=None):
+        assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
+        assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(depth_values.shape[1], num_depth)
+        B, C, h, w = features[0].shape
+        S = len(features) - 1
+        feat_cl = hip_ops.pack_features(torch.stack(list(features), 0).reshape(-1, C, h, w))
+        rt = hip_ops.relative_transforms(proj_matrices)
+        prev = None
+        if confidence_map is not None:
+            prev = torch.stack([c.reshape(B, c.shape[-2], c.shape[-1]) for c in confidence_map[:S]], 0).contiguous()
+        vw, pd, depth, conf = self.run(feat_cl, B, C, h, w, rt, depth_values, prev)
+        return self._as_dict(vw, pd, depth, conf, num_depth)
+
+    def _as_dict(self, vw, pd, depth, conf, num_depth):
+        S, B, h, w = vw.shape
+        maps = [vw[i].reshape(B, 1, h, w) for i in range(S)]
+        pair_confidence = list(maps)
+        if self.mirror_list_lengths:
+            # the reference appends one (identical) resampled map per view per hypothesis (adamvs.py:505-506);
+            # stage 1 keeps its S raw maps in front (adamvs.py:489-490)
+            pair_confidence = (maps if pd is not None else []) + maps * num_depth
+        pair_result = [pd[i] for i in range(S)] if pd is not None else []
+        return {"depth": depth, "photometric_confidence": conf, "pair_confidence": pair_confidence, "pair_result": pair_result}
+
+
+class Infer_AdaMVSNet(nn.Module):
+    """reference models/adamvs.py:537-620"""
+
+    def __init__(self, num_depth=384, ndepths=[48, 32, 8], depth_intervals_ratio=[4, 2, 1], share_cr=False,
+                 cr_base_chs=[8, 8, 8]):
+        super().__init__()
+        assert len(ndepths) == len(depth_intervals_ratio)
+        self.num_depth = num_depth
+        self.share_cr = share_cr                 # accepted and ignored, as in the reference (quirk Q8)
+        self.ndepths = list(ndepths)
+        self.depth_intervals_ratio = list(depth_intervals_ratio)
+        self.cr_base_chs = cr_base_chs
+        self.num_stage = len(ndepths)
+        self.stage_infos = {k: {"scale": float(v)} for k, v in STAGE_SCALE.items()}
+        self.feature = FeatureNet0(base_channels=8, stride=4, num_stage=self.num_stage)
+        ch = self.feature.out_channels
+        self.DepthNet = nn.ModuleList([InferDepthNet0(in_depths=self.ndepths[0], in_channels=ch[0]),
+                                       InferDepthNet0(in_depths=self.ndepths[0], in_channels=ch[1]),
+                                       InferDepthNet0(in_depths=self.ndepths[0], in_up=False, in_channels=ch[2])])
+
+    # ---- the hot path on pre-extracted features ---------------------------------------------
+    def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval):
+        """feats_cl[s]: [V*B, h*w, C] channel-last view-major; shapes[s] = (B, C, h, w).
+        Everything below is HIP."""
+        outputs = {}
+        depth, conf = None, None
+        for s in range(self.num_stage):
+            name = "stage%d" % (s + 1)
+            B, C, h, w = shapes[s]
+            cur = depth_values if depth is None else depth
+            planes = hip_ops.depth_range_samples(cur, self.ndepths[s], self.depth_intervals_ratio[s] * depth_interval, [B, h, w])
+            rt = hip_ops.relative_transforms(proj_matrices[name])
+            net = self.DepthNet[s]
+            vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, planes, conf)
+            conf = vw
+            st = net._as_dict(vw, pd, depth, pconf, self.ndepths[s])
+            outputs[name] = st
+            outputs.update(st)
+        return outputs
+
+    def extract_features(self, imgs):
+        """-> (feats_cl, shapes) for infer_from_features; FeatureNet0 on all B*V images in one batch."""
+        B, V = imgs.shape[:2]
+        f = self.feature(imgs.transpose(0, 1).reshape(B * V, *imgs.shape[2:]))    # view-major
+        feats_cl, shapes = [], []
+        for s in range(self.num_stage):
+            x = f["stage%d" % (s + 1)]
+            feats_cl.append(hip_ops.pack_features(x))
+            shapes.append((B, x.shape[1], x.shape[2], x.shape[3]))
+        return feats_cl, shapes
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        if not imgs.is_cuda:
+            raise AdaMVSHipError("Infer_AdaMVSNet runs on MI355X only: move the model and its inputs to the GPU "
+                                 "(no CPU fallback for the depth-inference path)")
+        depth_min = float(depth_values[0, 0].cpu().numpy())        # batch item 0 only, host sync (adamvs.py:569-571)
+        depth_max = float(depth_values[0, -1].cpu().numpy())
+        depth_interval = (depth_max - depth_min) / self.num_depth
+        feats_cl, shapes = self.extract_features(imgs)
+        return self.infer_from_features(feats_cl, shapes, proj_matrices, depth_values, depth_interval)

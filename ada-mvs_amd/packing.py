@@ -1,0 +1,107 @@
+"""Host-side weight repacking for the gfx950 kernels (done once per checkpoint).
+
+Convolution weights become MFMA A-fragment streams for v_mfma_f32_16x16x4_f32
+(lane l of a fragment holds W[cout = 16*tile + (l & 15)][cin = 4*kc + (l >> 4)]
+of one tap), eval-mode BatchNorm is folded into the CostRegNet2D weights.
+Layouts are specified in include/adamvs_hip.h.  Pure tensor shuffling on the
+CPU; no arithmetic of the hot path happens here.
+"""
+import torch
+
+BN_EPS = 1e-5
+
+REG_LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11", "prob")
+REG_TRANSPOSED = ("conv7", "conv9", "conv11")
+
+
+def _as_cout_cin_tap(w, transposed):
+    """-> [cout][cin][9] fp32."""
+    w = w.detach().to(torch.float32).cpu()
+    if transposed:                      # ConvTranspose2d stores [cin][cout][ky][kx]
+        w = w.permute(1, 0, 2, 3)
+    return w.reshape(w.shape[0], w.shape[1], 9).contiguous()
+
+
+def pack_small_conv(w, transposed=False):
+    """[cout][cin][3][3] -> A fragments [NT][9][cin/4][64], cout zero-padded to 16*NT."""
+    w = _as_cout_cin_tap(w, transposed)
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % 4 == 0
+    nt = (cout + 15) // 16
+    wp = torch.zeros(nt * 16, cin, 9)
+    wp[:cout] = w
+    # (nt, co16, kc, k4, tap) -> (nt, tap, kc, k4, co16): lane = k4*16 + co16
+    return wp.reshape(nt, 16, cin // 4, 4, 9).permute(0, 4, 2, 3, 1).contiguous().reshape(-1)
+
+
+def pad_bias(b, n):
+    out = torch.zeros(n)
+    out[:b.numel()] = b.detach().to(torch.float32).cpu().reshape(-1)
+    return out
+
+
+def pack_reg_layer(w, scale, shift, transposed):
+    """One CostRegNet2D layer -> [9][D/4][D/16][64] fragment floats + [D] bias floats."""
+    w = _as_cout_cin_tap(w, transposed) * scale.reshape(-1, 1, 1)
+    d = w.shape[0]
+    assert w.shape[1] == d and d % 16 == 0, "CostRegNet2D width must be a multiple of 16"
+    # (tile, co16, kc, k4, tap) -> (tap, kc, tile, k4, co16)
+    frag = w.reshape(d // 16, 16, d // 4, 4, 9).permute(4, 2, 0, 3, 1).contiguous().reshape(-1)
+    return torch.cat([frag, shift.detach().to(torch.float32).cpu().reshape(-1)])
+
+
+def pack_cost_reg_net_2d(sd, pre):
+    """All 11 layers of `pre` (e.g. 'DepthNet.0.reg.') from a reference-keyed state dict."""
+    chunks = []
+    for name in REG_LAYERS:
+        if name == "prob":
+            w = sd[pre + "prob.weight"]
+            scale = torch.ones(w.shape[0])
+            shift = sd[pre + "prob.bias"]
+            transposed = False
+        else:
+            transposed = name in REG_TRANSPOSED
+            wkey, bnpre = (pre + name + ".0.weight", pre + name + ".1.") if transposed else \
+                          (pre + name + ".conv.weight", pre + name + ".bn.")
+            w = sd[wkey]
+            g = sd[bnpre + "weight"].detach().float().cpu()
+            b = sd[bnpre + "bias"].detach().float().cpu()
+            mu = sd[bnpre + "running_mean"].detach().float().cpu()
+            var = sd[bnpre + "running_var"].detach().float().cpu()
+            scale = g / torch.sqrt(var + BN_EPS)
+            shift = b - mu * scale
+        chunks.append(pack_reg_layer(w, scale, shift, transposed))
+    return torch.cat(chunks)
+
+
+FUSE_FIELDS = ("conv1", "gates1", "gates1_b", "cand1", "cand1_b", "conv2", "gates2", "gates2_b",
+               "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w")
+
+
+def pack_slice_reg_net(sd, pre):
+    """SliceCostRegNetRED of `pre` (e.g. 'DepthNet.0.reg_fuse.') -> (flat fp32 tensor, {field: offset})."""
+    parts = {
+        "conv1": pack_small_conv(sd[pre + "conv1.conv.weight"]),
+        "gates1": pack_small_conv(sd[pre + "conv_gru1.conv_gates.0.weight"]),
+        "gates1_b": pad_bias(sd[pre + "conv_gru1.conv_gates.0.bias"], 16),
+        "cand1": pack_small_conv(sd[pre + "conv_gru1.convc.0.weight"]),
+        "cand1_b": pad_bias(sd[pre + "conv_gru1.convc.0.bias"], 16),
+        "conv2": pack_small_conv(sd[pre + "conv2.conv.weight"]),
+        "gates2": pack_small_conv(sd[pre + "conv_gru2.conv_gates.0.weight"]),
+        "gates2_b": pad_bias(sd[pre + "conv_gru2.conv_gates.0.bias"], 32),
+        "cand2": pack_small_conv(sd[pre + "conv_gru2.convc.0.weight"]),
+        "cand2_b": pad_bias(sd[pre + "conv_gru2.convc.0.bias"], 16),
+        "upconv1": pack_small_conv(sd[pre + "upconv1.weight"], transposed=True),
+        "upconv1_b": pad_bias(sd[pre + "upconv1.bias"], 16),
+        # [8][1][3][3] (transposed, stages 1-2) and [1][8][3][3] (stage 3) both flatten to c*9 + tap
+        "final_w": pad_bias(torch.cat([sd[pre + "upconv2d.weight"].detach().float().cpu().reshape(-1),
+                                       sd[pre + "upconv2d.bias"].detach().float().cpu().reshape(-1)]), 76),
+    }
+    offsets, chunks, o = {}, [], 0
+    for f in FUSE_FIELDS:
+        t = parts[f]
+        pad = (-t.numel()) % 64          # keep every field 256-byte aligned
+        offsets[f] = o
+        chunks.append(torch.cat([t, torch.zeros(pad)]))
+        o += t.numel() + pad
+    return torch.cat(chunks), offsets

@@ -1,0 +1,146 @@
+/* libadamvs_hip.so -- C ABI of the MI355X (gfx950) Ada-MVS depth-inference hot path.
+ *
+ * The reference (gpcv-liujin/Ada-MVS) is pure PyTorch and has no native seam;
+ * this header IS the seam a maintainer binds (ctypes stub: INTEGRATION.md).
+ * Each entry point names the reference code it replaces (paths relative to the
+ * reference repository root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise;
+ *     the caller (PyTorch) owns all memory, including the workspace; nothing
+ *     is allocated, freed or retained by the library;
+ *   - all work is enqueued on `stream` (a hipStream_t); no call synchronises,
+ *     so every call can be captured into a hipGraph;
+ *   - return 0 on success, <0 for an argument/shape error, >0 a hipError_t;
+ *     adamvs_last_error_string() describes the last failure on this thread;
+ *   - re-entrant; the only global state is the thread-local error string.
+ *
+ * Layouts ("channel-last"): feature maps [view][B][h*w][C], GRU states
+ * [B][h*w][ch], cost-regularisation activations [N][h*w][D]; hypothesis planes
+ * and output maps are [B][D][h*w] / [B][h*w] as in the reference.
+ */
+#ifndef ADAMVS_HIP_H
+#define ADAMVS_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADAMVS_ABI_VERSION 1
+
+int adamvs_version(void);
+const char* adamvs_last_error_string(void);
+
+/* ---- geometry ----------------------------------------------------------- */
+
+/* T = P_src . P_ref^-1 for every (batch, source view); models/module.py:539-541.
+ * proj [B][V][4][4] (view 0 = reference) -> rt [B][V-1][12] = {R row-major, t}. */
+int adamvs_relative_transforms(const float* proj, float* rt, int B, int V, void* stream);
+
+/* NCHW [B][C][h][w] -> channel-last [B][h*w][C] (one view slot) and back. C % 4 == 0. */
+int adamvs_pack_features(const float* nchw, float* nhwc, int B, int C, int h, int w, void* stream);
+int adamvs_unpack_features(const float* nhwc, float* nchw, int B, int C, int h, int w, void* stream);
+
+/* get_depth_range_samples, models/module.py:646-663: depth_values [B][2]={min,max}
+ * -> out [B][D][h][w], D uniform samples (the interval argument is ignored there). */
+int adamvs_depth_range_samples_uniform(const float* depth_values, float* out, int B, int D, int h, int w, void* stream);
+/* get_cur_depth_range_samples, models/module.py:628-643: window cur -+ D/2*interval,
+ * D samples, no clamping.  cur_depth [B][h][w] -> out [B][D][h][w]. */
+int adamvs_depth_range_samples_window(const float* cur_depth, float depth_interval_pixel, float* out, int B, int D,
+                                      int h, int w, void* stream);
+
+/* F.interpolate(x, [ho,wo], mode='bilinear', align_corners=False) on [N][hi][wi];
+ * models/adamvs.py:505 (view weights) and :522 (hypothesis plane). */
+int adamvs_resize_bilinear(const float* in, float* out, int N, int hi, int wi, int ho, int wo, void* stream);
+
+/* depth_regression, models/module.py:617-625: prob [B][D][h][w]; depth_values
+ * [B][D] (hd = wd = 0) or [B][D][hd][wd] (bilinearly resized to [h][w]) -> out [B][h][w]. */
+int adamvs_depth_regression(const float* prob, const float* depth_values, float* out, int B, int D, int h, int w,
+                            int hd, int wd, void* stream);
+
+/* homo_warping_float, models/module.py:527-568, on the reference's own layouts:
+ * src_fea [B][C][h][w], rt [B][12] (adamvs_relative_transforms of this view),
+ * depth_values [B][Nd][h][w] -> out [B][C][Nd][h][w]. */
+int adamvs_homo_warp(const float* src_fea, const float* rt, const float* depth_values, float* out, int B, int C,
+                     int Nd, int h, int w, void* stream);
+
+/* ---- stage 1, per-view weighting (InferDepthNet0.forward pass A) --------- */
+
+/* models/adamvs.py:464-478: sim[s][b][pix][d] = mean_c(ref[c] * warp_d(src_s)[c]).
+ * feat [V][B][h*w][C], rt [B][S][12], planes [B][D][h*w] -> sim [S][B][h*w][D]. C in {8,16,32}. */
+int adamvs_pair_similarity(const float* feat, const float* rt, const float* planes, float* sim, int B, int S, int C,
+                           int D, int h, int w, void* stream);
+
+/* CostRegNet2D.forward, models/adamvs.py:229-238, on x [N][h*w][D] -> score [N][h*w][D].
+ * wpk: 11 layers (conv0..conv6, conv7, conv9, conv11, prob), each 9*D*D floats in
+ * A-fragment order [tap][cin/4][cout/16][lane] with value
+ * W[cout = 16*tile + (lane&15)][cin = 4*kc + (lane>>4)][tap] * bn_scale[cout]
+ * (ConvTranspose2d layers: W[cin][cout][tap]) followed by D bias floats (folded BN shift,
+ * or the conv bias for `prob`).  D in {16,32,48,64,96,128,192,256}; h, w multiples of 8. */
+size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, int w);
+int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N, int D, int h, int w,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* models/adamvs.py:481-486 + module.py:617-625: softmax over D, its maximum (view
+ * weight) and the expectation of the hypothesis planes (pair depth).
+ * score [S*B][h*w][D], planes [B][D][h*w] -> view_weight, pair_depth [S][B][h*w]. */
+int adamvs_softmax_max_regress(const float* score, const float* planes, float* view_weight, float* pair_depth,
+                               int S, int B, int D, int h, int w, void* stream);
+
+/* ---- aggregation + recurrent regularisation (pass B) --------------------- */
+
+/* SliceCostRegNetRED weights (models/adamvs.py:400-413), packed by the host:
+ * conv weights as MFMA A fragments [cout tile][tap][cin/4][64 lanes] holding
+ * W[cout = 16*tile + (lane&15)][cin = 4*kc + (lane>>4)][tap] (0 beyond cout),
+ * biases zero-padded to 16 per tile. */
+typedef struct adamvs_fuse_weights {
+  const float* conv1;                           /* [1][9][C/4][64]          reg_fuse.conv1.conv.weight */
+  const float* gates1; const float* gates1_b;   /* [1][9][4][64], [16]      conv_gru1.conv_gates.0 */
+  const float* cand1;  const float* cand1_b;    /* [1][9][4][64], [16]      conv_gru1.convc.0 */
+  const float* conv2;                           /* [1][9][2][64]            conv2.conv.weight */
+  const float* gates2; const float* gates2_b;   /* [2][9][8][64], [32]      conv_gru2.conv_gates.0 */
+  const float* cand2;  const float* cand2_b;    /* [1][9][8][64], [16]      conv_gru2.convc.0 */
+  const float* upconv1; const float* upconv1_b; /* [1][9][4][64], [16]      upconv1 (transposed: W[cin][cout][tap]) */
+  const float* final_w;                         /* [73]: w[c*9+tap], bias   upconv2d */
+} adamvs_fuse_weights;
+
+/* models/adamvs.py:495-512 fused with conv1 of SliceCostRegNetRED (adamvs.py:416), for all
+ * D hypotheses at once: c1[d][b][pix][8] = ReLU(conv1(sum_v w_v warp_v ref / (1e-5 + sum_v w_v))).
+ * view_weight [S][B][h*w]. */
+int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* view_weight,
+                           const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, void* stream);
+
+/* SliceCostRegNetRED.forward, models/adamvs.py:415-424 (one recurrent step).
+ * cost [B][h*w][C]; state1 [B][h*w][8], state2 [B][(h/2)*(w/2)][16] updated in place;
+ * reg_cost [B][Ho*Wo] with Ho x Wo = 2h x 2w (in_up) or h x w.
+ * scratch: adamvs_slice_reg_step_scratch_bytes(B,h,w) bytes. */
+size_t adamvs_slice_reg_step_scratch_bytes(int B, int h, int w);
+int adamvs_slice_reg_step(const float* cost, float* state1, float* state2, const adamvs_fuse_weights* weights,
+                          float* reg_cost, int B, int C, int h, int w, int in_up, void* scratch, size_t scratch_bytes,
+                          void* stream);
+
+/* ---- whole stage: InferDepthNet0.forward, models/adamvs.py:433-533 -------- */
+typedef struct adamvs_stage_desc {
+  int B, S, C, h, w, D;   /* batch, source views, feature channels, feature rows/cols, hypotheses */
+  int in_up;              /* 1: maps come out at 2h x 2w (stages 1, 2); 0: h x w (stage 3) */
+  int first_stage;        /* 1: confidence_map is None -> pass A scores the views (stage 1) */
+  int prev_h, prev_w;     /* size of prev_conf maps when !first_stage */
+} adamvs_stage_desc;
+
+size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);
+
+/* feat [V=S+1][B][h*w][C]; rt [B][S][12]; planes [B][D][h*w];
+ * prev_conf [S][B][prev_h*prev_w] (previous stage's view weights; ignored when first_stage);
+ * w_reg: packed CostRegNet2D weights (first_stage only);
+ * outputs: view_weight [S][B][h*w] (what the next stage consumes as prev_conf),
+ *          pair_depth [S][B][h*w] (first_stage only), depth / confidence [B][Ho*Wo]. */
+int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt, const float* planes,
+                               const float* prev_conf, const float* w_reg, const adamvs_fuse_weights* w_fuse,
+                               float* view_weight, float* pair_depth, float* depth, float* confidence,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAMVS_HIP_H */

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    import torch
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim > 0 else z[k].item()) for k in z.files}
+
+
+def rel_l1(x, ref):
+    """mean|x-ref| / mean|ref|."""
+    x = x.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((x - ref).abs().mean() / ref.abs().mean().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

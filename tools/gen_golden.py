@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+Imports /root/reference/models/{adamvs,module}.py (read-only, never copied),
+with a harness-side no-op for the hard-coded `.cuda()` calls of the inference
+path (models/adamvs.py:448-459), feeds it the seeded recipes of
+ada-mvs_amd/synth.py and stores inputs + outputs as small fixtures.  The
+fixtures are data; the reference itself never travels to the GPU box.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+torch.Tensor.cuda = lambda self, *a, **k: self          # CPU run of a .cuda()-hard-coded path
+
+import ada_mvs_amd  # noqa: E402  (repo shim -> ada-mvs_amd/)
+from ada_mvs_amd import synth  # noqa: E402
+from models import adamvs as ref_adamvs  # noqa: E402   (the reference)
+from models import module as ref_module  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (npy(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+def build_ref_model(cfg):
+    c = synth.CONFIGS[cfg]
+    m = ref_adamvs.Infer_AdaMVSNet(num_depth=c["num_depth"], ndepths=c["ndepths"],
+                                   depth_intervals_ratio=synth.DEPTH_INTERVALS_RATIO[:len(c["ndepths"])],
+                                   share_cr=False, cr_base_chs=[8, 8, 8])
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m.eval()
+    return m
+
+
+@torch.no_grad()
+def op_level():
+    g = torch.Generator().manual_seed(1)
+    # ---- a3 warp: in-bounds rig + a wide-baseline rig with out-of-bounds taps
+    B, C, h, w = 2, 8, 24, 40
+    src = synth.smooth_features(B, C, h, w, seed=3)
+    for tag, baseline in (("warp_inb", 8.0), ("warp_oob", 150.0)):
+        proj = synth.rig_projections(3, 4 * h, 4 * w, batch=B, baseline=baseline)["stage1"]
+        depth = 400 + 200 * torch.rand(B, 3, h, w, generator=g)
+        out = ref_module.homo_warping_float(src, proj[:, 2], proj[:, 0], depth)
+        save("op_" + tag, src=src, src_proj=proj[:, 2], ref_proj=proj[:, 0], depth=depth, out=out)
+    # ---- a2 both branches
+    dv = torch.tensor([[400.0, 600.0], [380.0, 640.0]])
+    s1 = ref_module.get_depth_range_samples(dv, 12, 4 * 200 / 48, "cpu", torch.float32, [2, 6, 10])
+    cur = 400 + 200 * torch.rand(2, 6, 10, generator=g)
+    s2 = ref_module.get_depth_range_samples(cur, 8, 2 * 200 / 48, "cpu", torch.float32, [2, 6, 10])
+    save("op_depth_samples", dv=dv, s1=s1, cur=cur, s2=s2, interval1=4 * 200 / 48, interval2=2 * 200 / 48)
+    # ---- depth_regression (2-D and 4-D depth values) + softmax/max
+    p = torch.softmax(torch.randn(2, 12, 6, 10, generator=g), 1)
+    save("op_depth_regression", p=p, dv2=s1[:, :, 0, 0].contiguous(), out2=ref_module.depth_regression(p, s1[:, :, 0, 0]),
+         dv4=s1, out4=ref_module.depth_regression(p, s1))
+    # ---- a7 the two interpolate uses
+    x = torch.rand(2, 1, 6, 10, generator=g)
+    save("op_upsample2x", x=x, out=torch.nn.functional.interpolate(x, [12, 20], mode="bilinear", align_corners=False))
+
+
+@torch.no_grad()
+def net_level():
+    """a5 CostRegNet2D, a9 ConvGRUCell + SliceCostRegNetRED for the 3 stage variants."""
+    m = build_ref_model("tiny")           # D1 = 16
+    g = torch.Generator().manual_seed(2)
+    sd = {k: v for k, v in m.state_dict().items()}
+    x = torch.randn(2, 16, 16, 24, generator=g) * 0.5
+    save("net_costreg2d", x=x, out=m.DepthNet[0].reg(x))
+    for k, (C, h, w) in enumerate(((32, 16, 24), (16, 16, 24), (8, 16, 24))):
+        cost = torch.randn(2, C, h, w, generator=g) * 0.5
+        s1 = torch.randn(2, 8, h, w, generator=g) * 0.5
+        s2 = torch.randn(2, 16, h // 2, w // 2, generator=g) * 0.5
+        reg, n1, n2 = m.DepthNet[k].reg_fuse(cost, s1, s2)
+        save("net_slice_step%d" % k, cost=cost, state1=s1, state2=s2, reg=reg, new1=n1, new2=n2)
+    xg = torch.randn(2, 8, 10, 12, generator=g)
+    hg = torch.randn(2, 8, 10, 12, generator=g)
+    save("net_gru_cell", x=xg, h=hg, out=m.DepthNet[0].reg_fuse.conv_gru1(xg, hg)[0])
+    del sd
+
+
+@torch.no_grad()
+def end_to_end(cfg, with_inputs):
+    m = build_ref_model(cfg)
+    c = synth.CONFIGS[cfg]
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0)
+    feats = [m.feature(imgs[:, v]) for v in range(c["views"])]
+    out = m(imgs, proj, dv)
+    arrays = {}
+    for s in range(len(c["ndepths"])):
+        st = out["stage%d" % (s + 1)]
+        arrays["s%d_depth" % (s + 1)] = st["depth"]
+        arrays["s%d_conf" % (s + 1)] = st["photometric_confidence"]
+        S = c["views"] - 1
+        for i in range(S):
+            arrays["s%d_pairconf%d" % (s + 1, i)] = st["pair_confidence"][i]
+        for i, pr in enumerate(st["pair_result"]):
+            arrays["s%d_pairdepth%d" % (s + 1, i)] = pr
+        arrays["s%d_n_pairconf" % (s + 1)] = len(st["pair_confidence"])
+    arrays["depth"] = out["depth"]
+    arrays["photometric_confidence"] = out["photometric_confidence"]
+    if with_inputs:
+        arrays["imgs"] = imgs
+        arrays["depth_values"] = dv
+        for k, v in proj.items():
+            arrays["proj_" + k] = v
+        for s in (1, 2, 3):
+            arrays["feat_stage%d" % s] = torch.stack([f["stage%d" % s] for f in feats], 1)  # [B,V,C,h,w]
+    save("e2e_" + cfg, **arrays)
+
+    if with_inputs:
+        # second oracle: the vectorised train/test twin in eval mode
+        t = ref_adamvs.AdaMVSNet(ndepths=c["ndepths"], depth_intervals_ratio=synth.DEPTH_INTERVALS_RATIO)
+        t.load_state_dict(m.state_dict())
+        t.eval()
+        # its depth_values are [min, max, interval] (adamvs.py:344-347)
+        dv3 = torch.cat([dv, (dv[:, 1:2] - dv[:, 0:1]) / c["num_depth"]], 1)
+        o2 = t(imgs, proj, dv3)
+        save("e2e_" + cfg + "_twin", depth=o2["depth"], photometric_confidence=o2["photometric_confidence"])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    op_level()
+    net_level()
+    end_to_end("tiny", with_inputs=True)
+    end_to_end("cfg1", with_inputs=False)
