@@ -1,0 +1,107 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every
+symbol include/adamvs_hip.h declares, weight packing layouts, state-dict
+contract, loud failure without a GPU.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import ada_mvs_amd  # noqa: F401
+from ada_mvs_amd import _lib, packing, synth
+from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "adamvs_hip.h")).read()
+    declared = set(re.findall(r"\b(adamvs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.adamvs_version() == _lib.ABI_VERSION
+    assert ctypes.sizeof(_lib.FuseWeights) == 13 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.StageDesc) == 10 * ctypes.sizeof(ctypes.c_int)
+
+
+def test_argument_errors_surface_as_exceptions_without_a_gpu():
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    rc = lib.adamvs_pack_features(null, null, 1, 6, 4, 4, null)      # rejected before any launch
+    assert rc < 0
+    with pytest.raises(_lib.AdaMVSHipError, match="pack_features"):
+        _lib.check(rc, "pack_features")
+    desc = _lib.StageDesc(1, 2, 12, 8, 8, 16, 1, 1, 0, 0)            # C=12 unsupported
+    assert lib.adamvs_depth_stage_workspace_bytes(ctypes.byref(desc)) == 0
+    assert b"C=12" in lib.adamvs_last_error_string()
+    desc = _lib.StageDesc(8, 4, 32, 96, 192, 192, 1, 1, 0, 0)        # cfg2 stage 1, 8 tiles
+    assert lib.adamvs_depth_stage_workspace_bytes(ctypes.byref(desc)) > (1 << 30)
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    c = synth.CONFIGS["tiny"]
+    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8]).eval()
+    imgs, proj, dv = synth.tile_inputs("tiny")
+    with pytest.raises(_lib.AdaMVSHipError, match="no CPU fallback"):
+        m(imgs, proj, dv)
+    from ada_mvs_amd.models.module import homo_warping_float
+    with pytest.raises(_lib.AdaMVSHipError):
+        homo_warping_float(torch.zeros(1, 8, 4, 4), torch.eye(4)[None], torch.eye(4)[None], torch.ones(1, 1, 4, 4))
+
+
+def test_state_dict_contract():
+    m = Infer_AdaMVSNet(192, [48, 32, 8], [4, 2, 1], False, [8, 8, 8])
+    sd = m.state_dict()
+    assert len(sd) == 339
+    assert sd["DepthNet.0.reg.conv7.0.weight"].shape == (48, 48, 3, 3)
+    assert sd["DepthNet.1.reg_fuse.conv1.conv.weight"].shape == (8, 16, 3, 3)
+    assert sd["DepthNet.2.reg_fuse.upconv2d.weight"].shape == (1, 8, 3, 3)
+    assert sd["DepthNet.0.reg_fuse.upconv2d.weight"].shape == (8, 1, 3, 3)
+    assert sd["DepthNet.0.reg_fuse.conv_gru2.conv_gates.0.weight"].shape == (32, 32, 3, 3)
+    # 'module.'-prefixed checkpoints (predict_whu.py:82-89) load through DataParallel
+    dp = torch.nn.DataParallel(m)
+    dp.load_state_dict({"module." + k: v for k, v in synth.seeded_state_dict(m, 0).items()})
+
+
+def test_fragment_packing_layout():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(24, 8, 3, 3, generator=g)                        # 24 couts -> 2 tiles, second half padded
+    pk = packing.pack_small_conv(w).reshape(2, 9, 2, 64)
+    for nt, t, kc, lane in ((0, 0, 0, 0), (0, 4, 1, 37), (1, 8, 1, 7), (1, 3, 0, 63)):
+        co, ci = nt * 16 + (lane & 15), 4 * kc + (lane >> 4)
+        expect = w[co, ci, t // 3, t % 3] if co < 24 else 0.0
+        assert float(pk[nt, t, kc, lane]) == float(expect)
+    wt = torch.randn(16, 8, 3, 3, generator=g)                       # ConvTranspose2d layout [cin][cout]
+    pkt = packing.pack_small_conv(wt, transposed=True).reshape(1, 9, 4, 64)
+    assert float(pkt[0, 5, 2, 21]) == float(wt[4 * 2 + 1, 5, 1, 2])
+    # CostRegNet2D layer: [tap][kc][tile][lane], BN scale folded
+    D = 32
+    wl = torch.randn(D, D, 3, 3, generator=g)
+    scale = torch.rand(D, generator=g) + 0.5
+    pl = packing.pack_reg_layer(wl, scale, torch.zeros(D), False)
+    frag = pl[:9 * D * D].reshape(9, D // 4, D // 16, 64)
+    assert torch.isclose(frag[7, 5, 1, 50], wl[16 + (50 & 15), 20 + (50 >> 4), 2, 1] * scale[16 + (50 & 15)])
+    assert pl.numel() == 9 * D * D + D
+
+
+def test_packed_network_sizes_match_the_header():
+    m = Infer_AdaMVSNet(48, [48, 32, 8], [4, 2, 1], False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, 0)
+    reg = packing.pack_cost_reg_net_2d(sd, "DepthNet.0.reg.")
+    assert reg.numel() == 11 * (9 * 48 * 48 + 48)
+    flat, off = packing.pack_slice_reg_net(sd, "DepthNet.0.reg_fuse.")
+    assert list(off) == list(packing.FUSE_FIELDS)
+    assert all(o % 64 == 0 for o in off.values())
+    assert off["gates1"] - off["conv1"] == 9 * 8 * 64                # C=32 -> KC=8
+    assert flat.numel() >= off["final_w"] + 73
+
+
+def test_synthetic_recipes_are_deterministic():
+    a = synth.tile_inputs("tiny", batch=2, seed=3)
+    b = synth.tile_inputs("tiny", batch=2, seed=3)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1]["stage2"], b[1]["stage2"])
+    p = a[1]
+    assert torch.allclose(p["stage1"][:, :, :2] * 4, p["stage3"][:, :, :2]) and torch.equal(p["stage1"][:, :, 2:], p["stage3"][:, :, 2:])
