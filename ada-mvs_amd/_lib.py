@@ -45,6 +45,7 @@ SIGNATURES = {
     "adamvs_pair_similarity": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_cost_reg_net_2d_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "adamvs_cost_reg_net_2d": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_conv3x3_dd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_softmax_max_regress": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_aggregate_conv1": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_slice_reg_step_scratch_bytes": (c_sz, [c_i, c_i, c_i]),
@@ -52,10 +53,11 @@ SIGNATURES = {
                                     ctypes.c_void_p, c_sz, c_st]),
     "adamvs_depth_stage_workspace_bytes": (c_sz, [ctypes.POINTER(StageDesc)]),
     "adamvs_depth_stage_forward": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(FuseWeights),
-                                         c_f, c_f, c_f, c_f, ctypes.c_void_p, c_sz, c_st]),
+                                         c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p, c_sz, c_st]),
 }
 
 ABI_VERSION = 1
+PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15
 _lib = None
 
 

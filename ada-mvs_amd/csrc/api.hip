@@ -107,8 +107,8 @@ extern "C" size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* de
 extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt,
                                           const float* planes, const float* prev_conf, const float* w_reg,
                                           const adamvs_fuse_weights* w_fuse, float* view_weight, float* pair_depth,
-                                          float* depth, float* confidence, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+                                          float* depth, float* confidence, int phases, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   const adamvs_stage_desc& s = *desc;
@@ -124,7 +124,8 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   memcpy(&fw, w_fuse, sizeof(fw));
 
   // -- view weights: scored by CostRegNet2D (stage 1) or resampled from the previous stage
-  if (s.first_stage) {
+  if (!(phases & ADAMVS_PHASE_VIEW_WEIGHTS)) {
+  } else if (s.first_stage) {
     if ((rc = adamvs_pair_similarity(feat, rt, planes, ws + c.sim, s.B, s.S, s.C, s.D, s.h, s.w, stream))) return rc;
     if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, st))) return rc;
     if ((rc = launch_softmax_regress(ws + c.score, planes, view_weight, pair_depth, s.S, s.B, s.D, s.h, s.w, st))) return rc;
@@ -133,10 +134,12 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   }
 
   // -- weighted aggregation + conv1 for every hypothesis (state-independent)
-  if ((rc = launch_aggregate_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, s.B, s.S, s.C, s.D, s.h, s.w, st)))
+  if ((phases & ADAMVS_PHASE_AGGREGATE) &&
+      (rc = launch_aggregate_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, s.B, s.S, s.C, s.D, s.h, s.w, st)))
     return rc;
 
   // -- recurrence over hypotheses
+  if (phases & ADAMVS_PHASE_RECURRENCE) {
   hipError_t e = hipMemsetAsync(ws + c.h1, 0, (size_t)s.B * s.h * s.w * 8 * sizeof(float), st);
   if (e == hipSuccess) e = hipMemsetAsync(ws + c.h2, 0, (size_t)s.B * (s.h / 2) * (s.w / 2) * 16 * sizeof(float), st);
   if (e != hipSuccess) return set_error((int)e, "stage: hipMemsetAsync: %s", hipGetErrorString(e));
@@ -145,5 +148,7 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   for (int d = 0; d < s.D; ++d) {
     if ((rc = launch_slice_step(ws + c.c1 + d * c1_stride, fw, sb, ws + c.vol, s.B, s.h, s.w, s.D, d, s.in_up, st))) return rc;
   }
+  }
+  if (!(phases & ADAMVS_PHASE_SOFT_ARGMIN)) return 0;
   return launch_soft_argmin(ws + c.vol, planes, depth, confidence, s.B, s.D, s.h, s.w, s.in_up, st);
 }

@@ -279,6 +279,19 @@ extern "C" int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* s
   return launch_cost_reg_net_2d(x, wpk, (float*)workspace, score, N, D, h, w, (hipStream_t)stream);
 }
 
+extern "C" int adamvs_conv3x3_dd(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N,
+                                 int D, int hi, int wi, int mode, int relu, void* stream) {
+  ADAMVS_CHECK_ARG(in && wpk && bias && out && N > 0 && hi > 0 && wi > 0, "conv3x3_dd: bad arguments");
+  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "conv3x3_dd: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
+  ADAMVS_CHECK_ARG(mode >= 0 && mode <= 2, "conv3x3_dd: mode=%d (0 stride 1, 1 stride 2, 2 transposed stride 2)", mode);
+  ADAMVS_CHECK_ARG(mode != CONV_S2 || ((hi % 2) == 0 && (wi % 2) == 0), "conv3x3_dd: stride 2 needs even hi, wi");
+  ADAMVS_CHECK_ARG((size_t)N * 4 <= 65535, "conv3x3_dd: N=%d exceeds the grid z limit", N);
+  int ho = mode == CONV_S2 ? hi / 2 : (mode == CONV_T2 ? 2 * hi : hi);
+  int wo = mode == CONV_S2 ? wi / 2 : (mode == CONV_T2 ? 2 * wi : wi);
+  ConvDDArgs a{in, wpk, bias, skip, out, D, hi, wi, ho, wo, relu};
+  return launch_conv_dd(a, N, mode, (hipStream_t)stream);
+}
+
 extern "C" int adamvs_softmax_max_regress(const float* score, const float* planes, float* view_weight, float* pair_depth,
                                           int S, int B, int D, int h, int w, void* stream) {
   ADAMVS_CHECK_ARG(score && planes && view_weight && pair_depth && S > 0 && B > 0 && D > 0 && (D % 4) == 0 && h > 0 && w > 0,

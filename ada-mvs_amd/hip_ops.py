@@ -184,7 +184,17 @@ def depth_stage_workspace_bytes(desc):
     return n
 
 
-def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspace=None):
+def conv3x3_dd(x_cl, wpk_layer, bias, skip, N, D, hi, wi, mode, relu, out=None):
+    """One CostRegNet2D layer on channel-last maps (mode 0 stride 1, 1 stride 2, 2 transposed stride 2)."""
+    ho, wo = (hi // 2, wi // 2) if mode == 1 else ((2 * hi, 2 * wi) if mode == 2 else (hi, wi))
+    if out is None:
+        out = torch.empty(N, ho * wo, D, device=x_cl.device, dtype=torch.float32)
+    check(_lib.load().adamvs_conv3x3_dd(_p(x_cl), _p(wpk_layer), _p(bias), _p(skip) if skip is not None else ctypes.c_void_p(0),
+                                        _p(out), N, D, hi, wi, mode, int(relu), _stream()), "conv3x3_dd")
+    return out
+
+
+def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspace=None, phases=_lib.PHASE_ALL, outputs=None):
     """InferDepthNet0.forward (adamvs.py:433-533).  Returns (view_weight [S,B,h,w], pair_depth or None,
     depth [B,Ho,Wo], confidence [B,Ho,Wo])."""
     dev = feat.device
@@ -193,15 +203,18 @@ def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspac
     nbytes = depth_stage_workspace_bytes(desc)
     if workspace is None or workspace.numel() * 4 < nbytes:
         workspace = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
-    vw = torch.empty(S, B, h, w, device=dev, dtype=torch.float32)
-    pd = torch.empty(S, B, h, w, device=dev, dtype=torch.float32) if desc.first_stage else None
-    depth = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
-    conf = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
+    if outputs is not None:                 # piecewise (phase-by-phase) calls reuse one set of outputs
+        vw, pd, depth, conf = outputs
+    else:
+        vw = torch.empty(S, B, h, w, device=dev, dtype=torch.float32)
+        pd = torch.empty(S, B, h, w, device=dev, dtype=torch.float32) if desc.first_stage else None
+        depth = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
+        conf = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
     null = ctypes.c_void_p(0)
     check(_lib.load().adamvs_depth_stage_forward(
         ctypes.byref(desc), _p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")),
         _p(_dev(prev_conf, "prev_conf")) if prev_conf is not None else null,
         _p(w_reg) if w_reg is not None else null, fuse.ptr(),
-        _p(vw), _p(pd) if pd is not None else null, _p(depth), _p(conf), _p(workspace), nbytes, _stream()),
+        _p(vw), _p(pd) if pd is not None else null, _p(depth), _p(conf), int(phases), _p(workspace), nbytes, _stream()),
         "depth_stage_forward")
     return vw, pd, depth, conf

@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Throughput of the Ada-MVS depth-inference hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg1|tiny] [--batch B]
+
+A "step" = one pass of the hot path (reference models/adamvs.py:586-618 minus
+FeatureNet0: hypothesis sampling, plane sweep, per-view weighting, recurrent
+regularisation, soft-argmin) over a batch of B synthetic reference tiles per
+GPU, feature maps already resident in HBM.  N > 1: one process per GPU
+(torchrun), tiles sharded over ranks, one RCCL gather of the finished maps per
+step.  Rank 0 prints ONE JSON line (contract: see the task description).
+
+Also measured by rank 0 at N = 1 (after the timed region, same shapes):
+  roofline      per-kernel HIP-event timing of the stage run phase by phase through the C ABI
+  cpu_baseline  the CPU oracle ("port") on one tile of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import ada_mvs_amd  # noqa: E402
+from ada_mvs_amd import _lib, dist as adist, hip_ops, synth  # noqa: E402
+from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
+
+
+def build_model(cfg, device):
+    c = synth.CONFIGS[cfg]
+    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO[:len(c["ndepths"])], False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    return m.to(device).eval(), sd
+
+
+def algorithmic_work(cfg, B):
+    """bytes and conv flops per tile, fp32 (e = 4), per phase of every stage."""
+    c = synth.CONFIGS[cfg]
+    S, e = c["views"] - 1, 4
+    out = []
+    for s, D in enumerate(c["ndepths"]):
+        C = (32, 16, 8)[s]
+        h, w = c["H"] // (4, 2, 1)[s], c["W"] // (4, 2, 1)[s]
+        hw = h * w
+        HoWo = hw * (4 if s < 2 else 1)
+        st = {"stage": s + 1, "C": C, "h": h, "w": w, "D": D}
+        st["aggregate_bytes"] = B * D * ((S + 1) * C * hw * e + S * hw * 4 + hw * 4)
+        st["recurrence_bytes"] = B * D * (96 * hw)
+        st["softargmin_bytes"] = B * D * (24 * HoWo)
+        st["recurrence_flops"] = B * D * hw * 2 * 7560
+        st["conv1_flops"] = B * D * hw * 2 * 72 * C
+        if s == 0:
+            st["pair_similarity_bytes"] = B * (S * D * C * hw * e + S * C * hw * e + S * D * hw * 4)
+            st["costreg_bytes"] = B * 2 * S * D * hw * 4
+            st["softmax_bytes"] = B * (S * D * hw * 4 + 2 * S * hw * 4)
+            macs = 0
+            for res, n in ((1, 3), (4, 3), (16, 3), (64, 2)):         # layers per resolution (conv0,11,prob | 1,2,9 | 3,4,7 | 5,6)
+                macs += n * (hw // res) * D * D * 9
+            # transposed layers touch 2.25 taps on average instead of 9
+            macs -= (hw + hw // 4 + hw // 16) * D * D * 9 * (1 - 2.25 / 9)
+            st["costreg_flops"] = B * S * 2 * macs
+        out.append(st)
+    return out
+
+
+def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
+    """Run the cascade phase by phase through the C ABI with HIP events (torch.cuda.Event records on the
+    stream the kernels are launched on) around every phase.  -> {phase name: [ms per call]}"""
+    from collections import defaultdict
+    times = defaultdict(list)
+    evs = []
+
+    def mark(name, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        evs.append((name, a, b))
+        return r
+
+    for _ in range(steps):
+        depth, conf = None, None
+        for s in range(model.num_stage):
+            name = "stage%d" % (s + 1)
+            B, C, h, w = shapes[s]
+            net = model.DepthNet[s]
+            cur = dv if depth is None else depth
+            planes = hip_ops.depth_range_samples(cur, model.ndepths[s], model.depth_intervals_ratio[s] * interval, [B, h, w])
+            rt = hip_ops.relative_transforms(proj[name])
+            S = feats_cl[s].shape[0] // B - 1
+            D = model.ndepths[s]
+            first = conf is None
+            desc = hip_ops.stage_desc(B, S, C, h, w, D, net.in_up, first, (0, 0) if first else tuple(conf.shape[-2:]))
+            dev = feats_cl[s].device
+            Ho, Wo = (2 * h, 2 * w) if net.in_up else (h, w)
+            outs = (torch.empty(S, B, h, w, device=dev), torch.empty(S, B, h, w, device=dev) if first else None,
+                    torch.empty(B, Ho, Wo, device=dev), torch.empty(B, Ho, Wo, device=dev))
+            w_reg = net.reg.packed(dev) if first else None
+            fuse = net.reg_fuse.packed(dev)
+            ws = net._workspace
+
+            def phase(mask):
+                return hip_ops.depth_stage_forward(desc, feats_cl[s], rt, planes, conf, w_reg, fuse, ws, phases=mask, outputs=outs)
+
+            if first:
+                # pass A split further, op by op, so the dominant kernel is timed by itself
+                sim = mark("s%d.pair_similarity" % (s + 1), lambda: hip_ops.pair_similarity(feats_cl[s], rt, planes, B, S, C, D, h, w))
+                score = mark("s%d.cost_reg_net_2d" % (s + 1), lambda: hip_ops.cost_reg_net_2d(sim, w_reg, h, w))
+                vw_pd = mark("s%d.softmax_max_regress" % (s + 1), lambda: hip_ops.softmax_max_regress(score, planes, S, B, D, h, w))
+                outs[0].copy_(vw_pd[0])
+                del sim, score
+            else:
+                mark("s%d.view_weight_resample" % (s + 1), lambda: phase(_lib.PHASE_VIEW_WEIGHTS))
+            mark("s%d.aggregate_conv1" % (s + 1), lambda: phase(_lib.PHASE_AGGREGATE))
+            mark("s%d.recurrence" % (s + 1), lambda: phase(_lib.PHASE_RECURRENCE))
+            mark("s%d.soft_argmin" % (s + 1), lambda: phase(_lib.PHASE_SOFT_ARGMIN))
+            depth, conf = outs[2], outs[0]
+    torch.cuda.synchronize()
+    for name, a, b in evs:
+        times[name].append(a.elapsed_time(b))
+    return times
+
+
+def cpu_baseline(cfg, sd):
+    """The CPU oracle (a port of the reference's unfused PyTorch-CPU path) on ONE tile of the workload."""
+    from oracle import adamvs_oracle as O          # checker / baseline only
+    c = synth.CONFIGS[cfg]
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0)
+    sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        feats = [O.feature_net(imgs[:, v], sd_cpu) for v in range(c["views"])]
+        t0 = time.time()
+        O.infer_adamvs_forward(imgs, proj, dv, sd_cpu, c["num_depth"], c["ndepths"],
+                               synth.DEPTH_INTERVALS_RATIO[:len(c["ndepths"])], features=feats)
+        dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "depth maps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 tile of %s, hot path only (features precomputed), %.1f s, oracle/adamvs_oracle.py" % (cfg, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=list(synth.CONFIGS))
+    ap.add_argument("--batch", type=int, default=8, help="reference tiles per GPU per step")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = adist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.load()
+    cfg, B = args.workload, args.batch
+    c = synth.CONFIGS[cfg]
+    model, sd = build_model(cfg, dev)
+    n_tiles = world * B
+    my_tiles = adist.tiles_of_rank(n_tiles, rank, world)
+    # per-tile seeds = global tile index; this rank's tiles as one batch
+    imgs = torch.cat([synth.tile_inputs(cfg, 1, seed=t)[0] for t in my_tiles], 0).to(dev)
+    _, proj, dv = synth.tile_inputs(cfg, batch=B, seed=0)
+    proj = {k: v.to(dev) for k, v in proj.items()}
+    dv = dv.to(dev)
+    interval = (synth.DEPTH_RANGE[1] - synth.DEPTH_RANGE[0]) / c["num_depth"]
+
+    with torch.no_grad():
+        t0 = time.time()
+        feats_cl, shapes = model.extract_features(imgs)       # upstream of the hot path; untimed, reported
+        torch.cuda.synchronize()
+        t_feat_first = time.time() - t0
+        t0 = time.time()
+        feats_cl, shapes = model.extract_features(imgs)
+        torch.cuda.synchronize()
+        t_feat = time.time() - t0
+        del imgs
+
+        def hot_path():
+            out = model.infer_from_features(feats_cl, shapes, proj, dv, interval)
+            return out["depth"], out["photometric_confidence"]
+
+        for _ in range(max(args.warmup, 1)):
+            depth, conf = hot_path()
+        torch.cuda.synchronize()
+
+        graph = None
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                depth, conf = hot_path()
+            graph.replay()
+            torch.cuda.synchronize()
+
+        def step():
+            if graph is not None:
+                graph.replay()
+                d, p = depth, conf
+            else:
+                d, p = hot_path()
+            return adist.gather_maps(d, p, n_tiles, dst=0)
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gathered = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        result = None
+        if rank == 0:
+            assert gathered[0].shape[0] == n_tiles and bool(torch.isfinite(gathered[0]).all())
+            result = {
+                "metric": "depth maps/sec at 768x384x5-view x192-hyp (hot path, features resident in HBM)",
+                "value": n_tiles * args.steps / elapsed, "unit": "depth maps/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, fp32" % (
+                    cfg, c["views"], c["W"], c["H"], "/".join(map(str, c["ndepths"]))),
+                    "tiles_per_gpu_per_step": B, "global_tiles_per_step": n_tiles,
+                    "parallelism": "tile-sharded x%d, 1 RCCL gather per step" % world,
+                    "launch": "eager" if graph is None else "hipGraph replay"},
+                "feature_net_ms_per_tile": 1e3 * t_feat / B,
+            }
+
+        if rank == 0 and world == 1 and not args.no_roofline:
+            times = timed_phases(model, feats_cl, shapes, proj, dv, interval, max(2, min(args.steps, 5)))
+            work = algorithmic_work(cfg, B)
+            avg = {k: sum(v[1:]) / max(len(v) - 1, 1) for k, v in times.items()}        # drop the first call
+            result["phase_ms_per_step"] = {k: round(v, 4) for k, v in sorted(avg.items())}
+            dom = max(avg, key=avg.get)
+            st = work[int(dom[1]) - 1]
+            kind = dom.split(".", 1)[1]
+            if kind == "cost_reg_net_2d":
+                ach = st["costreg_flops"] / (avg[dom] * 1e-3) / 1e12
+                roof = {"kernel": "k_conv_dd (CostRegNet2D, 11 launches)", "bound": "mfma", "achieved": ach,
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None}
+            elif kind == "recurrence":
+                ach = st["recurrence_flops"] / (avg[dom] * 1e-3) / 1e12
+                roof = {"kernel": "k_conv_small/k_decoder (%d recurrent steps x 6 launches)" % st["D"], "bound": "mfma",
+                        "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                        "traffic": None}
+            else:
+                key = {"pair_similarity": "pair_similarity_bytes", "aggregate_conv1": "aggregate_bytes",
+                       "soft_argmin": "softargmin_bytes", "softmax_max_regress": "softmax_bytes",
+                       "view_weight_resample": "softmax_bytes"}[kind]
+                ach = st[key] / (avg[dom] * 1e-3) / 1e9
+                roof = {"kernel": "k_" + kind, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roof["launch_ms"] = avg[dom]
+            roof["dominant_phase"] = dom
+            result["roofline"] = roof
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, sd)
+        if rank == 0:
+            print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

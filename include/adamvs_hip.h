@@ -82,6 +82,13 @@ size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, int w);
 int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N, int D, int h, int w,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* One layer of CostRegNet2D: ConvBnReLU.forward (models/module.py:254-261) or the
+ * ConvTranspose2d-BN-ReLU blocks of models/adamvs.py:212-225, BN folded into wpk/bias,
+ * optional skip added after the ReLU.  mode 0: 3x3 stride 1; 1: stride 2; 2: transposed
+ * stride 2 (k3 p1 op1).  in [N][hi*wi][D] -> out [N][ho*wo][D]; wpk as one layer above. */
+int adamvs_conv3x3_dd(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
+                      int hi, int wi, int mode, int relu, void* stream);
+
 /* models/adamvs.py:481-486 + module.py:617-625: softmax over D, its maximum (view
  * weight) and the expectation of the hypothesis planes (pair depth).
  * score [S*B][h*w][D], planes [B][D][h*w] -> view_weight, pair_depth [S][B][h*w]. */
@@ -130,15 +137,23 @@ typedef struct adamvs_stage_desc {
 
 size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);
 
+/* phases of a stage; intermediate results live in the workspace between calls */
+#define ADAMVS_PHASE_VIEW_WEIGHTS 1  /* pass A (pair similarity, CostRegNet2D, softmax) or resample of prev_conf */
+#define ADAMVS_PHASE_AGGREGATE    2  /* weighted aggregation + conv1 for all hypotheses */
+#define ADAMVS_PHASE_RECURRENCE   4  /* D sequential ConvGRU encoder-decoder steps */
+#define ADAMVS_PHASE_SOFT_ARGMIN  8  /* depth / confidence from the regularised slices */
+#define ADAMVS_PHASE_ALL         15
+
 /* feat [V=S+1][B][h*w][C]; rt [B][S][12]; planes [B][D][h*w];
  * prev_conf [S][B][prev_h*prev_w] (previous stage's view weights; ignored when first_stage);
  * w_reg: packed CostRegNet2D weights (first_stage only);
  * outputs: view_weight [S][B][h*w] (what the next stage consumes as prev_conf),
- *          pair_depth [S][B][h*w] (first_stage only), depth / confidence [B][Ho*Wo]. */
+ *          pair_depth [S][B][h*w] (first_stage only), depth / confidence [B][Ho*Wo].
+ * phases: ADAMVS_PHASE_ALL, or a subset to run (and time) the stage piecewise in order. */
 int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt, const float* planes,
                                const float* prev_conf, const float* w_reg, const adamvs_fuse_weights* w_fuse,
                                float* view_weight, float* pair_depth, float* depth, float* confidence,
-                               void* workspace, size_t workspace_bytes, void* stream);
+                               int phases, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,72 @@
+"""N > 1 path on CPU: world_size 2, gloo.  Tile sharding + the final gather;
+the per-tile compute is replaced by a stand-in because the HIP path needs a GPU."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ada_mvs_amd  # noqa: F401
+from ada_mvs_amd import dist as adist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_tiles, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = adist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+
+    def infer(tiles):          # stand-in for the HIP hot path: map value = global tile index
+        d = torch.stack([torch.full((4, 6), float(t)) for t in tiles]) if tiles else torch.zeros(0, 4, 6)
+        return d, d + 0.5
+
+    depth, conf = adist.run_sharded(infer, n_tiles, dst=0)
+    if rank == 0:
+        q.put((depth.clone(), conf.clone()))
+    else:
+        assert depth is None and conf is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n_tiles):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_tiles, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    depth, conf = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return depth, conf
+
+
+def test_tile_ownership_is_a_partition():
+    for n, world in ((32, 8), (5, 2), (3, 4), (1, 8)):
+        owned = sum((adist.tiles_of_rank(n, r, world) for r in range(world)), [])
+        assert sorted(owned) == list(range(n))
+
+
+def test_gather_orders_tiles_globally_even_and_uneven():
+    for n_tiles in (4, 5):
+        depth, conf = _run(n_tiles)
+        assert depth.shape == (n_tiles, 4, 6)
+        for t in range(n_tiles):
+            assert float(depth[t].min()) == float(depth[t].max()) == float(t)
+            assert float(conf[t, 0, 0]) == t + 0.5
+
+
+def test_single_process_is_identity():
+    d, c = torch.ones(2, 3, 3), torch.zeros(2, 3, 3)
+    gd, gc = adist.gather_maps(d, c, 2)
+    assert gd is d and gc is c
