@@ -45,21 +45,34 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   const f32x4 ref4 = *(const f32x4*)ref;
   const float* pl = planes + (size_t)b * D * hw + pc;
   float* out = sim + (((size_t)s * B + b) * hw + pc) * D;
-  float keep = 0.f;
-  for (int d = 0; d < D; ++d) {
-    float depth = pl[(size_t)d * hw];
-    WarpTaps tp = warp_taps(r, (float)x, (float)y, depth, h, w);
-    f32x4 v = gather4(src, C, 4 * g, tp);
-    f32x4 m = v * ref4;
-    float part = (m.x + m.y) + (m.z + m.w);
+  // hypotheses in groups of G; inside a group U planes are gathered together (U*4 taps in flight per lane)
+  constexpr int U = (G < 4) ? G : 4;
+  for (int d0 = 0; d0 < D; d0 += G) {
+    float keep = 0.f;
 #pragma unroll
-    for (int o = 1; o < G; o <<= 1) part += __shfl_xor(part, o, 64);
-    float val = part * (1.0f / (float)C);
-    if ((d % G) == g) keep = val;
-    if ((d % G) == G - 1 || d == D - 1) {       // flush a group of G hypotheses: G lanes x 4 B contiguous
-      int dd = d - (d % G) + g;
-      if (live && dd <= d) out[dd] = keep;
+    for (int j0 = 0; j0 < G; j0 += U) {
+      WarpTaps tp[U];
+      f32x4 t00[U], t01[U], t10[U], t11[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        int d = min(d0 + j0 + j, D - 1);
+        tp[j] = warp_taps(r, (float)x, (float)y, pl[(size_t)d * hw], h, w);
+        const float* sp = src + 4 * g;
+        t00[j] = *(const f32x4*)(sp + (size_t)tp[j].o00 * C);
+        t01[j] = *(const f32x4*)(sp + (size_t)tp[j].o01 * C);
+        t10[j] = *(const f32x4*)(sp + (size_t)tp[j].o10 * C);
+        t11[j] = *(const f32x4*)(sp + (size_t)tp[j].o11 * C);
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        f32x4 m = (t00[j] * tp[j].w00 + t01[j] * tp[j].w01 + t10[j] * tp[j].w10 + t11[j] * tp[j].w11) * ref4;
+        float part = (m.x + m.y) + (m.z + m.w);
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) part += __shfl_xor(part, o, 64);
+        if (j0 + j == g) keep = part * (1.0f / (float)C);
+      }
     }
+    if (live && d0 + g < D) out[d0 + g] = keep;       // G lanes x 4 B contiguous per pixel
   }
 }
 
@@ -85,28 +98,67 @@ __global__ __launch_bounds__(256) void k_aggregate_conv1(const float* __restrict
 
   const float* refb = feat + (size_t)b * hw * C;
   const float* pl = planes + ((size_t)b * D + d) * hw;
-  for (int i = tid; i < LR * LC * G; i += 256) {
-    int g = i % G, pp = i / G;
-    int ry = pp / LC, rx = pp % LC;
-    int y = y0 - 1 + ry, x = x0 - 1 + rx;
-    f32x4 simv = {0.f, 0.f, 0.f, 0.f};
-    if (y >= 0 && y < h && x >= 0 && x < w) {
-      int pix = y * w + x;
-      float depth = pl[pix];
-      f32x4 ref4 = *(const f32x4*)(refb + (size_t)pix * C + 4 * g);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      float wsum = 1e-5f;                                            // adamvs.py:497
-      for (int s = 0; s < S; ++s) {
-        float wv = vw[((size_t)s * B + b) * hw + pix];
-        WarpTaps tp = warp_taps(rt + ((size_t)b * S + s) * 12, (float)x, (float)y, depth, h, w);
-        f32x4 v = gather4(feat + ((size_t)(s + 1) * B + b) * (size_t)hw * C, C, 4 * g, tp);
-        acc += (v * ref4) * wv;                                      // adamvs.py:504-508
-        wsum += wv;
-      }
-      simv = acc / wsum;                                             // adamvs.py:512
+  // UI items x US views are gathered together: UI*US*4 independent 16-byte taps in flight per lane
+  constexpr int UI = 2, US = 2, NITEMS = LR * LC * G;
+  for (int base = tid; base < NITEMS; base += 256 * UI) {
+    int pix[UI], lofs[UI], g4v[UI];
+    bool inimg[UI], live[UI];
+    float depth[UI], wsum[UI], fx[UI], fy[UI];
+    f32x4 ref4[UI], acc[UI];
+#pragma unroll
+    for (int u = 0; u < UI; ++u) {
+      int i = base + u * 256;
+      live[u] = i < NITEMS;
+      int ic = live[u] ? i : 0;
+      int g = ic % G, pp = ic / G;
+      int ry = pp / LC, rx = pp % LC;
+      int y = y0 - 1 + ry, x = x0 - 1 + rx;
+      inimg[u] = live[u] && y >= 0 && y < h && x >= 0 && x < w;
+      int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+      pix[u] = yc * w + xc;
+      fx[u] = (float)xc; fy[u] = (float)yc;
+      lofs[u] = (4 * g) * PLANE + ry * LC + rx;
+      g4v[u] = 4 * g;
+      depth[u] = pl[pix[u]];
+      ref4[u] = *(const f32x4*)(refb + (size_t)pix[u] * C + 4 * g);
+      acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      wsum[u] = 1e-5f;                                               // adamvs.py:497
     }
-    float* dl = lds + (4 * g) * PLANE + ry * LC + rx;
-    dl[0] = simv.x; dl[PLANE] = simv.y; dl[2 * PLANE] = simv.z; dl[3 * PLANE] = simv.w;
+    for (int s0 = 0; s0 < S; s0 += US) {
+      f32x4 t00[UI][US], t01[UI][US], t10[UI][US], t11[UI][US];
+      WarpTaps tp[UI][US];
+      float wv[UI][US];
+#pragma unroll
+      for (int u = 0; u < UI; ++u)
+#pragma unroll
+        for (int v = 0; v < US; ++v) {
+          int s = min(s0 + v, S - 1);
+          float wgt = vw[((size_t)s * B + b) * hw + pix[u]];
+          wv[u][v] = (s0 + v < S) ? wgt : 0.f;
+          tp[u][v] = warp_taps(rt + ((size_t)b * S + s) * 12, fx[u], fy[u], depth[u], h, w);
+          const float* src = feat + ((size_t)(s + 1) * B + b) * (size_t)hw * C + g4v[u];
+          t00[u][v] = *(const f32x4*)(src + (size_t)tp[u][v].o00 * C);
+          t01[u][v] = *(const f32x4*)(src + (size_t)tp[u][v].o01 * C);
+          t10[u][v] = *(const f32x4*)(src + (size_t)tp[u][v].o10 * C);
+          t11[u][v] = *(const f32x4*)(src + (size_t)tp[u][v].o11 * C);
+        }
+#pragma unroll
+      for (int u = 0; u < UI; ++u)
+#pragma unroll
+        for (int v = 0; v < US; ++v) {
+          f32x4 wrp = t00[u][v] * tp[u][v].w00 + t01[u][v] * tp[u][v].w01 + t10[u][v] * tp[u][v].w10 + t11[u][v] * tp[u][v].w11;
+          acc[u] += (wrp * ref4[u]) * wv[u][v];                        // adamvs.py:504-508
+          wsum[u] += wv[u][v];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UI; ++u) {
+      if (live[u]) {
+        f32x4 simv = inimg[u] ? acc[u] / wsum[u] : f32x4{0.f, 0.f, 0.f, 0.f};   // adamvs.py:512; zero padding outside
+        float* dl = lds + lofs[u];
+        dl[0] = simv.x; dl[PLANE] = simv.y; dl[2 * PLANE] = simv.z; dl[3 * PLANE] = simv.w;
+      }
+    }
   }
   __syncthreads();
 

@@ -47,18 +47,33 @@ __global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a) {
   float wf[NT][9][KC];
   load_wfrag<NT, KC>(wf, a.wpk, lane);
 
-  for (int i = tid; i < LR * LC * G; i += 256) {
+  // tile fill in two passes so that every global load of the tile is in flight at once
+  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
+  f32x4 stage[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int i = tid + it * 256;
     int g = i % G, pp = i / G;
     int r = pp / LC, c = pp % LC;
     int iy = iy0 + r, ix = ix0 + c;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) {
+    if (i < NITEMS && iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) {
       size_t pix = ((size_t)b * a.hi + iy) * a.wi + ix;
       if (4 * g < CA) v = *(const f32x4*)(a.srcA + pix * CA + 4 * g);
       else v = *(const f32x4*)(a.srcB + pix * CB + (4 * g - CA));
     }
-    float* dl = lds + (4 * g) * PLANE + r * LC + c;
-    dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    stage[it] = v;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int i = tid + it * 256;
+    if (i < NITEMS) {
+      int g = i % G, pp = i / G;
+      int r = pp / LC, c = pp % LC;
+      float* dl = lds + (4 * g) * PLANE + r * LC + c;
+      f32x4 v = stage[it];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
   }
   __syncthreads();
 
@@ -159,15 +174,29 @@ __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a) {
   float wf[1][9][4];
   load_wfrag<1, 4>(wf, a.wup1, lane);
 
-  for (int i = tid; i < HR * HCOLS * 4; i += 256) {
+  constexpr int NITEMS = HR * HCOLS * 4, NIT = (NITEMS + 255) / 256;
+  f32x4 stage[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int i = tid + it * 256;
     int g = i & 3, pp = i >> 2;
     int r = pp / HCOLS, c = pp % HCOLS;
     int iy = i0 + r, ix = j0 + c;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (iy >= 0 && iy < h2 && ix >= 0 && ix < w2)
+    if (i < NITEMS && iy >= 0 && iy < h2 && ix >= 0 && ix < w2)
       v = *(const f32x4*)(a.h2 + (((size_t)b * h2 + iy) * w2 + ix) * 16 + 4 * g);
-    float* dl = lh2 + (4 * g) * HPLANE + r * HCOLS + c;
-    dl[0] = v.x; dl[HPLANE] = v.y; dl[2 * HPLANE] = v.z; dl[3 * HPLANE] = v.w;
+    stage[it] = v;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int i = tid + it * 256;
+    if (i < NITEMS) {
+      int g = i & 3, pp = i >> 2;
+      int r = pp / HCOLS, c = pp % HCOLS;
+      float* dl = lh2 + (4 * g) * HPLANE + r * HCOLS + c;
+      f32x4 v = stage[it];
+      dl[0] = v.x; dl[HPLANE] = v.y; dl[2 * HPLANE] = v.z; dl[3 * HPLANE] = v.w;
+    }
   }
   __syncthreads();
 
@@ -301,30 +330,35 @@ __global__ void k_soft_argmin(const float* __restrict__ vol, const float* __rest
 // host-side launchers shared by the op-level entry point and the stage driver
 
 template <int CA, int CB, int NT, int STRIDE, int EPI, int TR>
-static int launch_small(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
+static int launch_small_tr(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
   constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
   constexpr int LC = (STRIDE == 1) ? 34 : 65;
   constexpr int PLANE = (STRIDE == 1) ? plane_pitch16(LR * LC) : ((LR * LC) | 1);
   size_t lds = (size_t)(CA + CB) * PLANE * sizeof(float);
-  auto kern = k_conv_small<CA, CB, NT, STRIDE, EPI, TR>;
-  static bool attr_done = false;
-  if (lds > 48 * 1024 && !attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return set_error((int)e, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(cdiv(a.wo, 32), cdiv(a.ho, TR), B), dim3(256), lds, st, a);
+  static_assert((CA + CB) * PLANE * sizeof(float) <= 48 * 1024, "tile exceeds the default dynamic LDS limit");
+  hipLaunchKernelGGL((k_conv_small<CA, CB, NT, STRIDE, EPI, TR>), dim3(cdiv(a.wo, 32), cdiv(a.ho, TR), B), dim3(256), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
   return 0;
 }
 
+// These kernels are latency-bound (load tile -> LDS -> MFMA chain -> store): pick the tile height so
+// that the launch has at least ~2 workgroups per CU and a wave owns as few 16-pixel runs as possible.
+template <int CA, int CB, int NT, int STRIDE, int EPI>
+static int launch_small(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
+  const long cols = cdiv(a.wo, 32);
+  auto blocks = [&](int tr) { return cols * cdiv(a.ho, tr) * B; };
+  if (blocks(8) >= 1024) return launch_small_tr<CA, CB, NT, STRIDE, EPI, 8>(a, B, st, name);
+  if (blocks(4) >= 1024) return launch_small_tr<CA, CB, NT, STRIDE, EPI, 4>(a, B, st, name);
+  return launch_small_tr<CA, CB, NT, STRIDE, EPI, 2>(a, B, st, name);
+}
+
 // conv1 as a standalone layer (op-level mirror only; the stage driver fuses it into the plane sweep)
 int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, hipStream_t st) {
   SmallConvArgs a{cost, nullptr, w, nullptr, c1, nullptr, h, w_, h, w_, 8};
-  if (C == 32) return launch_small<32, 0, 1, 1, EPI_RELU, 8>(a, B, st, "conv1");
-  if (C == 16) return launch_small<16, 0, 1, 1, EPI_RELU, 8>(a, B, st, "conv1");
-  if (C == 8) return launch_small<8, 0, 1, 1, EPI_RELU, 8>(a, B, st, "conv1");
+  if (C == 32) return launch_small<32, 0, 1, 1, EPI_RELU>(a, B, st, "conv1");
+  if (C == 16) return launch_small<16, 0, 1, 1, EPI_RELU>(a, B, st, "conv1");
+  if (C == 8) return launch_small<8, 0, 1, 1, EPI_RELU>(a, B, st, "conv1");
   return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
 }
 
@@ -334,19 +368,19 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   int h2 = h / 2, w2 = w / 2, rc;
   {  // GRU level 1: gates on cat(c1, h1), candidate on cat(c1, r*h1)
     SmallConvArgs g{c1, sb.h1, fw.gates1, fw.gates1_b, sb.rh1, sb.u1, h, w, h, w, 16};
-    if ((rc = launch_small<8, 8, 1, 1, EPI_GATES, 8>(g, B, st, "gates1"))) return rc;
+    if ((rc = launch_small<8, 8, 1, 1, EPI_GATES>(g, B, st, "gates1"))) return rc;
     SmallConvArgs c{c1, sb.rh1, fw.cand1, fw.cand1_b, sb.h1, sb.u1, h, w, h, w, 8};
-    if ((rc = launch_small<8, 8, 1, 1, EPI_CAND, 8>(c, B, st, "cand1"))) return rc;
+    if ((rc = launch_small<8, 8, 1, 1, EPI_CAND>(c, B, st, "cand1"))) return rc;
   }
   {  // conv2: 8 -> 16, stride 2, ReLU
     SmallConvArgs a{sb.h1, nullptr, fw.conv2, nullptr, sb.c2, nullptr, h, w, h2, w2, 16};
-    if ((rc = launch_small<8, 0, 1, 2, EPI_RELU, 8>(a, B, st, "conv2"))) return rc;
+    if ((rc = launch_small<8, 0, 1, 2, EPI_RELU>(a, B, st, "conv2"))) return rc;
   }
   {  // GRU level 2
     SmallConvArgs g{sb.c2, sb.h2, fw.gates2, fw.gates2_b, sb.rh2, sb.u2, h2, w2, h2, w2, 32};
-    if ((rc = launch_small<16, 16, 2, 1, EPI_GATES, 8>(g, B, st, "gates2"))) return rc;
+    if ((rc = launch_small<16, 16, 2, 1, EPI_GATES>(g, B, st, "gates2"))) return rc;
     SmallConvArgs c{sb.c2, sb.rh2, fw.cand2, fw.cand2_b, sb.h2, sb.u2, h2, w2, h2, w2, 16};
-    if ((rc = launch_small<16, 16, 1, 1, EPI_CAND, 8>(c, B, st, "cand2"))) return rc;
+    if ((rc = launch_small<16, 16, 1, 1, EPI_CAND>(c, B, st, "cand2"))) return rc;
   }
   DecoderArgs da{sb.h2, sb.h1, fw.upconv1, fw.upconv1_b, fw.final_w, vol, h, w, D, d};
   dim3 grid(cdiv(w, 30), cdiv(h, 14), B);

@@ -147,18 +147,18 @@ class InferDepthNet0(nn.Module):
         self.reg = CostRegNet2D(in_depths, base_channels)
         self.reg_fuse = SliceCostRegNetRED(in_channels, in_up, base_channels)
         self.mirror_list_lengths = True        # pair_confidence carries the reference's S*D duplicate entries (quirk Q1)
-        self._workspace = None
+        self._workspace = {}                   # one workspace per concurrent tile group
 
     def _apply(self, fn, *a, **k):             # .cuda()/.to(): repack on next use
         _drop_packed(self)
-        self._workspace = None
+        self._workspace = {}
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
         _drop_packed(self)
         return super()._load_from_state_dict(*a, **k)
 
-    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf):
+    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0):
         """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w];
         prev_conf None (stage 1) or [S,B,hp,wp].  -> (view_weight [S,B,h,w], pair_depth|None, depth, conf)"""
         S = feat_cl.shape[0] // B - 1
@@ -167,12 +167,12 @@ class InferDepthNet0(nn.Module):
         prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
         desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw)
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != feat_cl.device:
-            self._workspace = torch.empty(need, device=feat_cl.device, dtype=torch.float32)
+        ws = self._workspace.get(group)
+        if ws is None or ws.numel() < need or ws.device != feat_cl.device:
+            ws = self._workspace[group] = torch.empty(need, device=feat_cl.device, dtype=torch.float32)
         dev = feat_cl.device
         w_reg = self.reg.packed(dev) if first else None
-        return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev),
-                                           self._workspace)
+        return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev), ws)
 
     def forward(self, features, proj_matrices, depth_values, num_depth, confidence_map=None):
         assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
@@ -220,9 +220,10 @@ class Infer_AdaMVSNet(nn.Module):
                                        InferDepthNet0(in_depths=self.ndepths[0], in_up=False, in_channels=ch[2])])
 
     # ---- the hot path on pre-extracted features ---------------------------------------------
-    def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval):
+    def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval, group=0):
         """feats_cl[s]: [V*B, h*w, C] channel-last view-major; shapes[s] = (B, C, h, w).
-        Everything below is HIP."""
+        Everything below is HIP.  `group` selects the workspace: independent
+        tile groups may run concurrently on different streams (the recurrence is latency-bound per group)."""
         outputs = {}
         depth, conf = None, None
         for s in range(self.num_stage):
@@ -232,7 +233,7 @@ class Infer_AdaMVSNet(nn.Module):
             planes = hip_ops.depth_range_samples(cur, self.ndepths[s], self.depth_intervals_ratio[s] * depth_interval, [B, h, w])
             rt = hip_ops.relative_transforms(proj_matrices[name])
             net = self.DepthNet[s]
-            vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, planes, conf)
+            vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, planes, conf, group)
             conf = vw
             st = net._as_dict(vw, pd, depth, pconf, self.ndepths[s])
             outputs[name] = st

@@ -104,7 +104,7 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                     torch.empty(B, Ho, Wo, device=dev), torch.empty(B, Ho, Wo, device=dev))
             w_reg = net.reg.packed(dev) if first else None
             fuse = net.reg_fuse.packed(dev)
-            ws = net._workspace
+            ws = net._workspace[0]
 
             def phase(mask):
                 return hip_ops.depth_stage_forward(desc, feats_cl[s], rt, planes, conf, w_reg, fuse, ws, phases=mask, outputs=outs)
@@ -150,7 +150,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=list(synth.CONFIGS))
-    ap.add_argument("--batch", type=int, default=8, help="reference tiles per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="reference tiles per GPU per step")
+    ap.add_argument("--groups", type=int, default=1, help="independent tile groups run concurrently on separate HIP streams")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -174,20 +175,40 @@ def main():
     dv = dv.to(dev)
     interval = (synth.DEPTH_RANGE[1] - synth.DEPTH_RANGE[0]) / c["num_depth"]
 
+    G = args.groups
+    assert B % G == 0, "--batch must be a multiple of --groups"
+    Bg = B // G
     with torch.no_grad():
         t0 = time.time()
-        feats_cl, shapes = model.extract_features(imgs)       # upstream of the hot path; untimed, reported
+        groups = [model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]   # upstream of the hot path; untimed, reported
         torch.cuda.synchronize()
         t_feat_first = time.time() - t0
         t0 = time.time()
-        feats_cl, shapes = model.extract_features(imgs)
+        groups = [model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]
         torch.cuda.synchronize()
         t_feat = time.time() - t0
         del imgs
+        projs = [{k: v[g * Bg:(g + 1) * Bg].contiguous() for k, v in proj.items()} for g in range(G)]
+        dvs = [dv[g * Bg:(g + 1) * Bg].contiguous() for g in range(G)]
+        side = [torch.cuda.Stream() for _ in range(G - 1)]
+        feats_cl, shapes = groups[0]
 
         def hot_path():
-            out = model.infer_from_features(feats_cl, shapes, proj, dv, interval)
-            return out["depth"], out["photometric_confidence"]
+            """All groups, each on its own stream, forked from / joined to the current stream."""
+            cur = torch.cuda.current_stream()
+            outs = [None] * G
+            for g in range(G):
+                st = cur if g == 0 else side[g - 1]
+                if g:
+                    st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    o = model.infer_from_features(groups[g][0], groups[g][1], projs[g], dvs[g], interval, group=g)
+                    outs[g] = (o["depth"], o["photometric_confidence"])
+            for g in range(1, G):
+                cur.wait_stream(side[g - 1])
+            if G == 1:
+                return outs[0]
+            return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
 
         for _ in range(max(args.warmup, 1)):
             depth, conf = hot_path()
@@ -236,15 +257,15 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, fp32" % (
                     cfg, c["views"], c["W"], c["H"], "/".join(map(str, c["ndepths"]))),
-                    "tiles_per_gpu_per_step": B, "global_tiles_per_step": n_tiles,
+                    "tiles_per_gpu_per_step": B, "concurrent_tile_groups": G, "global_tiles_per_step": n_tiles,
                     "parallelism": "tile-sharded x%d, 1 RCCL gather per step" % world,
                     "launch": "eager" if graph is None else "hipGraph replay"},
                 "feature_net_ms_per_tile": 1e3 * t_feat / B,
             }
 
         if rank == 0 and world == 1 and not args.no_roofline:
-            times = timed_phases(model, feats_cl, shapes, proj, dv, interval, max(2, min(args.steps, 5)))
-            work = algorithmic_work(cfg, B)
+            times = timed_phases(model, feats_cl, shapes, projs[0], dvs[0], interval, max(2, min(args.steps, 5)))
+            work = algorithmic_work(cfg, Bg)
             avg = {k: sum(v[1:]) / max(len(v) - 1, 1) for k, v in times.items()}        # drop the first call
             result["phase_ms_per_step"] = {k: round(v, 4) for k, v in sorted(avg.items())}
             dom = max(avg, key=avg.get)
