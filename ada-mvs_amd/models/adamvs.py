@@ -15,8 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import hip_ops, packing
-from .._lib import AdaMVSHipError
+from ada_mvs_amd import hip_ops, packing
+from ada_mvs_amd._lib import AdaMVSHipError
 from .module import Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse
 
 STAGE_SCALE = {"stage1": 4, "stage2": 2, "stage3": 1}

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import hip_ops
+from ada_mvs_amd import hip_ops
 
 
 # ---- functions (reference models/module.py:527-663) -------------------------

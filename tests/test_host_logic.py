@@ -105,3 +105,16 @@ def test_synthetic_recipes_are_deterministic():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1]["stage2"], b[1]["stage2"])
     p = a[1]
     assert torch.allclose(p["stage1"][:, :, :2] * 4, p["stage3"][:, :, :2]) and torch.equal(p["stage1"][:, :, 2:], p["stage3"][:, :, 2:])
+
+
+def test_reference_style_import_path():
+    """predict_whu.py:72 does `from models.adamvs import Infer_AdaMVSNet`: works with ada-mvs_amd/ on sys.path."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import ada_mvs_amd; "
+            "from models.adamvs import Infer_AdaMVSNet; from models.module import homo_warping_float, depth_regression; "
+            "m = Infer_AdaMVSNet(num_depth=192, ndepths=[48, 32, 8], depth_intervals_ratio=[4.0, 2.0, 1.0], share_cr=False, "
+            "cr_base_chs=[8, 8, 8]); print(len(m.state_dict()))") % (ROOT, os.path.join(ROOT, "ada-mvs_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().endswith("339")
