@@ -23,7 +23,7 @@ static_assert(sizeof(FuseWeights) == sizeof(adamvs_fuse_weights), "adamvs_fuse_w
 static size_t align_up(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats: 256-byte slots
 
 struct StageCarve {
-  size_t c1, h1, rh1, u1, c2, h2, rh2, u2, vol, sim, score, creg, total;   // offsets in floats
+  size_t c1, h1, rh1, u1, c2, h2, rh2, u2, vol, agg, sim, score, creg, total;   // offsets in floats
 };
 
 static StageCarve carve(const adamvs_stage_desc& s) {
@@ -41,6 +41,7 @@ static StageCarve carve(const adamvs_stage_desc& s) {
   c.rh2 = take((size_t)s.B * hw4 * 16);
   c.u2 = take((size_t)s.B * hw4 * 16);
   c.vol = take((size_t)s.B * s.D * HW);
+  c.agg = take(sweep_workspace_floats(s.B, s.C, s.D, s.h, s.w));
   c.sim = c.score = c.creg = o;
   if (s.first_stage) {
     size_t F = (size_t)s.S * s.B * hw * s.D;
@@ -135,7 +136,7 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
 
   // -- weighted aggregation + conv1 for every hypothesis (state-independent)
   if ((phases & ADAMVS_PHASE_AGGREGATE) &&
-      (rc = launch_aggregate_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, s.B, s.S, s.C, s.D, s.h, s.w, st)))
+      (rc = launch_sweep_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, s.h, s.w, st)))
     return rc;
 
   // -- recurrence over hypotheses

@@ -27,6 +27,9 @@ int launch_soft_argmin(const float* vol, const float* planes, float* depth, floa
                        int in_up, hipStream_t st);
 int launch_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
                            float* c1, int B, int S, int C, int D, int h, int w, hipStream_t st);
+int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, hipStream_t st);
+size_t sweep_workspace_floats(int B, int C, int D, int h, int w);
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
                            hipStream_t st);
 int launch_softmax_regress(const float* score, const float* planes, float* vw, float* pd, int S, int B, int D, int h, int w,

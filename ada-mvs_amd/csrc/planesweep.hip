@@ -13,6 +13,8 @@
 // Feature maps are channel-last [view][B][h*w][C]; a bilinear tap of one
 // pixel is one contiguous C*4-byte line, fetched by C/4 neighbouring lanes as
 // one float4 each; the per-pixel channel reduction is a wavefront shuffle tree.
+#include <limits.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "conv_frag.h"
@@ -36,41 +38,53 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   const bool live = pix < hw;
   const int pc = live ? pix : hw - 1;
   const int y = pc / w, x = pc % w;
-  const float* ref = feat + ((size_t)b * hw + pc) * C + 4 * g;                 // view 0
-  const float* src = feat + ((size_t)(s + 1) * B + b) * (size_t)hw * C;
-  const float* rtp = rt + ((size_t)b * S + s) * 12;
-  float r[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) r[i] = rtp[i];
-  const f32x4 ref4 = *(const f32x4*)ref;
+  const f32x4 ref4 = *(const f32x4*)(feat + ((size_t)b * hw + pc) * C + 4 * g);       // view 0
+  const float* src = feat + ((size_t)(s + 1) * B + b) * (size_t)hw * C + 4 * g;
+  const float* r = rt + ((size_t)b * S + s) * 12;
+  const float fx = (float)x, fy = (float)y;
+  // rot_xyz = R.[x,y,1] once per pixel (module.py:549); per plane: * depth + t, divide (550-553)
+  const float ax = r[0] * fx + r[1] * fy + r[2], ay = r[3] * fx + r[4] * fy + r[5], az = r[6] * fx + r[7] * fy + r[8];
+  const float tx = r[9], ty = r[10], tz = r[11];
   const float* pl = planes + (size_t)b * D * hw + pc;
   float* out = sim + (((size_t)s * B + b) * hw + pc) * D;
-  // hypotheses in groups of G; inside a group U planes are gathered together (U*4 taps in flight per lane)
-  constexpr int U = (G < 4) ? G : 4;
+  // the 4 bilinear taps stay in registers while consecutive planes fall into the same source cell
+  int cx = INT_MIN, cy = INT_MIN;
+  f32x4 t00 = {0.f, 0.f, 0.f, 0.f}, t01 = t00, t10 = t00, t11 = t00;
+  float depth = pl[0];
   for (int d0 = 0; d0 < D; d0 += G) {
     float keep = 0.f;
 #pragma unroll
-    for (int j0 = 0; j0 < G; j0 += U) {
-      WarpTaps tp[U];
-      f32x4 t00[U], t01[U], t10[U], t11[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        int d = min(d0 + j0 + j, D - 1);
-        tp[j] = warp_taps(r, (float)x, (float)y, pl[(size_t)d * hw], h, w);
-        const float* sp = src + 4 * g;
-        t00[j] = *(const f32x4*)(sp + (size_t)tp[j].o00 * C);
-        t01[j] = *(const f32x4*)(sp + (size_t)tp[j].o01 * C);
-        t10[j] = *(const f32x4*)(sp + (size_t)tp[j].o10 * C);
-        t11[j] = *(const f32x4*)(sp + (size_t)tp[j].o11 * C);
+    for (int j = 0; j < G; ++j) {
+      const int d = d0 + j;                                        // planes past D-1 repeat the last one, never stored
+      float depth_next = pl[(size_t)min(d + 1, D - 1) * hw];
+      float X0 = ax * depth + tx, X1 = ay * depth + ty, X2 = az * depth + tz;
+      float u = X0 / X2, v = X1 / X2;
+      f32x4 wrp = {0.f, 0.f, 0.f, 0.f};
+      if (u > -1.0f && u < (float)w && v > -1.0f && v < (float)h) {
+        float fx0 = floorf(u), fy0 = floorf(v);
+        int ix = (int)fx0, iy = (int)fy0;
+        if (ix != cx || iy != cy) {
+          cx = ix; cy = iy;
+          int xa = max(ix, 0), xb = min(ix + 1, w - 1), ya = max(iy, 0), yb = min(iy + 1, h - 1);
+          t00 = *(const f32x4*)(src + ((size_t)ya * w + xa) * C);
+          t01 = *(const f32x4*)(src + ((size_t)ya * w + xb) * C);
+          t10 = *(const f32x4*)(src + ((size_t)yb * w + xa) * C);
+          t11 = *(const f32x4*)(src + ((size_t)yb * w + xb) * C);
+        }
+        float lx = u - fx0, ly = v - fy0;
+        bool vx0 = ix >= 0, vx1 = ix + 1 <= w - 1, vy0 = iy >= 0, vy1 = iy + 1 <= h - 1;
+        float w00 = (vy0 && vx0) ? (1.f - lx) * (1.f - ly) : 0.f;
+        float w01 = (vy0 && vx1) ? lx * (1.f - ly) : 0.f;
+        float w10 = (vy1 && vx0) ? (1.f - lx) * ly : 0.f;
+        float w11 = (vy1 && vx1) ? lx * ly : 0.f;
+        wrp = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
       }
+      f32x4 m = wrp * ref4;
+      float part = (m.x + m.y) + (m.z + m.w);
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        f32x4 m = (t00[j] * tp[j].w00 + t01[j] * tp[j].w01 + t10[j] * tp[j].w10 + t11[j] * tp[j].w11) * ref4;
-        float part = (m.x + m.y) + (m.z + m.w);
-#pragma unroll
-        for (int o = 1; o < G; o <<= 1) part += __shfl_xor(part, o, 64);
-        if (j0 + j == g) keep = part * (1.0f / (float)C);
-      }
+      for (int o = 1; o < G; o <<= 1) part += __shfl_xor(part, o, 64);
+      if (j == g) keep = part * (1.0f / (float)C);
+      depth = depth_next;
     }
     if (live && d0 + g < D) out[d0 + g] = keep;       // G lanes x 4 B contiguous per pixel
   }
@@ -218,10 +232,21 @@ int launch_aggregate_conv1(const float* feat, const float* rt, const float* plan
 }
 }  // namespace adamvs
 
+extern "C" size_t adamvs_aggregate_conv1_workspace_bytes(int B, int C, int D, int h, int w) {
+  return sweep_workspace_floats(B, C, D, h, w) * sizeof(float);
+}
+
 extern "C" int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* view_weight,
-                                      const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, void* stream) {
+                                      const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, int algo,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   ADAMVS_CHECK_ARG(feat && rt && planes && view_weight && w1pk && c1 && B > 0 && S > 0 && D > 0 && h > 1 && w > 1,
                    "aggregate_conv1: bad arguments");
   ADAMVS_CHECK_ARG((size_t)B * D <= 65535, "aggregate_conv1: B*D=%d exceeds the grid z limit", B * D);
+  if (algo == 0) {
+    ADAMVS_CHECK_ARG(workspace && workspace_bytes >= sweep_workspace_floats(B, C, D, h, w) * sizeof(float),
+                     "aggregate_conv1: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                     sweep_workspace_floats(B, C, D, h, w) * sizeof(float));
+    return launch_sweep_conv1(feat, rt, planes, view_weight, w1pk, c1, (float*)workspace, B, S, C, D, h, w, (hipStream_t)stream);
+  }
   return launch_aggregate_conv1(feat, rt, planes, view_weight, w1pk, c1, B, S, C, D, h, w, (hipStream_t)stream);
 }

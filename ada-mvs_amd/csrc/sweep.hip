@@ -1,0 +1,138 @@
+// Plane sweep with register-resident taps: weighted multi-view aggregation
+// (reference models/adamvs.py:495-512) for a run of hypotheses.
+//
+// Consecutive hypotheses of a reference pixel sample almost the same source
+// pixels (at stage 1 of the cascade 192 planes span about 1.5 px of disparity),
+// so the sweep runs with the hypothesis loop INSIDE the thread: C/4 lanes own
+// one reference pixel, keep the four bilinear taps of every source view in
+// registers and reload them only when the projection enters another source
+// cell.  The feature maps are then read about once per pixel instead of once
+// per pixel per plane; per plane only the projection, the bilinear weights and
+// the blend are recomputed.  Nothing is assumed about the planes (any order,
+// any geometry): the cell test is per lane and per plane.
+//
+// The aggregated similarity of the chunk goes to a workspace [Dc][B][hw][C] and
+// conv1 of SliceCostRegNetRED (adamvs.py:416) runs over it as an ordinary tiled
+// convolution on the matrix cores (slice_red.hip), writing c1[d].
+#include <limits.h>
+
+#include "common.h"
+#include "kernels.h"
+#include "warp_math.h"
+
+namespace adamvs {
+
+// grid: (ceil(hw / (256/G)), 1, B); block 256.  sim [d1-d0][B][hw][C].
+template <int C, int SV>
+__global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict__ feat, const float* __restrict__ rt,
+                                                         const float* __restrict__ planes, const float* __restrict__ vw,
+                                                         float* __restrict__ sim, int B, int S, int D, int d0, int d1,
+                                                         int h, int w) {
+  constexpr int G = C / 4, PPB = 256 / G;
+  const int hw = h * w;
+  const int tid = threadIdx.x, g = tid % G;
+  const int pix = blockIdx.x * PPB + tid / G;
+  const int b = blockIdx.z;
+  const bool live = pix < hw;
+  const int pc = live ? pix : hw - 1;
+  const float x = (float)(pc % w), y = (float)(pc / w);
+  const f32x4 ref4 = *(const f32x4*)(feat + ((size_t)b * hw + pc) * C + 4 * g);
+
+  // per view: rot_xyz = R.[x,y,1] (module.py:549), translation, view weight, cached cell + taps
+  float ax[SV], ay[SV], az[SV], tx[SV], ty[SV], tz[SV], wv[SV];
+  int cx[SV], cy[SV];
+  f32x4 t00[SV], t01[SV], t10[SV], t11[SV];
+  const float* src[SV];
+#pragma unroll
+  for (int s = 0; s < SV; ++s) {
+    const int sc = min(s, S - 1);
+    const float* r = rt + ((size_t)b * S + sc) * 12;
+    ax[s] = r[0] * x + r[1] * y + r[2];
+    ay[s] = r[3] * x + r[4] * y + r[5];
+    az[s] = r[6] * x + r[7] * y + r[8];
+    tx[s] = r[9]; ty[s] = r[10]; tz[s] = r[11];
+    wv[s] = (s < S) ? vw[((size_t)sc * B + b) * hw + pc] : 0.f;
+    src[s] = feat + ((size_t)(sc + 1) * B + b) * (size_t)hw * C + 4 * g;
+    cx[s] = INT_MIN; cy[s] = INT_MIN;
+    t00[s] = t01[s] = t10[s] = t11[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* pl = planes + (size_t)b * D * hw + pc;
+  float* out = sim + ((size_t)b * hw + pc) * C + 4 * g;
+  const size_t ostride = (size_t)B * hw * C;
+
+  float depth = pl[(size_t)d0 * hw];
+  for (int d = d0; d < d1; ++d) {
+    float depth_next = pl[(size_t)min(d + 1, d1 - 1) * hw];      // prefetch
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float wsum = 1e-5f;                                          // adamvs.py:497
+#pragma unroll
+    for (int s = 0; s < SV; ++s) {
+      if (s >= S) break;                                         // uniform
+      float X0 = ax[s] * depth + tx[s], X1 = ay[s] * depth + ty[s], X2 = az[s] * depth + tz[s];
+      float u = X0 / X2, v = X1 / X2;                            // module.py:553
+      f32x4 wrp = {0.f, 0.f, 0.f, 0.f};
+      if (u > -1.0f && u < (float)w && v > -1.0f && v < (float)h) {
+        float fx0 = floorf(u), fy0 = floorf(v);
+        int ix = (int)fx0, iy = (int)fy0;
+        if (ix != cx[s] || iy != cy[s]) {                        // entered another source cell: reload the 4 taps
+          cx[s] = ix; cy[s] = iy;
+          int xa = max(ix, 0), xb = min(ix + 1, w - 1), ya = max(iy, 0), yb = min(iy + 1, h - 1);
+          t00[s] = *(const f32x4*)(src[s] + ((size_t)ya * w + xa) * C);
+          t01[s] = *(const f32x4*)(src[s] + ((size_t)ya * w + xb) * C);
+          t10[s] = *(const f32x4*)(src[s] + ((size_t)yb * w + xa) * C);
+          t11[s] = *(const f32x4*)(src[s] + ((size_t)yb * w + xb) * C);
+        }
+        float lx = u - fx0, ly = v - fy0;
+        bool vx0 = ix >= 0, vx1 = ix + 1 <= w - 1, vy0 = iy >= 0, vy1 = iy + 1 <= h - 1;
+        float w00 = (vy0 && vx0) ? (1.f - lx) * (1.f - ly) : 0.f;
+        float w01 = (vy0 && vx1) ? lx * (1.f - ly) : 0.f;
+        float w10 = (vy1 && vx0) ? (1.f - lx) * ly : 0.f;
+        float w11 = (vy1 && vx1) ? lx * ly : 0.f;
+        wrp = t00[s] * w00 + t01[s] * w01 + t10[s] * w10 + t11[s] * w11;
+      }
+      acc += (wrp * ref4) * wv[s];                               // adamvs.py:504-508
+      wsum += wv[s];
+    }
+    if (live) *(f32x4*)(out + (size_t)(d - d0) * ostride) = acc / wsum;      // adamvs.py:512
+    depth = depth_next;
+  }
+}
+
+template <int C>
+static int launch_sweep_c(const float* feat, const float* rt, const float* planes, const float* vw, float* sim, int B, int S,
+                          int D, int d0, int d1, int h, int w, hipStream_t st) {
+  dim3 grid(cdiv(h * w, 256 / (C / 4)), 1, B);
+  if (S <= 4)
+    hipLaunchKernelGGL((k_sweep_aggregate<C, 4>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w);
+  else
+    hipLaunchKernelGGL((k_sweep_aggregate<C, 8>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w);
+  ADAMVS_CHECK_LAUNCH("sweep_aggregate");
+  return 0;
+}
+
+// chunk of planes held in the similarity workspace between the sweep and conv1
+int sweep_chunk_planes(int D) { return D < 32 ? D : 32; }
+
+size_t sweep_workspace_floats(int B, int C, int D, int h, int w) {
+  return (size_t)sweep_chunk_planes(D) * B * h * w * C;
+}
+
+int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, hipStream_t st) {
+  if (S > 8) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
+  const int dc = sweep_chunk_planes(D);
+  for (int d0 = 0; d0 < D; d0 += dc) {
+    const int d1 = (d0 + dc < D) ? d0 + dc : D;
+    int rc;
+    if (C == 32) rc = launch_sweep_c<32>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, st);
+    else if (C == 16) rc = launch_sweep_c<16>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, st);
+    else if (C == 8) rc = launch_sweep_c<8>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, st);
+    else return set_error(-1, "aggregate_conv1: C=%d unsupported (8, 16 or 32)", C);
+    if (rc) return rc;
+    // conv1 over the (d1-d0)*B similarity maps of the chunk; image n = dlocal*B + b lands in c1[d0 + dlocal][b]
+    if ((rc = launch_conv1(sim_ws, w1pk, c1 + (size_t)d0 * B * h * w * 8, (d1 - d0) * B, C, h, w, st))) return rc;
+  }
+  return 0;
+}
+
+}  // namespace adamvs

@@ -42,6 +42,28 @@ __device__ __forceinline__ WarpTaps warp_taps(const float* __restrict__ rt, floa
   return t;
 }
 
+// Projected pixel coordinates only (bounding boxes, LDS-resident sweeps).
+struct WarpUV {
+  float u, v;
+  bool ok;      // finite and at least one bilinear tap can fall inside the image
+  bool front;   // finite with X2 > 0: between two such planes the projection moves monotonically
+};
+
+__device__ __forceinline__ WarpUV warp_uv(const float* __restrict__ rt, float x, float y, float d, int h, int w) {
+  float a0 = rt[0] * x + rt[1] * y + rt[2];
+  float a1 = rt[3] * x + rt[4] * y + rt[5];
+  float a2 = rt[6] * x + rt[7] * y + rt[8];
+  float X0 = a0 * d + rt[9];
+  float X1 = a1 * d + rt[10];
+  float X2 = a2 * d + rt[11];
+  WarpUV r;
+  r.u = X0 / X2;
+  r.v = X1 / X2;
+  r.ok = (r.u > -1.0f && r.u < (float)w && r.v > -1.0f && r.v < (float)h);
+  r.front = X2 > 0.f && fabsf(r.u) < 1e30f && fabsf(r.v) < 1e30f;
+  return r;
+}
+
 // 4 channels of a channel-last feature map [hw][C] gathered with a tap set.
 __device__ __forceinline__ f32x4 gather4(const float* __restrict__ fea, int C, int c0, const WarpTaps& t) {
   const float* base = fea + c0;

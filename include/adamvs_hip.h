@@ -114,9 +114,14 @@ typedef struct adamvs_fuse_weights {
 
 /* models/adamvs.py:495-512 fused with conv1 of SliceCostRegNetRED (adamvs.py:416), for all
  * D hypotheses at once: c1[d][b][pix][8] = ReLU(conv1(sum_v w_v warp_v ref / (1e-5 + sum_v w_v))).
- * view_weight [S][B][h*w]. */
+ * view_weight [S][B][h*w].  algo 0 (what the stage driver uses): hypothesis loop inside the thread,
+ * bilinear taps cached in registers across planes, similarity of a chunk of planes through the
+ * workspace, conv1 as a tiled MFMA convolution; algo 1: one workgroup per (tile, plane), taps
+ * gathered per plane, similarity kept in LDS (no workspace). */
+size_t adamvs_aggregate_conv1_workspace_bytes(int B, int C, int D, int h, int w);
 int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* view_weight,
-                           const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, void* stream);
+                           const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, int algo,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* SliceCostRegNetRED.forward, models/adamvs.py:415-424 (one recurrent step).
  * cost [B][h*w][C]; state1 [B][h*w][8], state2 [B][(h/2)*(w/2)][16] updated in place;

@@ -151,25 +151,39 @@ def test_slice_reg_step_golden(hip, k):
     assert rel_l1(reg, g["reg"]) < OP_TOL, "decoder"
 
 
-@pytest.mark.parametrize("C,h,w", [(32, 16, 40), (16, 20, 36), (8, 24, 70)])
-def test_aggregate_conv1(hip, O, C, h, w):
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("C,h,w,D,baseline", [(32, 16, 40, 3, 80.0), (16, 20, 36, 3, 80.0), (8, 24, 70, 3, 80.0),
+                                              (32, 24, 40, 24, 8.0),        # narrow sweep: one LDS-resident chunk
+                                              (32, 24, 40, 16, 400.0),      # wide sweep: chunks split, patches leave the image
+                                              (16, 40, 24, 10, 2500.0)])    # extreme: per-plane patches / global fallback
+def test_aggregate_conv1(hip, O, C, h, w, D, baseline, algo):
+    """algo 0 = LDS-resident sweep (sweep.hip), algo 1 = per-plane global gathers (planesweep.hip)."""
     import torch.nn.functional as F
-    B, S, D = 2, 3, 3
+    B, S = 2, 3
     feats = [synth.smooth_features(B, C, h, w, seed=10 + v) for v in range(S + 1)]
-    proj = synth.rig_projections(S + 1, 4 * h, 4 * w, batch=B, baseline=80.0)["stage1"]
+    proj = synth.rig_projections(S + 1, 4 * h, 4 * w, batch=B, baseline=baseline)["stage1"]
     g = torch.Generator().manual_seed(3)
-    planes = 400 + 200 * torch.rand(B, D, h, w, generator=g)
+    if D <= 3:
+        planes = 400 + 200 * torch.rand(B, D, h, w, generator=g)            # independent random planes
+    else:                                                                    # per-pixel monotone sweeps, like the cascade
+        lo = 380 + 40 * torch.rand(B, 1, h, w, generator=g)
+        step = (200 + 40 * torch.rand(B, 1, h, w, generator=g)) / (D - 1)
+        planes = lo + step * torch.arange(D, dtype=torch.float32).reshape(1, D, 1, 1)
     vw = torch.rand(S, B, h, w, generator=g)
     w1 = torch.randn(8, C, 3, 3, generator=g) * 0.1
     from ada_mvs_amd import packing
     c1 = hip.aggregate_conv1(hip.pack_features(dev(torch.stack(feats, 0).reshape(-1, C, h, w))),
                              hip.relative_transforms(dev(proj)), dev(planes), dev(vw),
-                             packing.pack_small_conv(w1).cuda(), B, S, C, D, h, w).cpu()      # [D,B,hw,8]
+                             packing.pack_small_conv(w1).cuda(), B, S, C, D, h, w, algo=algo).cpu()      # [D,B,hw,8]
     Rs, ts = zip(*[O.relative_transform(proj[:, s + 1], proj[:, 0]) for s in range(S)])
+    zero_frac = 0.0
     for d in range(D):
         sim = O.aggregate_similarity(feats[0], feats[1:], Rs, ts, planes[:, d], [vw[s].unsqueeze(1) for s in range(S)])
+        zero_frac += float((sim.abs().sum(1) == 0).float().mean()) / D
         ref = F.relu(F.conv2d(sim, w1, None, 1, 1))
-        assert rel_l1(c1[d].reshape(B, h, w, 8).permute(0, 3, 1, 2), ref) < OP_TOL
+        assert rel_l1(c1[d].reshape(B, h, w, 8).permute(0, 3, 1, 2), ref) < OP_TOL, "plane %d" % d
+    if baseline >= 400.0:
+        assert zero_frac > 0.02, "case must include pixels whose every view projects outside (%g)" % zero_frac
 
 
 # --------------------------------------------------------------------------- stages / end to end
