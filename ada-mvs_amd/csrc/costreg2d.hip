@@ -62,9 +62,12 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
     for (int r = 0; r < NTR; ++r) acc[mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* xb = lds + q * PLANE + (wn * NTR * STR) * LC + p * STR;
-  for (int ch = 0; ch < D; ch += KB) {
-    // A fragments of this chunk: [tap][kc][mt]
-    float wf[NTY * NTX][KB / 4][MT];
+  constexpr int NTAP = NTY * NTX;
+  constexpr int NITEMS = LR * LC * (KB / 4), NITA = (NITEMS + 255) / 256;
+
+  // One wave per SIMD at this register budget, so latency is hidden by hand: the A fragments and the
+  // activation tile of chunk k+1 are requested before the MFMAs of chunk k and consumed after them.
+  auto load_w = [&](float (&wf)[NTAP][KB / 4][MT], int ch) {
 #pragma unroll
     for (int ty = 0; ty < NTY; ++ty)
 #pragma unroll
@@ -78,17 +81,45 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
             wf[ty * NTX + tx][kc][mt] =
                 a.wpk[((size_t)((ky * 3 + kx) * KCT + ch / 4 + kc) * NTILES + wm * MT + mt) * 64 + lane];
       }
-    __syncthreads();                    // previous chunk's readers are done
-    for (int i = tid; i < LR * LC * (KB / 4); i += 256) {
+  };
+  auto load_x = [&](f32x4 (&st)[NITA], int ch) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+      int i = tid + it * 256;
       int g = i % (KB / 4), pp = i / (KB / 4);
       int r = pp / LC, c = pp % LC;
       int iy = iy0 + r, ix = ix0 + c;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) v = *(const f32x4*)(inb + ((size_t)iy * a.wi + ix) * D + ch + 4 * g);
-      float* dl = lds + (4 * g) * PLANE + r * LC + c;
-      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+      if (i < NITEMS && iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi)
+        v = *(const f32x4*)(inb + ((size_t)iy * a.wi + ix) * D + ch + 4 * g);
+      st[it] = v;
     }
+  };
+  auto store_x = [&](const f32x4 (&st)[NITA]) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+      int i = tid + it * 256;
+      if (i < NITEMS) {
+        int g = i % (KB / 4), pp = i / (KB / 4);
+        int r = pp / LC, c = pp % LC;
+        float* dl = lds + (4 * g) * PLANE + r * LC + c;
+        dl[0] = st[it].x; dl[PLANE] = st[it].y; dl[2 * PLANE] = st[it].z; dl[3 * PLANE] = st[it].w;
+      }
+    }
+  };
+
+  float wf[NTAP][KB / 4][MT], wf_next[NTAP][KB / 4][MT];
+  f32x4 xs[NITA], xs_next[NITA];
+  load_w(wf, 0);
+  load_x(xs, 0);
+  for (int ch = 0; ch < D; ch += KB) {
+    __syncthreads();                    // previous chunk's readers are done
+    store_x(xs);
     __syncthreads();
+    if (ch + KB < D) {
+      load_w(wf_next, ch + KB);
+      load_x(xs_next, ch + KB);
+    }
 #pragma unroll
     for (int ty = 0; ty < NTY; ++ty)
 #pragma unroll
@@ -103,6 +134,16 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
 #pragma unroll
             for (int r = 0; r < NTR; ++r) acc[mt][r] = mfma16(wf[ty * NTX + tx][kc][mt], bv[r], acc[mt][r]);
         }
+    if (ch + KB < D) {
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int kc = 0; kc < KB / 4; ++kc)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) wf[t][kc][mt] = wf_next[t][kc][mt];
+#pragma unroll
+      for (int it = 0; it < NITA; ++it) xs[it] = xs_next[it];
+    }
   }
 
   // epilogue: lane owns channels co4..co4+3 of the pixel in column p

@@ -25,8 +25,6 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
                       int d, int in_up, hipStream_t st);
 int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,
                        int in_up, hipStream_t st);
-int launch_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
-                           float* c1, int B, int S, int C, int D, int h, int w, hipStream_t st);
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
                        float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, hipStream_t st);
 size_t sweep_workspace_floats(int B, int C, int D, int h, int w);

@@ -79,15 +79,26 @@ __global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a) {
 
   const int p = lane & 15, q = lane >> 4;
   const float* xb = lds + q * PLANE + p * STRIDE;
+  // A wave owns (2 TR)/4 runs of 16 pixels, one after the other (kept rolled: these kernels live on
+  // occupancy, and unrolling multiplies the live LDS fragments).  Operands the epilogue needs from
+  // global memory are requested before the run's MFMA chain and consumed after it.
+#pragma unroll 1
   for (int run = wave; run < TR * 2; run += 4) {
-    int row = run >> 1, col = (run & 1) * 16;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    conv3x3_run<NT, KC, STRIDE, PLANE, LC>(acc, wf, xb, row, col);
-    int oy = oy0 + row, ox = ox0 + col + p;
+    const int row = run >> 1, col = (run & 1) * 16;
+    const int oy = oy0 + row, ox = ox0 + col + p;
     const bool valid = oy < a.ho && ox < a.wo;
-    size_t opix = ((size_t)b * a.ho + oy) * a.wo + ox;
+    const size_t opix = ((size_t)b * a.ho + min(oy, a.ho - 1)) * a.wo + min(ox, a.wo - 1);
+    f32x4 acc[NT], pre_u[NT], pre_h[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int co4 = nt * 16 + 4 * q;
+      if (EPI == EPI_CAND && co4 < HC) {
+        pre_u[nt] = *(const f32x4*)(a.dst1 + opix * HC + co4);
+        pre_h[nt] = *(const f32x4*)(a.dst0 + opix * HC + co4);
+      }
+    }
+    conv3x3_run<NT, KC, STRIDE, PLANE, LC>(acc, wf, xb, row, col);
 #pragma unroll
     for (int nt = 0; nt < NT && valid; ++nt) {
       int co4 = nt * 16 + 4 * q;
@@ -113,8 +124,7 @@ __global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a) {
           f32x4 bb = *(const f32x4*)(a.bias + co4);
           v += bb;
           f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
-          f32x4 u4 = *(const f32x4*)(a.dst1 + opix * HC + co4);
-          f32x4 h4 = *(const f32x4*)(a.dst0 + opix * HC + co4);
+          f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
           *(f32x4*)(a.dst0 + opix * HC + co4) = u4 * h4 + (1.0f - u4) * cnd;
         }
       }
@@ -200,32 +210,32 @@ __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a) {
   }
   __syncthreads();
 
-  // --- upconv1 on the matrix cores, one parity class (py,px) x one s-row-of-class per run.
-  // out[2i+py][2j+px] = sum over (ky,kx) with ky = 2(i-iy)+py+1: py=0 -> (ky=1,di=0); py=1 -> (ky=2,di=0),(ky=0,di=1)
+  // --- upconv1 on the matrix cores: run = (parity class, row of that class), 32 runs, 8 per wave (rolled).
   const int p = lane & 15, q = lane >> 4;
   const f32x4 bup = *(const f32x4*)(a.bup1 + 4 * q);
+#pragma unroll 1
   for (int run = wave; run < 32; run += 4) {
-    int cls = run >> 3, k = run & 7;          // k-th row of this class
-    int py = cls >> 1, px = cls & 1;
-    // s-region row r / col c of lane's pixel, and its h2-region coordinates
-    int r = py ? 2 * k : 2 * k + 1;
-    int c = px ? 2 * p : 2 * p + 1;
-    int li = py ? k : k + 1;
-    int lj = px ? p : p + 1;
+    const int cls = run >> 3, k = run & 7;          // k-th row of this class; wave-uniform
+    const int py = cls >> 1, px = cls & 1;
+    const int r = py ? 2 * k : 2 * k + 1;            // s-region row / col of the lane's pixel
+    const int c = px ? 2 * p : 2 * p + 1;
+    const int li = py ? k : k + 1, lj = px ? p : p + 1;
+    const int ys = y0 - 1 + r, xs = x0 - 1 + c;
+    const bool sin = ys >= 0 && ys < h && xs >= 0 && xs < w;
+    f32x4 h1v = {0.f, 0.f, 0.f, 0.f};               // skip operand: in flight during the MFMAs
+    if (q < 2 && sin) h1v = *(const f32x4*)(a.h1 + (((size_t)b * h + ys) * w + xs) * 8 + 4 * q);
     const float* xb = lh2 + q * HPLANE + li * HCOLS + lj;
     f32x4 acc;
-    switch (cls) {            // wave-uniform
+    switch (cls) {
       case 0: acc = upconv1_class<0, 0, HPLANE, HCOLS>(wf, xb); break;
       case 1: acc = upconv1_class<0, 1, HPLANE, HCOLS>(wf, xb); break;
       case 2: acc = upconv1_class<1, 0, HPLANE, HCOLS>(wf, xb); break;
       default: acc = upconv1_class<1, 1, HPLANE, HCOLS>(wf, xb); break;
     }
     if (q < 2) {
-      int ys = y0 - 1 + r, xs = x0 - 1 + c;
       f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-      if (ys >= 0 && ys < h && xs >= 0 && xs < w) {
-        f32x4 h1v = *(const f32x4*)(a.h1 + (((size_t)b * h + ys) * w + xs) * 8 + 4 * q);
-        sv = acc + bup + h1v;                                      // adamvs.py:420-421
+      if (sin) {
+        sv = acc + bup + h1v;                                         // adamvs.py:420-421
         sv.x = fmaxf(sv.x, 0.f); sv.y = fmaxf(sv.y, 0.f); sv.z = fmaxf(sv.z, 0.f); sv.w = fmaxf(sv.w, 0.f);
       }
       float* dl = ls + (4 * q) * SPLANE + r * SC + c;
@@ -353,13 +363,79 @@ static int launch_small(const SmallConvArgs& a, int B, hipStream_t st, const cha
   return launch_small_tr<CA, CB, NT, STRIDE, EPI, 2>(a, B, st, name);
 }
 
-// conv1 as a standalone layer (op-level mirror only; the stage driver fuses it into the plane sweep)
-int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, hipStream_t st) {
-  SmallConvArgs a{cost, nullptr, w, nullptr, c1, nullptr, h, w_, h, w_, 8};
-  if (C == 32) return launch_small<32, 0, 1, 1, EPI_RELU>(a, B, st, "conv1");
-  if (C == 16) return launch_small<16, 0, 1, 1, EPI_RELU>(a, B, st, "conv1");
-  if (C == 8) return launch_small<8, 0, 1, 1, EPI_RELU>(a, B, st, "conv1");
-  return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
+// conv1 (C -> 8, ReLU; reference adamvs.py:416) in two-row form: the 16 MFMA rows are 8 output channels of
+// output row y and the same 8 channels of row y+1, fed by the same input-row fragment (tap ky for the first
+// half, ky-1 for the second), so no half of the tile is zero padding: 12 fragment passes per 2 rows instead of 18.
+// src [N][hw][C] -> c1 [N][hw][8].  grid (ceil(w/32), ceil(h/8), N); block 256; tile 8 rows x 32 columns.
+template <int C>
+__global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__ src, const float* __restrict__ wpk,
+                                                       float* __restrict__ c1, int h, int w) {
+  constexpr int KC = C / 4, G = C / 4, TR = 8, LR = TR + 2, LC = 34;
+  constexpr int PLANE = plane_pitch16(LR * LC);
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * TR;
+  float wf[12][KC];
+#pragma unroll
+  for (int t = 0; t < 12; ++t)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) wf[t][kc] = wpk[(t * KC + kc) * 64 + lane];
+
+  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
+  f32x4 stage[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int i = tid + it * 256;
+    int g = i % G, pp = i / G;
+    int r = pp / LC, c = pp % LC;
+    int iy = y0 - 1 + r, ix = x0 - 1 + c;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < NITEMS && iy >= 0 && iy < h && ix >= 0 && ix < w) v = *(const f32x4*)(src + (((size_t)n * h + iy) * w + ix) * C + 4 * g);
+    stage[it] = v;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int i = tid + it * 256;
+    if (i < NITEMS) {
+      int g = i % G, pp = i / G;
+      int r = pp / LC, c = pp % LC;
+      float* dl = lds + (4 * g) * PLANE + r * LC + c;
+      f32x4 v = stage[it];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  }
+  __syncthreads();
+
+  const int p = lane & 15, q = lane >> 4;
+  const float* xb = lds + q * PLANE + p;
+#pragma unroll 1
+  for (int run = wave; run < 8; run += 4) {          // run = (row pair, column half)
+    const int row = (run >> 1) * 2, col = (run & 1) * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) acc = mfma16(wf[rr * 3 + kx][kc], xb[(4 * kc) * PLANE + (row + rr) * LC + col + kx], acc);
+    const int y = y0 + row + (q >> 1), x = x0 + col + p;
+    if (y < h && x < w) {
+      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+      *(f32x4*)(c1 + (((size_t)n * h + y) * w + x) * 8 + 4 * (q & 1)) = acc;
+    }
+  }
+}
+
+int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st) {
+  dim3 grid(cdiv(w_, 32), cdiv(h, 8), N);
+  size_t lds = (size_t)C * plane_pitch16(10 * 34) * sizeof(float);
+  if (N > 65535) return set_error(-1, "conv1: %d maps exceed the grid z limit", N);
+  if (C == 32) hipLaunchKernelGGL((k_conv1_two_row<32>), grid, dim3(256), lds, st, cost, w, c1, h, w_);
+  else if (C == 16) hipLaunchKernelGGL((k_conv1_two_row<16>), grid, dim3(256), lds, st, cost, w, c1, h, w_);
+  else if (C == 8) hipLaunchKernelGGL((k_conv1_two_row<8>), grid, dim3(256), lds, st, cost, w, c1, h, w_);
+  else return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
+  ADAMVS_CHECK_LAUNCH("conv1");
+  return 0;
 }
 
 // One recurrent step after conv1: c1 -> GRU1 -> conv2 -> GRU2 -> decoder -> vol[:, d].

@@ -60,16 +60,24 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
   float* out = sim + ((size_t)b * hw + pc) * C + 4 * g;
   const size_t ostride = (size_t)B * hw * C;
 
-  float depth = pl[(size_t)d0 * hw];
-  for (int d = d0; d < d1; ++d) {
-    float depth_next = pl[(size_t)min(d + 1, d1 - 1) * hw];      // prefetch
+  constexpr int DG = 8;            // planes whose depths are fetched together: the loop body then has no load that
+  for (int dg = d0; dg < d1; dg += DG) {   // would queue behind the previous plane's store (vmcnt is in issue order)
+  float dep[DG];
+#pragma unroll
+  for (int j = 0; j < DG; ++j) dep[j] = pl[(size_t)min(dg + j, d1 - 1) * hw];
+#pragma unroll
+  for (int j = 0; j < DG; ++j) {
+    const int d = dg + j;
+    if (d >= d1) break;
+    const float depth = dep[j];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float wsum = 1e-5f;                                          // adamvs.py:497
 #pragma unroll
     for (int s = 0; s < SV; ++s) {
       if (s >= S) break;                                         // uniform
       float X0 = ax[s] * depth + tx[s], X1 = ay[s] * depth + ty[s], X2 = az[s] * depth + tz[s];
-      float u = X0 / X2, v = X1 / X2;                            // module.py:553
+      float rz = rcp_nr(X2);
+      float u = X0 * rz, v = X1 * rz;                            // module.py:553
       f32x4 wrp = {0.f, 0.f, 0.f, 0.f};
       if (u > -1.0f && u < (float)w && v > -1.0f && v < (float)h) {
         float fx0 = floorf(u), fy0 = floorf(v);
@@ -93,8 +101,8 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
       acc += (wrp * ref4) * wv[s];                               // adamvs.py:504-508
       wsum += wv[s];
     }
-    if (live) *(f32x4*)(out + (size_t)(d - d0) * ostride) = acc / wsum;      // adamvs.py:512
-    depth = depth_next;
+    if (live) *(f32x4*)(out + (size_t)(d - d0) * ostride) = acc * (1.0f / wsum);   // adamvs.py:512
+  }
   }
 }
 
@@ -119,7 +127,7 @@ size_t sweep_workspace_floats(int B, int C, int D, int h, int w) {
 
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
                        float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, hipStream_t st) {
-  if (S > 8) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
+  if (S > 8 || S < 1) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
   const int dc = sweep_chunk_planes(D);
   for (int d0 = 0; d0 < D; d0 += dc) {
     const int d1 = (d0 + dc < D) ? d0 + dc : D;

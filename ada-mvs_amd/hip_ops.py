@@ -138,13 +138,13 @@ def softmax_max_regress(score, planes, S, B, D, h, w):
     return vw, pd
 
 
-def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w, algo=0):
+def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w):
     c1 = torch.empty(D, B, h * w, 8, device=feat.device, dtype=torch.float32)
     lib = _lib.load()
     nbytes = lib.adamvs_aggregate_conv1_workspace_bytes(B, C, D, h, w)
     ws = torch.empty(max(nbytes // 4, 1), device=feat.device, dtype=torch.float32)
     check(_lib.load().adamvs_aggregate_conv1(_p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")),
-                                             _p(_dev(view_weight, "view_weight")), _p(w1pk), _p(c1), B, S, C, D, h, w, int(algo),
+                                             _p(_dev(view_weight, "view_weight")), _p(w1pk), _p(c1), B, S, C, D, h, w,
                                              _p(ws), nbytes, _stream()), "aggregate_conv1")
     return c1
 

@@ -34,6 +34,22 @@ def pack_small_conv(w, transposed=False):
     return wp.reshape(nt, 16, cin // 4, 4, 9).permute(0, 4, 2, 3, 1).contiguous().reshape(-1)
 
 
+def pack_conv1_two_row(w):
+    """conv1 [8][cin][3][3] -> [12 = (rr 0..3) x (kx 0..2)][cin/4][64] two-row A fragments (include/adamvs_hip.h):
+    MFMA rows 0-7 produce output row y (tap ky = rr), rows 8-15 output row y+1 (tap ky = rr-1)."""
+    w = w.detach().to(torch.float32).cpu()
+    cout, cin = w.shape[0], w.shape[1]
+    assert cout == 8 and cin % 4 == 0
+    wp = torch.zeros(4, 3, 16, cin)                       # [rr][kx][row16][cin]
+    for rr in range(4):
+        if rr <= 2:
+            wp[rr, :, :8] = w[:, :, rr, :].permute(2, 0, 1)       # [kx][co][cin]
+        if rr >= 1:
+            wp[rr, :, 8:] = w[:, :, rr - 1, :].permute(2, 0, 1)
+    # (rr, kx, row16, kc, k4) -> (rr, kx, kc, k4, row16): lane = k4*16 + row16
+    return wp.reshape(4, 3, 16, cin // 4, 4).permute(0, 1, 3, 4, 2).contiguous().reshape(-1)
+
+
 def pad_bias(b, n):
     out = torch.zeros(n)
     out[:b.numel()] = b.detach().to(torch.float32).cpu().reshape(-1)
@@ -81,7 +97,7 @@ FUSE_FIELDS = ("conv1", "gates1", "gates1_b", "cand1", "cand1_b", "conv2", "gate
 def pack_slice_reg_net(sd, pre):
     """SliceCostRegNetRED of `pre` (e.g. 'DepthNet.0.reg_fuse.') -> (flat fp32 tensor, {field: offset})."""
     parts = {
-        "conv1": pack_small_conv(sd[pre + "conv1.conv.weight"]),
+        "conv1": pack_conv1_two_row(sd[pre + "conv1.conv.weight"]),
         "gates1": pack_small_conv(sd[pre + "conv_gru1.conv_gates.0.weight"]),
         "gates1_b": pad_bias(sd[pre + "conv_gru1.conv_gates.0.bias"], 16),
         "cand1": pack_small_conv(sd[pre + "conv_gru1.convc.0.weight"]),

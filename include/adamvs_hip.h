@@ -100,9 +100,12 @@ int adamvs_softmax_max_regress(const float* score, const float* planes, float* v
 /* SliceCostRegNetRED weights (models/adamvs.py:400-413), packed by the host:
  * conv weights as MFMA A fragments [cout tile][tap][cin/4][64 lanes] holding
  * W[cout = 16*tile + (lane&15)][cin = 4*kc + (lane>>4)][tap] (0 beyond cout),
- * biases zero-padded to 16 per tile. */
+ * biases zero-padded to 16 per tile.  conv1 (8 output channels) uses the two-row form: fragment
+ * (rr, kx, kc), rr = 0..3, holds for lanes with (lane&15) < 8 the weights of output row y,
+ * W[lane&15][cin][ky = rr][kx] (0 if rr = 3), and for the other lanes those of output row y+1,
+ * W[(lane&15)-8][cin][ky = rr-1][kx] (0 if rr = 0), so one MFMA feeds two output rows. */
 typedef struct adamvs_fuse_weights {
-  const float* conv1;                           /* [1][9][C/4][64]          reg_fuse.conv1.conv.weight */
+  const float* conv1;                           /* [12][C/4][64] two-row form reg_fuse.conv1.conv.weight */
   const float* gates1; const float* gates1_b;   /* [1][9][4][64], [16]      conv_gru1.conv_gates.0 */
   const float* cand1;  const float* cand1_b;    /* [1][9][4][64], [16]      conv_gru1.convc.0 */
   const float* conv2;                           /* [1][9][2][64]            conv2.conv.weight */
@@ -114,13 +117,12 @@ typedef struct adamvs_fuse_weights {
 
 /* models/adamvs.py:495-512 fused with conv1 of SliceCostRegNetRED (adamvs.py:416), for all
  * D hypotheses at once: c1[d][b][pix][8] = ReLU(conv1(sum_v w_v warp_v ref / (1e-5 + sum_v w_v))).
- * view_weight [S][B][h*w].  algo 0 (what the stage driver uses): hypothesis loop inside the thread,
- * bilinear taps cached in registers across planes, similarity of a chunk of planes through the
- * workspace, conv1 as a tiled MFMA convolution; algo 1: one workgroup per (tile, plane), taps
- * gathered per plane, similarity kept in LDS (no workspace). */
+ * view_weight [S][B][h*w].  Hypothesis loop inside the thread, bilinear taps cached in registers
+ * across planes; the similarity of a chunk of planes goes through the workspace and conv1 runs
+ * over it as a tiled MFMA convolution.  S <= 8. */
 size_t adamvs_aggregate_conv1_workspace_bytes(int B, int C, int D, int h, int w);
 int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* view_weight,
-                           const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, int algo,
+                           const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* SliceCostRegNetRED.forward, models/adamvs.py:415-424 (one recurrent step).

@@ -151,13 +151,12 @@ def test_slice_reg_step_golden(hip, k):
     assert rel_l1(reg, g["reg"]) < OP_TOL, "decoder"
 
 
-@pytest.mark.parametrize("algo", [0, 1])
 @pytest.mark.parametrize("C,h,w,D,baseline", [(32, 16, 40, 3, 80.0), (16, 20, 36, 3, 80.0), (8, 24, 70, 3, 80.0),
                                               (32, 24, 40, 24, 8.0),        # narrow sweep: one LDS-resident chunk
                                               (32, 24, 40, 16, 400.0),      # wide sweep: chunks split, patches leave the image
                                               (16, 40, 24, 10, 2500.0)])    # extreme: per-plane patches / global fallback
-def test_aggregate_conv1(hip, O, C, h, w, D, baseline, algo):
-    """algo 0 = LDS-resident sweep (sweep.hip), algo 1 = per-plane global gathers (planesweep.hip)."""
+def test_aggregate_conv1(hip, O, C, h, w, D, baseline):
+    """Weighted aggregation (register-resident taps, arbitrary planes) + two-row conv1."""
     import torch.nn.functional as F
     B, S = 2, 3
     feats = [synth.smooth_features(B, C, h, w, seed=10 + v) for v in range(S + 1)]
@@ -174,7 +173,7 @@ def test_aggregate_conv1(hip, O, C, h, w, D, baseline, algo):
     from ada_mvs_amd import packing
     c1 = hip.aggregate_conv1(hip.pack_features(dev(torch.stack(feats, 0).reshape(-1, C, h, w))),
                              hip.relative_transforms(dev(proj)), dev(planes), dev(vw),
-                             packing.pack_small_conv(w1).cuda(), B, S, C, D, h, w, algo=algo).cpu()      # [D,B,hw,8]
+                             packing.pack_conv1_two_row(w1).cuda(), B, S, C, D, h, w).cpu()      # [D,B,hw,8]
     Rs, ts = zip(*[O.relative_transform(proj[:, s + 1], proj[:, 0]) for s in range(S)])
     zero_frac = 0.0
     for d in range(D):

@@ -77,6 +77,12 @@ def test_fragment_packing_layout():
     wt = torch.randn(16, 8, 3, 3, generator=g)                       # ConvTranspose2d layout [cin][cout]
     pkt = packing.pack_small_conv(wt, transposed=True).reshape(1, 9, 4, 64)
     assert float(pkt[0, 5, 2, 21]) == float(wt[4 * 2 + 1, 5, 1, 2])
+    # two-row conv1: rows 0-7 = output row y (ky = rr), rows 8-15 = output row y+1 (ky = rr-1)
+    w1 = torch.randn(8, 16, 3, 3, generator=g)
+    p2 = packing.pack_conv1_two_row(w1).reshape(4, 3, 4, 64)
+    assert float(p2[1, 2, 3, 2 * 16 + 5]) == float(w1[5, 14, 1, 2])         # lane: k4=2, row 5  -> cin 3*4+2
+    assert float(p2[1, 2, 3, 2 * 16 + 13]) == float(w1[5, 14, 0, 2])        # row 13 = channel 5 of row y+1, ky = 0
+    assert float(p2[0, 0, 0, 8]) == 0.0 and float(p2[3, 1, 1, 3]) == 0.0
     # CostRegNet2D layer: [tap][kc][tile][lane], BN scale folded
     D = 32
     wl = torch.randn(D, D, 3, 3, generator=g)
@@ -95,7 +101,7 @@ def test_packed_network_sizes_match_the_header():
     flat, off = packing.pack_slice_reg_net(sd, "DepthNet.0.reg_fuse.")
     assert list(off) == list(packing.FUSE_FIELDS)
     assert all(o % 64 == 0 for o in off.values())
-    assert off["gates1"] - off["conv1"] == 9 * 8 * 64                # C=32 -> KC=8
+    assert off["gates1"] - off["conv1"] == 12 * 8 * 64               # two-row conv1, C=32 -> KC=8
     assert flat.numel() >= off["final_w"] + 73
 
 
