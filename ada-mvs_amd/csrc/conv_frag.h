@@ -23,10 +23,17 @@ __device__ __forceinline__ void load_wfrag(float (&wf)[NT][9][KC], const float* 
       for (int kc = 0; kc < KC; ++kc) wf[nt][t][kc] = wpk[((nt * 9 + t) * KC + kc) * 64 + lane];
 }
 
+// LDS tile layout: channel c of pixel `pix` lives at (c >> 2) * GP + (c & 3) * PLANE + pix, with
+// PLANE % 32 == 16 (the two k-rows of a 32-lane group of a B-fragment read hit disjoint banks) and
+// GP = 4 * PLANE + 32 / (channel groups): when a tile is filled, the lanes of one ds_write cover a few pixels x
+// all channel groups, and the extra 32/G floats per group spread those groups over the 32 banks (without
+// them every group of a pixel lands on the same bank: an 8-way conflict for 32 input channels).
+__host__ __device__ constexpr int group_pitch(int plane, int groups) { return 4 * plane + (groups >= 2 ? 32 / groups : 0); }
+
 // One run of 16 output pixels.  `xb` = LDS tile + q*PLANE + p*STRIDE (lane's
 // own k-row and pixel); (row, col) = output coordinates inside the tile; the
 // tile origin is input coordinate (out_row0*STRIDE - 1, out_col0*STRIDE - 1).
-template <int NT, int KC, int STRIDE, int PLANE, int PITCH>
+template <int NT, int KC, int STRIDE, int GP, int PITCH>
 __device__ __forceinline__ void conv3x3_run(f32x4 (&acc)[NT], const float (&wf)[NT][9][KC], const float* xb, int row,
                                             int col) {
   const float* x0 = xb + (row * STRIDE) * PITCH + col * STRIDE;
@@ -36,7 +43,7 @@ __device__ __forceinline__ void conv3x3_run(f32x4 (&acc)[NT], const float (&wf)[
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        float bv = x0[(4 * kc) * PLANE + ky * PITCH + kx];
+        float bv = x0[kc * GP + ky * PITCH + kx];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[nt][ky * 3 + kx][kc], bv, acc[nt]);
       }

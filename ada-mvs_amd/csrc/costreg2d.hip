@@ -13,6 +13,7 @@
 // there is nothing to share through LDS); activations go through a planar LDS
 // tile shared by the block's four waves.
 #include "common.h"
+#include "conv_frag.h"
 #include "kernels.h"
 
 namespace adamvs {
@@ -41,7 +42,7 @@ constexpr int KB = 8;     // input channels per LDS chunk (2 MFMA k-steps)
 template <int MT, int WM, int MODE, int PY, int PX>
 __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
   using TG = TileGeom<MODE>;
-  constexpr int LR = TG::LR, LC = TG::LC, PLANE = TG::PLANE;
+  constexpr int LR = TG::LR, LC = TG::LC, PLANE = TG::PLANE, GP = group_pitch(PLANE, KB / 4);
   constexpr int WN = 4 / WM, NTR = 8 / WN;
   constexpr int STR = (MODE == CONV_S2) ? 2 : 1;
   constexpr int NTY = (MODE == CONV_T2) ? 1 + PY : 3;
@@ -102,7 +103,7 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
       if (i < NITEMS) {
         int g = i % (KB / 4), pp = i / (KB / 4);
         int r = pp / LC, c = pp % LC;
-        float* dl = lds + (4 * g) * PLANE + r * LC + c;
+        float* dl = lds + g * GP + r * LC + c;
         dl[0] = st[it].x; dl[PLANE] = st[it].y; dl[2 * PLANE] = st[it].z; dl[3 * PLANE] = st[it].w;
       }
     }
@@ -128,7 +129,7 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
         for (int kc = 0; kc < KB / 4; ++kc) {
           float bv[NTR];
 #pragma unroll
-          for (int r = 0; r < NTR; ++r) bv[r] = xb[(4 * kc) * PLANE + (r * STR + ty) * LC + tx];
+          for (int r = 0; r < NTR; ++r) bv[r] = xb[kc * GP + (r * STR + ty) * LC + tx];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -169,7 +170,7 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
 // grid: (ceil(cols/16), ceil(rows/8), N [*4 classes for CONV_T2]); block 256
 template <int MT, int WM, int MODE>
 __global__ __launch_bounds__(256) void k_conv_dd(ConvDDArgs a) {
-  __shared__ float lds[KB * TileGeom<MODE>::PLANE];
+  __shared__ float lds[(KB / 4) * group_pitch(TileGeom<MODE>::PLANE, KB / 4)];
   if (MODE == CONV_T2) {
     int n = blockIdx.z >> 2, cls = blockIdx.z & 3;
     switch (cls) {        // block-uniform

@@ -30,105 +30,132 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return 1.0f - 2.0f / (e + 1.0f);
 }
 
-// grid: (ceil(wo/32), ceil(ho/TR), B); block 256
+// Persistent workgroups.  These launches are short (a few thousand tiles of a few microseconds) and sit on the
+// sequential critical path of the recurrence, so what costs time is not the matrix work but its packaging: a grid
+// that is 1.8x the resident capacity runs as two "rounds" with the second one mostly empty, and every workgroup
+// of a round is in its load phase at the same time.  Here the grid is exactly the resident capacity (occupancy
+// query); workgroup i walks tiles i, i + grid, ..., requests the input tile of its NEXT tile before the MFMAs of
+// the current one (two LDS buffers, one barrier per tile) and fetches the A fragments once.  (A shared atomic
+// tile counter was tried and is slower: one word serves ~88 dequeues/us.)  Tile t -> (tile_x, tile_y, b).
 template <int CA, int CB, int NT, int STRIDE, int EPI, int TR>
-__global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a) {
+__global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a, int tiles_x, int tiles_y, int ntiles) {
   constexpr int CIN = CA + CB, KC = CIN / 4, G = CIN / 4;
   constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
   constexpr int LC = (STRIDE == 1) ? 34 : 65;
   constexpr int PLANE = (STRIDE == 1) ? plane_pitch16(LR * LC) : ((LR * LC) | 1);
+  constexpr int GP = group_pitch(PLANE, G);
   constexpr int HC = CB;                 // hidden width for the GRU epilogues
-  extern __shared__ float lds[];         // [CIN][PLANE]
+  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
+  extern __shared__ float lds_all[];     // [2][G][GP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z;
-  const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TR;
-  const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
+  const int p = lane & 15, q = lane >> 4;
 
   float wf[NT][9][KC];
   load_wfrag<NT, KC>(wf, a.wpk, lane);
 
-  // tile fill in two passes so that every global load of the tile is in flight at once
-  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
-  f32x4 stage[NIT];
+  auto tile_coords = [&](int t, int& b, int& ox0, int& oy0) {
+    int tx = t % tiles_x, r = t / tiles_x;
+    int ty = r % tiles_y;
+    b = r / tiles_y;
+    ox0 = tx * 32; oy0 = ty * TR;
+  };
+  auto load_tile = [&](f32x4 (&stage)[NIT], int t) {
+    int b, ox0, oy0;
+    tile_coords(t, b, ox0, oy0);
+    const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    int i = tid + it * 256;
-    int g = i % G, pp = i / G;
-    int r = pp / LC, c = pp % LC;
-    int iy = iy0 + r, ix = ix0 + c;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (i < NITEMS && iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) {
-      size_t pix = ((size_t)b * a.hi + iy) * a.wi + ix;
-      if (4 * g < CA) v = *(const f32x4*)(a.srcA + pix * CA + 4 * g);
-      else v = *(const f32x4*)(a.srcB + pix * CB + (4 * g - CA));
-    }
-    stage[it] = v;
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    int i = tid + it * 256;
-    if (i < NITEMS) {
+    for (int it = 0; it < NIT; ++it) {
+      int i = tid + it * 256;
       int g = i % G, pp = i / G;
       int r = pp / LC, c = pp % LC;
-      float* dl = lds + (4 * g) * PLANE + r * LC + c;
-      f32x4 v = stage[it];
-      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+      int iy = iy0 + r, ix = ix0 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < NITEMS && iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) {
+        size_t pix = ((size_t)b * a.hi + iy) * a.wi + ix;
+        if (4 * g < CA) v = *(const f32x4*)(a.srcA + pix * CA + 4 * g);
+        else v = *(const f32x4*)(a.srcB + pix * CB + (4 * g - CA));
+      }
+      stage[it] = v;
     }
-  }
-  __syncthreads();
-
-  const int p = lane & 15, q = lane >> 4;
-  const float* xb = lds + q * PLANE + p * STRIDE;
-  // A wave owns (2 TR)/4 runs of 16 pixels, one after the other (kept rolled: these kernels live on
-  // occupancy, and unrolling multiplies the live LDS fragments).  Operands the epilogue needs from
-  // global memory are requested before the run's MFMA chain and consumed after it.
-#pragma unroll 1
-  for (int run = wave; run < TR * 2; run += 4) {
-    const int row = run >> 1, col = (run & 1) * 16;
-    const int oy = oy0 + row, ox = ox0 + col + p;
-    const bool valid = oy < a.ho && ox < a.wo;
-    const size_t opix = ((size_t)b * a.ho + min(oy, a.ho - 1)) * a.wo + min(ox, a.wo - 1);
-    f32x4 acc[NT], pre_u[NT], pre_h[NT];
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NIT], float* lds) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int co4 = nt * 16 + 4 * q;
-      if (EPI == EPI_CAND && co4 < HC) {
-        pre_u[nt] = *(const f32x4*)(a.dst1 + opix * HC + co4);
-        pre_h[nt] = *(const f32x4*)(a.dst0 + opix * HC + co4);
+    for (int it = 0; it < NIT; ++it) {
+      int i = tid + it * 256;
+      if (i < NITEMS) {
+        int g = i % G, pp = i / G;
+        int r = pp / LC, c = pp % LC;
+        float* dl = lds + g * GP + r * LC + c;
+        f32x4 v = stage[it];
+        dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
       }
     }
-    conv3x3_run<NT, KC, STRIDE, PLANE, LC>(acc, wf, xb, row, col);
+  };
+
+  int t = blockIdx.x;
+  f32x4 stage[NIT];
+  if (t < ntiles) load_tile(stage, t);
+  for (int it = 0; t < ntiles; ++it) {
+    float* lds = lds_all + (it & 1) * (G * GP);
+    store_tile(stage, lds);
+    __syncthreads();        // tile visible; readers of this LDS buffer two iterations ago are done
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) load_tile(stage, tn);            // in flight during the MFMAs below
+
+    int b, ox0, oy0;
+    tile_coords(t, b, ox0, oy0);
+    const float* xb = lds + q * PLANE + p * STRIDE;
+    // A wave owns (2 TR)/4 runs of 16 pixels, one after the other (rolled: occupancy matters more than unrolling
+    // here).  Operands the epilogue needs from global memory are requested before the run's MFMA chain.
+#pragma unroll 1
+    for (int run = wave; run < TR * 2; run += 4) {
+      const int row = run >> 1, col = (run & 1) * 16;
+      const int oy = oy0 + row, ox = ox0 + col + p;
+      const bool valid = oy < a.ho && ox < a.wo;
+      const size_t opix = ((size_t)b * a.ho + min(oy, a.ho - 1)) * a.wo + min(ox, a.wo - 1);
+      f32x4 acc[NT], pre_u[NT], pre_h[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT && valid; ++nt) {
-      int co4 = nt * 16 + 4 * q;
-      f32x4 v = acc[nt];
-      if (EPI == EPI_RELU) {
-        if (co4 < a.cout) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          *(f32x4*)(a.dst0 + opix * a.cout + co4) = v;
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int co4 = nt * 16 + 4 * q;
+        if (EPI == EPI_CAND && co4 < HC) {
+          pre_u[nt] = *(const f32x4*)(a.dst1 + opix * HC + co4);
+          pre_h[nt] = *(const f32x4*)(a.dst0 + opix * HC + co4);
         }
-      } else if (EPI == EPI_GATES) {
-        f32x4 bb = *(const f32x4*)(a.bias + co4);
-        v += bb;
-        f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
-        if (co4 < HC) {                                   // reset gate -> r * h   (module.py:35-41)
-          const float* hl = lds + (CA + co4) * PLANE + (row + 1) * LC + col + p + 1;
-          f32x4 h4 = {hl[0], hl[PLANE], hl[2 * PLANE], hl[3 * PLANE]};
-          *(f32x4*)(a.dst0 + opix * HC + co4) = sg * h4;
-        } else if (co4 < 2 * HC) {                        // update gate
-          *(f32x4*)(a.dst1 + opix * HC + (co4 - HC)) = sg;
-        }
-      } else {                                            // EPI_CAND   (module.py:44-50)
-        if (co4 < HC) {
+      }
+      conv3x3_run<NT, KC, STRIDE, GP, LC>(acc, wf, xb, row, col);
+#pragma unroll
+      for (int nt = 0; nt < NT && valid; ++nt) {
+        int co4 = nt * 16 + 4 * q;
+        f32x4 v = acc[nt];
+        if (EPI == EPI_RELU) {
+          if (co4 < a.cout) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *(f32x4*)(a.dst0 + opix * a.cout + co4) = v;
+          }
+        } else if (EPI == EPI_GATES) {
           f32x4 bb = *(const f32x4*)(a.bias + co4);
           v += bb;
-          f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
-          f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
-          *(f32x4*)(a.dst0 + opix * HC + co4) = u4 * h4 + (1.0f - u4) * cnd;
+          f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+          if (co4 < HC) {                                   // reset gate -> r * h   (module.py:35-41)
+            const float* hl = lds + ((CA + co4) >> 2) * GP + (row + 1) * LC + col + p + 1;
+            f32x4 h4 = {hl[0], hl[PLANE], hl[2 * PLANE], hl[3 * PLANE]};
+            *(f32x4*)(a.dst0 + opix * HC + co4) = sg * h4;
+          } else if (co4 < 2 * HC) {                        // update gate
+            *(f32x4*)(a.dst1 + opix * HC + (co4 - HC)) = sg;
+          }
+        } else {                                            // EPI_CAND   (module.py:44-50)
+          if (co4 < HC) {
+            f32x4 bb = *(const f32x4*)(a.bias + co4);
+            v += bb;
+            f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+            f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
+            *(f32x4*)(a.dst0 + opix * HC + co4) = u4 * h4 + (1.0f - u4) * cnd;
+          }
         }
       }
     }
+    t = tn;
   }
 }
 
@@ -151,7 +178,7 @@ struct DecoderArgs {
 // ConvTranspose2d(k3, s2, p1, op1) restricted to one output parity class (PY,PX):
 // out[2i+PY][2j+PX] = sum over taps with ky = 2(i-iy)+PY+1, i.e. PY=0 -> (ky=1, iy=i);
 // PY=1 -> (ky=2, iy=i), (ky=0, iy=i+1); same along x.
-template <int PY, int PX, int HPLANE, int HCOLS>
+template <int PY, int PX, int HGP, int HCOLS>
 __device__ __forceinline__ f32x4 upconv1_class(const float (&wf)[1][9][4], const float* xb) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -162,7 +189,7 @@ __device__ __forceinline__ f32x4 upconv1_class(const float (&wf)[1][9][4], const
       const int kx = PX ? (tx ? 0 : 2) : 1;
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc)
-        acc = mfma16(wf[0][ky * 3 + kx][kc], xb[(4 * kc) * HPLANE + ty * HCOLS + tx], acc);
+        acc = mfma16(wf[0][ky * 3 + kx][kc], xb[kc * HGP + ty * HCOLS + tx], acc);
     }
   }
   return acc;
@@ -170,11 +197,12 @@ __device__ __forceinline__ f32x4 upconv1_class(const float (&wf)[1][9][4], const
 
 template <bool IN_UP>
 __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a) {
-  constexpr int HR = 10, HCOLS = 18, HPLANE = plane_pitch16(HR * HCOLS);   // h2 region, 16 planes
+  constexpr int HR = 10, HCOLS = 18, HPLANE = plane_pitch16(HR * HCOLS);   // h2 region, 16 planes in 4 groups
+  constexpr int HGP = group_pitch(HPLANE, 4);
   constexpr int SR = 16, SC = 32, SPLANE = plane_pitch16(SR * SC);        // s region, 8 planes
-  __shared__ float lds[16 * HPLANE + 8 * SPLANE];
+  __shared__ float lds[4 * HGP + 8 * SPLANE];
   float* lh2 = lds;
-  float* ls = lds + 16 * HPLANE;
+  float* ls = lds + 4 * HGP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int x0 = blockIdx.x * 30, y0 = blockIdx.y * 14;     // both even
@@ -203,7 +231,7 @@ __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a) {
     if (i < NITEMS) {
       int g = i & 3, pp = i >> 2;
       int r = pp / HCOLS, c = pp % HCOLS;
-      float* dl = lh2 + (4 * g) * HPLANE + r * HCOLS + c;
+      float* dl = lh2 + g * HGP + r * HCOLS + c;
       f32x4 v = stage[it];
       dl[0] = v.x; dl[HPLANE] = v.y; dl[2 * HPLANE] = v.z; dl[3 * HPLANE] = v.w;
     }
@@ -227,10 +255,10 @@ __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a) {
     const float* xb = lh2 + q * HPLANE + li * HCOLS + lj;
     f32x4 acc;
     switch (cls) {
-      case 0: acc = upconv1_class<0, 0, HPLANE, HCOLS>(wf, xb); break;
-      case 1: acc = upconv1_class<0, 1, HPLANE, HCOLS>(wf, xb); break;
-      case 2: acc = upconv1_class<1, 0, HPLANE, HCOLS>(wf, xb); break;
-      default: acc = upconv1_class<1, 1, HPLANE, HCOLS>(wf, xb); break;
+      case 0: acc = upconv1_class<0, 0, HGP, HCOLS>(wf, xb); break;
+      case 1: acc = upconv1_class<0, 1, HGP, HCOLS>(wf, xb); break;
+      case 2: acc = upconv1_class<1, 0, HGP, HCOLS>(wf, xb); break;
+      default: acc = upconv1_class<1, 1, HGP, HCOLS>(wf, xb); break;
     }
     if (q < 2) {
       f32x4 sv = {0.f, 0.f, 0.f, 0.f};
@@ -339,27 +367,39 @@ __global__ void k_soft_argmin(const float* __restrict__ vol, const float* __rest
 // ---------------------------------------------------------------------------
 // host-side launchers shared by the op-level entry point and the stage driver
 
+// workgroups of `kernel` that stay resident per CU (occupancy query, cached per instantiation by the caller)
+template <typename K>
+static int resident_blocks(K kernel, int threads, size_t lds) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) n = 1;
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  return n * cus;
+}
+
 template <int CA, int CB, int NT, int STRIDE, int EPI, int TR>
 static int launch_small_tr(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
   constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
   constexpr int LC = (STRIDE == 1) ? 34 : 65;
   constexpr int PLANE = (STRIDE == 1) ? plane_pitch16(LR * LC) : ((LR * LC) | 1);
-  size_t lds = (size_t)(CA + CB) * PLANE * sizeof(float);
-  static_assert((CA + CB) * PLANE * sizeof(float) <= 48 * 1024, "tile exceeds the default dynamic LDS limit");
-  hipLaunchKernelGGL((k_conv_small<CA, CB, NT, STRIDE, EPI, TR>), dim3(cdiv(a.wo, 32), cdiv(a.ho, TR), B), dim3(256), lds, st, a);
+  constexpr size_t lds = (size_t)2 * ((CA + CB) / 4) * group_pitch(PLANE, (CA + CB) / 4) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "double-buffered tile exceeds the default dynamic LDS limit");
+  auto kern = k_conv_small<CA, CB, NT, STRIDE, EPI, TR>;
+  static int capacity = 0;              // per instantiation; a pure function of the kernel and the device
+  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  const int tiles_x = cdiv(a.wo, 32), tiles_y = cdiv(a.ho, TR);
+  const int ntiles = tiles_x * tiles_y * B;
+  const int grid = ntiles < capacity ? ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
   return 0;
 }
 
-// These kernels are latency-bound (load tile -> LDS -> MFMA chain -> store): pick the tile height so
-// that the launch has at least ~2 workgroups per CU and a wave owns as few 16-pixel runs as possible.
+// Tile height 4 (two 16-pixel runs per wave): short tiles keep the end-of-launch imbalance small.
 template <int CA, int CB, int NT, int STRIDE, int EPI>
 static int launch_small(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
-  const long cols = cdiv(a.wo, 32);
-  auto blocks = [&](int tr) { return cols * cdiv(a.ho, tr) * B; };
-  if (blocks(8) >= 1024) return launch_small_tr<CA, CB, NT, STRIDE, EPI, 8>(a, B, st, name);
-  if (blocks(4) >= 1024) return launch_small_tr<CA, CB, NT, STRIDE, EPI, 4>(a, B, st, name);
+  if ((long)cdiv(a.ho, 4) * cdiv(a.wo, 32) * B >= 2048) return launch_small_tr<CA, CB, NT, STRIDE, EPI, 4>(a, B, st, name);
   return launch_small_tr<CA, CB, NT, STRIDE, EPI, 2>(a, B, st, name);
 }
 
@@ -371,8 +411,8 @@ template <int C>
 __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__ src, const float* __restrict__ wpk,
                                                        float* __restrict__ c1, int h, int w) {
   constexpr int KC = C / 4, G = C / 4, TR = 8, LR = TR + 2, LC = 34;
-  constexpr int PLANE = plane_pitch16(LR * LC);
-  extern __shared__ float lds[];
+  constexpr int PLANE = plane_pitch16(LR * LC), GP = group_pitch(PLANE, G);
+  extern __shared__ float lds[];           // [G][GP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * TR;
   float wf[12][KC];
@@ -399,7 +439,7 @@ __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__
     if (i < NITEMS) {
       int g = i % G, pp = i / G;
       int r = pp / LC, c = pp % LC;
-      float* dl = lds + (4 * g) * PLANE + r * LC + c;
+      float* dl = lds + g * GP + r * LC + c;
       f32x4 v = stage[it];
       dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
     }
@@ -408,27 +448,37 @@ __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__
 
   const int p = lane & 15, q = lane >> 4;
   const float* xb = lds + q * PLANE + p;
-#pragma unroll 1
-  for (int run = wave; run < 8; run += 4) {          // run = (row pair, column half)
-    const int row = (run >> 1) * 2, col = (run & 1) * 16;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // a wave owns two runs (row pair, column half); their accumulators are independent, so their MFMAs alternate
+  {
+    const int row0 = (wave >> 1) * 2, col0 = (wave & 1) * 16;        // run = wave
+    const int row1 = row0 + 4, col1 = col0;                            // run = wave + 4
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) acc = mfma16(wf[rr * 3 + kx][kc], xb[(4 * kc) * PLANE + (row + rr) * LC + col + kx], acc);
-    const int y = y0 + row + (q >> 1), x = x0 + col + p;
-    if (y < h && x < w) {
-      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-      *(f32x4*)(c1 + (((size_t)n * h + y) * w + x) * 8 + 4 * (q & 1)) = acc;
+        for (int kc = 0; kc < KC; ++kc) {
+          float b0 = xb[kc * GP + (row0 + rr) * LC + col0 + kx];
+          float b1 = xb[kc * GP + (row1 + rr) * LC + col1 + kx];
+          acc0 = mfma16(wf[rr * 3 + kx][kc], b0, acc0);
+          acc1 = mfma16(wf[rr * 3 + kx][kc], b1, acc1);
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 acc = j ? acc1 : acc0;
+      const int y = y0 + (j ? row1 : row0) + (q >> 1), x = x0 + col0 + p;
+      if (y < h && x < w) {
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        *(f32x4*)(c1 + (((size_t)n * h + y) * w + x) * 8 + 4 * (q & 1)) = acc;
+      }
     }
   }
 }
 
 int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st) {
   dim3 grid(cdiv(w_, 32), cdiv(h, 8), N);
-  size_t lds = (size_t)C * plane_pitch16(10 * 34) * sizeof(float);
+  size_t lds = (size_t)(C / 4) * group_pitch(plane_pitch16(10 * 34), C / 4) * sizeof(float);
   if (N > 65535) return set_error(-1, "conv1: %d maps exceed the grid z limit", N);
   if (C == 32) hipLaunchKernelGGL((k_conv1_two_row<32>), grid, dim3(256), lds, st, cost, w, c1, h, w_);
   else if (C == 16) hipLaunchKernelGGL((k_conv1_two_row<16>), grid, dim3(256), lds, st, cost, w, c1, h, w_);
