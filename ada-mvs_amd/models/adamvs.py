@@ -212,6 +212,7 @@ class Infer_AdaMVSNet(nn.Module):
         self.depth_intervals_ratio = list(depth_intervals_ratio)
         self.cr_base_chs = cr_base_chs
         self.num_stage = len(ndepths)
+        self.feature_chunk = 40                  # images per FeatureNet0 call (extract_features)
         self.stage_infos = {k: {"scale": float(v)} for k, v in STAGE_SCALE.items()}
         self.feature = FeatureNet0(base_channels=8, stride=4, num_stage=self.num_stage)
         ch = self.feature.out_channels
@@ -243,7 +244,10 @@ class Infer_AdaMVSNet(nn.Module):
     def extract_features(self, imgs):
         """-> (feats_cl, shapes) for infer_from_features; FeatureNet0 on all B*V images in one batch."""
         B, V = imgs.shape[:2]
-        f = self.feature(imgs.transpose(0, 1).reshape(B * V, *imgs.shape[2:]))    # view-major
+        x = imgs.transpose(0, 1).reshape(B * V, *imgs.shape[2:])                  # view-major
+        # MIOpen has tuned solvers for moderate batches only (very large ones fall to its naive kernels): chunk
+        chunks = [self.feature(x[i:i + self.feature_chunk]) for i in range(0, B * V, self.feature_chunk)]
+        f = chunks[0] if len(chunks) == 1 else {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}
         feats_cl, shapes = [], []
         for s in range(self.num_stage):
             x = f["stage%d" % (s + 1)]

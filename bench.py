@@ -110,9 +110,10 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 return hip_ops.depth_stage_forward(desc, feats_cl[s], rt, planes, conf, w_reg, fuse, ws, phases=mask, outputs=outs)
 
             if first:
-                # pass A split further, op by op, so the dominant kernel is timed by itself
+                # pass A split further, op by op; CostRegNet2D layer by layer so that every launch of its
+                # convolution kernel is timed by itself (the roofline object is per launch of one kernel)
                 sim = mark("s%d.pair_similarity" % (s + 1), lambda: hip_ops.pair_similarity(feats_cl[s], rt, planes, B, S, C, D, h, w))
-                score = mark("s%d.cost_reg_net_2d" % (s + 1), lambda: hip_ops.cost_reg_net_2d(sim, w_reg, h, w))
+                score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w)
                 vw_pd = mark("s%d.softmax_max_regress" % (s + 1), lambda: hip_ops.softmax_max_regress(score, planes, S, B, D, h, w))
                 outs[0].copy_(vw_pd[0])
                 del sim, score
@@ -128,20 +129,45 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
     return times
 
 
+COSTREG_PLAN = (  # (layer, mode 0 s1 / 1 s2 / 2 transposed, relu, input, skip), CostRegNet2D.forward (adamvs.py:229-238)
+    ("conv0", 0, 1, "x", None), ("conv1", 1, 1, "conv0", None), ("conv2", 0, 1, "conv1", None), ("conv3", 1, 1, "conv2", None),
+    ("conv4", 0, 1, "conv3", None), ("conv5", 1, 1, "conv4", None), ("conv6", 0, 1, "conv5", None),
+    ("conv7", 2, 1, "conv6", "conv4"), ("conv9", 2, 1, "conv7", "conv2"), ("conv11", 2, 1, "conv9", "conv0"),
+    ("prob", 0, 0, "conv11", None))
+
+
+def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w):
+    """CostRegNet2D through the one-layer C-ABI op, one timing mark per launch."""
+    LW = 9 * D * D + D
+    acts = {"x": (x, h, w)}
+    for i, (name, mode, relu, src, skip) in enumerate(COSTREG_PLAN):
+        xin, hi, wi = acts[src]
+        wl = wpk[i * LW:(i + 1) * LW]
+        sk = acts[skip][0] if skip else None
+        out = mark("s%d.costreg.%s.mode%d" % (stage, name, mode),
+                   lambda: hip_ops.conv3x3_dd(xin, wl, wl[9 * D * D:], sk, N, D, hi, wi, mode, relu))
+        ho, wo = (hi // 2, wi // 2) if mode == 1 else ((2 * hi, 2 * wi) if mode == 2 else (hi, wi))
+        acts[name] = (out, ho, wo)
+    return acts["prob"][0]
+
+
 def cpu_baseline(cfg, sd):
     """The CPU oracle (a port of the reference's unfused PyTorch-CPU path) on ONE tile of the workload."""
     from oracle import adamvs_oracle as O          # checker / baseline only
     c = synth.CONFIGS[cfg]
     imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0)
     sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
-    with torch.no_grad():
+    threads = min(os.cpu_count() or 1, 32)          # more threads than that only add scheduling overhead to the small ops
+    torch.set_num_threads(threads)
+    with torch.no_grad(), O.use_grid_sample():
         feats = [O.feature_net(imgs[:, v], sd_cpu) for v in range(c["views"])]
         t0 = time.time()
         O.infer_adamvs_forward(imgs, proj, dv, sd_cpu, c["num_depth"], c["ndepths"],
                                synth.DEPTH_INTERVALS_RATIO[:len(c["ndepths"])], features=feats)
         dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "depth maps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 tile of %s, hot path only (features precomputed), %.1f s, oracle/adamvs_oracle.py" % (cfg, dt)}
+    return {"value": 1.0 / dt, "unit": "depth maps/s", "cores": threads, "kind": "port",
+            "sample": "1 tile of %s, hot path only (features precomputed), %.1f s, oracle/adamvs_oracle.py "
+                      "(grid_sample form of the warp, as the reference issues it)" % (cfg, dt)}
 
 
 def main():
@@ -267,27 +293,47 @@ def main():
             times = timed_phases(model, feats_cl, shapes, projs[0], dvs[0], interval, max(2, min(args.steps, 5)))
             work = algorithmic_work(cfg, Bg)
             avg = {k: sum(v[1:]) / max(len(v) - 1, 1) for k, v in times.items()}        # drop the first call
-            result["phase_ms_per_step"] = {k: round(v, 4) for k, v in sorted(avg.items())}
-            dom = max(avg, key=avg.get)
+            phases = {}
+            for k, v in avg.items():                                                   # fold the per-layer marks
+                key = k.split(".costreg.")[0] + ".cost_reg_net_2d" if ".costreg." in k else k
+                phases[key] = phases.get(key, 0.0) + v
+            result["phase_ms_per_step"] = {k: round(v, 4) for k, v in sorted(phases.items())}
+            dom = max(phases, key=phases.get)
             st = work[int(dom[1]) - 1]
             kind = dom.split(".", 1)[1]
+            c0 = synth.CONFIGS[cfg]
             if kind == "cost_reg_net_2d":
-                ach = st["costreg_flops"] / (avg[dom] * 1e-3) / 1e12
-                roof = {"kernel": "k_conv_dd (CostRegNet2D, 11 launches)", "bound": "mfma", "achieved": ach,
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None}
+                # dominant kernel = the stride-1 instantiation of k_conv_dd (conv0, conv2, conv4, conv6, prob)
+                lay = {k: v for k, v in avg.items() if ".costreg." in k and k.endswith("mode0")}
+                hw0, Dd, N = st["h"] * st["w"], st["D"], (c0["views"] - 1) * Bg
+                res = {"conv0": 1, "conv2": 4, "conv4": 16, "conv6": 64, "prob": 1}
+                flops = sum(2.0 * N * (hw0 // res[k.split(".")[2]]) * Dd * Dd * 9 for k in lay)
+                ms = sum(lay.values())
+                ach = flops / (ms * 1e-3) / 1e12
+                roof = {"kernel": "k_conv_dd<MT,WM,CONV_S1> (CostRegNet2D 3x3 stride-1 layers, %d launches per step)" % len(lay),
+                        "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "launch_ms": ms / len(lay),
+                        "flops_per_launch": flops / len(lay), "traffic": None}
+                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                if os.path.exists(tpath):          # HBM bytes per launch from the committed PMC passes, same workload and batch
+                    tj = json.load(open(tpath))
+                    if tj["config"] == {"workload": cfg, "tiles_per_launch": Bg}:
+                        k0 = [v for k, v in tj["kernels"].items() if "k_conv_dd<3, 4, 0>" in k]
+                        if k0:
+                            roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
+                            roof["traffic_note"] = "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), profiles/r01_traffic.json"
             elif kind == "recurrence":
                 ach = st["recurrence_flops"] / (avg[dom] * 1e-3) / 1e12
-                roof = {"kernel": "k_conv_small/k_decoder (%d recurrent steps x 6 launches)" % st["D"], "bound": "mfma",
+                roof = {"kernel": "recurrent step kernels (%d steps x 6 launches)" % st["D"], "bound": "mfma",
                         "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                        "traffic": None}
+                        "launch_ms": avg[dom] / (6 * st["D"]), "traffic": None}
             else:
                 key = {"pair_similarity": "pair_similarity_bytes", "aggregate_conv1": "aggregate_bytes",
                        "soft_argmin": "softargmin_bytes", "softmax_max_regress": "softmax_bytes",
                        "view_weight_resample": "softmax_bytes"}[kind]
                 ach = st[key] / (avg[dom] * 1e-3) / 1e9
                 roof = {"kernel": "k_" + kind, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
-            roof["launch_ms"] = avg[dom]
+                        "frac": ach / HBM_PEAK_GBS, "launch_ms": avg[dom], "traffic": None}
             roof["dominant_phase"] = dom
             result["roofline"] = roof
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

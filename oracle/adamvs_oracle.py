@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 
 __all__ = [
-    "relative_transform", "warp_plane", "depth_range_samples", "upsample2x",
+    "relative_transform", "warp_plane", "warp_plane_grid_sample", "use_grid_sample", "depth_range_samples", "upsample2x",
     "pair_similarity_volume", "cost_reg_net_2d", "softmax_max_regress",
     "aggregate_similarity", "conv_gru_cell", "slice_reg_step", "infer_depth_stage",
     "feature_net", "infer_adamvs_forward",
@@ -77,6 +77,34 @@ def warp_plane(src_fea, R, t, depth):
         g = torch.gather(flat, 2, idx.unsqueeze(1).expand(B, C, h * w))
         out += g * (ww * ok.to(ww.dtype)).unsqueeze(1)
     return out.reshape(B, C, h, w)
+
+
+def warp_plane_grid_sample(src_fea, R, t, depth):
+    """Same warp through F.grid_sample, the way the reference issues it (module.py:554-564).  Used by the timed
+    CPU baseline (ATen's vectorised sampler instead of the explicit gather above); tests hold the two equal."""
+    B, C, h, w = src_fea.shape
+    dev = src_fea.device
+    y, x = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev),
+                          torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
+    xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(h * w, device=dev)))
+    p = torch.matmul(R, xyz.unsqueeze(0).expand(B, 3, h * w)) * depth.reshape(B, 1, h * w) + t.reshape(B, 3, 1)
+    gx = (p[:, 0] / p[:, 2]) / ((w - 1) / 2) - 1
+    gy = (p[:, 1] / p[:, 2]) / ((h - 1) / 2) - 1
+    grid = torch.stack((gx, gy), dim=2).view(B, h, w, 2)
+    return F.grid_sample(src_fea, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+
+
+_WARP = [warp_plane]          # the sampler the composite functions below use (swapped by use_grid_sample)
+
+
+class use_grid_sample:
+    """Context manager: run the composite oracle functions with the grid_sample form of the warp."""
+
+    def __enter__(self):
+        _WARP[0] = warp_plane_grid_sample
+
+    def __exit__(self, *a):
+        _WARP[0] = warp_plane
 
 
 # ----------------------------------------------------------------------------
@@ -136,7 +164,7 @@ def pair_similarity_volume(ref_fea, src_fea, R, t, depth_values):
     D = depth_values.shape[1]
     sims = []
     for d in range(D):
-        warped = warp_plane(src_fea, R, t, depth_values[:, d])
+        warped = _WARP[0](src_fea, R, t, depth_values[:, d])
         sims.append((ref_fea * warped).mean(dim=1))
     return torch.stack(sims, dim=1)
 
@@ -189,7 +217,7 @@ def aggregate_similarity(ref_fea, src_feas, Rs, ts, depth_plane, view_weights):
     sim_sum = 0
     w_sum = 1e-5
     for src, R, t, wgt in zip(src_feas, Rs, ts, view_weights):
-        warped = warp_plane(src, R, t, depth_plane)
+        warped = _WARP[0](src, R, t, depth_plane)
         sim_sum = sim_sum + (warped * ref_fea) * wgt
         w_sum = w_sum + wgt
     return sim_sum / w_sum

@@ -19,6 +19,7 @@ def test_warp_in_bounds_and_out_of_bounds():
         for d in range(g["depth"].shape[1]):
             out = O.warp_plane(g["src"], R, t, g["depth"][:, d])
             assert rel_l1(out, g["out"][:, :, d]) < TOL, name
+            assert rel_l1(O.warp_plane_grid_sample(g["src"], R, t, g["depth"][:, d]), out) < 1e-5     # baseline form
     g = load_golden("op_warp_oob")
     zero_frac = float((g["out"].abs().sum(1) == 0).float().mean())
     assert 0.05 < zero_frac < 0.95, "fixture must mix in- and out-of-bounds pixels (%g)" % zero_frac
