@@ -195,8 +195,9 @@ __device__ __forceinline__ f32x4 upconv1_class(const float (&wf)[1][9][4], const
   return acc;
 }
 
+// Persistent like k_conv_small: grid = resident capacity, workgroup i takes tiles i, i + grid, ...
 template <bool IN_UP>
-__global__ __launch_bounds__(256) void k_decoder(DecoderArgs a) {
+__global__ __launch_bounds__(256) void k_decoder(DecoderArgs a, int tiles_x, int tiles_y, int ntiles) {
   constexpr int HR = 10, HCOLS = 18, HPLANE = plane_pitch16(HR * HCOLS);   // h2 region, 16 planes in 4 groups
   constexpr int HGP = group_pitch(HPLANE, 4);
   constexpr int SR = 16, SC = 32, SPLANE = plane_pitch16(SR * SC);        // s region, 8 planes
@@ -204,13 +205,14 @@ __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a) {
   float* lh2 = lds;
   float* ls = lds + 4 * HGP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z;
-  const int x0 = blockIdx.x * 30, y0 = blockIdx.y * 14;     // both even
   const int h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1;
-  const int i0 = (y0 >> 1) - 1, j0 = (x0 >> 1) - 1;         // h2-region origin
-
   float wf[1][9][4];
   load_wfrag<1, 4>(wf, a.wup1, lane);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int b = tile / (tiles_x * tiles_y);
+  const int x0 = (tile % tiles_x) * 30, y0 = ((tile / tiles_x) % tiles_y) * 14;     // both even
+  const int i0 = (y0 >> 1) - 1, j0 = (x0 >> 1) - 1;         // h2-region origin
 
   constexpr int NITEMS = HR * HCOLS * 4, NIT = (NITEMS + 255) / 256;
   f32x4 stage[NIT];
@@ -317,6 +319,8 @@ __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a) {
         }
       out[(size_t)y * w + x] = accv;
     }
+  }
+  __syncthreads();     // the next tile reuses both LDS regions
   }
 }
 
@@ -509,9 +513,15 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
     if ((rc = launch_small<16, 16, 1, 1, EPI_CAND>(c, B, st, "cand2"))) return rc;
   }
   DecoderArgs da{sb.h2, sb.h1, fw.upconv1, fw.upconv1_b, fw.final_w, vol, h, w, D, d};
-  dim3 grid(cdiv(w, 30), cdiv(h, 14), B);
-  if (in_up) hipLaunchKernelGGL((k_decoder<true>), grid, dim3(256), 0, st, da);
-  else hipLaunchKernelGGL((k_decoder<false>), grid, dim3(256), 0, st, da);
+  const int tiles_x = cdiv(w, 30), tiles_y = cdiv(h, 14), ntiles = tiles_x * tiles_y * B;
+  static int cap_up = 0, cap_flat = 0;          // resident capacity per instantiation (pure function of kernel + device)
+  if (in_up) {
+    if (!cap_up) cap_up = resident_blocks(k_decoder<true>, 256, 0);
+    hipLaunchKernelGGL((k_decoder<true>), dim3(ntiles < cap_up ? ntiles : cap_up), dim3(256), 0, st, da, tiles_x, tiles_y, ntiles);
+  } else {
+    if (!cap_flat) cap_flat = resident_blocks(k_decoder<false>, 256, 0);
+    hipLaunchKernelGGL((k_decoder<false>), dim3(ntiles < cap_flat ? ntiles : cap_flat), dim3(256), 0, st, da, tiles_x, tiles_y, ntiles);
+  }
   ADAMVS_CHECK_LAUNCH("decoder");
   return 0;
 }

@@ -21,7 +21,7 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ADAMVS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -47,7 +47,10 @@ def gather_maps(depth, conf, n_tiles, dst=0):
     rank, world = dist.get_rank(), dist.get_world_size()
     per_rank = (n_tiles + world - 1) // world
     H, W = depth.shape[-2:]
-    pack = torch.zeros(2, per_rank, H, W, device=depth.device, dtype=depth.dtype)
+    dev = depth.device
+    if dist.get_backend() == "gloo" and dev.type != "cpu":
+        dev = torch.device("cpu")          # gloo gathers host tensors (CPU tests, single-GPU dry runs of the N > 1 path)
+    pack = torch.zeros(2, per_rank, H, W, device=dev, dtype=depth.dtype)
     own = depth.shape[0]
     pack[0, :own] = depth
     pack[1, :own] = conf
@@ -55,7 +58,7 @@ def gather_maps(depth, conf, n_tiles, dst=0):
     dist.gather(pack, bufs, dst=dst)
     if rank != dst:
         return None, None
-    out_d = torch.empty(n_tiles, H, W, device=depth.device, dtype=depth.dtype)
+    out_d = torch.empty(n_tiles, H, W, device=dev, dtype=depth.dtype)
     out_c = torch.empty_like(out_d)
     for r in range(world):
         idx = tiles_of_rank(n_tiles, r, world)

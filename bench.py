@@ -186,6 +186,8 @@ def main():
     rank, world, local = adist.init_from_env()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if os.environ.get("ADAMVS_BENCH_ONE_DEVICE"):     # dry run of the N > 1 path on a 1-GPU box (with ADAMVS_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()
@@ -269,7 +271,7 @@ def main():
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            t = torch.tensor([elapsed], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
 
