@@ -27,7 +27,7 @@ class FuseWeights(ctypes.Structure):
 
 class StageDesc(ctypes.Structure):
     """adamvs_stage_desc"""
-    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w")]
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision")]
 
 
 # name -> (restype, argtypes); every symbol include/adamvs_hip.h declares
@@ -44,8 +44,8 @@ SIGNATURES = {
     "adamvs_homo_warp": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_pair_similarity": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_cost_reg_net_2d_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
-    "adamvs_cost_reg_net_2d": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
-    "adamvs_conv3x3_dd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_cost_reg_net_2d": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_conv3x3_dd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_softmax_max_regress": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_aggregate_conv1_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "adamvs_aggregate_conv1": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
@@ -58,6 +58,7 @@ SIGNATURES = {
 }
 
 ABI_VERSION = 1
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15
 _lib = None
 

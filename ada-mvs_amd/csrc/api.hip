@@ -60,7 +60,10 @@ static int check_desc(const adamvs_stage_desc* d) {
   ADAMVS_CHECK_ARG(d->C == 8 || d->C == 16 || d->C == 32, "stage: C=%d unsupported (8, 16 or 32)", d->C);
   ADAMVS_CHECK_ARG((d->h % 2) == 0 && (d->w % 2) == 0, "stage: h=%d w=%d must be even", d->h, d->w);
   ADAMVS_CHECK_ARG((size_t)d->B * d->D <= 65535, "stage: B*D=%d exceeds the grid z limit", d->B * d->D);
+  ADAMVS_CHECK_ARG(d->precision == PRECISION_FP32 || d->precision == PRECISION_BF16X3, "stage: precision=%d (0 fp32, 1 bf16x3)", d->precision);
   if (d->first_stage) {
+    ADAMVS_CHECK_ARG(d->precision == PRECISION_FP32 || costreg_bf16x3_depth_supported(d->D),
+                     "stage: bf16x3 CostRegNet2D needs D in {32,64,96,128,192,256}, got %d", d->D);
     ADAMVS_CHECK_ARG(costreg_depth_supported(d->D), "stage: D=%d unsupported by CostRegNet2D (16,32,48,64,96,128,192,256)", d->D);
     ADAMVS_CHECK_ARG((d->h % 8) == 0 && (d->w % 8) == 0, "stage: first stage needs h=%d w=%d multiples of 8", d->h, d->w);
   } else {
@@ -128,7 +131,7 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   if (!(phases & ADAMVS_PHASE_VIEW_WEIGHTS)) {
   } else if (s.first_stage) {
     if ((rc = adamvs_pair_similarity(feat, rt, planes, ws + c.sim, s.B, s.S, s.C, s.D, s.h, s.w, stream))) return rc;
-    if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, st))) return rc;
+    if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, s.precision, st))) return rc;
     if ((rc = launch_softmax_regress(ws + c.score, planes, view_weight, pair_depth, s.S, s.B, s.D, s.h, s.w, st))) return rc;
   } else {
     if ((rc = adamvs_resize_bilinear(prev_conf, view_weight, s.S * s.B, s.prev_h, s.prev_w, s.h, s.w, stream))) return rc;

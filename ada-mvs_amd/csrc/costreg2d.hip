@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
 // Layer plan.  Packed weights: 11 layers x (9*D*D fragment floats + D bias floats), in the order
 // conv0..conv6, conv7, conv9, conv11, prob.  Workspace: 3 * N*h*w*D floats.
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
-                           hipStream_t st) {
+                           int precision, hipStream_t st) {
   const size_t F = (size_t)N * h * w * D;
   const size_t LW = (size_t)9 * D * D + D;
   float* conv0 = ws;                  // F
@@ -284,9 +284,15 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
   };
   for (int i = 0; i < 11; ++i) {
     const float* wl = wpk + (size_t)i * LW;
-    ConvDDArgs a{plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, D,
-                 plan[i].hi, plan[i].wi, plan[i].ho, plan[i].wo, plan[i].relu};
-    int rc = launch_conv_dd(a, N, plan[i].mode, st);
+    int rc;
+    if (precision == PRECISION_BF16X3) {
+      rc = launch_conv_dd_bf16x3(plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, N, D, plan[i].hi,
+                                 plan[i].wi, plan[i].ho, plan[i].wo, plan[i].mode, plan[i].relu, st);
+    } else {
+      ConvDDArgs a{plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, D,
+                   plan[i].hi, plan[i].wi, plan[i].ho, plan[i].wo, plan[i].relu};
+      rc = launch_conv_dd(a, N, plan[i].mode, st);
+    }
     if (rc) return rc;
   }
   return 0;
@@ -309,8 +315,16 @@ extern "C" size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, in
   return (size_t)3 * N * h * w * D * sizeof(float);
 }
 
+static int check_precision(int precision, int D, const char* who) {
+  ADAMVS_CHECK_ARG(precision == PRECISION_FP32 || precision == PRECISION_BF16X3, "%s: precision=%d (0 fp32, 1 bf16x3)", who, precision);
+  ADAMVS_CHECK_ARG(precision == PRECISION_FP32 || costreg_bf16x3_depth_supported(D),
+                   "%s: bf16x3 needs D in {32,64,96,128,192,256}, got %d", who, D);
+  return 0;
+}
+
 extern "C" int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N, int D, int h, int w,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+                                      int precision, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_precision(precision, D, "cost_reg_net_2d")) return rc;
   ADAMVS_CHECK_ARG(x && wpk && score && workspace && N > 0 && h > 0 && w > 0, "cost_reg_net_2d: bad arguments");
   ADAMVS_CHECK_ARG(costreg_depth_supported(D), "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
   ADAMVS_CHECK_ARG((h % 8) == 0 && (w % 8) == 0, "cost_reg_net_2d: h=%d w=%d must be multiples of 8 (three stride-2 levels)", h, w);
@@ -318,11 +332,12 @@ extern "C" int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* s
                    "cost_reg_net_2d: workspace too small (%zu < %zu bytes)", workspace_bytes,
                    adamvs_cost_reg_net_2d_workspace_bytes(N, D, h, w));
   ADAMVS_CHECK_ARG((size_t)N * 4 <= 65535, "cost_reg_net_2d: N=%d exceeds the grid z limit", N);
-  return launch_cost_reg_net_2d(x, wpk, (float*)workspace, score, N, D, h, w, (hipStream_t)stream);
+  return launch_cost_reg_net_2d(x, wpk, (float*)workspace, score, N, D, h, w, precision, (hipStream_t)stream);
 }
 
 extern "C" int adamvs_conv3x3_dd(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N,
-                                 int D, int hi, int wi, int mode, int relu, void* stream) {
+                                 int D, int hi, int wi, int mode, int relu, int precision, void* stream) {
+  if (int rc = check_precision(precision, D, "conv3x3_dd")) return rc;
   ADAMVS_CHECK_ARG(in && wpk && bias && out && N > 0 && hi > 0 && wi > 0, "conv3x3_dd: bad arguments");
   ADAMVS_CHECK_ARG(costreg_depth_supported(D), "conv3x3_dd: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
   ADAMVS_CHECK_ARG(mode >= 0 && mode <= 2, "conv3x3_dd: mode=%d (0 stride 1, 1 stride 2, 2 transposed stride 2)", mode);
@@ -330,6 +345,8 @@ extern "C" int adamvs_conv3x3_dd(const float* in, const float* wpk, const float*
   ADAMVS_CHECK_ARG((size_t)N * 4 <= 65535, "conv3x3_dd: N=%d exceeds the grid z limit", N);
   int ho = mode == CONV_S2 ? hi / 2 : (mode == CONV_T2 ? 2 * hi : hi);
   int wo = mode == CONV_S2 ? wi / 2 : (mode == CONV_T2 ? 2 * wi : wi);
+  if (precision == PRECISION_BF16X3)
+    return launch_conv_dd_bf16x3(in, wpk, bias, skip, out, N, D, hi, wi, ho, wo, mode, relu, (hipStream_t)stream);
   ConvDDArgs a{in, wpk, bias, skip, out, D, hi, wi, ho, wo, relu};
   return launch_conv_dd(a, N, mode, (hipStream_t)stream);
 }

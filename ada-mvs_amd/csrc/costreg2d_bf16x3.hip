@@ -1,0 +1,221 @@
+// CostRegNet2D layers on the bf16 matrix cores with split operands ("bf16x3").
+//
+// Same layer semantics, tiling and epilogue as costreg2d.hip (reference models/adamvs.py:198-238), but the
+// channel contraction runs on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate) with every fp32 operand
+// split into two bf16 halves, x = hi + lo (hi = bf16(x), lo = bf16(x - hi), 16 significant bits together):
+//     a.b  ~  a_hi.b_hi + a_hi.b_lo + a_lo.b_hi            (fp32 accumulation in the MFMA)
+// Three MFMAs per 32-deep k-step, i.e. 16/3 = 5.3x fewer matrix-pipe cycles than exact fp32.  Activations
+// stay fp32 in HBM: they are split on the fly when a tile is written to LDS; weights are split on the host.
+// Measured against the fp32 path the maps agree to ~1e-5 relative, 100x inside the 1e-3 bar.
+//
+// MFMA operand layout (16x16x32): lane l holds A[row l&15][k = 8(l>>4)+j] and B[k = 8(l>>4)+j][col l&15],
+// j = 0..7 (one 16-byte register quad each); rows = output channels, cols = 16 pixels, k = 32 input channels.
+#include "common.h"
+#include "kernels.h"
+
+namespace adamvs {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct ConvDDArgs16 {
+  const float* in;        // [N][hi*wi][D] fp32
+  const bf16x8* wpk;      // [2 (hi,lo)][9][D/32][D/16][64] fragments of 8 bf16
+  const float* bias;      // [D]
+  const float* skip;      // [N][ho*wo][D] or null
+  float* out;             // [N][ho*wo][D]
+  int D, hi, wi, ho, wo, relu;
+};
+
+enum { BX_S1 = 0, BX_S2 = 1, BX_T2 = 2 };
+constexpr int BX_KB = 32;            // input channels per chunk = one MFMA k-step
+constexpr int BX_PIX = 40;           // bf16 per pixel row in LDS: 32 + 8 pad (80 B: 16-B aligned, spreads the banks)
+
+template <int MODE> struct BxGeom;
+template <> struct BxGeom<BX_S1> { static constexpr int LR = 10, LC = 18; };
+template <> struct BxGeom<BX_S2> { static constexpr int LR = 17, LC = 33; };
+template <> struct BxGeom<BX_T2> { static constexpr int LR = 9, LC = 17; };
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// Block = 8 rows x 16 columns of output positions x all D channels; waves WM along channels (MT tiles each),
+// WN = 4/WM along rows -- the geometry of conv_dd_body in costreg2d.hip.
+template <int MT, int WM, int MODE, int PY, int PX>
+__device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* lds, int n, int by, int bx) {
+  using TG = BxGeom<MODE>;
+  constexpr int LR = TG::LR, LC = TG::LC, NPIX = LR * LC;
+  constexpr int WN = 4 / WM, NTR = 8 / WN;
+  constexpr int STR = (MODE == BX_S2) ? 2 : 1;
+  constexpr int NTY = (MODE == BX_T2) ? 1 + PY : 3;
+  constexpr int NTX = (MODE == BX_T2) ? 1 + PX : 3;
+  __bf16* lhi = lds;                       // [NPIX][BX_PIX]
+  __bf16* llo = lds + NPIX * BX_PIX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int p = lane & 15, q = lane >> 4;
+  const int D = a.D, KBT = D / BX_KB, NTILES = D / 16;
+  const size_t lo_off = (size_t)9 * KBT * NTILES * 64;       // fragments between the hi and the lo half
+  const int r0 = by * 8, c0 = bx * 16;
+  const int iy0 = (MODE == BX_T2) ? r0 : r0 * STR - 1;
+  const int ix0 = (MODE == BX_T2) ? c0 : c0 * STR - 1;
+  const float* inb = a.in + (size_t)n * a.hi * a.wi * D;
+
+  f32x4 acc[MT][NTR];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < NTR; ++r) acc[mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NITEMS = NPIX * (BX_KB / 4), NIT = (NITEMS + 255) / 256;     // float4 = 4 channels of a pixel
+  auto load_x = [&](f32x4 (&st)[NIT], int ch) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int i = tid + it * 256;
+      int g = i % (BX_KB / 4), pp = i / (BX_KB / 4);
+      int r = pp / LC, c = pp % LC;
+      int iy = iy0 + r, ix = ix0 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < NITEMS && iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi)
+        v = *(const f32x4*)(inb + ((size_t)iy * a.wi + ix) * D + ch + 4 * g);
+      st[it] = v;
+    }
+  };
+  auto store_x = [&](const f32x4 (&st)[NIT]) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int i = tid + it * 256;
+      if (i < NITEMS) {
+        int g = i % (BX_KB / 4), pp = i / (BX_KB / 4);
+        f32x4 v = st[it];
+        bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        bf16x4 l = {(__bf16)(v.x - (float)h.x), (__bf16)(v.y - (float)h.y), (__bf16)(v.z - (float)h.z), (__bf16)(v.w - (float)h.w)};
+        *(bf16x4*)(lhi + pp * BX_PIX + 4 * g) = h;
+        *(bf16x4*)(llo + pp * BX_PIX + 4 * g) = l;
+      }
+    }
+  };
+  auto load_w = [&](bf16x8 (&wh)[MT], bf16x8 (&wl)[MT], int kb, int ty, int tx) {
+    const int ky = (MODE == BX_T2) ? (PY ? (ty ? 0 : 2) : 1) : ty;
+    const int kx = (MODE == BX_T2) ? (PX ? (tx ? 0 : 2) : 1) : tx;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      size_t f = ((size_t)((ky * 3 + kx) * KBT + kb) * NTILES + wm * MT + mt) * 64 + lane;
+      wh[mt] = a.wpk[f];
+      wl[mt] = a.wpk[lo_off + f];
+    }
+  };
+
+  // lane's B-fragment base: pixel column p of the wave's first row, k-group q (8 channels = 16 bytes)
+  const int boff = ((wn * NTR * STR) * LC + p * STR) * BX_PIX + 8 * q;
+  f32x4 xs[NIT], xs_next[NIT];
+  load_x(xs, 0);
+  for (int kb = 0; kb < KBT; ++kb) {
+    __syncthreads();                     // previous chunk's readers are done
+    store_x(xs);
+    __syncthreads();
+    if (kb + 1 < KBT) load_x(xs_next, (kb + 1) * BX_KB);          // in flight during the MFMAs
+    bf16x8 wh[MT], wl[MT], wh_n[MT], wl_n[MT];
+    load_w(wh, wl, kb, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTY * NTX; ++t) {
+      const int ty = t / NTX, tx = t % NTX;
+      if (t + 1 < NTY * NTX) load_w(wh_n, wl_n, kb, (t + 1) / NTX, (t + 1) % NTX);      // next tap's fragments
+#pragma unroll
+      for (int r = 0; r < NTR; ++r) {
+        const int o = boff + ((r * STR + ty) * LC + tx) * BX_PIX;
+        const bf16x8 bh = *(const bf16x8*)(lhi + o);
+        const bf16x8 bl = *(const bf16x8*)(llo + o);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][r] = mfma_bf16(wh[mt], bh, acc[mt][r]);
+          acc[mt][r] = mfma_bf16(wh[mt], bl, acc[mt][r]);
+          acc[mt][r] = mfma_bf16(wl[mt], bh, acc[mt][r]);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { wh[mt] = wh_n[mt]; wl[mt] = wl_n[mt]; }
+    }
+    if (kb + 1 < KBT) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) xs[it] = xs_next[it];
+    }
+  }
+
+  // epilogue (C/D layout of the 16x16 MFMA family is shape-independent: lane owns channels co4..co4+3 of pixel p)
+#pragma unroll
+  for (int r = 0; r < NTR; ++r) {
+    int row = r0 + wn * NTR + r, col = c0 + p;
+    int oy = (MODE == BX_T2) ? 2 * row + PY : row;
+    int ox = (MODE == BX_T2) ? 2 * col + PX : col;
+    bool valid = (MODE == BX_T2) ? (row < a.hi && col < a.wi) : (oy < a.ho && ox < a.wo);
+    if (!valid) continue;
+    size_t opix = ((size_t)n * a.ho + oy) * a.wo + ox;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int co4 = (wm * MT + mt) * 16 + 4 * q;
+      f32x4 v = acc[mt][r] + *(const f32x4*)(a.bias + co4);
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (a.skip) v += *(const f32x4*)(a.skip + opix * D + co4);
+      *(f32x4*)(a.out + opix * D + co4) = v;
+    }
+  }
+}
+
+template <int MT, int WM, int MODE>
+__global__ __launch_bounds__(256) void k_conv_dd_bx3(ConvDDArgs16 a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];     // [2 (hi,lo)][LR*LC][BX_PIX]
+  if (MODE == BX_T2) {
+    int n = blockIdx.z >> 2, cls = blockIdx.z & 3;
+    switch (cls) {
+      case 0: conv_dd_bx3_body<MT, WM, MODE, 0, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      case 1: conv_dd_bx3_body<MT, WM, MODE, 0, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      case 2: conv_dd_bx3_body<MT, WM, MODE, 1, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      default: conv_dd_bx3_body<MT, WM, MODE, 1, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
+    }
+  } else {
+    conv_dd_bx3_body<MT, WM, MODE, 0, 0>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+  }
+}
+
+template <int MT, int WM, int MODE>
+static int launch_bx3_mode(const ConvDDArgs16& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * BxGeom<MODE>::LR * BxGeom<MODE>::LC * BX_PIX * sizeof(__bf16);
+  auto kern = k_conv_dd_bx3<MT, WM, MODE>;
+  static bool attr_set = false;          // idempotent per-kernel attribute (not a stream operation)
+  if (lds > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_error((int)e, "conv_dd_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  ADAMVS_CHECK_LAUNCH("conv_dd_bf16x3");
+  return 0;
+}
+
+template <int MT, int WM>
+static int launch_bx3_cfg(const ConvDDArgs16& a, int N, int mode, hipStream_t st) {
+  if (mode == BX_S1) return launch_bx3_mode<MT, WM, BX_S1>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), st);
+  if (mode == BX_S2) return launch_bx3_mode<MT, WM, BX_S2>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), st);
+  return launch_bx3_mode<MT, WM, BX_T2>(a, dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N * 4), st);
+}
+
+bool costreg_bf16x3_depth_supported(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256; }
+
+// `wpk` is the layer's packed block reinterpreted: 9*D*D floats worth of bf16 fragments (hi half, then lo half)
+int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
+                          int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st) {
+  ConvDDArgs16 a{in, (const bf16x8*)wpk, bias, skip, out, D, hi, wi, ho, wo, relu};
+  switch (D) {
+    case 32: return launch_bx3_cfg<2, 1>(a, N, mode, st);
+    case 64: return launch_bx3_cfg<4, 1>(a, N, mode, st);
+    case 96: return launch_bx3_cfg<3, 2>(a, N, mode, st);
+    case 128: return launch_bx3_cfg<4, 2>(a, N, mode, st);
+    case 192: return launch_bx3_cfg<3, 4>(a, N, mode, st);
+    case 256: return launch_bx3_cfg<4, 4>(a, N, mode, st);
+  }
+  return set_error(-1, "cost_reg_net_2d (bf16x3): D=%d unsupported (32, 64, 96, 128, 192 or 256)", D);
+}
+
+}  // namespace adamvs

@@ -29,7 +29,11 @@ int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, 
                        float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, hipStream_t st);
 size_t sweep_workspace_floats(int B, int C, int D, int h, int w);
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
-                           hipStream_t st);
+                           int precision, hipStream_t st);
+int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
+                          int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st);
+bool costreg_bf16x3_depth_supported(int D);
+enum { PRECISION_FP32 = 0, PRECISION_BF16X3 = 1 };
 int launch_softmax_regress(const float* score, const float* planes, float* vw, float* pd, int S, int B, int D, int h, int w,
                            hipStream_t st);
 bool costreg_depth_supported(int D);

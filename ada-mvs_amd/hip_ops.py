@@ -118,7 +118,7 @@ def pair_similarity(feat, rt, planes, B, S, C, D, h, w):
     return sim
 
 
-def cost_reg_net_2d(x_cl, wpk, h, w):
+def cost_reg_net_2d(x_cl, wpk, h, w, precision=0):
     """x_cl [N,hw,D] channel-last -> score [N,hw,D]   (adamvs.py:229-238)"""
     x_cl = _dev(x_cl, "x")
     N, hw, D = x_cl.shape
@@ -126,7 +126,8 @@ def cost_reg_net_2d(x_cl, wpk, h, w):
     nbytes = lib.adamvs_cost_reg_net_2d_workspace_bytes(N, D, h, w)
     ws = torch.empty(nbytes // 4, device=x_cl.device, dtype=torch.float32)
     score = torch.empty_like(x_cl)
-    check(lib.adamvs_cost_reg_net_2d(_p(x_cl), _p(wpk), _p(score), N, D, h, w, _p(ws), nbytes, _stream()), "cost_reg_net_2d")
+    check(lib.adamvs_cost_reg_net_2d(_p(x_cl), _p(wpk), _p(score), N, D, h, w, int(precision), _p(ws), nbytes, _stream()),
+          "cost_reg_net_2d")
     return score
 
 
@@ -176,8 +177,8 @@ def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up):
     return reg
 
 
-def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0)):
-    return StageDesc(B, S, C, h, w, D, int(in_up), int(first_stage), int(prev_hw[0]), int(prev_hw[1]))
+def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0), precision=0):
+    return StageDesc(B, S, C, h, w, D, int(in_up), int(first_stage), int(prev_hw[0]), int(prev_hw[1]), int(precision))
 
 
 def depth_stage_workspace_bytes(desc):
@@ -187,13 +188,13 @@ def depth_stage_workspace_bytes(desc):
     return n
 
 
-def conv3x3_dd(x_cl, wpk_layer, bias, skip, N, D, hi, wi, mode, relu, out=None):
+def conv3x3_dd(x_cl, wpk_layer, bias, skip, N, D, hi, wi, mode, relu, out=None, precision=0):
     """One CostRegNet2D layer on channel-last maps (mode 0 stride 1, 1 stride 2, 2 transposed stride 2)."""
     ho, wo = (hi // 2, wi // 2) if mode == 1 else ((2 * hi, 2 * wi) if mode == 2 else (hi, wi))
     if out is None:
         out = torch.empty(N, ho * wo, D, device=x_cl.device, dtype=torch.float32)
     check(_lib.load().adamvs_conv3x3_dd(_p(x_cl), _p(wpk_layer), _p(bias), _p(skip) if skip is not None else ctypes.c_void_p(0),
-                                        _p(out), N, D, hi, wi, mode, int(relu), _stream()), "conv3x3_dd")
+                                        _p(out), N, D, hi, wi, mode, int(relu), int(precision), _stream()), "conv3x3_dd")
     return out
 
 

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ada_mvs_amd import hip_ops, packing
-from ada_mvs_amd._lib import AdaMVSHipError
+from ada_mvs_amd._lib import AdaMVSHipError, PRECISIONS as _PRECISIONS
 from .module import Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse
 
 STAGE_SCALE = {"stage1": 4, "stage2": 2, "stage3": 1}
@@ -85,16 +85,22 @@ class CostRegNet2D(nn.Module):
                 nn.ConvTranspose2d(d, d, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
                 nn.BatchNorm2d(d), nn.ReLU(inplace=True)))
         self.prob = nn.Conv2d(d, d, 3, stride=1, padding=1)
+        self.precision = "fp32"            # or "bf16x3": split-bf16 MFMA, fp32-equivalent to ~1e-5 (needs d % 32 == 0)
         self._packed = None
 
+    def effective_precision(self):
+        return self.precision if self.prob.weight.shape[0] % 32 == 0 else "fp32"
+
     def packed(self, device):
-        if self._packed is None or self._packed.device != device:
-            self._packed = packing.pack_cost_reg_net_2d(self.state_dict(), "").to(device)
-        return self._packed
+        prec = self.effective_precision()
+        if self._packed is None or self._packed[0] != prec or self._packed[1].device != device:
+            self._packed = (prec, packing.pack_cost_reg_net_2d(self.state_dict(), "", prec).to(device))
+        return self._packed[1]
 
     def forward(self, x):
         N, D, h, w = x.shape
-        score = hip_ops.cost_reg_net_2d(hip_ops.pack_features(x), self.packed(x.device), h, w)
+        score = hip_ops.cost_reg_net_2d(hip_ops.pack_features(x), self.packed(x.device), h, w,
+                                        _PRECISIONS[self.effective_precision()])
         return hip_ops.unpack_features(score, h, w)
 
 
@@ -165,7 +171,7 @@ class InferDepthNet0(nn.Module):
         D = depth_values.shape[1]
         first = prev_conf is None
         prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
-        desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw)
+        desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()])
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4
         ws = self._workspace.get(group)
         if ws is None or ws.numel() < need or ws.device != feat_cl.device:
@@ -203,8 +209,9 @@ class Infer_AdaMVSNet(nn.Module):
     """reference models/adamvs.py:537-620"""
 
     def __init__(self, num_depth=384, ndepths=[48, 32, 8], depth_intervals_ratio=[4, 2, 1], share_cr=False,
-                 cr_base_chs=[8, 8, 8]):
+                 cr_base_chs=[8, 8, 8], precision="fp32"):
         super().__init__()
+        assert precision in _PRECISIONS, "precision must be one of %s" % sorted(_PRECISIONS)
         assert len(ndepths) == len(depth_intervals_ratio)
         self.num_depth = num_depth
         self.share_cr = share_cr                 # accepted and ignored, as in the reference (quirk Q8)
@@ -219,6 +226,16 @@ class Infer_AdaMVSNet(nn.Module):
         self.DepthNet = nn.ModuleList([InferDepthNet0(in_depths=self.ndepths[0], in_channels=ch[0]),
                                        InferDepthNet0(in_depths=self.ndepths[0], in_channels=ch[1]),
                                        InferDepthNet0(in_depths=self.ndepths[0], in_up=False, in_channels=ch[2])])
+        self.set_precision(precision)
+
+    def set_precision(self, precision):
+        """"fp32": exact fp32 MFMA everywhere (default).  "bf16x3": CostRegNet2D on the bf16 matrix cores with split
+        operands (hi + lo bf16, three MFMAs per product), fp32 accumulation -- agrees with fp32 to ~1e-5."""
+        assert precision in _PRECISIONS
+        self.precision = precision
+        for net in self.DepthNet:
+            net.reg.precision = precision
+            net.reg._packed = None
 
     # ---- the hot path on pre-extracted features ---------------------------------------------
     def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval, group=0):

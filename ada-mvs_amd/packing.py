@@ -66,8 +66,31 @@ def pack_reg_layer(w, scale, shift, transposed):
     return torch.cat([frag, shift.detach().to(torch.float32).cpu().reshape(-1)])
 
 
-def pack_cost_reg_net_2d(sd, pre):
+def split_bf16(x):
+    """fp32 -> (hi, lo) bf16 with hi + lo = x to 16 significant bits."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.to(torch.float32)).to(torch.bfloat16)
+    return hi, lo
+
+
+def pack_reg_layer_bf16x3(w, scale, shift, transposed):
+    """One CostRegNet2D layer for the split-bf16 kernels: 9*D*D floats worth of bf16 fragments
+    [hi|lo][tap][cin/32][cout/16][lane][8] (include/adamvs_hip.h) + [D] fp32 bias; same size as the fp32 packing."""
+    w = _as_cout_cin_tap(w, transposed) * scale.reshape(-1, 1, 1)
+    d = w.shape[0]
+    assert w.shape[1] == d and d % 32 == 0, "bf16x3 CostRegNet2D width must be a multiple of 32"
+    halves = []
+    for part in split_bf16(w):
+        # (tile, co16, kb, kg4, j8, tap) -> (tap, kb, tile, kg4, co16, j8): lane = kg4*16 + co16, 8 bf16 per lane
+        halves.append(part.reshape(d // 16, 16, d // 32, 4, 8, 9).permute(5, 2, 0, 3, 1, 4).contiguous().reshape(-1))
+    frag = torch.cat(halves).view(torch.float32)          # reinterpret the bf16 stream as floats: 9*d*d of them
+    assert frag.numel() == 9 * d * d
+    return torch.cat([frag, shift.detach().to(torch.float32).cpu().reshape(-1)])
+
+
+def pack_cost_reg_net_2d(sd, pre, precision="fp32"):
     """All 11 layers of `pre` (e.g. 'DepthNet.0.reg.') from a reference-keyed state dict."""
+    pack_layer = pack_reg_layer if precision == "fp32" else pack_reg_layer_bf16x3
     chunks = []
     for name in REG_LAYERS:
         if name == "prob":
@@ -86,7 +109,7 @@ def pack_cost_reg_net_2d(sd, pre):
             var = sd[bnpre + "running_var"].detach().float().cpu()
             scale = g / torch.sqrt(var + BN_EPS)
             shift = b - mu * scale
-        chunks.append(pack_reg_layer(w, scale, shift, transposed))
+        chunks.append(pack_layer(w, scale, shift, transposed))
     return torch.cat(chunks)
 
 

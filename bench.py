@@ -32,9 +32,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
 
 
-def build_model(cfg, device):
+def build_model(cfg, device, precision="fp32"):
     c = synth.CONFIGS[cfg]
-    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO[:len(c["ndepths"])], False, [8, 8, 8])
+    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO[:len(c["ndepths"])], False, [8, 8, 8],
+                        precision=precision)
     sd = synth.seeded_state_dict(m, seed=0)
     m.load_state_dict(sd)
     return m.to(device).eval(), sd
@@ -97,7 +98,8 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
             S = feats_cl[s].shape[0] // B - 1
             D = model.ndepths[s]
             first = conf is None
-            desc = hip_ops.stage_desc(B, S, C, h, w, D, net.in_up, first, (0, 0) if first else tuple(conf.shape[-2:]))
+            desc = hip_ops.stage_desc(B, S, C, h, w, D, net.in_up, first, (0, 0) if first else tuple(conf.shape[-2:]),
+                                      _lib.PRECISIONS[net.reg.effective_precision()])
             dev = feats_cl[s].device
             Ho, Wo = (2 * h, 2 * w) if net.in_up else (h, w)
             outs = (torch.empty(S, B, h, w, device=dev), torch.empty(S, B, h, w, device=dev) if first else None,
@@ -113,7 +115,7 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 # pass A split further, op by op; CostRegNet2D layer by layer so that every launch of its
                 # convolution kernel is timed by itself (the roofline object is per launch of one kernel)
                 sim = mark("s%d.pair_similarity" % (s + 1), lambda: hip_ops.pair_similarity(feats_cl[s], rt, planes, B, S, C, D, h, w))
-                score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w)
+                score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w, _lib.PRECISIONS[net.reg.effective_precision()])
                 vw_pd = mark("s%d.softmax_max_regress" % (s + 1), lambda: hip_ops.softmax_max_regress(score, planes, S, B, D, h, w))
                 outs[0].copy_(vw_pd[0])
                 del sim, score
@@ -136,7 +138,7 @@ COSTREG_PLAN = (  # (layer, mode 0 s1 / 1 s2 / 2 transposed, relu, input, skip),
     ("prob", 0, 0, "conv11", None))
 
 
-def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w):
+def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0):
     """CostRegNet2D through the one-layer C-ABI op, one timing mark per launch."""
     LW = 9 * D * D + D
     acts = {"x": (x, h, w)}
@@ -145,7 +147,7 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w):
         wl = wpk[i * LW:(i + 1) * LW]
         sk = acts[skip][0] if skip else None
         out = mark("s%d.costreg.%s.mode%d" % (stage, name, mode),
-                   lambda: hip_ops.conv3x3_dd(xin, wl, wl[9 * D * D:], sk, N, D, hi, wi, mode, relu))
+                   lambda: hip_ops.conv3x3_dd(xin, wl, wl[9 * D * D:], sk, N, D, hi, wi, mode, relu, precision=precision))
         ho, wo = (hi // 2, wi // 2) if mode == 1 else ((2 * hi, 2 * wi) if mode == 2 else (hi, wi))
         acts[name] = (out, ho, wo)
     return acts["prob"][0]
@@ -178,6 +180,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=list(synth.CONFIGS))
     ap.add_argument("--batch", type=int, default=32, help="reference tiles per GPU per step")
     ap.add_argument("--groups", type=int, default=1, help="independent tile groups run concurrently on separate HIP streams")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="fp32: exact fp32 MFMA (the cfg2 headline); bf16x3: split-bf16 MFMA in CostRegNet2D (~1e-5 of fp32)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -193,7 +197,7 @@ def main():
     _lib.load()
     cfg, B = args.workload, args.batch
     c = synth.CONFIGS[cfg]
-    model, sd = build_model(cfg, dev)
+    model, sd = build_model(cfg, dev, args.precision)
     n_tiles = world * B
     my_tiles = adist.tiles_of_rank(n_tiles, rank, world)
     # per-tile seeds = global tile index; this rank's tiles as one batch
@@ -282,7 +286,9 @@ def main():
                 "metric": "depth maps/sec at 768x384x5-view x192-hyp (hot path, features resident in HBM)",
                 "value": n_tiles * args.steps / elapsed, "unit": "depth maps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA, fp32 accumulate) in CostRegNet2D, f32 elsewhere",
+                "data": "synthetic",
                 "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, fp32" % (
                     cfg, c["views"], c["W"], c["H"], "/".join(map(str, c["ndepths"]))),
                     "tiles_per_gpu_per_step": B, "concurrent_tile_groups": G, "global_tiles_per_step": n_tiles,

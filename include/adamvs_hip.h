@@ -77,17 +77,25 @@ int adamvs_pair_similarity(const float* feat, const float* rt, const float* plan
  * A-fragment order [tap][cin/4][cout/16][lane] with value
  * W[cout = 16*tile + (lane&15)][cin = 4*kc + (lane>>4)][tap] * bn_scale[cout]
  * (ConvTranspose2d layers: W[cin][cout][tap]) followed by D bias floats (folded BN shift,
- * or the conv bias for `prob`).  D in {16,32,48,64,96,128,192,256}; h, w multiples of 8. */
+ * or the conv bias for `prob`).  D in {16,32,48,64,96,128,192,256}; h, w multiples of 8.
+ *
+ * precision ADAMVS_PRECISION_FP32 (0): exact fp32 MFMA.  ADAMVS_PRECISION_BF16X3 (1): bf16 MFMA with every
+ * operand split into two bf16 halves, a.b ~ a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulation (maps agree
+ * with the fp32 path to ~1e-5); D must then be a multiple of 32 and each layer's 9*D*D-float block of wpk holds
+ * bf16 fragments instead: [hi|lo][tap][cin/32][cout/16][lane][8] with element j of lane l =
+ * W[cout = 16*tile + (l&15)][cin = 32*kb + 8*(l>>4) + j][tap] * bn_scale[cout] (same total size). */
+#define ADAMVS_PRECISION_FP32 0
+#define ADAMVS_PRECISION_BF16X3 1
 size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, int w);
 int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N, int D, int h, int w,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One layer of CostRegNet2D: ConvBnReLU.forward (models/module.py:254-261) or the
  * ConvTranspose2d-BN-ReLU blocks of models/adamvs.py:212-225, BN folded into wpk/bias,
  * optional skip added after the ReLU.  mode 0: 3x3 stride 1; 1: stride 2; 2: transposed
  * stride 2 (k3 p1 op1).  in [N][hi*wi][D] -> out [N][ho*wo][D]; wpk as one layer above. */
 int adamvs_conv3x3_dd(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
-                      int hi, int wi, int mode, int relu, void* stream);
+                      int hi, int wi, int mode, int relu, int precision, void* stream);
 
 /* models/adamvs.py:481-486 + module.py:617-625: softmax over D, its maximum (view
  * weight) and the expectation of the hypothesis planes (pair depth).
@@ -140,6 +148,7 @@ typedef struct adamvs_stage_desc {
   int in_up;              /* 1: maps come out at 2h x 2w (stages 1, 2); 0: h x w (stage 3) */
   int first_stage;        /* 1: confidence_map is None -> pass A scores the views (stage 1) */
   int prev_h, prev_w;     /* size of prev_conf maps when !first_stage */
+  int precision;          /* ADAMVS_PRECISION_* for CostRegNet2D (w_reg must be packed accordingly) */
 } adamvs_stage_desc;
 
 size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);

@@ -128,6 +128,39 @@ def test_cost_reg_net_2d_widths(hip, O, D, h, w):
     assert rel_l1(out, ref) < OP_TOL
 
 
+@pytest.mark.parametrize("D,h,w", [(32, 16, 24), (64, 8, 16), (192, 8, 16), (256, 8, 8)])
+def test_cost_reg_net_2d_bf16x3(hip, O, D, h, w):
+    """Split-bf16 MFMA path (three bf16 MFMAs per product, fp32 accumulate) against the fp32 oracle."""
+    from ada_mvs_amd.models.adamvs import CostRegNet2D
+    net = CostRegNet2D(D)
+    sd = synth.seeded_state_dict(net, seed=1)
+    net.load_state_dict(sd)
+    net.precision = "bf16x3"
+    x = torch.randn(2, D, h, w, generator=torch.Generator().manual_seed(D)) * 0.5
+    ref = O.cost_reg_net_2d(x, sd, "")
+    out = net.cuda()(dev(x))
+    err = rel_l1(out, ref)
+    assert err < 2e-4, err            # 16 significant bits per operand, 11 layers deep; fp32 path: < 5e-5
+
+
+def test_end_to_end_bf16x3(hip, O):
+    """Whole cascade with precision='bf16x3' (D1 = 32 so that the split-bf16 kernels are actually used)."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    cfg = dict(views=3, H=64, W=96, ndepths=[32, 8, 4], num_depth=32)
+    m = Infer_AdaMVSNet(cfg["num_depth"], cfg["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8], precision="bf16x3")
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    assert m.DepthNet[0].reg.effective_precision() == "bf16x3"
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=2, seed=4)
+    with torch.no_grad():
+        out = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+        ref = O.infer_adamvs_forward(imgs, proj, dv, sd, cfg["num_depth"], cfg["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    for key in ("depth", "photometric_confidence"):
+        assert rel_l1(out[key], ref[key]) < NORTH_STAR_TOL / 2, key
+    assert rel_l1(out["stage1"]["pair_confidence"][0], ref["stage1"]["pair_confidence"][0]) < NORTH_STAR_TOL / 2
+
+
 def test_softmax_max_regress(hip, O):
     S, B, D, h, w = 2, 2, 48, 6, 10
     g = torch.Generator().manual_seed(5)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.adamvs_version() == _lib.ABI_VERSION
     assert ctypes.sizeof(_lib.FuseWeights) == 13 * ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_lib.StageDesc) == 10 * ctypes.sizeof(ctypes.c_int)
+    assert ctypes.sizeof(_lib.StageDesc) == 11 * ctypes.sizeof(ctypes.c_int)
 
 
 def test_argument_errors_surface_as_exceptions_without_a_gpu():
@@ -34,10 +34,10 @@ def test_argument_errors_surface_as_exceptions_without_a_gpu():
     assert rc < 0
     with pytest.raises(_lib.AdaMVSHipError, match="pack_features"):
         _lib.check(rc, "pack_features")
-    desc = _lib.StageDesc(1, 2, 12, 8, 8, 16, 1, 1, 0, 0)            # C=12 unsupported
+    desc = _lib.StageDesc(1, 2, 12, 8, 8, 16, 1, 1, 0, 0, 0)            # C=12 unsupported
     assert lib.adamvs_depth_stage_workspace_bytes(ctypes.byref(desc)) == 0
     assert b"C=12" in lib.adamvs_last_error_string()
-    desc = _lib.StageDesc(8, 4, 32, 96, 192, 192, 1, 1, 0, 0)        # cfg2 stage 1, 8 tiles
+    desc = _lib.StageDesc(8, 4, 32, 96, 192, 192, 1, 1, 0, 0, 0)        # cfg2 stage 1, 8 tiles
     assert lib.adamvs_depth_stage_workspace_bytes(ctypes.byref(desc)) > (1 << 30)
 
 
@@ -91,6 +91,23 @@ def test_fragment_packing_layout():
     frag = pl[:9 * D * D].reshape(9, D // 4, D // 16, 64)
     assert torch.isclose(frag[7, 5, 1, 50], wl[16 + (50 & 15), 20 + (50 >> 4), 2, 1] * scale[16 + (50 & 15)])
     assert pl.numel() == 9 * D * D + D
+
+
+def test_split_bf16_packing_layout():
+    g = torch.Generator().manual_seed(1)
+    D = 64
+    w = torch.randn(D, D, 3, 3, generator=g)
+    scale = torch.rand(D, generator=g) + 0.5
+    pk = packing.pack_reg_layer_bf16x3(w, scale, torch.zeros(D), False)
+    assert pk.numel() == 9 * D * D + D                                  # same size as the fp32 packing
+    frag = pk[:9 * D * D].view(torch.bfloat16).reshape(2, 9, D // 32, D // 16, 64, 8)
+    ws = w * scale.reshape(-1, 1, 1, 1)
+    hi, lo = packing.split_bf16(ws)
+    tap, kb, tile, lane, j = 5, 1, 2, 37, 6
+    co, ci = 16 * tile + (lane & 15), 32 * kb + 8 * (lane >> 4) + j
+    assert frag[0, tap, kb, tile, lane, j] == hi[co, ci, tap // 3, tap % 3]
+    assert frag[1, tap, kb, tile, lane, j] == lo[co, ci, tap // 3, tap % 3]
+    assert float((hi.float() + lo.float() - ws).abs().max() / ws.abs().max()) < 2 ** -15
 
 
 def test_packed_network_sizes_match_the_header():
