@@ -110,7 +110,7 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
   };
 
   float wf[NTAP][KB / 4][MT], wf_next[NTAP][KB / 4][MT];
-  f32x4 xs[NITA], xs_next[NITA];
+  f32x4 xs[NITA];
   load_w(wf, 0);
   load_x(xs, 0);
   for (int ch = 0; ch < D; ch += KB) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
     __syncthreads();
     if (ch + KB < D) {
       load_w(wf_next, ch + KB);
-      load_x(xs_next, ch + KB);
+      load_x(xs, ch + KB);              // single staging set: stored to LDS at the top of the next iteration
     }
 #pragma unroll
     for (int ty = 0; ty < NTY; ++ty)
@@ -142,8 +142,6 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
         for (int kc = 0; kc < KB / 4; ++kc)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) wf[t][kc][mt] = wf_next[t][kc][mt];
-#pragma unroll
-      for (int it = 0; it < NITA; ++it) xs[it] = xs_next[it];
     }
   }
 

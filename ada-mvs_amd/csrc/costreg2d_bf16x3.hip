@@ -31,22 +31,25 @@ enum { BX_S1 = 0, BX_S2 = 1, BX_T2 = 2 };
 constexpr int BX_KB = 32;            // input channels per chunk = one MFMA k-step
 constexpr int BX_PIX = 40;           // bf16 per pixel row in LDS: 32 + 8 pad (80 B: 16-B aligned, spreads the banks)
 
+// Block rows: 16 for the stride-1 and transposed layers (the A fragments stream from L2 at 5x the fp32 kernel's
+// rate per MFMA cycle, so each fragment should feed as many pixel runs as the accumulators allow), 8 for stride 2
+// (its input tile is 4x larger per output row).
 template <int MODE> struct BxGeom;
-template <> struct BxGeom<BX_S1> { static constexpr int LR = 10, LC = 18; };
-template <> struct BxGeom<BX_S2> { static constexpr int LR = 17, LC = 33; };
-template <> struct BxGeom<BX_T2> { static constexpr int LR = 9, LC = 17; };
+template <> struct BxGeom<BX_S1> { static constexpr int BR = 16, LR = BR + 2, LC = 18; };
+template <> struct BxGeom<BX_S2> { static constexpr int BR = 8, LR = 2 * BR + 1, LC = 33; };
+template <> struct BxGeom<BX_T2> { static constexpr int BR = 16, LR = BR + 1, LC = 17; };
 
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// Block = 8 rows x 16 columns of output positions x all D channels; waves WM along channels (MT tiles each),
-// WN = 4/WM along rows -- the geometry of conv_dd_body in costreg2d.hip.
+// Block = BR rows x 16 columns of output positions x all D channels; waves WM along channels (MT tiles each),
+// WN = 4/WM along rows -- the geometry of conv_dd_body in costreg2d.hip with taller blocks.
 template <int MT, int WM, int MODE, int PY, int PX>
 __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* lds, int n, int by, int bx) {
   using TG = BxGeom<MODE>;
   constexpr int LR = TG::LR, LC = TG::LC, NPIX = LR * LC;
-  constexpr int WN = 4 / WM, NTR = 8 / WN;
+  constexpr int BR = TG::BR, WN = 4 / WM, NTR = BR / WN;
   constexpr int STR = (MODE == BX_S2) ? 2 : 1;
   constexpr int NTY = (MODE == BX_T2) ? 1 + PY : 3;
   constexpr int NTX = (MODE == BX_T2) ? 1 + PX : 3;
@@ -57,7 +60,7 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
   const int p = lane & 15, q = lane >> 4;
   const int D = a.D, KBT = D / BX_KB, NTILES = D / 16;
   const size_t lo_off = (size_t)9 * KBT * NTILES * 64;       // fragments between the hi and the lo half
-  const int r0 = by * 8, c0 = bx * 16;
+  const int r0 = by * BR, c0 = bx * 16;
   const int iy0 = (MODE == BX_T2) ? r0 : r0 * STR - 1;
   const int ix0 = (MODE == BX_T2) ? c0 : c0 * STR - 1;
   const float* inb = a.in + (size_t)n * a.hi * a.wi * D;
@@ -109,20 +112,20 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
 
   // lane's B-fragment base: pixel column p of the wave's first row, k-group q (8 channels = 16 bytes)
   const int boff = ((wn * NTR * STR) * LC + p * STR) * BX_PIX + 8 * q;
-  f32x4 xs[NIT], xs_next[NIT];
+  f32x4 xs[NIT];
   load_x(xs, 0);
   for (int kb = 0; kb < KBT; ++kb) {
     __syncthreads();                     // previous chunk's readers are done
     store_x(xs);
     __syncthreads();
-    if (kb + 1 < KBT) load_x(xs_next, (kb + 1) * BX_KB);          // in flight during the MFMAs
+    if (kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);               // in flight during the MFMAs, stored at the next top
     bf16x8 wh[MT], wl[MT], wh_n[MT], wl_n[MT];
     load_w(wh, wl, kb, 0, 0);
-#pragma unroll
+#pragma unroll 1                     // rolled: a full unroll lets the scheduler hoist every LDS fragment of the chunk (spills)
     for (int t = 0; t < NTY * NTX; ++t) {
       const int ty = t / NTX, tx = t % NTX;
       if (t + 1 < NTY * NTX) load_w(wh_n, wl_n, kb, (t + 1) / NTX, (t + 1) % NTX);      // next tap's fragments
-#pragma unroll
+#pragma unroll                       // static accumulator indices (a runtime index would send acc to scratch)
       for (int r = 0; r < NTR; ++r) {
         const int o = boff + ((r * STR + ty) * LC + tx) * BX_PIX;
         const bf16x8 bh = *(const bf16x8*)(lhi + o);
@@ -136,10 +139,6 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) { wh[mt] = wh_n[mt]; wl[mt] = wl_n[mt]; }
-    }
-    if (kb + 1 < KBT) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) xs[it] = xs_next[it];
     }
   }
 
@@ -196,9 +195,9 @@ static int launch_bx3_mode(const ConvDDArgs16& a, dim3 grid, hipStream_t st) {
 
 template <int MT, int WM>
 static int launch_bx3_cfg(const ConvDDArgs16& a, int N, int mode, hipStream_t st) {
-  if (mode == BX_S1) return launch_bx3_mode<MT, WM, BX_S1>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), st);
-  if (mode == BX_S2) return launch_bx3_mode<MT, WM, BX_S2>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), st);
-  return launch_bx3_mode<MT, WM, BX_T2>(a, dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N * 4), st);
+  if (mode == BX_S1) return launch_bx3_mode<MT, WM, BX_S1>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, BxGeom<BX_S1>::BR), N), st);
+  if (mode == BX_S2) return launch_bx3_mode<MT, WM, BX_S2>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, BxGeom<BX_S2>::BR), N), st);
+  return launch_bx3_mode<MT, WM, BX_T2>(a, dim3(cdiv(a.wi, 16), cdiv(a.hi, BxGeom<BX_T2>::BR), N * 4), st);
 }
 
 bool costreg_bf16x3_depth_supported(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256; }
