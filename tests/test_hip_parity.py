@@ -277,6 +277,23 @@ def test_drop_in_forward_tiny_and_cfg1(hip):
         _check_against_golden(cfg, g, out, NORTH_STAR_TOL)
 
 
+def test_nine_views_end_to_end(hip, O):
+    """BASELINE cfg5 has 8 source views: the S > 4 instantiation of the sweep, small size, against the oracle."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    cfg = dict(views=9, H=64, W=96, ndepths=[16, 8, 4], num_depth=16)
+    m = Infer_AdaMVSNet(cfg["num_depth"], cfg["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=9)
+    with torch.no_grad():
+        out = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+        ref = O.infer_adamvs_forward(imgs, proj, dv, sd, cfg["num_depth"], cfg["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    assert len(out["stage1"]["pair_result"]) == 8
+    for key in ("depth", "photometric_confidence"):
+        assert rel_l1(out[key], ref[key]) < E2E_TOL, key
+
+
 def test_data_parallel_wrapper_and_module_prefixed_checkpoint(hip):
     """predict_whu.py:82-89 wraps the model in nn.DataParallel and loads 'module.'-prefixed keys."""
     from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
