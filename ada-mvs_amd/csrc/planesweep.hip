@@ -51,41 +51,24 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   const float tx = r[9], ty = r[10], tz = r[11];
   const float* pl = planes + (size_t)b * D * hw + pc;
   float* out = sim + (((size_t)s * B + b) * hw + pc) * D;
-  // the 4 bilinear taps stay in registers while consecutive planes fall into the same source cell
-  int cx = INT_MIN, cy = INT_MIN;
+  // the 4 bilinear taps stay in registers while consecutive planes fall into the same source cell; the G lanes of
+  // a pixel project G different planes (lane g: plane d0+g) and pass cell + weights around with ds_bpermute
+  int ccell = -1;
   f32x4 t00 = {0.f, 0.f, 0.f, 0.f}, t01 = t00, t10 = t00, t11 = t00;
+  const int gbase = (threadIdx.x & 63) & ~(G - 1);
   for (int d0 = 0; d0 < D; d0 += G) {
     float keep = 0.f;
-    float dep[G];                                                  // the group's planes: independent loads, no load in
-#pragma unroll                                                     // the loop below has to queue behind a store
-    for (int j = 0; j < G; ++j) dep[j] = pl[(size_t)min(d0 + j, D - 1) * hw];
+    const PlaneTaps mine = plane_taps(ax, ay, az, tx, ty, tz, pl[(size_t)min(d0 + g, D - 1) * hw], h, w);
 #pragma unroll
     for (int j = 0; j < G; ++j) {                                  // planes past D-1 repeat the last one, never stored
-      const float depth = dep[j];
-      float X0 = ax * depth + tx, X1 = ay * depth + ty, X2 = az * depth + tz;
-      float rz = rcp_nr(X2);
-      float u = X0 * rz, v = X1 * rz;
-      f32x4 wrp = {0.f, 0.f, 0.f, 0.f};
-      if (u > -1.0f && u < (float)w && v > -1.0f && v < (float)h) {
-        float fx0 = floorf(u), fy0 = floorf(v);
-        int ix = (int)fx0, iy = (int)fy0;
-        if (ix != cx || iy != cy) {
-          cx = ix; cy = iy;
-          int xa = max(ix, 0), xb = min(ix + 1, w - 1), ya = max(iy, 0), yb = min(iy + 1, h - 1);
-          t00 = *(const f32x4*)(src + ((size_t)ya * w + xa) * C);
-          t01 = *(const f32x4*)(src + ((size_t)ya * w + xb) * C);
-          t10 = *(const f32x4*)(src + ((size_t)yb * w + xa) * C);
-          t11 = *(const f32x4*)(src + ((size_t)yb * w + xb) * C);
-        }
-        float lx = u - fx0, ly = v - fy0;
-        bool vx0 = ix >= 0, vx1 = ix + 1 <= w - 1, vy0 = iy >= 0, vy1 = iy + 1 <= h - 1;
-        float w00 = (vy0 && vx0) ? (1.f - lx) * (1.f - ly) : 0.f;
-        float w01 = (vy0 && vx1) ? lx * (1.f - ly) : 0.f;
-        float w10 = (vy1 && vx0) ? (1.f - lx) * ly : 0.f;
-        float w11 = (vy1 && vx1) ? lx * ly : 0.f;
-        wrp = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
+      const int cell = __shfl(mine.cell, gbase + j, 64);
+      const float w00 = __shfl(mine.w00, gbase + j, 64), w01 = __shfl(mine.w01, gbase + j, 64);
+      const float w10 = __shfl(mine.w10, gbase + j, 64), w11 = __shfl(mine.w11, gbase + j, 64);
+      if (cell != -1 && cell != ccell) {
+        ccell = cell;
+        load_cell_taps(src, C, cell, h, w, t00, t01, t10, t11);
       }
-      f32x4 m = wrp * ref4;
+      f32x4 m = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * ref4;
       float part = group_sum<G>((m.x + m.y) + (m.z + m.w));
       if (j == g) keep = part * (1.0f / (float)C);
     }

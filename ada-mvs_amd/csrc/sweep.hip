@@ -38,66 +38,65 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
   const float x = (float)(pc % w), y = (float)(pc / w);
   const f32x4 ref4 = *(const f32x4*)(feat + ((size_t)b * hw + pc) * C + 4 * g);
 
-  // per view: rot_xyz = R.[x,y,1] (module.py:549), translation, view weight, cached cell + taps
-  float ax[SV], ay[SV], az[SV], tx[SV], ty[SV], tz[SV], wv[SV];
-  int cx[SV], cy[SV];
+  // The G lanes of a pixel share the projection work: lane g projects the pixel into views g, g+G, ... and hands the
+  // packed cell and the four bilinear weights to the other lanes (ds_bpermute), so a projection is computed once
+  // per pixel, view and plane instead of once per lane.
+  constexpr int VPL = (SV + G - 1) / G;            // views a lane projects
+  float ax[VPL], ay[VPL], az[VPL], tx[VPL], ty[VPL], tz[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int sc = min(g + k * G, S - 1);
+    const float* r = rt + ((size_t)b * S + sc) * 12;
+    ax[k] = r[0] * x + r[1] * y + r[2];              // rot_xyz = R.[x,y,1] (module.py:549)
+    ay[k] = r[3] * x + r[4] * y + r[5];
+    az[k] = r[6] * x + r[7] * y + r[8];
+    tx[k] = r[9]; ty[k] = r[10]; tz[k] = r[11];
+  }
+  // per view (all lanes): view weight, cached cell + its 4 taps
+  float wv[SV];
+  int ccell[SV];
   f32x4 t00[SV], t01[SV], t10[SV], t11[SV];
   const float* src[SV];
 #pragma unroll
   for (int s = 0; s < SV; ++s) {
     const int sc = min(s, S - 1);
-    const float* r = rt + ((size_t)b * S + sc) * 12;
-    ax[s] = r[0] * x + r[1] * y + r[2];
-    ay[s] = r[3] * x + r[4] * y + r[5];
-    az[s] = r[6] * x + r[7] * y + r[8];
-    tx[s] = r[9]; ty[s] = r[10]; tz[s] = r[11];
     wv[s] = (s < S) ? vw[((size_t)sc * B + b) * hw + pc] : 0.f;
     src[s] = feat + ((size_t)(sc + 1) * B + b) * (size_t)hw * C + 4 * g;
-    cx[s] = INT_MIN; cy[s] = INT_MIN;
+    ccell[s] = -1;
     t00[s] = t01[s] = t10[s] = t11[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const int gbase = (threadIdx.x & 63) & ~(G - 1);   // first lane of this pixel's group
   const float* pl = planes + (size_t)b * D * hw + pc;
   float* out = sim + ((size_t)b * hw + pc) * C + 4 * g;
   const size_t ostride = (size_t)B * hw * C;
 
-  constexpr int DG = 8;            // planes whose depths are fetched together: the loop body then has no load that
-  for (int dg = d0; dg < d1; dg += DG) {   // would queue behind the previous plane's store (vmcnt is in issue order)
-  float dep[DG];
-#pragma unroll
-  for (int j = 0; j < DG; ++j) dep[j] = pl[(size_t)min(dg + j, d1 - 1) * hw];
-#pragma unroll
-  for (int j = 0; j < DG; ++j) {
+  // depths: lane g of a pixel fetches plane dg+g, the group reads them back lane by lane -- one load per G planes,
+  // so the (rolled) plane loop has no load that would queue behind the previous plane's store (vmcnt is in issue order)
+  for (int dg = d0; dg < d1; dg += G) {
+  const float mydepth = pl[(size_t)min(dg + g, d1 - 1) * hw];
+#pragma unroll 1
+  for (int j = 0; j < G; ++j) {
     const int d = dg + j;
     if (d >= d1) break;
-    const float depth = dep[j];
+    const float depth = __shfl(mydepth, gbase + j, 64);
+    PlaneTaps mine[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) mine[k] = plane_taps(ax[k], ay[k], az[k], tx[k], ty[k], tz[k], depth, h, w);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float wsum = 1e-5f;                                          // adamvs.py:497
 #pragma unroll
     for (int s = 0; s < SV; ++s) {
       if (s >= S) break;                                         // uniform
-      float X0 = ax[s] * depth + tx[s], X1 = ay[s] * depth + ty[s], X2 = az[s] * depth + tz[s];
-      float rz = rcp_nr(X2);
-      float u = X0 * rz, v = X1 * rz;                            // module.py:553
-      f32x4 wrp = {0.f, 0.f, 0.f, 0.f};
-      if (u > -1.0f && u < (float)w && v > -1.0f && v < (float)h) {
-        float fx0 = floorf(u), fy0 = floorf(v);
-        int ix = (int)fx0, iy = (int)fy0;
-        if (ix != cx[s] || iy != cy[s]) {                        // entered another source cell: reload the 4 taps
-          cx[s] = ix; cy[s] = iy;
-          int xa = max(ix, 0), xb = min(ix + 1, w - 1), ya = max(iy, 0), yb = min(iy + 1, h - 1);
-          t00[s] = *(const f32x4*)(src[s] + ((size_t)ya * w + xa) * C);
-          t01[s] = *(const f32x4*)(src[s] + ((size_t)ya * w + xb) * C);
-          t10[s] = *(const f32x4*)(src[s] + ((size_t)yb * w + xa) * C);
-          t11[s] = *(const f32x4*)(src[s] + ((size_t)yb * w + xb) * C);
-        }
-        float lx = u - fx0, ly = v - fy0;
-        bool vx0 = ix >= 0, vx1 = ix + 1 <= w - 1, vy0 = iy >= 0, vy1 = iy + 1 <= h - 1;
-        float w00 = (vy0 && vx0) ? (1.f - lx) * (1.f - ly) : 0.f;
-        float w01 = (vy0 && vx1) ? lx * (1.f - ly) : 0.f;
-        float w10 = (vy1 && vx0) ? (1.f - lx) * ly : 0.f;
-        float w11 = (vy1 && vx1) ? lx * ly : 0.f;
-        wrp = t00[s] * w00 + t01[s] * w01 + t10[s] * w10 + t11[s] * w11;
+      const int from = gbase + (s % G);
+      const PlaneTaps& m = mine[s / G];
+      const int cell = __shfl(m.cell, from, 64);
+      const float w00 = __shfl(m.w00, from, 64), w01 = __shfl(m.w01, from, 64);
+      const float w10 = __shfl(m.w10, from, 64), w11 = __shfl(m.w11, from, 64);
+      if (cell != -1 && cell != ccell[s]) {                      // entered another source cell: reload the 4 taps
+        ccell[s] = cell;
+        load_cell_taps(src[s], C, cell, h, w, t00[s], t01[s], t10[s], t11[s]);
       }
+      f32x4 wrp = t00[s] * w00 + t01[s] * w01 + t10[s] * w10 + t11[s] * w11;     // all-zero weights when padding
       acc += (wrp * ref4) * wv[s];                               // adamvs.py:504-508
       wsum += wv[s];
     }

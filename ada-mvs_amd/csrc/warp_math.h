@@ -72,6 +72,47 @@ __device__ __forceinline__ WarpUV warp_uv(const float* __restrict__ rt, float x,
   return r;
 }
 
+// Projection of one pixel onto one plane, in the form the register-resident sweeps pass between lanes:
+// the source cell packed into one int ((ix+1) | (iy+1) << 16, or -1 when every tap is padding) and the four
+// bilinear weights with the per-tap zero padding already folded in.
+struct PlaneTaps {
+  int cell;
+  float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ PlaneTaps plane_taps(float ax, float ay, float az, float tx, float ty, float tz, float depth,
+                                                int h, int w) {
+  float X0 = ax * depth + tx, X1 = ay * depth + ty, X2 = az * depth + tz;      // module.py:550-552
+  float rz = rcp_nr(X2);
+  float u = X0 * rz, v = X1 * rz;                                              // module.py:553
+  PlaneTaps t;
+  t.cell = -1;
+  t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+  if (u > -1.0f && u < (float)w && v > -1.0f && v < (float)h) {
+    float fx0 = floorf(u), fy0 = floorf(v);
+    int ix = (int)fx0, iy = (int)fy0;
+    float lx = u - fx0, ly = v - fy0;
+    bool vx0 = ix >= 0, vx1 = ix + 1 <= w - 1, vy0 = iy >= 0, vy1 = iy + 1 <= h - 1;
+    t.w00 = (vy0 && vx0) ? (1.f - lx) * (1.f - ly) : 0.f;
+    t.w01 = (vy0 && vx1) ? lx * (1.f - ly) : 0.f;
+    t.w10 = (vy1 && vx0) ? (1.f - lx) * ly : 0.f;
+    t.w11 = (vy1 && vx1) ? lx * ly : 0.f;
+    t.cell = (ix + 1) | ((iy + 1) << 16);
+  }
+  return t;
+}
+
+// the four taps of a packed cell (clamped to the image; padding taps carry weight 0)
+__device__ __forceinline__ void load_cell_taps(const float* __restrict__ src, int C, int cell, int h, int w, f32x4& t00,
+                                               f32x4& t01, f32x4& t10, f32x4& t11) {
+  int ix = (cell & 0xFFFF) - 1, iy = (cell >> 16) - 1;
+  int xa = max(ix, 0), xb = min(ix + 1, w - 1), ya = max(iy, 0), yb = min(iy + 1, h - 1);
+  t00 = *(const f32x4*)(src + ((size_t)ya * w + xa) * C);
+  t01 = *(const f32x4*)(src + ((size_t)ya * w + xb) * C);
+  t10 = *(const f32x4*)(src + ((size_t)yb * w + xa) * C);
+  t11 = *(const f32x4*)(src + ((size_t)yb * w + xb) * C);
+}
+
 // 4 channels of a channel-last feature map [hw][C] gathered with a tap set.
 __device__ __forceinline__ f32x4 gather4(const float* __restrict__ fea, int C, int c0, const WarpTaps& t) {
   const float* base = fea + c0;
