@@ -413,49 +413,59 @@ static int launch_small(const SmallConvArgs& a, int B, hipStream_t st, const cha
 // src [N][hw][C] -> c1 [N][hw][8].  grid (ceil(w/32), ceil(h/8), N); block 256; tile 8 rows x 32 columns.
 template <int C>
 __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__ src, const float* __restrict__ wpk,
-                                                       float* __restrict__ c1, int h, int w) {
+                                                       float* __restrict__ c1, int h, int w, int tiles_x, int tiles_y,
+                                                       int ntiles) {
   constexpr int KC = C / 4, G = C / 4, TR = 8, LR = TR + 2, LC = 34;
   constexpr int PLANE = plane_pitch16(LR * LC), GP = group_pitch(PLANE, G);
+  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
   extern __shared__ float lds[];           // [G][GP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * TR;
+  const int p = lane & 15, q = lane >> 4;
   float wf[12][KC];
 #pragma unroll
   for (int t = 0; t < 12; ++t)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) wf[t][kc] = wpk[(t * KC + kc) * 64 + lane];
 
-  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
-  f32x4 stage[NIT];
+  auto load_tile = [&](f32x4 (&stage)[NIT], int t) {
+    const int n = t / (tiles_x * tiles_y), x0 = (t % tiles_x) * 32, y0 = ((t / tiles_x) % tiles_y) * TR;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    int i = tid + it * 256;
-    int g = i % G, pp = i / G;
-    int r = pp / LC, c = pp % LC;
-    int iy = y0 - 1 + r, ix = x0 - 1 + c;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (i < NITEMS && iy >= 0 && iy < h && ix >= 0 && ix < w) v = *(const f32x4*)(src + (((size_t)n * h + iy) * w + ix) * C + 4 * g);
-    stage[it] = v;
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    int i = tid + it * 256;
-    if (i < NITEMS) {
+    for (int it = 0; it < NIT; ++it) {
+      int i = tid + it * 256;
       int g = i % G, pp = i / G;
       int r = pp / LC, c = pp % LC;
-      float* dl = lds + g * GP + r * LC + c;
-      f32x4 v = stage[it];
-      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+      int iy = y0 - 1 + r, ix = x0 - 1 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < NITEMS && iy >= 0 && iy < h && ix >= 0 && ix < w) v = *(const f32x4*)(src + (((size_t)n * h + iy) * w + ix) * C + 4 * g);
+      stage[it] = v;
     }
-  }
-  __syncthreads();
+  };
 
-  const int p = lane & 15, q = lane >> 4;
-  const float* xb = lds + q * PLANE + p;
-  // a wave owns two runs (row pair, column half); their accumulators are independent, so their MFMAs alternate
-  {
+  // persistent: workgroup i takes tiles i, i + grid, ...; the next tile is in flight (registers) during the MFMAs
+  f32x4 stage[NIT];
+  int t = blockIdx.x;
+  if (t < ntiles) load_tile(stage, t);
+  for (; t < ntiles; t += gridDim.x) {
+    __syncthreads();                         // the previous tile's readers are done
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int i = tid + it * 256;
+      if (i < NITEMS) {
+        int g = i % G, pp = i / G;
+        int r = pp / LC, c = pp % LC;
+        float* dl = lds + g * GP + r * LC + c;
+        f32x4 v = stage[it];
+        dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+      }
+    }
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) load_tile(stage, t + gridDim.x);
+
+    const int n = t / (tiles_x * tiles_y), x0 = (t % tiles_x) * 32, y0 = ((t / tiles_x) % tiles_y) * TR;
+    const float* xb = lds + q * PLANE + p;
+    // a wave owns two runs (row pair, column half); their accumulators are independent, so their MFMAs alternate
     const int row0 = (wave >> 1) * 2, col0 = (wave & 1) * 16;        // run = wave
-    const int row1 = row0 + 4, col1 = col0;                            // run = wave + 4
+    const int row1 = row0 + 4;                                         // run = wave + 4
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
           float b0 = xb[kc * GP + (row0 + rr) * LC + col0 + kx];
-          float b1 = xb[kc * GP + (row1 + rr) * LC + col1 + kx];
+          float b1 = xb[kc * GP + (row1 + rr) * LC + col0 + kx];
           acc0 = mfma16(wf[rr * 3 + kx][kc], b0, acc0);
           acc1 = mfma16(wf[rr * 3 + kx][kc], b1, acc1);
         }
@@ -480,16 +490,26 @@ __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__
   }
 }
 
-int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st) {
-  dim3 grid(cdiv(w_, 32), cdiv(h, 8), N);
-  size_t lds = (size_t)(C / 4) * group_pitch(plane_pitch16(10 * 34), C / 4) * sizeof(float);
-  if (N > 65535) return set_error(-1, "conv1: %d maps exceed the grid z limit", N);
-  if (C == 32) hipLaunchKernelGGL((k_conv1_two_row<32>), grid, dim3(256), lds, st, cost, w, c1, h, w_);
-  else if (C == 16) hipLaunchKernelGGL((k_conv1_two_row<16>), grid, dim3(256), lds, st, cost, w, c1, h, w_);
-  else if (C == 8) hipLaunchKernelGGL((k_conv1_two_row<8>), grid, dim3(256), lds, st, cost, w, c1, h, w_);
-  else return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
+template <int C>
+static int launch_conv1_c(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
+  constexpr size_t lds = (size_t)(C / 4) * group_pitch(plane_pitch16(10 * 34), C / 4) * sizeof(float);
+  auto kern = k_conv1_two_row<C>;
+  static int capacity = 0;
+  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  const int tiles_x = cdiv(w_, 32), tiles_y = cdiv(h, 8);
+  const long ntiles = (long)tiles_x * tiles_y * N;
+  if (ntiles > 0x7fffffffL) return set_error(-1, "conv1: too many tiles");
+  const int grid = ntiles < capacity ? (int)ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, cost, w, c1, h, w_, tiles_x, tiles_y, (int)ntiles);
   ADAMVS_CHECK_LAUNCH("conv1");
   return 0;
+}
+
+int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st) {
+  if (C == 32) return launch_conv1_c<32>(cost, w, c1, N, h, w_, st);
+  if (C == 16) return launch_conv1_c<16>(cost, w, c1, N, h, w_, st);
+  if (C == 8) return launch_conv1_c<8>(cost, w, c1, N, h, w_, st);
+  return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
 }
 
 // One recurrent step after conv1: c1 -> GRU1 -> conv2 -> GRU2 -> decoder -> vol[:, d].
