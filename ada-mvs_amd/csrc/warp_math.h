@@ -50,36 +50,6 @@ __device__ __forceinline__ float rcp_nr(float x) {
   return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
 
-// 1/x to within ~1 ulp: v_rcp_f32 + one Newton step (3 instructions instead of the ~11 of an IEEE divide;
-// the plane sweep does two divisions per view per plane).  |error| of u = X0 * rcp(X2) stays below 2e-5 px
-// for coordinates up to a few hundred pixels.
-__device__ __forceinline__ float rcp_nr(float x) {
-  float r = __builtin_amdgcn_rcpf(x);
-  return fmaf(fmaf(-x, r, 1.0f), r, r);
-}
-
-// Projected pixel coordinates only (bounding boxes, LDS-resident sweeps).
-struct WarpUV {
-  float u, v;
-  bool ok;      // finite and at least one bilinear tap can fall inside the image
-  bool front;   // finite with X2 > 0: between two such planes the projection moves monotonically
-};
-
-__device__ __forceinline__ WarpUV warp_uv(const float* __restrict__ rt, float x, float y, float d, int h, int w) {
-  float a0 = rt[0] * x + rt[1] * y + rt[2];
-  float a1 = rt[3] * x + rt[4] * y + rt[5];
-  float a2 = rt[6] * x + rt[7] * y + rt[8];
-  float X0 = a0 * d + rt[9];
-  float X1 = a1 * d + rt[10];
-  float X2 = a2 * d + rt[11];
-  WarpUV r;
-  r.u = X0 / X2;
-  r.v = X1 / X2;
-  r.ok = (r.u > -1.0f && r.u < (float)w && r.v > -1.0f && r.v < (float)h);
-  r.front = X2 > 0.f && fabsf(r.u) < 1e30f && fabsf(r.v) < 1e30f;
-  return r;
-}
-
 // Projection of one pixel onto one plane, in the form the register-resident sweeps pass between lanes:
 // the source cell packed into one int ((ix+1) | (iy+1) << 16, or -1 when every tap is padding) and the four
 // bilinear weights with the per-tap zero padding already folded in.
