@@ -27,7 +27,7 @@ class FuseWeights(ctypes.Structure):
 
 class StageDesc(ctypes.Structure):
     """adamvs_stage_desc"""
-    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision")]
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision", "precision_fuse")]
 
 
 # name -> (restype, argtypes); every symbol include/adamvs_hip.h declares
@@ -48,9 +48,9 @@ SIGNATURES = {
     "adamvs_conv3x3_dd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_softmax_max_regress": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_aggregate_conv1_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
-    "adamvs_aggregate_conv1": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_aggregate_conv1": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_slice_reg_step_scratch_bytes": (c_sz, [c_i, c_i, c_i]),
-    "adamvs_slice_reg_step": (c_i, [c_f, c_f, c_f, ctypes.POINTER(FuseWeights), c_f, c_i, c_i, c_i, c_i, c_i,
+    "adamvs_slice_reg_step": (c_i, [c_f, c_f, c_f, ctypes.POINTER(FuseWeights), c_f, c_i, c_i, c_i, c_i, c_i, c_i,
                                     ctypes.c_void_p, c_sz, c_st]),
     "adamvs_depth_stage_workspace_bytes": (c_sz, [ctypes.POINTER(StageDesc)]),
     "adamvs_depth_stage_forward": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(FuseWeights),

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libadamvs_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = ["api.hip", "geometry.hip", "planesweep.hip", "sweep.hip", "costreg2d.hip", "costreg2d_bf16x3.hip", "slice_red.hip"]
+SOURCES = ["api.hip", "geometry.hip", "planesweep.hip", "sweep.hip", "costreg2d.hip", "costreg2d_bf16x3.hip", "slice_red.hip", "slice_red_bf16x3.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I", INCLUDE, "-I", CSRC]

@@ -61,6 +61,8 @@ static int check_desc(const adamvs_stage_desc* d) {
   ADAMVS_CHECK_ARG((d->h % 2) == 0 && (d->w % 2) == 0, "stage: h=%d w=%d must be even", d->h, d->w);
   ADAMVS_CHECK_ARG((size_t)d->B * d->D <= 65535, "stage: B*D=%d exceeds the grid z limit", d->B * d->D);
   ADAMVS_CHECK_ARG(d->precision == PRECISION_FP32 || d->precision == PRECISION_BF16X3, "stage: precision=%d (0 fp32, 1 bf16x3)", d->precision);
+  ADAMVS_CHECK_ARG(d->precision_fuse == PRECISION_FP32 || d->precision_fuse == PRECISION_BF16X3,
+                   "stage: precision_fuse=%d (0 fp32, 1 bf16x3)", d->precision_fuse);
   if (d->first_stage) {
     ADAMVS_CHECK_ARG(d->precision == PRECISION_FP32 || costreg_bf16x3_depth_supported(d->D),
                      "stage: bf16x3 CostRegNet2D needs D in {32,64,96,128,192,256}, got %d", d->D);
@@ -85,8 +87,9 @@ extern "C" size_t adamvs_slice_reg_step_scratch_bytes(int B, int h, int w) {
 }
 
 extern "C" int adamvs_slice_reg_step(const float* cost, float* state1, float* state2, const adamvs_fuse_weights* weights,
-                                     float* reg_cost, int B, int C, int h, int w, int in_up, void* scratch,
+                                     float* reg_cost, int B, int C, int h, int w, int in_up, int precision, void* scratch,
                                      size_t scratch_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(precision == PRECISION_FP32 || precision == PRECISION_BF16X3, "slice_reg_step: precision=%d (0 fp32, 1 bf16x3)", precision);
   ADAMVS_CHECK_ARG(cost && state1 && state2 && weights && reg_cost && scratch, "slice_reg_step: null pointer");
   ADAMVS_CHECK_ARG(B > 0 && h > 1 && w > 1 && (h % 2) == 0 && (w % 2) == 0, "slice_reg_step: bad shape (B=%d h=%d w=%d, even sizes)", B, h, w);
   ADAMVS_CHECK_ARG(C == 8 || C == 16 || C == 32, "slice_reg_step: C=%d unsupported (8, 16 or 32)", C);
@@ -98,9 +101,9 @@ extern "C" int adamvs_slice_reg_step(const float* cost, float* state1, float* st
   StepBuffers sb{state1, s + n1, s + 2 * n1, s + 3 * n1, state2, s + 3 * n1 + n2, s + 3 * n1 + 2 * n2};
   FuseWeights fw;
   memcpy(&fw, weights, sizeof(fw));
-  int rc = launch_conv1(cost, fw.conv1, c1, B, C, h, w, st);
+  int rc = launch_conv1(cost, fw.conv1, c1, B, C, h, w, precision, st);
   if (rc) return rc;
-  return launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, st);
+  return launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, precision, st);
 }
 
 extern "C" size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc) {
@@ -139,7 +142,8 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
 
   // -- weighted aggregation + conv1 for every hypothesis (state-independent)
   if ((phases & ADAMVS_PHASE_AGGREGATE) &&
-      (rc = launch_sweep_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, s.h, s.w, st)))
+      (rc = launch_sweep_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, s.h, s.w,
+                               s.precision_fuse, st)))
     return rc;
 
   // -- recurrence over hypotheses
@@ -150,7 +154,8 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   StepBuffers sb{ws + c.h1, ws + c.rh1, ws + c.u1, ws + c.c2, ws + c.h2, ws + c.rh2, ws + c.u2};
   const size_t c1_stride = (size_t)s.B * s.h * s.w * 8;
   for (int d = 0; d < s.D; ++d) {
-    if ((rc = launch_slice_step(ws + c.c1 + d * c1_stride, fw, sb, ws + c.vol, s.B, s.h, s.w, s.D, d, s.in_up, st))) return rc;
+    if ((rc = launch_slice_step(ws + c.c1 + d * c1_stride, fw, sb, ws + c.vol, s.B, s.h, s.w, s.D, d, s.in_up, s.precision_fuse, st)))
+      return rc;
   }
   }
   if (!(phases & ADAMVS_PHASE_SOFT_ARGMIN)) return 0;

@@ -30,6 +30,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
 
 // Uniform (scalar-cache) view of read-only parameters.
 typedef const float __attribute__((address_space(4))) cfloat;

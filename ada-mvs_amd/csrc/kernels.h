@@ -4,6 +4,8 @@
 
 namespace adamvs {
 
+enum { PRECISION_FP32 = 0, PRECISION_BF16X3 = 1 };
+
 struct FuseWeights {          // mirrors adamvs_fuse_weights in include/adamvs_hip.h
   const float* conv1;         // [1][9][C/4][64]
   const float* gates1; const float* gates1_b;   // [1][9][4][64], [16]
@@ -20,20 +22,22 @@ struct StepBuffers {          // all channel-last
   float* c2; float* h2; float* rh2; float* u2;   // [B][hw/4][16]
 };
 
-int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, hipStream_t st);
+int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, int precision, hipStream_t st);
+int launch_conv1_bf16x3(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st);
+int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBuffers& sb, int B, int h, int w, hipStream_t st);
 int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers& sb, float* vol, int B, int h, int w, int D,
-                      int d, int in_up, hipStream_t st);
+                      int d, int in_up, int precision, hipStream_t st);
 int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,
                        int in_up, hipStream_t st);
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
-                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, hipStream_t st);
+                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, hipStream_t st);
 size_t sweep_workspace_floats(int B, int C, int D, int h, int w);
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
                            int precision, hipStream_t st);
 int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
                           int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st);
 bool costreg_bf16x3_depth_supported(int D);
-enum { PRECISION_FP32 = 0, PRECISION_BF16X3 = 1 };
+
 int launch_softmax_regress(const float* score, const float* planes, float* vw, float* pd, int S, int B, int D, int h, int w,
                            hipStream_t st);
 bool costreg_depth_supported(int D);

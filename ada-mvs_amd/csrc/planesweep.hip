@@ -102,13 +102,15 @@ extern "C" size_t adamvs_aggregate_conv1_workspace_bytes(int B, int C, int D, in
 }
 
 extern "C" int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* view_weight,
-                                      const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w,
+                                      const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, int precision,
                                       void* workspace, size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(precision == PRECISION_FP32 || precision == PRECISION_BF16X3, "aggregate_conv1: precision=%d (0 fp32, 1 bf16x3)", precision);
   ADAMVS_CHECK_ARG(feat && rt && planes && view_weight && w1pk && c1 && B > 0 && S > 0 && D > 0 && h > 1 && w > 1,
                    "aggregate_conv1: bad arguments");
   ADAMVS_CHECK_ARG(C == 8 || C == 16 || C == 32, "aggregate_conv1: C=%d unsupported (8, 16 or 32)", C);
   ADAMVS_CHECK_ARG(workspace && workspace_bytes >= sweep_workspace_floats(B, C, D, h, w) * sizeof(float),
                    "aggregate_conv1: workspace too small (%zu < %zu bytes)", workspace_bytes,
                    sweep_workspace_floats(B, C, D, h, w) * sizeof(float));
-  return launch_sweep_conv1(feat, rt, planes, view_weight, w1pk, c1, (float*)workspace, B, S, C, D, h, w, (hipStream_t)stream);
+  return launch_sweep_conv1(feat, rt, planes, view_weight, w1pk, c1, (float*)workspace, B, S, C, D, h, w, precision,
+                            (hipStream_t)stream);
 }

@@ -25,10 +25,6 @@ struct SmallConvArgs {
   int hi, wi, ho, wo, cout;
 };
 
-__device__ __forceinline__ float tanh_fast(float x) {
-  float e = __expf(2.0f * x);
-  return 1.0f - 2.0f / (e + 1.0f);
-}
 
 // Persistent workgroups.  These launches are short (a few thousand tiles of a few microseconds) and sit on the
 // sequential critical path of the recurrence, so what costs time is not the matrix work but its packaging: a grid
@@ -505,7 +501,8 @@ static int launch_conv1_c(const float* cost, const float* w, float* c1, int N, i
   return 0;
 }
 
-int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st) {
+int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int precision, hipStream_t st) {
+  if (precision == PRECISION_BF16X3) return launch_conv1_bf16x3(cost, w, c1, N, C, h, w_, st);
   if (C == 32) return launch_conv1_c<32>(cost, w, c1, N, h, w_, st);
   if (C == 16) return launch_conv1_c<16>(cost, w, c1, N, h, w_, st);
   if (C == 8) return launch_conv1_c<8>(cost, w, c1, N, h, w_, st);
@@ -514,8 +511,11 @@ int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int
 
 // One recurrent step after conv1: c1 -> GRU1 -> conv2 -> GRU2 -> decoder -> vol[:, d].
 int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers& sb, float* vol, int B, int h, int w, int D,
-                      int d, int in_up, hipStream_t st) {
+                      int d, int in_up, int precision, hipStream_t st) {
   int h2 = h / 2, w2 = w / 2, rc;
+  if (precision == PRECISION_BF16X3) {
+    if ((rc = launch_gru_convs_bf16x3(c1, fw, sb, B, h, w, st))) return rc;
+  } else {
   {  // GRU level 1: gates on cat(c1, h1), candidate on cat(c1, r*h1)
     SmallConvArgs g{c1, sb.h1, fw.gates1, fw.gates1_b, sb.rh1, sb.u1, h, w, h, w, 16};
     if ((rc = launch_small<8, 8, 1, 1, EPI_GATES>(g, B, st, "gates1"))) return rc;
@@ -531,6 +531,7 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
     if ((rc = launch_small<16, 16, 2, 1, EPI_GATES>(g, B, st, "gates2"))) return rc;
     SmallConvArgs c{sb.c2, sb.rh2, fw.cand2, fw.cand2_b, sb.h2, sb.u2, h2, w2, h2, w2, 16};
     if ((rc = launch_small<16, 16, 1, 1, EPI_CAND>(c, B, st, "cand2"))) return rc;
+  }
   }
   DecoderArgs da{sb.h2, sb.h1, fw.upconv1, fw.upconv1_b, fw.final_w, vol, h, w, D, d};
   const int tiles_x = cdiv(w, 30), tiles_y = cdiv(h, 14), ntiles = tiles_x * tiles_y * B;

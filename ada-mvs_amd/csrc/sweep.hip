@@ -125,7 +125,7 @@ size_t sweep_workspace_floats(int B, int C, int D, int h, int w) {
 }
 
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
-                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, hipStream_t st) {
+                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, hipStream_t st) {
   if (S > 8 || S < 1) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
   const int dc = sweep_chunk_planes(D);
   for (int d0 = 0; d0 < D; d0 += dc) {
@@ -137,7 +137,7 @@ int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, 
     else return set_error(-1, "aggregate_conv1: C=%d unsupported (8, 16 or 32)", C);
     if (rc) return rc;
     // conv1 over the (d1-d0)*B similarity maps of the chunk; image n = dlocal*B + b lands in c1[d0 + dlocal][b]
-    if ((rc = launch_conv1(sim_ws, w1pk, c1 + (size_t)d0 * B * h * w * 8, (d1 - d0) * B, C, h, w, st))) return rc;
+    if ((rc = launch_conv1(sim_ws, w1pk, c1 + (size_t)d0 * B * h * w * 8, (d1 - d0) * B, C, h, w, precision, st))) return rc;
   }
   return 0;
 }

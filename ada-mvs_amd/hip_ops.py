@@ -139,13 +139,13 @@ def softmax_max_regress(score, planes, S, B, D, h, w):
     return vw, pd
 
 
-def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w):
+def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w, precision=0):
     c1 = torch.empty(D, B, h * w, 8, device=feat.device, dtype=torch.float32)
     lib = _lib.load()
     nbytes = lib.adamvs_aggregate_conv1_workspace_bytes(B, C, D, h, w)
     ws = torch.empty(max(nbytes // 4, 1), device=feat.device, dtype=torch.float32)
     check(_lib.load().adamvs_aggregate_conv1(_p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")),
-                                             _p(_dev(view_weight, "view_weight")), _p(w1pk), _p(c1), B, S, C, D, h, w,
+                                             _p(_dev(view_weight, "view_weight")), _p(w1pk), _p(c1), B, S, C, D, h, w, int(precision),
                                              _p(ws), nbytes, _stream()), "aggregate_conv1")
     return c1
 
@@ -165,7 +165,7 @@ class PackedFuse:
         return ctypes.c_void_p(getattr(self.struct, name))
 
 
-def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up):
+def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up, precision=0):
     """SliceCostRegNetRED.forward on channel-last maps; states updated in place. -> reg [B,1,Ho,Wo]"""
     lib = _lib.load()
     Ho, Wo = (2 * h, 2 * w) if in_up else (h, w)
@@ -173,12 +173,13 @@ def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up):
     nbytes = lib.adamvs_slice_reg_step_scratch_bytes(B, h, w)
     scratch = torch.empty(nbytes // 4, device=cost_cl.device, dtype=torch.float32)
     check(lib.adamvs_slice_reg_step(_p(_dev(cost_cl, "cost")), _p(state1), _p(state2), fuse.ptr(), _p(reg), B, C, h, w,
-                                    int(in_up), _p(scratch), nbytes, _stream()), "slice_reg_step")
+                                    int(in_up), int(precision), _p(scratch), nbytes, _stream()), "slice_reg_step")
     return reg
 
 
-def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0), precision=0):
-    return StageDesc(B, S, C, h, w, D, int(in_up), int(first_stage), int(prev_hw[0]), int(prev_hw[1]), int(precision))
+def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0), precision=0, precision_fuse=0):
+    return StageDesc(B, S, C, h, w, D, int(in_up), int(first_stage), int(prev_hw[0]), int(prev_hw[1]), int(precision),
+                     int(precision_fuse))
 
 
 def depth_stage_workspace_bytes(desc):

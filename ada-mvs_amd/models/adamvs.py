@@ -120,21 +120,23 @@ class SliceCostRegNetRED(nn.Module):
             self.upconv2d = nn.ConvTranspose2d(c, 1, kernel_size=3, stride=2, padding=1, output_padding=1)
         else:
             self.upconv2d = nn.Conv2d(c, 1, kernel_size=3, stride=1, padding=1)
+        self.precision = "fp32"            # or "bf16x3" (split-bf16 MFMA for conv1 and the ConvGRU convolutions)
         self._packed = None
 
     def packed(self, device):
         if self.base_channels != 8:
             raise AdaMVSHipError("SliceCostRegNetRED: the reference hard-codes 8/16 GRU widths (adamvs.py:448-449)")
-        if self._packed is None or self._packed.buf.device != device:
-            flat, offsets = packing.pack_slice_reg_net(self.state_dict(), "")
-            self._packed = hip_ops.PackedFuse(flat, offsets, device)
-        return self._packed
+        if self._packed is None or self._packed[0] != self.precision or self._packed[1].buf.device != device:
+            flat, offsets = packing.pack_slice_reg_net(self.state_dict(), "", self.precision)
+            self._packed = (self.precision, hip_ops.PackedFuse(flat, offsets, device))
+        return self._packed[1]
 
     def forward(self, cost, state1, state2):
         B, C, h, w = cost.shape
         s1 = hip_ops.pack_features(state1)
         s2 = hip_ops.pack_features(state2)
-        reg = hip_ops.slice_reg_step(hip_ops.pack_features(cost), s1, s2, self.packed(cost.device), B, C, h, w, self.up)
+        reg = hip_ops.slice_reg_step(hip_ops.pack_features(cost), s1, s2, self.packed(cost.device), B, C, h, w, self.up,
+                                     _PRECISIONS[self.precision])
         return reg, hip_ops.unpack_features(s1, h, w), hip_ops.unpack_features(s2, h // 2, w // 2)
 
 
@@ -171,7 +173,8 @@ class InferDepthNet0(nn.Module):
         D = depth_values.shape[1]
         first = prev_conf is None
         prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
-        desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()])
+        desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()],
+                                  _PRECISIONS[self.reg_fuse.precision])
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4
         ws = self._workspace.get(group)
         if ws is None or ws.numel() < need or ws.device != feat_cl.device:
@@ -229,13 +232,14 @@ class Infer_AdaMVSNet(nn.Module):
         self.set_precision(precision)
 
     def set_precision(self, precision):
-        """"fp32": exact fp32 MFMA everywhere (default).  "bf16x3": CostRegNet2D on the bf16 matrix cores with split
-        operands (hi + lo bf16, three MFMAs per product), fp32 accumulation -- agrees with fp32 to ~1e-5."""
+        """"fp32": exact fp32 MFMA everywhere (default).  "bf16x3": CostRegNet2D, conv1 and the ConvGRU convolutions
+        on the bf16 matrix cores with split operands (hi + lo bf16, three MFMAs per product), fp32 accumulation --
+        agrees with fp32 to ~1e-5."""
         assert precision in _PRECISIONS
         self.precision = precision
         for net in self.DepthNet:
-            net.reg.precision = precision
-            net.reg._packed = None
+            net.reg.precision = net.reg_fuse.precision = precision
+            net.reg._packed = net.reg_fuse._packed = None
 
     # ---- the hot path on pre-extracted features ---------------------------------------------
     def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval, group=0):

@@ -22,6 +22,13 @@ def _as_cout_cin_tap(w, transposed):
     return w.reshape(w.shape[0], w.shape[1], 9).contiguous()
 
 
+def split_bf16(x):
+    """fp32 -> (hi, lo) bf16 with hi + lo = x to 16 significant bits."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.to(torch.float32)).to(torch.bfloat16)
+    return hi, lo
+
+
 def pack_small_conv(w, transposed=False):
     """[cout][cin][3][3] -> A fragments [NT][9][cin/4][64], cout zero-padded to 16*NT."""
     w = _as_cout_cin_tap(w, transposed)
@@ -50,6 +57,49 @@ def pack_conv1_two_row(w):
     return wp.reshape(4, 3, 16, cin // 4, 4).permute(0, 1, 3, 4, 2).contiguous().reshape(-1)
 
 
+def _pack_rows_bf16x3(wm):
+    """[16*NT rows][K] fp32 matrix -> split-bf16 A fragments [NT][hi|lo][K/32][64][8] (K zero-padded to 32),
+    returned as a float32 view of the bf16 stream (include/adamvs_hip.h)."""
+    rows, k = wm.shape
+    nt, nkb = rows // 16, (k + 31) // 32
+    wp = torch.zeros(rows, nkb * 32)
+    wp[:, :k] = wm
+    parts = []
+    for part in split_bf16(wp):
+        # (nt, co16, kb, kg4, j8) -> (nt, kb, kg4, co16, j8): lane = kg4*16 + co16
+        parts.append(part.reshape(nt, 16, nkb, 4, 8).permute(0, 2, 3, 1, 4).contiguous())
+    frag = torch.stack(parts, 1).contiguous().reshape(-1)           # [nt][hi|lo][kb][lane][8]
+    if frag.numel() % 2:
+        frag = torch.cat([frag, torch.zeros(1, dtype=torch.bfloat16)])
+    return frag.view(torch.float32)
+
+
+def pack_small_conv_bf16x3(w):
+    """[cout][cin][3][3] -> split-bf16 fragments with k = (ky*3+kx)*cin_total + cin, cout zero-padded to 16*NT."""
+    w = _as_cout_cin_tap(w, False)                      # [cout][cin][9]
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % 8 == 0
+    nt = (cout + 15) // 16
+    wm = torch.zeros(nt * 16, 9 * cin)
+    wm[:cout] = w.permute(0, 2, 1).reshape(cout, 9 * cin)           # [cout][tap][cin]
+    return _pack_rows_bf16x3(wm)
+
+
+def pack_conv1_two_row_bf16x3(w):
+    """conv1 [8][cin][3][3] in two-row form (rows 0-7: output row y, ky = rr; rows 8-15: row y+1, ky = rr-1),
+    k = (rr*3+kx)*cin + cin_idx, rr = 0..3."""
+    w = w.detach().to(torch.float32).cpu()
+    cout, cin = w.shape[0], w.shape[1]
+    assert cout == 8 and cin % 8 == 0
+    wm = torch.zeros(16, 4, 3, cin)                                 # [row][rr][kx][cin]
+    for rr in range(4):
+        if rr <= 2:
+            wm[:8, rr] = w[:, :, rr, :].permute(0, 2, 1)            # [co][kx][cin]
+        if rr >= 1:
+            wm[8:, rr] = w[:, :, rr - 1, :].permute(0, 2, 1)
+    return _pack_rows_bf16x3(wm.reshape(16, 12 * cin))
+
+
 def pad_bias(b, n):
     out = torch.zeros(n)
     out[:b.numel()] = b.detach().to(torch.float32).cpu().reshape(-1)
@@ -64,13 +114,6 @@ def pack_reg_layer(w, scale, shift, transposed):
     # (tile, co16, kc, k4, tap) -> (tap, kc, tile, k4, co16)
     frag = w.reshape(d // 16, 16, d // 4, 4, 9).permute(4, 2, 0, 3, 1).contiguous().reshape(-1)
     return torch.cat([frag, shift.detach().to(torch.float32).cpu().reshape(-1)])
-
-
-def split_bf16(x):
-    """fp32 -> (hi, lo) bf16 with hi + lo = x to 16 significant bits."""
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.to(torch.float32)).to(torch.bfloat16)
-    return hi, lo
 
 
 def pack_reg_layer_bf16x3(w, scale, shift, transposed):
@@ -117,18 +160,21 @@ FUSE_FIELDS = ("conv1", "gates1", "gates1_b", "cand1", "cand1_b", "conv2", "gate
                "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w")
 
 
-def pack_slice_reg_net(sd, pre):
-    """SliceCostRegNetRED of `pre` (e.g. 'DepthNet.0.reg_fuse.') -> (flat fp32 tensor, {field: offset})."""
+def pack_slice_reg_net(sd, pre, precision="fp32"):
+    """SliceCostRegNetRED of `pre` (e.g. 'DepthNet.0.reg_fuse.') -> (flat fp32 tensor, {field: offset}).
+    precision "bf16x3": conv1 / gates / cand / conv2 as split-bf16 fragments (upconv1, final layer, biases stay fp32)."""
+    pack_small, pack_c1 = (pack_small_conv, pack_conv1_two_row) if precision == "fp32" else \
+                          (pack_small_conv_bf16x3, pack_conv1_two_row_bf16x3)
     parts = {
-        "conv1": pack_conv1_two_row(sd[pre + "conv1.conv.weight"]),
-        "gates1": pack_small_conv(sd[pre + "conv_gru1.conv_gates.0.weight"]),
+        "conv1": pack_c1(sd[pre + "conv1.conv.weight"]),
+        "gates1": pack_small(sd[pre + "conv_gru1.conv_gates.0.weight"]),
         "gates1_b": pad_bias(sd[pre + "conv_gru1.conv_gates.0.bias"], 16),
-        "cand1": pack_small_conv(sd[pre + "conv_gru1.convc.0.weight"]),
+        "cand1": pack_small(sd[pre + "conv_gru1.convc.0.weight"]),
         "cand1_b": pad_bias(sd[pre + "conv_gru1.convc.0.bias"], 16),
-        "conv2": pack_small_conv(sd[pre + "conv2.conv.weight"]),
-        "gates2": pack_small_conv(sd[pre + "conv_gru2.conv_gates.0.weight"]),
+        "conv2": pack_small(sd[pre + "conv2.conv.weight"]),
+        "gates2": pack_small(sd[pre + "conv_gru2.conv_gates.0.weight"]),
         "gates2_b": pad_bias(sd[pre + "conv_gru2.conv_gates.0.bias"], 32),
-        "cand2": pack_small_conv(sd[pre + "conv_gru2.convc.0.weight"]),
+        "cand2": pack_small(sd[pre + "conv_gru2.convc.0.weight"]),
         "cand2_b": pad_bias(sd[pre + "conv_gru2.convc.0.bias"], 16),
         "upconv1": pack_small_conv(sd[pre + "upconv1.weight"], transposed=True),
         "upconv1_b": pad_bias(sd[pre + "upconv1.bias"], 16),

@@ -99,7 +99,7 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
             D = model.ndepths[s]
             first = conf is None
             desc = hip_ops.stage_desc(B, S, C, h, w, D, net.in_up, first, (0, 0) if first else tuple(conf.shape[-2:]),
-                                      _lib.PRECISIONS[net.reg.effective_precision()])
+                                      _lib.PRECISIONS[net.reg.effective_precision()], _lib.PRECISIONS[net.reg_fuse.precision])
             dev = feats_cl[s].device
             Ho, Wo = (2 * h, 2 * w) if net.in_up else (h, w)
             outs = (torch.empty(S, B, h, w, device=dev), torch.empty(S, B, h, w, device=dev) if first else None,
@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="reference tiles per GPU per step")
     ap.add_argument("--groups", type=int, default=1, help="independent tile groups run concurrently on separate HIP streams")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
-                    help="fp32: exact fp32 MFMA (the cfg2 headline); bf16x3: split-bf16 MFMA in CostRegNet2D (~1e-5 of fp32)")
+                    help="fp32: exact fp32 MFMA (the cfg2 headline); bf16x3: split-bf16 MFMA for the convolutions (~1e-5 of fp32)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -287,7 +287,7 @@ def main():
                 "value": n_tiles * args.steps / elapsed, "unit": "depth maps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA, fp32 accumulate) in CostRegNet2D, f32 elsewhere",
+                "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA, fp32 accumulate) for the convolutions, f32 elsewhere",
                 "data": "synthetic",
                 "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, fp32" % (
                     cfg, c["views"], c["W"], c["H"], "/".join(map(str, c["ndepths"]))),

@@ -111,7 +111,12 @@ int adamvs_softmax_max_regress(const float* score, const float* planes, float* v
  * biases zero-padded to 16 per tile.  conv1 (8 output channels) uses the two-row form: fragment
  * (rr, kx, kc), rr = 0..3, holds for lanes with (lane&15) < 8 the weights of output row y,
  * W[lane&15][cin][ky = rr][kx] (0 if rr = 3), and for the other lanes those of output row y+1,
- * W[(lane&15)-8][cin][ky = rr-1][kx] (0 if rr = 0), so one MFMA feeds two output rows. */
+ * W[(lane&15)-8][cin][ky = rr-1][kx] (0 if rr = 0), so one MFMA feeds two output rows.
+ *
+ * With precision ADAMVS_PRECISION_BF16X3 the conv1 / gates / cand / conv2 fields point to split-bf16 fragments
+ * instead: the contraction index is flattened, k = pos*cin_total + cin (pos = tap ky*3+kx, or rr*3+kx for the
+ * two-row conv1), zero-padded to a multiple of 32; layout [cout tile][hi|lo][k/32][lane][8 bf16], element j of
+ * lane l = W[16*tile + (l&15)][k = 32*kb + 8*(l>>4) + j].  upconv1 / final_w / the biases keep the fp32 form. */
 typedef struct adamvs_fuse_weights {
   const float* conv1;                           /* [12][C/4][64] two-row form reg_fuse.conv1.conv.weight */
   const float* gates1; const float* gates1_b;   /* [1][9][4][64], [16]      conv_gru1.conv_gates.0 */
@@ -130,7 +135,7 @@ typedef struct adamvs_fuse_weights {
  * over it as a tiled MFMA convolution.  S <= 8. */
 size_t adamvs_aggregate_conv1_workspace_bytes(int B, int C, int D, int h, int w);
 int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* view_weight,
-                           const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w,
+                           const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, int precision,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* SliceCostRegNetRED.forward, models/adamvs.py:415-424 (one recurrent step).
@@ -139,8 +144,8 @@ int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* plan
  * scratch: adamvs_slice_reg_step_scratch_bytes(B,h,w) bytes. */
 size_t adamvs_slice_reg_step_scratch_bytes(int B, int h, int w);
 int adamvs_slice_reg_step(const float* cost, float* state1, float* state2, const adamvs_fuse_weights* weights,
-                          float* reg_cost, int B, int C, int h, int w, int in_up, void* scratch, size_t scratch_bytes,
-                          void* stream);
+                          float* reg_cost, int B, int C, int h, int w, int in_up, int precision, void* scratch,
+                          size_t scratch_bytes, void* stream);
 
 /* ---- whole stage: InferDepthNet0.forward, models/adamvs.py:433-533 -------- */
 typedef struct adamvs_stage_desc {
@@ -149,6 +154,7 @@ typedef struct adamvs_stage_desc {
   int first_stage;        /* 1: confidence_map is None -> pass A scores the views (stage 1) */
   int prev_h, prev_w;     /* size of prev_conf maps when !first_stage */
   int precision;          /* ADAMVS_PRECISION_* for CostRegNet2D (w_reg must be packed accordingly) */
+  int precision_fuse;     /* ADAMVS_PRECISION_* for conv1 and the ConvGRU convolutions (w_fuse packed accordingly) */
 } adamvs_stage_desc;
 
 size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);

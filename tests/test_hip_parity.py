@@ -151,7 +151,7 @@ def test_end_to_end_bf16x3(hip, O):
     sd = synth.seeded_state_dict(m, seed=0)
     m.load_state_dict(sd)
     m = m.cuda().eval()
-    assert m.DepthNet[0].reg.effective_precision() == "bf16x3"
+    assert m.DepthNet[0].reg.effective_precision() == "bf16x3" and m.DepthNet[2].reg_fuse.precision == "bf16x3"
     imgs, proj, dv = synth.tile_inputs(cfg, batch=2, seed=4)
     with torch.no_grad():
         out = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
@@ -184,12 +184,26 @@ def test_slice_reg_step_golden(hip, k):
     assert rel_l1(reg, g["reg"]) < OP_TOL, "decoder"
 
 
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_slice_reg_step_bf16x3(hip, k):
+    """One recurrent step with the split-bf16 convolutions against the reference fixture (fp32)."""
+    g = load_golden("net_slice_step%d" % k)
+    m, _ = _model("tiny")
+    net = m.DepthNet[k].reg_fuse
+    net.precision = "bf16x3"
+    reg, n1, n2 = net(dev(g["cost"]), dev(g["state1"]), dev(g["state2"]))
+    assert rel_l1(n1, g["new1"]) < 2e-4, "GRU level 1"
+    assert rel_l1(n2, g["new2"]) < 2e-4, "GRU level 2"
+    assert rel_l1(reg, g["reg"]) < 2e-4, "decoder"
+
+
 @pytest.mark.parametrize("C,h,w,D,baseline", [(32, 16, 40, 3, 80.0), (16, 20, 36, 3, 80.0), (8, 24, 70, 3, 80.0),
                                               (32, 24, 40, 24, 8.0),        # narrow sweep: one LDS-resident chunk
                                               (32, 24, 40, 16, 400.0),      # wide sweep: chunks split, patches leave the image
                                               (16, 40, 24, 10, 2500.0)])    # extreme: per-plane patches / global fallback
-def test_aggregate_conv1(hip, O, C, h, w, D, baseline):
-    """Weighted aggregation (register-resident taps, arbitrary planes) + two-row conv1."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_aggregate_conv1(hip, O, C, h, w, D, baseline, precision):
+    """Weighted aggregation (register-resident taps, arbitrary planes) + two-row conv1 (fp32 and split-bf16 MFMA)."""
     import torch.nn.functional as F
     B, S = 2, 3
     feats = [synth.smooth_features(B, C, h, w, seed=10 + v) for v in range(S + 1)]
@@ -206,14 +220,15 @@ def test_aggregate_conv1(hip, O, C, h, w, D, baseline):
     from ada_mvs_amd import packing
     c1 = hip.aggregate_conv1(hip.pack_features(dev(torch.stack(feats, 0).reshape(-1, C, h, w))),
                              hip.relative_transforms(dev(proj)), dev(planes), dev(vw),
-                             packing.pack_conv1_two_row(w1).cuda(), B, S, C, D, h, w).cpu()      # [D,B,hw,8]
+                             (packing.pack_conv1_two_row(w1) if precision == "fp32" else packing.pack_conv1_two_row_bf16x3(w1)).cuda(),
+                             B, S, C, D, h, w, precision=0 if precision == "fp32" else 1).cpu()      # [D,B,hw,8]
     Rs, ts = zip(*[O.relative_transform(proj[:, s + 1], proj[:, 0]) for s in range(S)])
     zero_frac = 0.0
     for d in range(D):
         sim = O.aggregate_similarity(feats[0], feats[1:], Rs, ts, planes[:, d], [vw[s].unsqueeze(1) for s in range(S)])
         zero_frac += float((sim.abs().sum(1) == 0).float().mean()) / D
         ref = F.relu(F.conv2d(sim, w1, None, 1, 1))
-        assert rel_l1(c1[d].reshape(B, h, w, 8).permute(0, 3, 1, 2), ref) < OP_TOL, "plane %d" % d
+        assert rel_l1(c1[d].reshape(B, h, w, 8).permute(0, 3, 1, 2), ref) < (OP_TOL if precision == "fp32" else 2e-4), "plane %d" % d
     if baseline >= 400.0:
         assert zero_frac > 0.02, "case must include pixels whose every view projects outside (%g)" % zero_frac
 
