@@ -29,11 +29,35 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~10 fewer VALU instructions per value in the
+// gate epilogues, far inside the parity tolerance.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_fast(float x) {
   float e = __expf(2.0f * x);
-  return 1.0f - 2.0f / (e + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+
+// s_waitcnt vmcnt(0) as a real instruction (not inline asm), so the compiler's own wait insertion knows that no
+// vector-memory result is pending after it.  gfx9 encoding: vmcnt [3:0]+[15:14], expcnt [6:4], lgkmcnt [11:8].
+__device__ __forceinline__ void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// ---- buffer addressing: workgroup-uniform base (128-bit descriptor in SGPRs) + 32-bit lane offset.
+// No per-lane 64-bit address arithmetic, and the range check does the masking: a lane offset >= num_records
+// (BUF_OOB) makes a load return zeros and a store disappear, so edge handling is one v_cndmask, not a branch.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* base) {      // base must be workgroup-uniform
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(buf_rsrc r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_store4(buf_rsrc r, unsigned byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
+}
+// Pin a per-lane constant in a register: computed once, never rematerialised or sunk into a branch.
+template <typename T> __device__ __forceinline__ void pin(T& x) { asm volatile("" : "+v"(x)); }
 
 // Uniform (scalar-cache) view of read-only parameters.
 typedef const float __attribute__((address_space(4))) cfloat;

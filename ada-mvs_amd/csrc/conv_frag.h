@@ -49,4 +49,21 @@ __device__ __forceinline__ void conv3x3_run(f32x4 (&acc)[NT], const float (&wf)[
       }
 }
 
+// Same, with the lane's B-fragment origin given as one pinned LDS byte offset per k-chunk: every read is
+// base register + immediate (tap offsets fit the ds_read2 immediates), no address arithmetic in the chain.
+template <int NT, int KC, int STRIDE, int PITCH>
+__device__ __forceinline__ void conv3x3_run_at(f32x4 (&acc)[NT], const float (&wf)[NT][9][KC], const float* lds,
+                                               const unsigned (&xbyte)[KC]) {
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        float bv = *(const float*)((const char*)lds + xbyte[kc] + (ky * PITCH + kx) * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[nt][ky * 3 + kx][kc], bv, acc[nt]);
+      }
+}
+
 }  // namespace adamvs

@@ -26,132 +26,219 @@ struct SmallConvArgs {
 };
 
 
-// Persistent workgroups.  These launches are short (a few thousand tiles of a few microseconds) and sit on the
-// sequential critical path of the recurrence, so what costs time is not the matrix work but its packaging: a grid
-// that is 1.8x the resident capacity runs as two "rounds" with the second one mostly empty, and every workgroup
-// of a round is in its load phase at the same time.  Here the grid is exactly the resident capacity (occupancy
-// query); workgroup i walks tiles i, i + grid, ..., requests the input tile of its NEXT tile before the MFMAs of
-// the current one (two LDS buffers, one barrier per tile) and fetches the A fragments once.  (A shared atomic
-// tile counter was tried and is slower: one word serves ~88 dequeues/us.)  Tile t -> (tile_x, tile_y, b).
-template <int CA, int CB, int NT, int STRIDE, int EPI, int TR>
-__global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a, int tiles_x, int tiles_y, int ntiles) {
-  constexpr int CIN = CA + CB, KC = CIN / 4, G = CIN / 4;
+// Tile bookkeeping of the persistent kernels: tile t -> (tile_x, tile_y, b) with the two divisions done as
+// multiply-high by constants prepared on the host (t is workgroup-uniform, so this stays on the scalar unit).
+struct TileGrid {
+  int tiles_x, tiles_y, ntiles;
+  unsigned mx, my;       // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y); unused when the divisor is 1
+};
+__device__ __forceinline__ void tile_coords(const TileGrid& g, int t, int& b, int& tx, int& ty) {
+  unsigned r = g.tiles_x == 1 ? (unsigned)t : __umulhi((unsigned)t, g.mx);
+  tx = t - (int)r * g.tiles_x;
+  unsigned bb = g.tiles_y == 1 ? r : __umulhi(r, g.my);
+  ty = (int)r - (int)bb * g.tiles_y;
+  b = (int)bb;
+}
+static int make_tile_grid(TileGrid& g, int tiles_x, int tiles_y, int B) {
+  long n = (long)tiles_x * tiles_y * B;
+  // exactness of the multiply-high quotient needs t * divisor < 2^32
+  if (n <= 0 || n * (tiles_x > tiles_y ? tiles_x : tiles_y) >= (1L << 32)) return set_error(-1, "too many tiles (%ld)", n);
+  g.tiles_x = tiles_x; g.tiles_y = tiles_y; g.ntiles = (int)n;
+  g.mx = (unsigned)(((1ull << 32) + tiles_x - 1) / tiles_x);
+  g.my = (unsigned)(((1ull << 32) + tiles_y - 1) / tiles_y);
+  return 0;
+}
+
+// Persistent workgroups.  These launches are short (thousands of tiles of about a microsecond) and sit on the
+// sequential critical path of the recurrence, so what costs time is not the matrix work but its packaging.
+//  * The grid is exactly the resident capacity (occupancy query); workgroup i walks tiles i, i + grid, ...
+//    (A shared atomic tile counter was tried and is slower: one word serves ~88 dequeues/us.)
+//  * A tile is TR rows x 16*RW columns = four 16-pixel runs, one per wave.
+//  * fp32 MFMA and the vector ALU are the same lanes (the fp32 matrix rate of the chip IS its packed-fp32 vector
+//    rate): every VALU instruction is a slot an MFMA does not get, whatever the occupancy.  Measured here: with
+//    loads, epilogue and barriers stripped the kernels run at the MFMA bound; each phase put back added its
+//    VALU instruction count, nothing else.  So everything per-lane that does not depend on the tile (LDS
+//    addresses, offsets inside the tile window, output offsets) is computed once before the loop, the tile
+//    enters only through workgroup-uniform base pointers (scalar unit; global accesses are base + 32-bit lane
+//    offset), interior tiles take a path with no bounds checks, and the gate non-linearities use v_rcp/v_exp
+//    directly.
+//  * One wait point per tile.  vmcnt retires in order, so any wait on a late load also waits for everything
+//    issued before it.  Per tile: request the epilogue operands of this tile and the input of the NEXT tile; run
+//    the MFMA chain out of LDS; only then wait, barrier, refill the LDS tile, epilogue, stores, barrier.
+//    Nothing is waited for before it has had a whole MFMA phase to arrive; the stores drain under the next chain.
+template <int CA, int CB, int NT, int STRIDE, int EPI, int TR, int RW>
+__global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a, TileGrid tg) {
+  static_assert(TR * RW == 4, "one run per wave");
+  constexpr int CIN = CA + CB, KC = CIN / 4, G = CIN / 4, GA = CA / 4, GB = CB / 4, TC = 16 * RW;
   constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
-  constexpr int LC = (STRIDE == 1) ? 34 : 65;
-  constexpr int PLANE = (STRIDE == 1) ? plane_pitch16(LR * LC) : ((LR * LC) | 1);
+  constexpr int LC = (STRIDE == 1) ? TC + 2 : 2 * TC + 1;
+  constexpr int NPIX = LR * LC;
+  constexpr int PLANE = (STRIDE == 1) ? plane_pitch16(NPIX) : (NPIX | 1);
   constexpr int GP = group_pitch(PLANE, G);
   constexpr int HC = CB;                 // hidden width for the GRU epilogues
-  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
-  extern __shared__ float lds_all[];     // [2][G][GP]
+  // one load instruction covers 256 (pixel, channel group) items of ONE source, so that its base is uniform
+  constexpr int NA = (NPIX * GA + 255) / 256, NB = (NPIX * GB + 255) / 256, NL = NA + NB;
+  extern __shared__ float lds[];         // [G][GP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, q = lane >> 4;
+  const int row = wave / RW, col = (wave % RW) * 16;      // the wave's run inside a tile
 
   float wf[NT][9][KC];
   load_wfrag<NT, KC>(wf, a.wpk, lane);
-
-  auto tile_coords = [&](int t, int& b, int& ox0, int& oy0) {
-    int tx = t % tiles_x, r = t / tiles_x;
-    int ty = r % tiles_y;
-    b = r / tiles_y;
-    ox0 = tx * 32; oy0 = ty * TR;
-  };
-  auto load_tile = [&](f32x4 (&stage)[NIT], int t) {
-    int b, ox0, oy0;
-    tile_coords(t, b, ox0, oy0);
-    const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
+  f32x4 bias[NT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int i = tid + it * 256;
-      int g = i % G, pp = i / G;
-      int r = pp / LC, c = pp % LC;
-      int iy = iy0 + r, ix = ix0 + c;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i < NITEMS && iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) {
-        size_t pix = ((size_t)b * a.hi + iy) * a.wi + ix;
-        if (4 * g < CA) v = *(const f32x4*)(a.srcA + pix * CA + 4 * g);
-        else v = *(const f32x4*)(a.srcB + pix * CB + (4 * g - CA));
+  for (int nt = 0; nt < NT; ++nt)
+    bias[nt] = (EPI == EPI_RELU) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.bias + nt * 16 + 4 * q);
+
+  // ---- per-lane constants of the tile window
+  unsigned goff[NL];      // byte offset of the item from the window's first pixel in its source
+  unsigned lbyte[NL];     // LDS byte offset of the item's first channel plane
+  int rc[NL];             // window row | column << 16 (edge tiles only)
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    const int gs = isA ? GA : GB, cs = isA ? CA : CB;
+    int j = tid + (isA ? k : k - NA) * 256;
+    j = min(j, NPIX * gs - 1);           // surplus lanes repeat the last item (same value to the same place)
+    const int g = j % gs, pp = j / gs, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * a.wi + c) * cs + 4 * g) * 4);
+    lbyte[k] = (unsigned)((((isA ? 0 : GA) + g) * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xbyte[KC];     // B-fragment origin of the run, per k-chunk
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    xbyte[kc] = (unsigned)((kc * GP + q * PLANE + (row * STRIDE) * LC + (col + p) * STRIDE) * 4);
+    pin(xbyte[kc]);
+  }
+  unsigned hbyte[NT];     // GATES: hidden-state channels co4..co4+3 of the lane's own pixel
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    hbyte[nt] = (unsigned)((((CA + min(nt * 16 + 4 * q, HC - 4)) >> 2) * GP + (row + 1) * LC + col + p + 1) * 4);
+    pin(hbyte[nt]);
+  }
+  // output offsets (bytes) of the lane's pixel inside the tile, per 16-channel slice
+  const int CO = (EPI == EPI_RELU) ? a.cout : HC;
+  // ooff: destination 0 (RELU out, GATES r*h, CAND h); ooff1: destination 1 (GATES u).  Rows that do not
+  // belong to a destination carry BUF_OOB, so every store is issued by all lanes with one uniform descriptor.
+  unsigned ooff[NT], ooff1[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co4 = nt * 16 + 4 * q;
+    const unsigned at = (unsigned)(((row * a.wo + col + p) * CO + (EPI == EPI_GATES && co4 >= HC ? co4 - HC : co4)) * 4);
+    const bool to0 = (EPI == EPI_RELU) ? co4 < a.cout : co4 < HC;
+    const bool to1 = EPI == EPI_GATES && co4 >= HC && co4 < 2 * HC;
+    ooff[nt] = to0 ? at : BUF_OOB;
+    ooff1[nt] = to1 ? at : BUF_OOB;
+    pin(ooff[nt]); pin(ooff1[nt]);
+  }
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int b, int tx, int ty) {
+    const int ix0 = tx * TC * STRIDE - 1, iy0 = ty * TR * STRIDE - 1;
+    const long pix0 = ((long)b * a.hi + iy0) * a.wi + ix0;                 // may point one row/column outside
+    const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
+    const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + LR <= a.hi && ix0 + LC <= a.wi;
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        stage[k] = buf_load4(k < NA ? ra : rb, ok ? goff[k] : BUF_OOB);              // zero padding
       }
-      stage[it] = v;
     }
   };
-  auto store_tile = [&](const f32x4 (&stage)[NIT], float* lds) {
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int i = tid + it * 256;
-      if (i < NITEMS) {
-        int g = i % G, pp = i / G;
-        int r = pp / LC, c = pp % LC;
-        float* dl = lds + g * GP + r * LC + c;
-        f32x4 v = stage[it];
-        dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
-      }
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
     }
   };
 
   int t = blockIdx.x;
-  f32x4 stage[NIT];
-  if (t < ntiles) load_tile(stage, t);
-  for (int it = 0; t < ntiles; ++it) {
-    float* lds = lds_all + (it & 1) * (G * GP);
-    store_tile(stage, lds);
-    __syncthreads();        // tile visible; readers of this LDS buffer two iterations ago are done
-    const int tn = t + gridDim.x;
-    if (tn < ntiles) load_tile(stage, tn);            // in flight during the MFMAs below
+  if (t >= tg.ntiles) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, b, tx, ty);
+  wait_vmem_all();                     // fragments, biases and the first tile: nothing is pending inside the loop
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)b * a.ho + oy0) * a.wo + ox0;
+    const bool full = oy0 + TR <= a.ho && ox0 + TC <= a.wo;            // uniform: no output of the tile is outside
+    const buf_rsrc r0 = make_rsrc((char*)a.dst0 + opix0 * (CO * 4));
+    const buf_rsrc r1 = make_rsrc((char*)a.dst1 + opix0 * (HC * 4));
+    unsigned oo[NT], oo1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { oo[nt] = ooff[nt]; oo1[nt] = ooff1[nt]; }
+    if (!full) {
+      const bool valid = oy0 + row < a.ho && ox0 + col + p < a.wo;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { oo[nt] = valid ? ooff[nt] : BUF_OOB; oo1[nt] = valid ? ooff1[nt] : BUF_OOB; }
+    }
 
-    int b, ox0, oy0;
-    tile_coords(t, b, ox0, oy0);
-    const float* xb = lds + q * PLANE + p * STRIDE;
-    // A wave owns (2 TR)/4 runs of 16 pixels, one after the other (rolled: occupancy matters more than unrolling
-    // here).  Operands the epilogue needs from global memory are requested before the run's MFMA chain.
-#pragma unroll 1
-    for (int run = wave; run < TR * 2; run += 4) {
-      const int row = run >> 1, col = (run & 1) * 16;
-      const int oy = oy0 + row, ox = ox0 + col + p;
-      const bool valid = oy < a.ho && ox < a.wo;
-      const size_t opix = ((size_t)b * a.ho + min(oy, a.ho - 1)) * a.wo + min(ox, a.wo - 1);
-      f32x4 acc[NT], pre_u[NT], pre_h[NT];
+    // requests: epilogue operands first, then the next tile
+    f32x4 pre_u[NT], pre_h[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int co4 = nt * 16 + 4 * q;
-        if (EPI == EPI_CAND && co4 < HC) {
-          pre_u[nt] = *(const f32x4*)(a.dst1 + opix * HC + co4);
-          pre_h[nt] = *(const f32x4*)(a.dst0 + opix * HC + co4);
-        }
-      }
-      conv3x3_run<NT, KC, STRIDE, GP, LC>(acc, wf, xb, row, col);
-#pragma unroll
-      for (int nt = 0; nt < NT && valid; ++nt) {
-        int co4 = nt * 16 + 4 * q;
-        f32x4 v = acc[nt];
-        if (EPI == EPI_RELU) {
-          if (co4 < a.cout) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            *(f32x4*)(a.dst0 + opix * a.cout + co4) = v;
-          }
-        } else if (EPI == EPI_GATES) {
-          f32x4 bb = *(const f32x4*)(a.bias + co4);
-          v += bb;
-          f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
-          if (co4 < HC) {                                   // reset gate -> r * h   (module.py:35-41)
-            const float* hl = lds + ((CA + co4) >> 2) * GP + (row + 1) * LC + col + p + 1;
-            f32x4 h4 = {hl[0], hl[PLANE], hl[2 * PLANE], hl[3 * PLANE]};
-            *(f32x4*)(a.dst0 + opix * HC + co4) = sg * h4;
-          } else if (co4 < 2 * HC) {                        // update gate
-            *(f32x4*)(a.dst1 + opix * HC + (co4 - HC)) = sg;
-          }
-        } else {                                            // EPI_CAND   (module.py:44-50)
-          if (co4 < HC) {
-            f32x4 bb = *(const f32x4*)(a.bias + co4);
-            v += bb;
-            f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
-            f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
-            *(f32x4*)(a.dst0 + opix * HC + co4) = u4 * h4 + (1.0f - u4) * cnd;
-          }
-        }
+    for (int nt = 0; nt < NT; ++nt) {
+      if (EPI == EPI_CAND && nt * 16 < HC) {
+        pre_u[nt] = buf_load4(r1, oo[nt]);
+        pre_h[nt] = buf_load4(r0, oo[nt]);
       }
     }
-    t = tn;
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_tile(stage, bn, txn, tyn);
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv3x3_run_at<NT, KC, STRIDE, LC>(acc, wf, lds, xbyte);
+
+    f32x4 hc[NT];      // GATES: the hidden state of the lane's pixel, from the tile (module.py:35-41)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (EPI == EPI_GATES && nt * 16 < HC) {
+        const float* hl = (const float*)((const char*)lds + hbyte[nt]);
+        hc[nt] = f32x4{hl[0], hl[PLANE], hl[2 * PLANE], hl[3 * PLANE]};
+      }
+    }
+
+    wait_vmem_all();                   // the wait point (explicit, so that no other wait is scheduled elsewhere)
+    __syncthreads();                   // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 v = acc[nt] + bias[nt];
+      if (EPI == EPI_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        buf_store4(r0, oo[nt], v);
+      } else if (EPI == EPI_GATES) {
+        f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+        if (nt * 16 < HC) buf_store4(r0, oo[nt], sg * hc[nt]);              // reset-gate rows -> r * h
+        if (nt * 16 + 16 > HC) buf_store4(r1, oo1[nt], sg);                 // update-gate rows -> u
+      } else if (nt * 16 < HC) {                        // EPI_CAND   (module.py:44-50)
+        f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+        f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
+        buf_store4(r0, oo[nt], u4 * h4 + (1.0f - u4) * cnd);
+      }
+    }
+    if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; b = bn; tx = txn; ty = tyn;
   }
 }
 
@@ -377,30 +464,30 @@ static int resident_blocks(K kernel, int threads, size_t lds) {
   return n * cus;
 }
 
-template <int CA, int CB, int NT, int STRIDE, int EPI, int TR>
-static int launch_small_tr(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
+template <int CA, int CB, int NT, int STRIDE, int EPI, int TR, int RW>
+static int launch_small_shape(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
+  constexpr int TC = 16 * RW;
   constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
-  constexpr int LC = (STRIDE == 1) ? 34 : 65;
+  constexpr int LC = (STRIDE == 1) ? TC + 2 : 2 * TC + 1;
   constexpr int PLANE = (STRIDE == 1) ? plane_pitch16(LR * LC) : ((LR * LC) | 1);
-  constexpr size_t lds = (size_t)2 * ((CA + CB) / 4) * group_pitch(PLANE, (CA + CB) / 4) * sizeof(float);
-  static_assert(lds <= 64 * 1024, "double-buffered tile exceeds the default dynamic LDS limit");
-  auto kern = k_conv_small<CA, CB, NT, STRIDE, EPI, TR>;
+  constexpr size_t lds = (size_t)((CA + CB) / 4) * group_pitch(PLANE, (CA + CB) / 4) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
+  auto kern = k_conv_small<CA, CB, NT, STRIDE, EPI, TR, RW>;
   static int capacity = 0;              // per instantiation; a pure function of the kernel and the device
   if (!capacity) capacity = resident_blocks(kern, 256, lds);
-  const int tiles_x = cdiv(a.wo, 32), tiles_y = cdiv(a.ho, TR);
-  const int ntiles = tiles_x * tiles_y * B;
-  const int grid = ntiles < capacity ? ntiles : capacity;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tiles_x, tiles_y, ntiles);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(a.wo, TC), cdiv(a.ho, TR), B)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tg);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
   return 0;
 }
 
-// Tile height 4 (two 16-pixel runs per wave): short tiles keep the end-of-launch imbalance small.
+// Tile = 4 rows x 16 columns: the smallest halo (6 x 18 input pixels for 64 outputs) of the one-run-per-wave shapes.
 template <int CA, int CB, int NT, int STRIDE, int EPI>
 static int launch_small(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
-  if ((long)cdiv(a.ho, 4) * cdiv(a.wo, 32) * B >= 2048) return launch_small_tr<CA, CB, NT, STRIDE, EPI, 4>(a, B, st, name);
-  return launch_small_tr<CA, CB, NT, STRIDE, EPI, 2>(a, B, st, name);
+  return launch_small_shape<CA, CB, NT, STRIDE, EPI, 4, 1>(a, B, st, name);
 }
 
 // conv1 (C -> 8, ReLU; reference adamvs.py:416) in two-row form: the 16 MFMA rows are 8 output channels of

@@ -197,6 +197,25 @@ def test_slice_reg_step_bf16x3(hip, k):
     assert rel_l1(reg, g["reg"]) < 2e-4, "decoder"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_slice_reg_step_many_tiles(hip, precision):
+    """Persistent kernels past their resident capacity (every workgroup walks several tiles, interior and edge):
+    a batch of identical tiles must give, entry by entry, the single-tile result (itself pinned by the fixtures)."""
+    m, _ = _model("tiny")
+    net = m.DepthNet[0].reg_fuse
+    net.precision = precision
+    C, h, w, B = net.in_channels, 64, 96, 80
+    g = torch.Generator().manual_seed(11)
+    cost = torch.randn(1, C, h, w, generator=g)
+    s1 = torch.randn(1, 8, h, w, generator=g) * 0.5
+    s2 = torch.randn(1, 16, h // 2, w // 2, generator=g) * 0.5
+    reg1, a1, b1 = net(dev(cost), dev(s1), dev(s2))
+    regB, aB, bB = net(dev(cost).expand(B, -1, -1, -1).contiguous(), dev(s1).expand(B, -1, -1, -1).contiguous(),
+                       dev(s2).expand(B, -1, -1, -1).contiguous())
+    for one, many, name in ((reg1, regB, "decoder"), (a1, aB, "GRU level 1"), (b1, bB, "GRU level 2")):
+        assert torch.equal(many, one.expand_as(many)), name
+
+
 @pytest.mark.parametrize("C,h,w,D,baseline", [(32, 16, 40, 3, 80.0), (16, 20, 36, 3, 80.0), (8, 24, 70, 3, 80.0),
                                               (32, 24, 40, 24, 8.0),        # narrow sweep: one LDS-resident chunk
                                               (32, 24, 40, 16, 400.0),      # wide sweep: chunks split, patches leave the image
