@@ -253,16 +253,17 @@ struct DecoderArgs {
   const float* h1;     // [B][h*w][8]
   const float* wup1;   // A fragments [1][9][4][64]: A[cout][cin] of tap (ky,kx)
   const float* bup1;   // [16] zero padded
-  const float* wfin;   // [72] index c*9 + ky*3 + kx, then bias at [72]
+  const float* wfin;   // [72] index (ky*3 + kx)*8 + c, then bias at [72]
   float* vol;          // [B][D][Ho*Wo]
   int h, w, D, d;
 };
 
 // ConvTranspose2d(k3, s2, p1, op1) restricted to one output parity class (PY,PX):
 // out[2i+PY][2j+PX] = sum over taps with ky = 2(i-iy)+PY+1, i.e. PY=0 -> (ky=1, iy=i);
-// PY=1 -> (ky=2, iy=i), (ky=0, iy=i+1); same along x.
+// PY=1 -> (ky=2, iy=i), (ky=0, iy=i+1); same along x.  `xbyte` = LDS byte offset of the lane's
+// B-fragment origin (k-row q, h2 pixel (li, lj)) in the planar h2 tile.
 template <int PY, int PX, int HGP, int HCOLS>
-__device__ __forceinline__ f32x4 upconv1_class(const float (&wf)[1][9][4], const float* xb) {
+__device__ __forceinline__ f32x4 upconv1_class(const float (&wf)[1][9][4], const float* lds, unsigned xbyte) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ty = 0; ty < (PY ? 2 : 1); ++ty) {
@@ -272,138 +273,219 @@ __device__ __forceinline__ f32x4 upconv1_class(const float (&wf)[1][9][4], const
       const int kx = PX ? (tx ? 0 : 2) : 1;
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc)
-        acc = mfma16(wf[0][ky * 3 + kx][kc], xb[kc * HGP + ty * HCOLS + tx], acc);
+        acc = mfma16(wf[0][ky * 3 + kx][kc], *(const float*)((const char*)lds + xbyte + (kc * HGP + ty * HCOLS + tx) * 4), acc);
     }
   }
   return acc;
 }
 
-// Persistent like k_conv_small: grid = resident capacity, workgroup i takes tiles i, i + grid, ...
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Persistent, software-pipelined like k_conv_small (same reasoning: uniform descriptors + pinned lane offsets,
+// no bounds checks on interior tiles, one wait per tile).  A tile is 6 x 30 pixels of s (full resolution h x w);
+// its s region is 8 x 32 (one pixel of halo each side), fed by a 5 x 17 region of h2.
+//   phase 1  upconv1 on the matrix cores: 16 runs = 4 parity classes x 4 rows; wave k takes row k of every
+//            class (equal MFMA counts).  + bias + h1 (requested during the previous tile) -> ReLU -> s in LDS.
+//   phase 2  last layer on the vector units.  Transposed (IN_UP): one thread per s pixel produces its 2 x 2
+//            output quad from s[i..i+1][j..j+1] (72 FMAs, weights as scalar operands), two 8-byte stores.
+//            Flat: one thread per pixel, 3 x 3 x 8 FMAs.
 template <bool IN_UP>
-__global__ __launch_bounds__(256) void k_decoder(DecoderArgs a, int tiles_x, int tiles_y, int ntiles) {
-  constexpr int HR = 10, HCOLS = 18, HPLANE = plane_pitch16(HR * HCOLS);   // h2 region, 16 planes in 4 groups
+__global__ __launch_bounds__(256) void k_decoder(DecoderArgs a, TileGrid tg) {
+  constexpr int TRI = 6, TCI = 30;                                          // inner tile of s
+  constexpr int SR = 8, SC = 32, SPX = 12;        // s region, channel-last, 8 channels + 4 floats of padding per
+                                                  // pixel: 16-byte lane accesses at a 48-byte stride are conflict-free
+  constexpr int HR = 5, HCOLS = 17, HPLANE = plane_pitch16(HR * HCOLS);     // h2 region, 16 planes in 4 groups
   constexpr int HGP = group_pitch(HPLANE, 4);
-  constexpr int SR = 16, SC = 32, SPLANE = plane_pitch16(SR * SC);        // s region, 8 planes
-  __shared__ float lds[4 * HGP + 8 * SPLANE];
+  constexpr int NH = (HR * HCOLS * 4 + 255) / 256;                          // h2 load instructions per tile
+  __shared__ __attribute__((aligned(16))) float lds[4 * HGP + SR * SC * SPX];
   float* lh2 = lds;
   float* ls = lds + 4 * HGP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, q = lane >> 4;
   const int h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1;
   float wf[1][9][4];
   load_wfrag<1, 4>(wf, a.wup1, lane);
+  const f32x4 bup = *(const f32x4*)(a.bup1 + 4 * q);
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const int b = tile / (tiles_x * tiles_y);
-  const int x0 = (tile % tiles_x) * 30, y0 = ((tile / tiles_x) % tiles_y) * 14;     // both even
-  const int i0 = (y0 >> 1) - 1, j0 = (x0 >> 1) - 1;         // h2-region origin
-
-  constexpr int NITEMS = HR * HCOLS * 4, NIT = (NITEMS + 255) / 256;
-  f32x4 stage[NIT];
+  // ---- per-lane constants
+  unsigned h2off[NH], h2lds[NH];
+  int h2rc[NH];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    int i = tid + it * 256;
-    int g = i & 3, pp = i >> 2;
-    int r = pp / HCOLS, c = pp % HCOLS;
-    int iy = i0 + r, ix = j0 + c;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (i < NITEMS && iy >= 0 && iy < h2 && ix >= 0 && ix < w2)
-      v = *(const f32x4*)(a.h2 + (((size_t)b * h2 + iy) * w2 + ix) * 16 + 4 * g);
-    stage[it] = v;
+  for (int k = 0; k < NH; ++k) {
+    const int j = min(tid + k * 256, HR * HCOLS * 4 - 1);
+    const int g = j & 3, pp = j >> 2, r = pp / HCOLS, c = pp % HCOLS;
+    h2off[k] = (unsigned)(((r * w2 + c) * 16 + 4 * g) * 4);
+    h2lds[k] = (unsigned)((g * HGP + r * HCOLS + c) * 4);
+    h2rc[k] = r | (c << 16);
+    pin(h2off[k]); pin(h2lds[k]); pin(h2rc[k]);
   }
+  // run j of this wave = parity class j (py = j >> 1, px = j & 1), row k = wave of that class
+  unsigned xbyte[4], h1off[4], sbyte[4];
+  int src[4];          // s-region row | column << 16 of the lane's pixel
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    int i = tid + it * 256;
-    if (i < NITEMS) {
-      int g = i & 3, pp = i >> 2;
-      int r = pp / HCOLS, c = pp % HCOLS;
-      float* dl = lh2 + g * HGP + r * HCOLS + c;
-      f32x4 v = stage[it];
+  for (int j = 0; j < 4; ++j) {
+    const int py = j >> 1, px = j & 1, k = wave;
+    const int r = py ? 2 * k : 2 * k + 1, c = px ? 2 * p : 2 * p + 1;
+    const int li = py ? k : k + 1, lj = px ? p : p + 1;
+    xbyte[j] = (unsigned)((q * HPLANE + li * HCOLS + lj) * 4);
+    h1off[j] = q < 2 ? (unsigned)(((r * w + c) * 8 + 4 * q) * 4) : BUF_OOB;       // rows 8-15 of the tile are padding
+    sbyte[j] = (unsigned)(((r * SC + c) * SPX + 4 * (q & 1)) * 4);
+    src[j] = r | (c << 16);
+    pin(xbyte[j]); pin(h1off[j]); pin(sbyte[j]); pin(src[j]);
+  }
+  // phase 2: thread -> inner pixel (i, j)
+  const bool worker = tid < TRI * TCI;
+  const int pi = min(tid, TRI * TCI - 1) / TCI, pj = min(tid, TRI * TCI - 1) % TCI;
+  unsigned qbyte = (unsigned)(((IN_UP ? (pi + 1) * SC + pj + 1 : pi * SC + pj)) * SPX * 4);   // first s pixel the thread reads
+  const int Ho = IN_UP ? 2 * h : h, Wo = IN_UP ? 2 * w : w;
+  unsigned ooff = worker ? (unsigned)((IN_UP ? (2 * pi * Wo + 2 * pj) : (pi * Wo + pj)) * 4) : BUF_OOB;
+  pin(qbyte); pin(ooff);
+  cfloat* wfin0 = as_const(a.wfin);
+
+  auto load_h2 = [&](f32x4 (&stage)[NH], int b, int tx, int ty) {
+    const int i0 = ty * (TRI / 2) - 1, j0 = tx * (TCI / 2) - 1;
+    const buf_rsrc rh = make_rsrc((const char*)a.h2 + (((long)b * h2 + i0) * w2 + j0) * 64);
+    if (i0 >= 0 && j0 >= 0 && i0 + HR <= h2 && j0 + HCOLS <= w2) {
+#pragma unroll
+      for (int k = 0; k < NH; ++k) stage[k] = buf_load4(rh, h2off[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int iy = i0 + (h2rc[k] & 0xffff), ix = j0 + (h2rc[k] >> 16);
+        stage[k] = buf_load4(rh, ((unsigned)iy < (unsigned)h2 && (unsigned)ix < (unsigned)w2) ? h2off[k] : BUF_OOB);
+      }
+    }
+  };
+  // skip operand h1 of the lane's four pixels; returns which of them lie inside the image (bit j; 15 for every
+  // lane of an interior tile, which the caller tests with a uniform branch)
+  auto load_h1 = [&](f32x4 (&hreg)[4], int b, int tx, int ty) -> unsigned {
+    const int ys0 = ty * TRI - 1, xs0 = tx * TCI - 1;
+    const buf_rsrc r1 = make_rsrc((const char*)a.h1 + (((long)b * h + ys0) * w + xs0) * 32);
+    if (ys0 >= 0 && xs0 >= 0 && ys0 + SR <= h && xs0 + SC <= w) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hreg[j] = buf_load4(r1, h1off[j]);
+      return 15u;
+    }
+    unsigned in = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ys = ys0 + (src[j] & 0xffff), xs = xs0 + (src[j] >> 16);
+      const bool ok = (unsigned)ys < (unsigned)h && (unsigned)xs < (unsigned)w;
+      hreg[j] = buf_load4(r1, ok ? h1off[j] : BUF_OOB);
+      in |= ok ? (1u << j) : 0u;
+    }
+    return in;
+  };
+  auto store_h2 = [&](const f32x4 (&stage)[NH]) {
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      float* dl = (float*)((char*)lh2 + h2lds[k]);
+      f32x4 v = stage[k];
       dl[0] = v.x; dl[HPLANE] = v.y; dl[2 * HPLANE] = v.z; dl[3 * HPLANE] = v.w;
     }
-  }
-  __syncthreads();
+  };
 
-  // --- upconv1 on the matrix cores: run = (parity class, row of that class), 32 runs, 8 per wave (rolled).
-  const int p = lane & 15, q = lane >> 4;
-  const f32x4 bup = *(const f32x4*)(a.bup1 + 4 * q);
-#pragma unroll 1
-  for (int run = wave; run < 32; run += 4) {
-    const int cls = run >> 3, k = run & 7;          // k-th row of this class; wave-uniform
-    const int py = cls >> 1, px = cls & 1;
-    const int r = py ? 2 * k : 2 * k + 1;            // s-region row / col of the lane's pixel
-    const int c = px ? 2 * p : 2 * p + 1;
-    const int li = py ? k : k + 1, lj = px ? p : p + 1;
-    const int ys = y0 - 1 + r, xs = x0 - 1 + c;
-    const bool sin = ys >= 0 && ys < h && xs >= 0 && xs < w;
-    f32x4 h1v = {0.f, 0.f, 0.f, 0.f};               // skip operand: in flight during the MFMAs
-    if (q < 2 && sin) h1v = *(const f32x4*)(a.h1 + (((size_t)b * h + ys) * w + xs) * 8 + 4 * q);
-    const float* xb = lh2 + q * HPLANE + li * HCOLS + lj;
-    f32x4 acc;
-    switch (cls) {
-      case 0: acc = upconv1_class<0, 0, HGP, HCOLS>(wf, xb); break;
-      case 1: acc = upconv1_class<0, 1, HGP, HCOLS>(wf, xb); break;
-      case 2: acc = upconv1_class<1, 0, HGP, HCOLS>(wf, xb); break;
-      default: acc = upconv1_class<1, 1, HGP, HCOLS>(wf, xb); break;
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 stage[NH], hreg[4];
+  load_h2(stage, b, tx, ty);
+  unsigned inside = load_h1(hreg, b, tx, ty);
+  wait_vmem_all();
+  store_h2(stage);
+  __syncthreads();
+  for (;;) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_h2(stage, bn, txn, tyn);                 // in flight during phases 1 and 2
     }
+
+    // ---- phase 1
+    f32x4 sv[4];
+    sv[0] = upconv1_class<0, 0, HGP, HCOLS>(wf, lh2, xbyte[0]);
+    sv[1] = upconv1_class<0, 1, HGP, HCOLS>(wf, lh2, xbyte[1]);
+    sv[2] = upconv1_class<1, 0, HGP, HCOLS>(wf, lh2, xbyte[2]);
+    sv[3] = upconv1_class<1, 1, HGP, HCOLS>(wf, lh2, xbyte[3]);
+    const bool all_in = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(inside != 15u) == 0) != 0;
     if (q < 2) {
-      f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-      if (sin) {
-        sv = acc + bup + h1v;                                         // adamvs.py:420-421
-        sv.x = fmaxf(sv.x, 0.f); sv.y = fmaxf(sv.y, 0.f); sv.z = fmaxf(sv.z, 0.f); sv.w = fmaxf(sv.w, 0.f);
-      }
-      float* dl = ls + (4 * q) * SPLANE + r * SC + c;
-      dl[0] = sv.x; dl[SPLANE] = sv.y; dl[2 * SPLANE] = sv.z; dl[3 * SPLANE] = sv.w;
-    }
-  }
-  __syncthreads();
-
-  // --- last layer (8 -> 1) on the vector units
-  cfloat* wfin = as_const(a.wfin);
-  const float bfin = wfin[72];
-  if (IN_UP) {
-    const int Ho = 2 * h, Wo = 2 * w;
-    float* out = a.vol + ((size_t)b * a.D + a.d) * (size_t)Ho * Wo;
-    for (int i = tid; i < 28 * 60; i += 256) {
-      int ry = i / 60, rx = i % 60;
-      int Y = 2 * y0 + ry, X = 2 * x0 + rx;
-      if (Y >= Ho || X >= Wo) continue;
-      // Y = 2 iy - 1 + ky: Y even -> (ky=1, iy=Y/2); Y odd -> (ky=2, iy=(Y-1)/2), (ky=0, iy=(Y+1)/2)
-      int nyt = (Y & 1) ? 2 : 1, nxt = (X & 1) ? 2 : 1;
-      float accv = bfin;
-      for (int ty = 0; ty < nyt; ++ty) {
-        int ky = (Y & 1) ? (ty ? 0 : 2) : 1;
-        int iy = (Y + 1 - ky) >> 1;
-        int r = iy - (y0 - 1);
-        for (int tx = 0; tx < nxt; ++tx) {
-          int kx = (X & 1) ? (tx ? 0 : 2) : 1;
-          int ix = (X + 1 - kx) >> 1;
-          int c = ix - (x0 - 1);
-          const float* sp = ls + r * SC + c;
 #pragma unroll
-          for (int ch = 0; ch < 8; ++ch) accv += sp[ch * SPLANE] * wfin[ch * 9 + ky * 3 + kx];
-        }
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = sv[j] + bup + hreg[j];                                  // adamvs.py:420-421
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        sv[j] = v;
       }
-      out[(size_t)Y * Wo + X] = accv;
+      if (!all_in) {                                                      // s is zero outside the image
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!((inside >> j) & 1u)) sv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)((char*)ls + sbyte[j]) = sv[j];
     }
-  } else {
-    float* out = a.vol + ((size_t)b * a.D + a.d) * (size_t)h * w;
-    for (int i = tid; i < 14 * 30; i += 256) {
-      int ry = i / 30, rx = i % 30;
-      int y = y0 + ry, x = x0 + rx;
-      if (y >= h || x >= w) continue;
-      float accv = bfin;
+    unsigned inside_n = 15u;
+    if (more) inside_n = load_h1(hreg, bn, txn, tyn);                     // hreg is free again
+    __syncthreads();                                                      // s complete
+
+    // ---- phase 2
+    const int y0 = ty * TRI, x0 = tx * TCI;
+    const bool full = y0 + TRI <= h && x0 + TCI <= w;
+    unsigned oo = ooff;
+    if (!full) oo = (y0 + pi < h && x0 + pj < w) ? ooff : BUF_OOB;
+    const char* sp = (const char*)ls + qbyte;
+    // 73 scalar weights do not fit next to everything else that is uniform here; hidden from loop-invariant
+    // motion, they are fetched per tile through the scalar cache (SMEM) instead of being spilled to VGPR
+    // lanes and read back with one v_readlane each.
+    cfloat* wfin = wfin0;
+    asm volatile("" : "+s"(wfin));
+    // s pixel (dy, dx) from the thread's first pixel: 8 channels as four packed pairs
+    auto spix = [&](int dy, int dx, f32x2 (&v)[4]) {
+      const f32x4 lo = *(const f32x4*)(sp + (dy * SC + dx) * SPX * 4), hi = *(const f32x4*)(sp + (dy * SC + dx) * SPX * 4 + 16);
+      v[0] = f32x2{lo.x, lo.y}; v[1] = f32x2{lo.z, lo.w}; v[2] = f32x2{hi.x, hi.y}; v[3] = f32x2{hi.z, hi.w};
+    };
+    // acc += w[tap][0..7] . v  (packed FMAs, the weight pair is a scalar operand)
+    auto tap = [&](f32x2& acc, int t9, const f32x2 (&v)[4]) {
+#pragma unroll
+      for (int c2 = 0; c2 < 4; ++c2) acc += *(const f32x2 __attribute__((address_space(4)))*)(wfin + t9 * 8 + 2 * c2) * v[c2];
+    };
+    const float bf = wfin[72];
+    if (IN_UP) {
+      const buf_rsrc ro = make_rsrc((char*)a.vol + ((((long)b * a.D + a.d) * Ho + 2 * y0) * (long)Wo + 2 * x0) * 4);
+      // quad of s pixel (i, j): out[2i][2j] = w11 s00;  out[2i][2j+1] = w12 s00 + w10 s01;
+      // out[2i+1][2j] = w21 s00 + w01 s10;  out[2i+1][2j+1] = w22 s00 + w20 s01 + w02 s10 + w00 s11
+      f32x2 s00[4], s01[4], s10[4], s11[4];
+      spix(0, 0, s00); spix(0, 1, s01); spix(1, 0, s10); spix(1, 1, s11);
+      f32x2 o00 = {bf, 0.f}, o01 = {bf, 0.f}, o10 = {bf, 0.f}, o11 = {bf, 0.f};
+      tap(o00, 4, s00);
+      tap(o01, 5, s00); tap(o01, 3, s01);
+      tap(o10, 7, s00); tap(o10, 1, s10);
+      tap(o11, 8, s00); tap(o11, 6, s01); tap(o11, 2, s10); tap(o11, 0, s11);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o00.x + o00.y), __float_as_uint(o01.x + o01.y)}, ro, oo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o10.x + o10.y), __float_as_uint(o11.x + o11.y)}, ro,
+                                            oo == BUF_OOB ? BUF_OOB : oo + (unsigned)Wo * 4u, 0, 0);
+    } else {
+      const buf_rsrc ro = make_rsrc((char*)a.vol + ((((long)b * a.D + a.d) * Ho + y0) * (long)Wo + x0) * 4);
+      f32x2 o = {bf, 0.f};
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const float* sp = ls + (ry + ky) * SC + rx + kx;
-#pragma unroll
-          for (int ch = 0; ch < 8; ++ch) accv += sp[ch * SPLANE] * wfin[ch * 9 + ky * 3 + kx];
+          f32x2 v[4];
+          spix(ky, kx, v);
+          tap(o, ky * 3 + kx, v);
         }
-      out[(size_t)y * w + x] = accv;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.x + o.y), ro, oo, 0, 0);
     }
-  }
-  __syncthreads();     // the next tile reuses both LDS regions
+    if (!more) break;
+    wait_vmem_all();                                                      // next tile's h2 and h1 have arrived
+    __syncthreads();                                                      // every wave is done with s and h2
+    store_h2(stage);
+    __syncthreads();
+    t = tn; b = bn; tx = txn; ty = tyn; inside = inside_n;
   }
 }
 
@@ -621,14 +703,15 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   }
   }
   DecoderArgs da{sb.h2, sb.h1, fw.upconv1, fw.upconv1_b, fw.final_w, vol, h, w, D, d};
-  const int tiles_x = cdiv(w, 30), tiles_y = cdiv(h, 14), ntiles = tiles_x * tiles_y * B;
+  TileGrid tg;
+  if ((rc = make_tile_grid(tg, cdiv(w, 30), cdiv(h, 6), B))) return rc;
   static int cap_up = 0, cap_flat = 0;          // resident capacity per instantiation (pure function of kernel + device)
   if (in_up) {
     if (!cap_up) cap_up = resident_blocks(k_decoder<true>, 256, 0);
-    hipLaunchKernelGGL((k_decoder<true>), dim3(ntiles < cap_up ? ntiles : cap_up), dim3(256), 0, st, da, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL((k_decoder<true>), dim3(tg.ntiles < cap_up ? tg.ntiles : cap_up), dim3(256), 0, st, da, tg);
   } else {
     if (!cap_flat) cap_flat = resident_blocks(k_decoder<false>, 256, 0);
-    hipLaunchKernelGGL((k_decoder<false>), dim3(ntiles < cap_flat ? ntiles : cap_flat), dim3(256), 0, st, da, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL((k_decoder<false>), dim3(tg.ntiles < cap_flat ? tg.ntiles : cap_flat), dim3(256), 0, st, da, tg);
   }
   ADAMVS_CHECK_LAUNCH("decoder");
   return 0;

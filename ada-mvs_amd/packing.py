@@ -178,8 +178,9 @@ def pack_slice_reg_net(sd, pre, precision="fp32"):
         "cand2_b": pad_bias(sd[pre + "conv_gru2.convc.0.bias"], 16),
         "upconv1": pack_small_conv(sd[pre + "upconv1.weight"], transposed=True),
         "upconv1_b": pad_bias(sd[pre + "upconv1.bias"], 16),
-        # [8][1][3][3] (transposed, stages 1-2) and [1][8][3][3] (stage 3) both flatten to c*9 + tap
-        "final_w": pad_bias(torch.cat([sd[pre + "upconv2d.weight"].detach().float().cpu().reshape(-1),
+        # [8][1][3][3] (transposed, stages 1-2) and [1][8][3][3] (stage 3) both flatten to c*9 + tap; stored
+        # tap-major, w[tap*8 + c], so that a channel pair of one tap is one 64-bit scalar operand
+        "final_w": pad_bias(torch.cat([sd[pre + "upconv2d.weight"].detach().float().cpu().reshape(8, 9).t().reshape(-1),
                                        sd[pre + "upconv2d.bias"].detach().float().cpu().reshape(-1)]), 76),
     }
     offsets, chunks, o = {}, [], 0

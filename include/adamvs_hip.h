@@ -125,7 +125,7 @@ typedef struct adamvs_fuse_weights {
   const float* gates2; const float* gates2_b;   /* [2][9][8][64], [32]      conv_gru2.conv_gates.0 */
   const float* cand2;  const float* cand2_b;    /* [1][9][8][64], [16]      conv_gru2.convc.0 */
   const float* upconv1; const float* upconv1_b; /* [1][9][4][64], [16]      upconv1 (transposed: W[cin][cout][tap]) */
-  const float* final_w;                         /* [73]: w[c*9+tap], bias   upconv2d */
+  const float* final_w;                         /* [73]: w[tap*8+c], bias   upconv2d */
 } adamvs_fuse_weights;
 
 /* models/adamvs.py:495-512 fused with conv1 of SliceCostRegNetRED (adamvs.py:416), for all
