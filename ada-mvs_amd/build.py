@@ -18,6 +18,11 @@ LIB = os.path.join(HERE, "libadamvs_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = ["api.hip", "geometry.hip", "planesweep.hip", "sweep.hip", "costreg2d.hip", "costreg2d_bf16x3.hip", "slice_red.hip", "slice_red_bf16x3.hip"]
 ARCH = "gfx950"
+# Per-source flags.  slice_red.hip: the IR load/store vectorizer fuses the three horizontally adjacent taps of an
+# MFMA B-fragment into one ds_read_b96 at a 4-byte-aligned address; gfx950 executes those with "unaligned" stalls
+# (SQ_LDS_UNALIGNED_STALL ~ the MFMA busy time in the two-row conv1).  Without it the reads stay dword pairs
+# (ds_read2_b32, formed later by the machine pass); every intended wide access in that file is an explicit vector type.
+SOURCE_FLAGS = {"slice_red.hip": ["-mllvm", "-amdgpu-load-store-vectorizer=0"]}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I", INCLUDE, "-I", CSRC]
 
@@ -41,7 +46,7 @@ def _compile(src, extra):
     hdr_time = max(hdr_time, os.path.getmtime(os.path.join(INCLUDE, "adamvs_hip.h")))
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), hdr_time) and not extra:
         return obj, False
-    cmd = [_hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc()] + FLAGS + SOURCE_FLAGS.get(src, []) + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout[-4000:], r.stderr[-8000:]))

@@ -575,14 +575,14 @@ static int launch_small(const SmallConvArgs& a, int B, hipStream_t st, const cha
 // conv1 (C -> 8, ReLU; reference adamvs.py:416) in two-row form: the 16 MFMA rows are 8 output channels of
 // output row y and the same 8 channels of row y+1, fed by the same input-row fragment (tap ky for the first
 // half, ky-1 for the second), so no half of the tile is zero padding: 12 fragment passes per 2 rows instead of 18.
-// src [N][hw][C] -> c1 [N][hw][8].  grid (ceil(w/32), ceil(h/8), N); block 256; tile 8 rows x 32 columns.
+// src [N][hw][C] -> c1 [N][hw][8].  Persistent and pipelined like k_conv_small; tile 8 rows x 16 columns = four
+// row pairs, one per wave (12 * C/4 MFMAs each).
 template <int C>
 __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__ src, const float* __restrict__ wpk,
-                                                       float* __restrict__ c1, int h, int w, int tiles_x, int tiles_y,
-                                                       int ntiles) {
-  constexpr int KC = C / 4, G = C / 4, TR = 8, LR = TR + 2, LC = 34;
-  constexpr int PLANE = plane_pitch16(LR * LC), GP = group_pitch(PLANE, G);
-  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
+                                                       float* __restrict__ c1, int h, int w, TileGrid tg) {
+  constexpr int KC = C / 4, G = C / 4, TR = 8, TC = 16, LR = TR + 2, LC = TC + 2, NPIX = LR * LC;
+  constexpr int PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
+  constexpr int NL = (NPIX * G + 255) / 256;
   extern __shared__ float lds[];           // [G][GP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, q = lane >> 4;
@@ -592,87 +592,262 @@ __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) wf[t][kc] = wpk[(t * KC + kc) * 64 + lane];
 
-  auto load_tile = [&](f32x4 (&stage)[NIT], int t) {
-    const int n = t / (tiles_x * tiles_y), x0 = (t % tiles_x) * 32, y0 = ((t / tiles_x) % tiles_y) * TR;
+  // ---- per-lane constants
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int i = tid + it * 256;
-      int g = i % G, pp = i / G;
-      int r = pp / LC, c = pp % LC;
-      int iy = y0 - 1 + r, ix = x0 - 1 + c;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i < NITEMS && iy >= 0 && iy < h && ix >= 0 && ix < w) v = *(const f32x4*)(src + (((size_t)n * h + iy) * w + ix) * C + 4 * g);
-      stage[it] = v;
+  for (int k = 0; k < NL; ++k) {
+    const int j = min(tid + k * 256, NPIX * G - 1);          // surplus lanes repeat the last item
+    const int g = j % G, pp = j / G, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * w + c) * C + 4 * g) * 4);
+    lbyte[k] = (unsigned)((g * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xbyte[KC];                                         // B-fragment origin of the wave's row pair
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    xbyte[kc] = (unsigned)((kc * GP + q * PLANE + (2 * wave) * LC + p) * 4);
+    pin(xbyte[kc]);
+  }
+  const int orow = 2 * wave + (q >> 1);                       // lane's output pixel (orow, p), channels 4*(q&1)..
+  unsigned ooff = (unsigned)(((orow * w + p) * 8 + 4 * (q & 1)) * 4);
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int n, int tx, int ty) {
+    const int ix0 = tx * TC - 1, iy0 = ty * TR - 1;
+    const buf_rsrc rs = make_rsrc((const char*)src + (((long)n * h + iy0) * w + ix0) * (C * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= h && ix0 + LC <= w) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(rs, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        stage[k] = buf_load4(rs, ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? goff[k] : BUF_OOB);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
     }
   };
 
-  // persistent: workgroup i takes tiles i, i + grid, ...; the next tile is in flight (registers) during the MFMAs
-  f32x4 stage[NIT];
   int t = blockIdx.x;
-  if (t < ntiles) load_tile(stage, t);
-  for (; t < ntiles; t += gridDim.x) {
-    __syncthreads();                         // the previous tile's readers are done
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int i = tid + it * 256;
-      if (i < NITEMS) {
-        int g = i % G, pp = i / G;
-        int r = pp / LC, c = pp % LC;
-        float* dl = lds + g * GP + r * LC + c;
-        f32x4 v = stage[it];
-        dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
-      }
+  if (t >= tg.ntiles) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);               // in flight during the MFMA chain
     }
-    __syncthreads();
-    if (t + (int)gridDim.x < ntiles) load_tile(stage, t + gridDim.x);
-
-    const int n = t / (tiles_x * tiles_y), x0 = (t % tiles_x) * 32, y0 = ((t / tiles_x) % tiles_y) * TR;
-    const float* xb = lds + q * PLANE + p;
-    // a wave owns two runs (row pair, column half); their accumulators are independent, so their MFMAs alternate
-    const int row0 = (wave >> 1) * 2, col0 = (wave & 1) * 16;        // run = wave
-    const int row1 = row0 + 4;                                         // run = wave + 4
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-          float b0 = xb[kc * GP + (row0 + rr) * LC + col0 + kx];
-          float b1 = xb[kc * GP + (row1 + rr) * LC + col0 + kx];
-          acc0 = mfma16(wf[rr * 3 + kx][kc], b0, acc0);
-          acc1 = mfma16(wf[rr * 3 + kx][kc], b1, acc1);
-        }
+        for (int kc = 0; kc < KC; ++kc)
+          acc = mfma16(wf[rr * 3 + kx][kc], *(const float*)((const char*)lds + xbyte[kc] + (rr * LC + kx) * 4), acc);
+
+    wait_vmem_all();
+    __syncthreads();                                // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+    const int y0 = ty * TR, x0 = tx * TC;
+    const buf_rsrc ro = make_rsrc((char*)c1 + (((long)n * h + y0) * w + x0) * 32);
+    unsigned oo = ooff;
+    if (!(y0 + TR <= h && x0 + TC <= w)) oo = (y0 + orow < h && x0 + p < w) ? ooff : BUF_OOB;
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    buf_store4(ro, oo, acc);
+    if (!more) break;
+    __syncthreads();                                // next tile visible
+    t = tn; n = nn; tx = txn; ty = tyn;
+  }
+}
+
+// The same convolution for wide inputs (C = 32) with the contraction split over the waves.  Held in full, the
+// A fragments are 12 * C/4 = 96 registers per lane and leave room for two waves per SIMD, too few to cover the
+// load / LDS-fill / epilogue phases of each other.  Here wave k owns input channels 8k..8k+7 (24 fragment
+// registers) and computes partial sums for all four row pairs of the tile; the partials meet in LDS, wave k adds
+// up row pair k in a fixed order (deterministic) and writes it out.  Same MFMA count, half the registers.
+template <int C>
+__global__ __launch_bounds__(256, 3) void k_conv1_ksplit(const float* __restrict__ src, const float* __restrict__ wpk,
+                                                      float* __restrict__ c1, int h, int w, TileGrid tg) {
+  static_assert(C == 32, "four waves x two k-chunks");
+  constexpr int KC = C / 4, G = C / 4, KW = KC / 4, TR = 8, TC = 16, LR = TR + 2, LC = TC + 2, NPIX = LR * LC;
+  constexpr int PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
+  constexpr int NL = (NPIX * G + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];           // tile [G][GP], then partials [12][64][4]
+  float* red = lds + G * GP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  float wf[12][KW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f32x4 acc = j ? acc1 : acc0;
-      const int y = y0 + (j ? row1 : row0) + (q >> 1), x = x0 + col0 + p;
-      if (y < h && x < w) {
-        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-        *(f32x4*)(c1 + (((size_t)n * h + y) * w + x) * 8 + 4 * (q & 1)) = acc;
+  for (int t = 0; t < 12; ++t)
+#pragma unroll
+    for (int kc = 0; kc < KW; ++kc) wf[t][kc] = wpk[(t * KC + wave * KW + kc) * 64 + lane];
+
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int j = min(tid + k * 256, NPIX * G - 1);
+    const int g = j % G, pp = j / G, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * w + c) * C + 4 * g) * 4);
+    lbyte[k] = (unsigned)((g * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xbyte[KW];                                         // B-fragment origin of row pair 0 in the wave's channels
+#pragma unroll
+  for (int kc = 0; kc < KW; ++kc) {
+    xbyte[kc] = (unsigned)(((wave * KW + kc) * GP + q * PLANE + p) * 4);
+    pin(xbyte[kc]);
+  }
+  // partial of (source wave s, row pair rp != s) lives in slot s*3 + (rp > s ? rp - 1 : rp)
+  unsigned wbyte = (unsigned)(((wave * 3) * 64 + lane) * 16);            // first slot this wave writes
+  unsigned rbyte[3];                                                     // slots this wave reads, sources in order
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int s = i < wave ? i : i + 1;                                  // the other waves, ascending
+    rbyte[i] = (unsigned)(((s * 3 + (wave > s ? wave - 1 : wave)) * 64 + lane) * 16);
+    pin(rbyte[i]);
+  }
+  pin(wbyte);
+  const int orow = 2 * wave + (q >> 1);
+  unsigned ooff = (unsigned)(((orow * w + p) * 8 + 4 * (q & 1)) * 4);
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int n, int tx, int ty) {
+    const int ix0 = tx * TC - 1, iy0 = ty * TR - 1;
+    const buf_rsrc rs = make_rsrc((const char*)src + (((long)n * h + iy0) * w + ix0) * (C * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= h && ix0 + LC <= w) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(rs, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        stage[k] = buf_load4(rs, ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? goff[k] : BUF_OOB);
       }
     }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);               // in flight during the MFMA chains
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp) acc[rp] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kc = 0; kc < KW; ++kc)
+#pragma unroll
+          for (int rp = 0; rp < 4; ++rp)            // four independent chains
+            acc[rp] = mfma16(wf[rr * 3 + kx][kc],
+                             *(const float*)((const char*)lds + xbyte[kc] + ((2 * rp + rr) * LC + kx) * 4), acc[rp]);
+    // partials of the row pairs the other waves finish
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp)
+      if (rp != wave) *(f32x4*)((char*)red + wbyte + (rp > wave ? rp - 1 : rp) * 1024) = acc[rp];
+
+    wait_vmem_all();
+    __syncthreads();                                // partials visible; every wave is done reading the tile
+    if (more) store_tile(stage);
+
+    f32x4 own = wave == 0 ? acc[0] : (wave == 1 ? acc[1] : (wave == 2 ? acc[2] : acc[3]));
+    f32x4 part[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) part[i] = *(const f32x4*)((const char*)red + rbyte[i]);
+    // fixed order of the four channel slices: 0, 1, 2, 3
+    f32x4 sum;
+    if (wave == 0) sum = ((own + part[0]) + part[1]) + part[2];
+    else if (wave == 1) sum = ((part[0] + own) + part[1]) + part[2];
+    else if (wave == 2) sum = ((part[0] + part[1]) + own) + part[2];
+    else sum = ((part[0] + part[1]) + part[2]) + own;
+
+    const int y0 = ty * TR, x0 = tx * TC;
+    const buf_rsrc ro = make_rsrc((char*)c1 + (((long)n * h + y0) * w + x0) * 32);
+    unsigned oo = ooff;
+    if (!(y0 + TR <= h && x0 + TC <= w)) oo = (y0 + orow < h && x0 + p < w) ? ooff : BUF_OOB;
+    sum.x = fmaxf(sum.x, 0.f); sum.y = fmaxf(sum.y, 0.f); sum.z = fmaxf(sum.z, 0.f); sum.w = fmaxf(sum.w, 0.f);
+    buf_store4(ro, oo, sum);
+    if (!more) break;
+    __syncthreads();                                // next tile visible; partials consumed
+    t = tn; n = nn; tx = txn; ty = tyn;
   }
+}
+
+static int launch_conv1_ksplit32(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
+  constexpr int C = 32;
+  constexpr size_t lds = ((size_t)(C / 4) * group_pitch(plane_pitch16(10 * 18), C / 4) + 12 * 64 * 4) * sizeof(float);
+  auto kern = k_conv1_ksplit<C>;
+  static int capacity = 0;
+  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(w_, 16), cdiv(h, 8), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, cost, w, c1, h, w_, tg);
+  ADAMVS_CHECK_LAUNCH("conv1");
+  return 0;
 }
 
 template <int C>
 static int launch_conv1_c(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
-  constexpr size_t lds = (size_t)(C / 4) * group_pitch(plane_pitch16(10 * 34), C / 4) * sizeof(float);
+  constexpr size_t lds = (size_t)(C / 4) * group_pitch(plane_pitch16(10 * 18), C / 4) * sizeof(float);
   auto kern = k_conv1_two_row<C>;
   static int capacity = 0;
   if (!capacity) capacity = resident_blocks(kern, 256, lds);
-  const int tiles_x = cdiv(w_, 32), tiles_y = cdiv(h, 8);
-  const long ntiles = (long)tiles_x * tiles_y * N;
-  if (ntiles > 0x7fffffffL) return set_error(-1, "conv1: too many tiles");
-  const int grid = ntiles < capacity ? (int)ntiles : capacity;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, cost, w, c1, h, w_, tiles_x, tiles_y, (int)ntiles);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(w_, 16), cdiv(h, 8), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, cost, w, c1, h, w_, tg);
   ADAMVS_CHECK_LAUNCH("conv1");
   return 0;
 }
 
 int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int precision, hipStream_t st) {
   if (precision == PRECISION_BF16X3) return launch_conv1_bf16x3(cost, w, c1, N, C, h, w_, st);
-  if (C == 32) return launch_conv1_c<32>(cost, w, c1, N, h, w_, st);
+  if (C == 32) return launch_conv1_ksplit32(cost, w, c1, N, h, w_, st);
   if (C == 16) return launch_conv1_c<16>(cost, w, c1, N, h, w_, st);
   if (C == 8) return launch_conv1_c<8>(cost, w, c1, N, h, w_, st);
   return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);

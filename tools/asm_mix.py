@@ -11,6 +11,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ada_mvs_amd  # noqa: E402,F401
+from ada_mvs_amd.build import SOURCE_FLAGS  # noqa: E402
 
 
 def main():
@@ -19,7 +22,8 @@ def main():
     out = "/tmp/asm_mix.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-I",
                     os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "ada-mvs_amd", "csrc"), "-S",
-                    "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+                    "--cuda-device-only", src, "-o", out] + SOURCE_FLAGS.get(os.path.basename(src), []), check=True,
+                   stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*" + re.escape(pat) + r"\S*:", l))
     print(lines[start])
