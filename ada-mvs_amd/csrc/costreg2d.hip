@@ -34,12 +34,22 @@ template <> struct TileGeom<CONV_S1> { static constexpr int LR = 10, LC = 18, PL
 template <> struct TileGeom<CONV_S2> { static constexpr int LR = 17, LC = 33, PLANE = (17 * 33) | 1; };
 template <> struct TileGeom<CONV_T2> { static constexpr int LR = 9, LC = 17, PLANE = plane_pitch16(9 * 17); };
 
-constexpr int KB = 8;     // input channels per LDS chunk (2 MFMA k-steps)
+// KB = input channels per LDS chunk (template parameter: 8 = two MFMA k-steps, 4 = one)
 
 // Block = 8 rows x 16 columns of output positions x all D output channels.
 // Waves: WM along output channels (MT tiles of 16 each), WN = 4/WM along rows.
 // PY/PX: output parity class, CONV_T2 only (ConvTranspose2d k3 s2 p1 op1).
-template <int MT, int WM, int MODE, int PY, int PX>
+//
+// fp32 MFMA shares the vector lanes (tools/microbench/mfma_issue.hip: every extra VALU instruction per MFMA costs
+// 3-6 cycles of matrix time, at any occupancy), and at this register budget there is one wave per SIMD, so the
+// chunk loop is written to contain matrix instructions and nothing else that needs the vector ALU:
+//  * global accesses are buffer loads: uniform descriptor, per-lane byte offset computed once (bounds folded in
+//    as BUF_OOB -> zero fill), the chunk enters as the scalar offset operand;
+//  * LDS addresses of the tile fill and of the B-fragment reads are per-lane constants, pinned in registers;
+//  * two named register sets for the A fragments and two chunks per loop trip: the fragments and the activation
+//    tile of chunk k+1 are requested before the MFMAs of chunk k and waited for once, after them (vmcnt retires
+//    in order; a single explicit wait keeps the compiler from scheduling its own in the middle of the chain).
+template <int MT, int WM, int MODE, int KB, int PY, int PX>
 __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
   using TG = TileGeom<MODE>;
   constexpr int LR = TG::LR, LC = TG::LC, PLANE = TG::PLANE, GP = group_pitch(PLANE, KB / 4);
@@ -47,14 +57,40 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
   constexpr int STR = (MODE == CONV_S2) ? 2 : 1;
   constexpr int NTY = (MODE == CONV_T2) ? 1 + PY : 3;
   constexpr int NTX = (MODE == CONV_T2) ? 1 + PX : 3;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   const int wm = wave % WM, wn = wave / WM;
   const int p = lane & 15, q = lane >> 4;
   const int D = a.D, KCT = D / 4, NTILES = D / 16;
   const int r0 = by * 8, c0 = bx * 16;                       // block origin (output rows/cols, or input i/j for T2)
   const int iy0 = (MODE == CONV_T2) ? r0 : r0 * STR - 1;
   const int ix0 = (MODE == CONV_T2) ? c0 : c0 * STR - 1;
-  const float* inb = a.in + (size_t)n * a.hi * a.wi * D;
+  constexpr int NTAP = NTY * NTX;
+  constexpr int NITEMS = LR * LC * (KB / 4), NITA = (NITEMS + 255) / 256;
+
+  // ---- per-lane constants
+  // activation tile: item = (pixel of the window, group of 4 channels); out-of-image pixels read as zero
+  const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
+  unsigned xoff[NITA], xlds[NITA];
+#pragma unroll
+  for (int it = 0; it < NITA; ++it) {
+    const int i = min(tid + it * 256, NITEMS - 1);           // surplus lanes repeat the last item
+    const int g = i % (KB / 4), pp = i / (KB / 4), r = pp / LC, c = pp % LC;
+    const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi;
+    xoff[it] = ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB;
+    xlds[it] = (unsigned)((g * GP + r * LC + c) * 4);
+    pin(xoff[it]); pin(xlds[it]);
+  }
+  // A fragments: [tap][D/4][D/16][64]; lane offset only, the rest is uniform
+  const buf_rsrc rw = make_rsrc(a.wpk);
+  unsigned woff = (unsigned)(lane * 4);
+  pin(woff);
+  // B fragments: lane's k-row and pixel, per k-chunk of the LDS tile
+  unsigned xb[KB / 4];
+#pragma unroll
+  for (int kc = 0; kc < KB / 4; ++kc) {
+    xb[kc] = (unsigned)((kc * GP + q * PLANE + (wn * NTR * STR) * LC + p * STR) * 4);
+    pin(xb[kc]);
+  }
 
   f32x4 acc[MT][NTR];
 #pragma unroll
@@ -62,12 +98,6 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
 #pragma unroll
     for (int r = 0; r < NTR; ++r) acc[mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* xb = lds + q * PLANE + (wn * NTR * STR) * LC + p * STR;
-  constexpr int NTAP = NTY * NTX;
-  constexpr int NITEMS = LR * LC * (KB / 4), NITA = (NITEMS + 255) / 256;
-
-  // One wave per SIMD at this register budget, so latency is hidden by hand: the A fragments and the
-  // activation tile of chunk k+1 are requested before the MFMAs of chunk k and consumed after them.
   auto load_w = [&](float (&wf)[NTAP][KB / 4][MT], int ch) {
 #pragma unroll
     for (int ty = 0; ty < NTY; ++ty)
@@ -78,49 +108,25 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
 #pragma unroll
         for (int kc = 0; kc < KB / 4; ++kc)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            wf[ty * NTX + tx][kc][mt] =
-                a.wpk[((size_t)((ky * 3 + kx) * KCT + ch / 4 + kc) * NTILES + wm * MT + mt) * 64 + lane];
+          for (int mt = 0; mt < MT; ++mt) {
+            const unsigned frag = (unsigned)(((ky * 3 + kx) * KCT + ch / 4 + kc) * NTILES + wm * MT + mt) * 256u;   // uniform
+            wf[ty * NTX + tx][kc][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, frag, 0));
+          }
       }
   };
   auto load_x = [&](f32x4 (&st)[NITA], int ch) {
 #pragma unroll
-    for (int it = 0; it < NITA; ++it) {
-      int i = tid + it * 256;
-      int g = i % (KB / 4), pp = i / (KB / 4);
-      int r = pp / LC, c = pp % LC;
-      int iy = iy0 + r, ix = ix0 + c;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i < NITEMS && iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi)
-        v = *(const f32x4*)(inb + ((size_t)iy * a.wi + ix) * D + ch + 4 * g);
-      st[it] = v;
-    }
+    for (int it = 0; it < NITA; ++it)
+      st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
   };
   auto store_x = [&](const f32x4 (&st)[NITA]) {
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
-      int i = tid + it * 256;
-      if (i < NITEMS) {
-        int g = i % (KB / 4), pp = i / (KB / 4);
-        int r = pp / LC, c = pp % LC;
-        float* dl = lds + g * GP + r * LC + c;
-        dl[0] = st[it].x; dl[PLANE] = st[it].y; dl[2 * PLANE] = st[it].z; dl[3 * PLANE] = st[it].w;
-      }
+      float* dl = (float*)((char*)lds + xlds[it]);
+      dl[0] = st[it].x; dl[PLANE] = st[it].y; dl[2 * PLANE] = st[it].z; dl[3 * PLANE] = st[it].w;
     }
   };
-
-  float wf[NTAP][KB / 4][MT], wf_next[NTAP][KB / 4][MT];
-  f32x4 xs[NITA];
-  load_w(wf, 0);
-  load_x(xs, 0);
-  for (int ch = 0; ch < D; ch += KB) {
-    __syncthreads();                    // previous chunk's readers are done
-    store_x(xs);
-    __syncthreads();
-    if (ch + KB < D) {
-      load_w(wf_next, ch + KB);
-      load_x(xs, ch + KB);              // single staging set: stored to LDS at the top of the next iteration
-    }
+  auto mfma_chunk = [&](const float (&wf)[NTAP][KB / 4][MT]) {
 #pragma unroll
     for (int ty = 0; ty < NTY; ++ty)
 #pragma unroll
@@ -129,20 +135,36 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
         for (int kc = 0; kc < KB / 4; ++kc) {
           float bv[NTR];
 #pragma unroll
-          for (int r = 0; r < NTR; ++r) bv[r] = xb[kc * GP + (r * STR + ty) * LC + tx];
+          for (int r = 0; r < NTR; ++r) bv[r] = *(const float*)((const char*)lds + xb[kc] + ((r * STR + ty) * LC + tx) * 4);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < NTR; ++r) acc[mt][r] = mfma16(wf[ty * NTX + tx][kc][mt], bv[r], acc[mt][r]);
         }
-    if (ch + KB < D) {
-#pragma unroll
-      for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-        for (int kc = 0; kc < KB / 4; ++kc)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) wf[t][kc][mt] = wf_next[t][kc][mt];
+  };
+
+  float wfA[NTAP][KB / 4][MT], wfB[NTAP][KB / 4][MT];
+  f32x4 xs[NITA];
+  load_w(wfA, 0);
+  load_x(xs, 0);
+  for (int ch = 0; ch < D; ch += 2 * KB) {       // D / KB is even for every supported D
+    wait_vmem_all();
+    __syncthreads();                    // previous chunk's readers are done
+    store_x(xs);
+    __syncthreads();
+    load_w(wfB, ch + KB);
+    load_x(xs, ch + KB);
+    mfma_chunk(wfA);
+
+    wait_vmem_all();
+    __syncthreads();
+    store_x(xs);
+    __syncthreads();
+    if (ch + 2 * KB < D) {
+      load_w(wfA, ch + 2 * KB);
+      load_x(xs, ch + 2 * KB);
     }
+    mfma_chunk(wfB);
   }
 
   // epilogue: lane owns channels co4..co4+3 of the pixel in column p
@@ -166,30 +188,34 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
 }
 
 // grid: (ceil(cols/16), ceil(rows/8), N [*4 classes for CONV_T2]); block 256
-template <int MT, int WM, int MODE>
-__global__ __launch_bounds__(256) void k_conv_dd(ConvDDArgs a) {
+template <int MT, int WM, int MODE, int KB>
+__global__ __launch_bounds__(256, (MT == 4 && WM == 4) ? 1 : 2) void k_conv_dd(ConvDDArgs a) {
   __shared__ float lds[(KB / 4) * group_pitch(TileGeom<MODE>::PLANE, KB / 4)];
   if (MODE == CONV_T2) {
     int n = blockIdx.z >> 2, cls = blockIdx.z & 3;
     switch (cls) {        // block-uniform
-      case 0: conv_dd_body<MT, WM, MODE, 0, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
-      case 1: conv_dd_body<MT, WM, MODE, 0, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
-      case 2: conv_dd_body<MT, WM, MODE, 1, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
-      default: conv_dd_body<MT, WM, MODE, 1, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      case 0: conv_dd_body<MT, WM, MODE, KB, 0, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      case 1: conv_dd_body<MT, WM, MODE, KB, 0, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      case 2: conv_dd_body<MT, WM, MODE, KB, 1, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
+      default: conv_dd_body<MT, WM, MODE, KB, 1, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
     }
   } else {
-    conv_dd_body<MT, WM, MODE, 0, 0>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+    conv_dd_body<MT, WM, MODE, KB, 0, 0>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
   }
 }
 
+// Two waves per SIMD (a single wave feeding the matrix pipe from LDS reaches ~83 % of it, two reach ~92 %:
+// tools/microbench/mfma_issue.hip), i.e. at most 256 registers: the widest tilings take one k-step per chunk
+// (D = 256 does not fit even so and keeps one wave).
 template <int MT, int WM>
 static int launch_conv_dd_cfg(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
+  constexpr int KB = (WM == 4 || (MT == 4 && WM == 2)) ? 4 : 8;
   if (mode == CONV_S1)
-    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S1>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S1, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
   else if (mode == CONV_S2)
-    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S2>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_T2>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N * 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_T2, KB>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N * 4), dim3(256), 0, st, a);
   ADAMVS_CHECK_LAUNCH("conv_dd");
   return 0;
 }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a, TileGrid tg
   // one load instruction covers 256 (pixel, channel group) items of ONE source, so that its base is uniform
   constexpr int NA = (NPIX * GA + 255) / 256, NB = (NPIX * GB + 255) / 256, NL = NA + NB;
   extern __shared__ float lds[];         // [G][GP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   const int p = lane & 15, q = lane >> 4;
   const int row = wave / RW, col = (wave % RW) * 16;      // the wave's run inside a tile
 
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a, TileGrid tg) {
   __shared__ __attribute__((aligned(16))) float lds[4 * HGP + SR * SC * SPX];
   float* lh2 = lds;
   float* ls = lds + 4 * HGP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   const int p = lane & 15, q = lane >> 4;
   const int h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1;
   float wf[1][9][4];
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__
   constexpr int PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
   constexpr int NL = (NPIX * G + 255) / 256;
   extern __shared__ float lds[];           // [G][GP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   const int p = lane & 15, q = lane >> 4;
   float wf[12][KC];
 #pragma unroll
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1_ksplit(const float* __restrict
   constexpr int NL = (NPIX * G + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float lds[];           // tile [G][GP], then partials [12][64][4]
   float* red = lds + G * GP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   const int p = lane & 15, q = lane >> 4;
   float wf[12][KW];
 #pragma unroll

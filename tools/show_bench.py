@@ -1,0 +1,16 @@
+"""Print the essentials of bench.py JSON lines: python tools/show_bench.py file.json [...]"""
+import json
+import sys
+
+for path in sys.argv[1:]:
+    for line in open(path):
+        line = line.strip()
+        if not line.startswith("{"):
+            continue
+        d = json.loads(line)
+        print("%s: %.1f %s, %.2f ms/step, %s" % (path, d["value"], d["unit"], d["ms_per_step"], d["config"]["workload"]))
+        if "phase_ms_per_step" in d:
+            print("   phases:", "  ".join("%s %.2f" % (k.split(".", 1)[-1], v) for k, v in d["phase_ms_per_step"].items()))
+        r = d.get("roofline")
+        if r:
+            print("   roofline: %.1f %s (%.1f %% of %.1f), %.2f ms per launch" % (r["achieved"], r["unit"], 100 * r["frac"], r["peak"], r["launch_ms"]))
