@@ -306,6 +306,9 @@ def main():
                 key = k.split(".costreg.")[0] + ".cost_reg_net_2d" if ".costreg." in k else k
                 phases[key] = phases.get(key, 0.0) + v
             result["phase_ms_per_step"] = {k: round(v, 4) for k, v in sorted(phases.items())}
+            layers = {k.split(".costreg.")[1]: round(v, 4) for k, v in avg.items() if ".costreg." in k}
+            if layers:
+                result["cost_reg_layers_ms"] = layers          # one launch each: <layer>.mode<0 s1 | 1 s2 | 2 transposed>
             dom = max(phases, key=phases.get)
             st = work[int(dom[1]) - 1]
             kind = dom.split(".", 1)[1]

@@ -19,10 +19,10 @@ __global__ __launch_bounds__(256) void kl(float* out, int iters, float a, float 
   const int lane = threadIdx.x & 63;
   const float* xb = tile + (lane >> 4) * 208 + (lane & 15) + (threadIdx.x >> 6) * 36;
   for (int i = 0; i < iters; ++i) {
-    if (LDSMODE == 1) {            // one ds_read_b32 (or ds_read2) per MFMA, compiler-scheduled
+    if (LDSMODE % 10 == 1) {            // one ds_read_b32 (or ds_read2) per MFMA, compiler-scheduled
 #pragma unroll
       for (int u = 0; u < 48; ++u) acc[u % CHAINS] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[(u % 3) + (u / 3) * 18 + (i & 1) * 836], acc[u % CHAINS], 0, 0, 0);
-    } else if (LDSMODE == 2) {     // like the two-row conv1 chain: 4 row pairs share rows
+    } else if (LDSMODE % 10 == 2) {     // like the two-row conv1 chain: 4 row pairs share rows
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -152,12 +152,14 @@ int main() {
       rund<1>("random operands", out, vals, 2, iters);
     }
   }
-  for (int waves : {3}) {
+  for (int waves : {1, 2, 3, 4, 5}) {
     runl<1, 0>("builtin, 1 chain, no LDS", out, waves);
     runl<4, 0>("builtin, 4 chains, no LDS", out, waves);
     runl<1, 1>("1 chain, B from LDS (1 read/MFMA)", out, waves);
     runl<4, 1>("4 chains, B from LDS (1 read/MFMA)", out, waves);
     runl<4, 2>("4 chains, conv1 pattern", out, waves);
+    runl<4, 12>("conv1 pattern + barrier / 48 MFMA", out, waves);
+    runl<1, 11>("1 chain LDS + barrier / 48 MFMA", out, waves);
   }
   for (int waves : {2}) {
     run<1, true, 0>("1 chain, AGPR", out, waves);

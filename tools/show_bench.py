@@ -11,6 +11,8 @@ for path in sys.argv[1:]:
         print("%s: %.1f %s, %.2f ms/step, %s" % (path, d["value"], d["unit"], d["ms_per_step"], d["config"]["workload"]))
         if "phase_ms_per_step" in d:
             print("   phases:", "  ".join("%s %.2f" % (k.split(".", 1)[-1], v) for k, v in d["phase_ms_per_step"].items()))
+        if "cost_reg_layers_ms" in d:
+            print("   CostRegNet2D layers:", "  ".join("%s %.2f" % kv for kv in d["cost_reg_layers_ms"].items()))
         r = d.get("roofline")
         if r:
             print("   roofline: %.1f %s (%.1f %% of %.1f), %.2f ms per launch" % (r["achieved"], r["unit"], 100 * r["frac"], r["peak"], r["launch_ms"]))
