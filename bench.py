@@ -289,8 +289,8 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA, fp32 accumulate) for the convolutions, f32 elsewhere",
                 "data": "synthetic",
-                "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, fp32" % (
-                    cfg, c["views"], c["W"], c["H"], "/".join(map(str, c["ndepths"]))),
+                "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, %s" % (
+                    cfg, c["views"], c["W"], c["H"], "/".join(map(str, c["ndepths"])), args.precision),
                     "tiles_per_gpu_per_step": B, "concurrent_tile_groups": G, "global_tiles_per_step": n_tiles,
                     "parallelism": "tile-sharded x%d, 1 RCCL gather per step" % world,
                     "launch": "eager" if graph is None else "hipGraph replay"},
@@ -325,11 +325,11 @@ def main():
                         "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "launch_ms": ms / len(lay),
                         "flops_per_launch": flops / len(lay), "traffic": None}
-                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")          # tools/profile_round.sh
                 if os.path.exists(tpath):          # HBM bytes per launch from the committed PMC passes, same workload and batch
                     tj = json.load(open(tpath))
                     if tj["config"] == {"workload": cfg, "tiles_per_launch": Bg}:
-                        k0 = [v for k, v in tj["kernels"].items() if "k_conv_dd<3, 4, 0>" in k]
+                        k0 = [v for k, v in tj["kernels"].items() if "k_conv_dd<3, 4, 0" in k]        # stride-1 instantiation
                         if k0:
                             roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
                             roof["traffic_note"] = "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), profiles/r01_traffic.json"
