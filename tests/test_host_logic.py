@@ -120,6 +120,13 @@ def test_packed_network_sizes_match_the_header():
     assert all(o % 64 == 0 for o in off.values())
     assert off["gates1"] - off["conv1"] == 12 * 8 * 64               # two-row conv1, C=32 -> KC=8
     assert flat.numel() >= off["final_w"] + 73
+    # last layer: tap-major (a channel pair of one tap is one 64-bit scalar operand of the packed FMA), bias at [72]
+    w_up = sd["DepthNet.0.reg_fuse.upconv2d.weight"]                  # ConvTranspose2d: [8][1][3][3]
+    fw = flat[off["final_w"]:off["final_w"] + 73]
+    assert fw[(2 * 3 + 1) * 8 + 5] == w_up[5, 0, 2, 1] and fw[72] == sd["DepthNet.0.reg_fuse.upconv2d.bias"][0]
+    flat3, off3 = packing.pack_slice_reg_net(sd, "DepthNet.2.reg_fuse.")
+    w_fl = sd["DepthNet.2.reg_fuse.upconv2d.weight"]                  # Conv2d: [1][8][3][3]
+    assert flat3[off3["final_w"] + (0 * 3 + 2) * 8 + 3] == w_fl[0, 3, 0, 2]
 
 
 def test_synthetic_recipes_are_deterministic():
