@@ -31,13 +31,13 @@ enum { BX_S1 = 0, BX_S2 = 1, BX_T2 = 2 };
 constexpr int BX_KB = 32;            // input channels per chunk = one MFMA k-step
 constexpr int BX_PIX = 40;           // bf16 per pixel row in LDS: 32 + 8 pad (80 B: 16-B aligned, spreads the banks)
 
-// Block rows: 16 for the stride-1 and transposed layers (the A fragments stream from L2 at 5x the fp32 kernel's
-// rate per MFMA cycle, so each fragment should feed as many pixel runs as the accumulators allow), 8 for stride 2
-// (its input tile is 4x larger per output row).
+// Block rows: 8.  (16-row blocks reuse each streamed A fragment twice as often, but their 192 accumulator
+// registers leave one wave per SIMD; two waves feeding the matrix pipe from LDS are worth more: 4.0 -> 3.5 ms on
+// the full-resolution layers.)  The stride-2 layers stage a 17 x 33 window and keep one wave.
 template <int MODE> struct BxGeom;
-template <> struct BxGeom<BX_S1> { static constexpr int BR = 16, LR = BR + 2, LC = 18; };
+template <> struct BxGeom<BX_S1> { static constexpr int BR = 8, LR = BR + 2, LC = 18; };
 template <> struct BxGeom<BX_S2> { static constexpr int BR = 8, LR = 2 * BR + 1, LC = 33; };
-template <> struct BxGeom<BX_T2> { static constexpr int BR = 16, LR = BR + 1, LC = 17; };
+template <> struct BxGeom<BX_T2> { static constexpr int BR = 8, LR = BR + 1, LC = 17; };
 
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -163,7 +163,7 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
 }
 
 template <int MT, int WM, int MODE>
-__global__ __launch_bounds__(256) void k_conv_dd_bx3(ConvDDArgs16 a) {
+__global__ __launch_bounds__(256, (MODE == BX_S2 || (MT == 4 && WM == 4)) ? 1 : 2) void k_conv_dd_bx3(ConvDDArgs16 a) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];     // [2 (hi,lo)][LR*LC][BX_PIX]
   if (MODE == BX_T2) {
     int n = blockIdx.z >> 2, cls = blockIdx.z & 3;
