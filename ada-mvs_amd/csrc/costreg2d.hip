@@ -241,6 +241,9 @@ static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) 
 // ---------------------------------------------------------------------------
 // softmax over D, max probability, expectation of depth.  16 lanes per pixel.
 // score [N=S*B][hw][D] (n = s*B + b), planes [B][D][hw] -> vw, pd [S*B][hw].
+// NQ = D/64 rounded up: the lane's scores stay in registers between the max pass and the exp pass, so the
+// score volume is read once (NQ = 0: any D, two passes over global memory).
+template <int NQ>
 __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict__ score, const float* __restrict__ planes,
                                                          float* __restrict__ vw, float* __restrict__ pd, int B, int D, int hw,
                                                          size_t npix) {
@@ -253,18 +256,36 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
   const float* sc = score + pix * D;
   const float* pl = planes + b * D * hw + pp;
   float m = -INFINITY;
-  for (int d = 4 * l; d < D; d += 64) {
-    f32x4 v = *(const f32x4*)(sc + d);
-    m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+  f32x4 keep[NQ > 0 ? NQ : 1];
+  if (NQ > 0) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int d = 4 * l + 64 * i;
+      keep[i] = d < D ? *(const f32x4*)(sc + d) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      m = fmaxf(m, fmaxf(fmaxf(keep[i].x, keep[i].y), fmaxf(keep[i].z, keep[i].w)));
+    }
+  } else {
+    for (int d = 4 * l; d < D; d += 64) {
+      f32x4 v = *(const f32x4*)(sc + d);
+      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
   }
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   float se = 0.f, sd = 0.f;
-  for (int d = 4 * l; d < D; d += 64) {
-    f32x4 v = *(const f32x4*)(sc + d);
+  auto term = [&](f32x4 v, int d) {
     float e0 = __expf(v.x - m), e1 = __expf(v.y - m), e2 = __expf(v.z - m), e3 = __expf(v.w - m);
     se += (e0 + e1) + (e2 + e3);
     sd += e0 * pl[(size_t)d * hw] + e1 * pl[(size_t)(d + 1) * hw] + e2 * pl[(size_t)(d + 2) * hw] + e3 * pl[(size_t)(d + 3) * hw];
+  };
+  if (NQ > 0) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int d = 4 * l + 64 * i;
+      if (d < D) term(keep[i], d);
+    }
+  } else {
+    for (int d = 4 * l; d < D; d += 64) term(*(const f32x4*)(sc + d), d);
   }
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) { se += __shfl_xor(se, o, 64); sd += __shfl_xor(sd, o, 64); }
@@ -325,8 +346,14 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
 int launch_softmax_regress(const float* score, const float* planes, float* vw, float* pd, int S, int B, int D, int h, int w,
                            hipStream_t st) {
   size_t npix = (size_t)S * B * h * w;
-  hipLaunchKernelGGL(k_softmax_regress, dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, st, score, planes, vw, pd, B, D,
-                     h * w, npix);
+  const dim3 grid((unsigned)((npix + 15) / 16));
+  switch ((D + 63) / 64) {
+    case 1: hipLaunchKernelGGL(k_softmax_regress<1>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
+    case 2: hipLaunchKernelGGL(k_softmax_regress<2>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
+    case 3: hipLaunchKernelGGL(k_softmax_regress<3>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
+    case 4: hipLaunchKernelGGL(k_softmax_regress<4>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
+    default: hipLaunchKernelGGL(k_softmax_regress<0>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
+  }
   ADAMVS_CHECK_LAUNCH("softmax_regress");
   return 0;
 }
