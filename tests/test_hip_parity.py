@@ -197,15 +197,17 @@ def test_slice_reg_step_bf16x3(hip, k):
     assert rel_l1(reg, g["reg"]) < 2e-4, "decoder"
 
 
+@pytest.mark.parametrize("k", [0, 1, 2])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_slice_reg_step_many_tiles(hip, precision):
-    """Persistent kernels past their resident capacity (every workgroup walks several tiles, interior and edge):
-    a batch of identical tiles must give, entry by entry, the single-tile result (itself pinned by the fixtures)."""
+def test_slice_reg_step_many_tiles(hip, precision, k):
+    """Persistent kernels past their resident capacity (every workgroup walks several tiles, interior and edge),
+    for the three stage variants (C = 32 / 16 / 8 conv1, transposed and flat last layer): a batch of identical tiles
+    must give, entry by entry, the single-tile result (itself pinned by the fixtures)."""
     m, _ = _model("tiny")
-    net = m.DepthNet[0].reg_fuse
+    net = m.DepthNet[k].reg_fuse
     net.precision = precision
     C, h, w, B = net.in_channels, 64, 96, 80
-    g = torch.Generator().manual_seed(11)
+    g = torch.Generator().manual_seed(11 + k)
     cost = torch.randn(1, C, h, w, generator=g)
     s1 = torch.randn(1, 8, h, w, generator=g) * 0.5
     s2 = torch.randn(1, 16, h // 2, w // 2, generator=g) * 0.5
