@@ -1,6 +1,6 @@
 // Split-bf16 ("bf16x3") versions of the small 3x3 convolutions of SliceCostRegNetRED
 // (reference models/adamvs.py:400-424, models/module.py:5-52): conv1 (two-row form), the two ConvGRU gate /
-// candidate convolutions and conv2.  Same tiles, persistent grids and fused epilogues as slice_red.hip; the
+// candidate convolutions and conv2.  Same persistent pipeline and fused epilogues as slice_red.hip; the
 // channel contraction runs on v_mfma_f32_16x16x32_bf16 with every fp32 operand split into hi + lo bf16 halves
 // (a.b ~ a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulation; see costreg2d_bf16x3.hip).
 //
@@ -10,6 +10,7 @@
 // [pixel][CIN + 8 pad] of bf16 (hi and lo images); the activations are split when the tile is written.
 #include "common.h"
 #include "kernels.h"
+#include "persistent.h"
 
 namespace adamvs {
 
@@ -40,28 +41,33 @@ struct SmallConvArgsBx {
   int hi, wi, ho, wo, cout;
 };
 
-// grid = resident capacity, workgroup i takes tiles i, i + grid, ...; block 256.
-// NPOS = 9 taps, or 12 (rr,kx) positions for the two-row conv1 (then a run is 2 output rows x 16 pixels).
-template <int CA, int CB, int NT, int STRIDE, int EPI, int TR>
-__global__ __launch_bounds__(256) void k_conv_small_bx3(SmallConvArgsBx a, int tiles_x, int tiles_y, int ntiles) {
+// Persistent and pipelined exactly like k_conv_small in slice_red.hip (uniform buffer descriptors + pinned lane
+// offsets, interior tiles without bounds checks, one wait per tile, requests before the MFMA chain, stores after
+// it); what differs is the tile in LDS (pixel-major bf16, hi and lo images, written through split_store), the
+// chain (flattened k, three MFMAs per k-block) and the GRU state of the lane's own pixel, which the reset gate
+// multiplies in full fp32 and therefore comes from global memory with the other epilogue operands.
+// Tile = 4 rows x 16 columns, one run per wave; the two-row conv1 takes 8 x 16 (a run = 2 output rows).
+// NPOS = 9 taps, or 12 (rr,kx) positions for the two-row conv1.
+template <int CA, int CB, int NT, int STRIDE, int EPI>
+__global__ __launch_bounds__(256) void k_conv_small_bx3(SmallConvArgsBx a, TileGrid tg) {
   constexpr bool TWO = (EPI == BXE_TWO_ROW);
-  constexpr int CIN = CA + CB, G = CIN / 4, HC = CB;
+  constexpr int CIN = CA + CB, GA = CA / 4, GB = CB / 4, HC = CB;
   constexpr int NPOS = TWO ? 12 : 9;
   constexpr int NKB = (NPOS * CIN + 31) / 32;
+  constexpr int TR = TWO ? 8 : 4, TC = 16;
   constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
-  constexpr int LC = (STRIDE == 1) ? 34 : 65;
+  constexpr int LC = (STRIDE == 1) ? TC + 2 : 2 * TC + 1;
+  constexpr int NPIX = LR * LC;
   constexpr int PP = CIN + 8;                         // bf16 per pixel (16-byte pad spreads the banks)
-  constexpr int NITEMS = LR * LC * G, NIT = (NITEMS + 255) / 256;
-  constexpr int RUNS = TWO ? TR : 2 * TR;             // two-row: (row pair, column half); else (row, column half)
-  extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];     // [hi|lo][LR*LC][PP]
-  __bf16* lhi = ldsb;
-  __bf16* llo = ldsb + LR * LC * PP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int LO = NPIX * PP * 2;                   // byte offset of the lo image
+  constexpr int NA = (NPIX * GA + 255) / 256, NB = (NPIX * GB + 255) / 256, NL = NA + NB;
+  extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];     // [hi|lo][NPIX][PP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, q = lane >> 4;
+  const int row = TWO ? 2 * wave : wave;              // first output row of the wave's run
 
-  // A fragments (hi, lo) and the lane's LDS offset of every k-block
+  // A fragments (hi, lo)
   bf16x8 wh[NT][NKB], wl[NT][NKB];
-  int off[NKB];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -69,132 +75,174 @@ __global__ __launch_bounds__(256) void k_conv_small_bx3(SmallConvArgsBx a, int t
       wh[nt][kb] = a.wpk[((nt * 2 + 0) * NKB + kb) * 64 + lane];
       wl[nt][kb] = a.wpk[((nt * 2 + 1) * NKB + kb) * 64 + lane];
     }
+  f32x4 bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    bias[nt] = (EPI == BXE_GATES || EPI == BXE_CAND) ? *(const f32x4*)(a.bias + nt * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-lane constants
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    const int gs = isA ? GA : GB, cs = isA ? CA : CB;
+    int j = tid + (isA ? k : k - NA) * 256;
+    j = min(j, NPIX * gs - 1);                        // surplus lanes repeat the last item
+    const int g = j % gs, pp = j / gs, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * a.wi + c) * cs + 4 * g) * 4);
+    lbyte[k] = (unsigned)((pp * PP + (isA ? 0 : CA) + 4 * g) * 2);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xoff[NKB];                                 // B fragment of k-block kb: 8 channels of one position
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     int kk = 32 * kb + 8 * q;
     int pos = kk / CIN, c0 = kk % CIN;
     if (pos >= NPOS) { pos = 0; c0 = 0; }             // zero-weight padding: any valid address
-    int dy = pos / 3, dx = pos % 3;
-    off[kb] = (dy * LC + dx) * PP + c0;
+    const int dy = pos / 3, dx = pos % 3;
+    xoff[kb] = (unsigned)(((((row * STRIDE) + dy) * LC + p * STRIDE + dx) * PP + c0) * 2);
+    pin(xoff[kb]);
+  }
+  // outputs: lane's pixel (orow, p); two-row: lanes q < 2 own row `row`, q >= 2 row + 1 (channels 4(q&1)..)
+  const int orow = TWO ? row + (q >> 1) : row;
+  const int CO = (EPI == BXE_RELU) ? a.cout : (TWO ? 8 : HC);
+  unsigned ooff[NT], ooff1[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co4 = TWO ? 4 * (q & 1) : nt * 16 + 4 * q;
+    const unsigned at = (unsigned)(((orow * a.wo + p) * CO + (EPI == BXE_GATES && co4 >= HC ? co4 - HC : co4)) * 4);
+    const bool to0 = TWO ? true : (EPI == BXE_RELU ? co4 < a.cout : co4 < HC);
+    const bool to1 = EPI == BXE_GATES && co4 >= HC && co4 < 2 * HC;
+    ooff[nt] = to0 ? at : BUF_OOB;
+    ooff1[nt] = to1 ? at : BUF_OOB;
+    pin(ooff[nt]); pin(ooff1[nt]);
   }
 
-  auto load_tile = [&](f32x4 (&stage)[NIT], int t) {
-    const int b = t / (tiles_x * tiles_y), ox0 = (t % tiles_x) * 32, oy0 = ((t / tiles_x) % tiles_y) * TR;
-    const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
+  auto load_tile = [&](f32x4 (&stage)[NL], int b, int tx, int ty) {
+    const int ix0 = tx * TC * STRIDE - 1, iy0 = ty * TR * STRIDE - 1;
+    const long pix0 = ((long)b * a.hi + iy0) * a.wi + ix0;
+    const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
+    const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= a.hi && ix0 + LC <= a.wi) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int i = tid + it * 256;
-      int g = i % G, pp = i / G;
-      int r = pp / LC, c = pp % LC;
-      int iy = iy0 + r, ix = ix0 + c;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i < NITEMS && iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) {
-        size_t pix = ((size_t)b * a.hi + iy) * a.wi + ix;
-        if (4 * g < CA) v = *(const f32x4*)(a.srcA + pix * CA + 4 * g);
-        else v = *(const f32x4*)(a.srcB + pix * CB + (4 * g - CA));
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        stage[k] = buf_load4(k < NA ? ra : rb, ok ? goff[k] : BUF_OOB);
       }
-      stage[it] = v;
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      __bf16* hi = (__bf16*)((char*)ldsb + lbyte[k]);
+      split_store(hi, (__bf16*)((char*)hi + LO), stage[k]);
     }
   };
 
-  f32x4 stage[NIT];
   int t = blockIdx.x;
-  if (t < ntiles) load_tile(stage, t);
-  for (; t < ntiles; t += gridDim.x) {
-    __syncthreads();                         // the previous tile's readers are done
+  if (t >= tg.ntiles) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, b, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)b * a.ho + oy0) * a.wo + ox0;
+    const bool full = oy0 + TR <= a.ho && ox0 + TC <= a.wo;
+    const buf_rsrc r0 = make_rsrc((char*)a.dst0 + opix0 * (CO * 4));
+    const buf_rsrc r1 = make_rsrc((char*)a.dst1 + opix0 * (HC * 4));
+    const buf_rsrc rh = make_rsrc((const char*)a.hsrc + opix0 * (HC * 4));
+    unsigned oo[NT], oo1[NT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int i = tid + it * 256;
-      if (i < NITEMS) {
-        int g = i % G, pp = i / G;
-        split_store(lhi + pp * PP + 4 * g, llo + pp * PP + 4 * g, stage[it]);
-      }
+    for (int nt = 0; nt < NT; ++nt) { oo[nt] = ooff[nt]; oo1[nt] = ooff1[nt]; }
+    if (!full) {
+      const bool valid = oy0 + orow < a.ho && ox0 + p < a.wo;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { oo[nt] = valid ? ooff[nt] : BUF_OOB; oo1[nt] = valid ? ooff1[nt] : BUF_OOB; }
     }
-    __syncthreads();
-    if (t + (int)gridDim.x < ntiles) load_tile(stage, t + gridDim.x);      // in flight during the MFMAs
 
-    const int b = t / (tiles_x * tiles_y), ox0 = (t % tiles_x) * 32, oy0 = ((t / tiles_x) % tiles_y) * TR;
-#pragma unroll 1
-    for (int run = wave; run < RUNS; run += 4) {
-      const int row = TWO ? (run >> 1) * 2 : (run >> 1), col = (run & 1) * 16;
-      // output pixel(s) of this lane: TWO -> lanes q<2 own row `row`, q>=2 own row+1 (channels 4(q&1)..)
-      const int oy = oy0 + row + (TWO ? (q >> 1) : 0), ox = ox0 + col + p;
-      const bool valid = oy < a.ho && ox < a.wo;
-      const size_t opix = ((size_t)b * a.ho + min(oy, a.ho - 1)) * a.wo + min(ox, a.wo - 1);
-      f32x4 acc[NT], pre_u[NT], pre_h[NT];
+    // requests: epilogue operands first, then the next tile
+    f32x4 pre_u[NT], pre_h[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (EPI == BXE_CAND && nt * 16 < HC) {
+        pre_u[nt] = buf_load4(r1, oo[nt]);
+        pre_h[nt] = buf_load4(r0, oo[nt]);
+      }
+      if (EPI == BXE_GATES && nt * 16 < HC) pre_h[nt] = buf_load4(rh, oo[nt]);      // h of the lane's pixel, fp32
+    }
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_tile(stage, bn, txn, tyn);
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bf16x8 bh = *(const bf16x8*)((const char*)ldsb + xoff[kb]);
+      const bf16x8 bl = *(const bf16x8*)((const char*)ldsb + xoff[kb] + LO);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int co4 = nt * 16 + 4 * q;
-        if (EPI == BXE_CAND && co4 < HC) {
-          pre_u[nt] = *(const f32x4*)(a.dst1 + opix * HC + co4);
-          pre_h[nt] = *(const f32x4*)(a.dst0 + opix * HC + co4);
-        }
-        if (EPI == BXE_GATES && co4 < HC) pre_h[nt] = *(const f32x4*)(a.hsrc + opix * HC + co4);
-      }
-      const int base = ((row * STRIDE) * LC + (col + p) * STRIDE) * PP;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const bf16x8 bh = *(const bf16x8*)(lhi + base + off[kb]);
-        const bf16x8 bl = *(const bf16x8*)(llo + base + off[kb]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          acc[nt] = mfma_bx(wh[nt][kb], bh, acc[nt]);
-          acc[nt] = mfma_bx(wh[nt][kb], bl, acc[nt]);
-          acc[nt] = mfma_bx(wl[nt][kb], bh, acc[nt]);
-        }
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT && valid; ++nt) {
-        const int co4 = nt * 16 + 4 * q;
-        f32x4 v = acc[nt];
-        if (EPI == BXE_RELU) {
-          if (co4 < a.cout) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            *(f32x4*)(a.dst0 + opix * a.cout + co4) = v;
-          }
-        } else if (EPI == BXE_TWO_ROW) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          *(f32x4*)(a.dst0 + opix * 8 + 4 * (q & 1)) = v;
-        } else if (EPI == BXE_GATES) {
-          v += *(const f32x4*)(a.bias + co4);
-          f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
-          if (co4 < HC) *(f32x4*)(a.dst0 + opix * HC + co4) = sg * pre_h[nt];          // r * h
-          else if (co4 < 2 * HC) *(f32x4*)(a.dst1 + opix * HC + (co4 - HC)) = sg;       // u
-        } else if (co4 < HC) {                                                          // BXE_CAND
-          v += *(const f32x4*)(a.bias + co4);
-          f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
-          f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
-          *(f32x4*)(a.dst0 + opix * HC + co4) = u4 * h4 + (1.0f - u4) * cnd;
-        }
+        acc[nt] = mfma_bx(wh[nt][kb], bh, acc[nt]);
+        acc[nt] = mfma_bx(wh[nt][kb], bl, acc[nt]);
+        acc[nt] = mfma_bx(wl[nt][kb], bh, acc[nt]);
       }
     }
+
+    wait_vmem_all();                   // the one wait point of the tile
+    __syncthreads();                   // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 v = acc[nt] + bias[nt];
+      if (EPI == BXE_RELU || EPI == BXE_TWO_ROW) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        buf_store4(r0, oo[nt], v);
+      } else if (EPI == BXE_GATES) {
+        f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+        if (nt * 16 < HC) buf_store4(r0, oo[nt], sg * pre_h[nt]);              // reset-gate rows -> r * h
+        if (nt * 16 + 16 > HC) buf_store4(r1, oo1[nt], sg);                     // update-gate rows -> u
+      } else if (nt * 16 < HC) {                                                // BXE_CAND
+        f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+        f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
+        buf_store4(r0, oo[nt], u4 * h4 + (1.0f - u4) * cnd);
+      }
+    }
+    if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; b = bn; tx = txn; ty = tyn;
   }
 }
 
-template <typename K>
-static int resident_blocks_bx(K kernel, int threads, size_t lds) {
-  int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) n = 1;
-  int cus = 256, dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  return n * cus;
-}
-
-template <int CA, int CB, int NT, int STRIDE, int EPI, int TR>
+template <int CA, int CB, int NT, int STRIDE, int EPI>
 static int launch_bx(const SmallConvArgsBx& a, int N, hipStream_t st, const char* name) {
+  constexpr int TR = (EPI == BXE_TWO_ROW) ? 8 : 4, TC = 16;
   constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
-  constexpr int LC = (STRIDE == 1) ? 34 : 65;
+  constexpr int LC = (STRIDE == 1) ? TC + 2 : 2 * TC + 1;
   constexpr size_t lds = (size_t)2 * LR * LC * (CA + CB + 8) * sizeof(__bf16);
   static_assert(lds <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
-  auto kern = k_conv_small_bx3<CA, CB, NT, STRIDE, EPI, TR>;
+  auto kern = k_conv_small_bx3<CA, CB, NT, STRIDE, EPI>;
   static int capacity = 0;              // per instantiation; a pure function of the kernel and the device
-  if (!capacity) capacity = resident_blocks_bx(kern, 256, lds);
-  const int tiles_x = cdiv(a.wo, 32), tiles_y = cdiv(a.ho, TR);
-  const long ntiles = (long)tiles_x * tiles_y * N;
-  if (ntiles > 0x7fffffffL) return set_error(-1, "%s: too many tiles", name);
-  const int grid = ntiles < capacity ? (int)ntiles : capacity;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tiles_x, tiles_y, (int)ntiles);
+  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(a.wo, TC), cdiv(a.ho, TR), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tg);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
   return 0;
@@ -202,9 +250,9 @@ static int launch_bx(const SmallConvArgsBx& a, int N, hipStream_t st, const char
 
 int launch_conv1_bf16x3(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st) {
   SmallConvArgsBx a{cost, nullptr, (const bf16x8*)w, nullptr, c1, nullptr, nullptr, h, w_, h, w_, 8};
-  if (C == 32) return launch_bx<32, 0, 1, 1, BXE_TWO_ROW, 8>(a, N, st, "conv1 (bf16x3)");
-  if (C == 16) return launch_bx<16, 0, 1, 1, BXE_TWO_ROW, 8>(a, N, st, "conv1 (bf16x3)");
-  if (C == 8) return launch_bx<8, 0, 1, 1, BXE_TWO_ROW, 8>(a, N, st, "conv1 (bf16x3)");
+  if (C == 32) return launch_bx<32, 0, 1, 1, BXE_TWO_ROW>(a, N, st, "conv1 (bf16x3)");
+  if (C == 16) return launch_bx<16, 0, 1, 1, BXE_TWO_ROW>(a, N, st, "conv1 (bf16x3)");
+  if (C == 8) return launch_bx<8, 0, 1, 1, BXE_TWO_ROW>(a, N, st, "conv1 (bf16x3)");
   return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
 }
 
@@ -214,19 +262,19 @@ int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBu
   int rc;
   {
     SmallConvArgsBx g{c1, sb.h1, (const bf16x8*)fw.gates1, fw.gates1_b, sb.rh1, sb.u1, sb.h1, h, w, h, w, 16};
-    if ((rc = launch_bx<8, 8, 1, 1, BXE_GATES, 4>(g, B, st, "gates1 (bf16x3)"))) return rc;
+    if ((rc = launch_bx<8, 8, 1, 1, BXE_GATES>(g, B, st, "gates1 (bf16x3)"))) return rc;
     SmallConvArgsBx c{c1, sb.rh1, (const bf16x8*)fw.cand1, fw.cand1_b, sb.h1, sb.u1, nullptr, h, w, h, w, 8};
-    if ((rc = launch_bx<8, 8, 1, 1, BXE_CAND, 4>(c, B, st, "cand1 (bf16x3)"))) return rc;
+    if ((rc = launch_bx<8, 8, 1, 1, BXE_CAND>(c, B, st, "cand1 (bf16x3)"))) return rc;
   }
   {
     SmallConvArgsBx a{sb.h1, nullptr, (const bf16x8*)fw.conv2, nullptr, sb.c2, nullptr, nullptr, h, w, h2, w2, 16};
-    if ((rc = launch_bx<8, 0, 1, 2, BXE_RELU, 4>(a, B, st, "conv2 (bf16x3)"))) return rc;
+    if ((rc = launch_bx<8, 0, 1, 2, BXE_RELU>(a, B, st, "conv2 (bf16x3)"))) return rc;
   }
   {
     SmallConvArgsBx g{sb.c2, sb.h2, (const bf16x8*)fw.gates2, fw.gates2_b, sb.rh2, sb.u2, sb.h2, h2, w2, h2, w2, 32};
-    if ((rc = launch_bx<16, 16, 2, 1, BXE_GATES, 4>(g, B, st, "gates2 (bf16x3)"))) return rc;
+    if ((rc = launch_bx<16, 16, 2, 1, BXE_GATES>(g, B, st, "gates2 (bf16x3)"))) return rc;
     SmallConvArgsBx c{sb.c2, sb.rh2, (const bf16x8*)fw.cand2, fw.cand2_b, sb.h2, sb.u2, nullptr, h2, w2, h2, w2, 16};
-    if ((rc = launch_bx<16, 16, 1, 1, BXE_CAND, 4>(c, B, st, "cand2 (bf16x3)"))) return rc;
+    if ((rc = launch_bx<16, 16, 1, 1, BXE_CAND>(c, B, st, "cand2 (bf16x3)"))) return rc;
   }
   return 0;
 }
