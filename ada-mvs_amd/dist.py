@@ -50,20 +50,22 @@ def gather_maps(depth, conf, n_tiles, dst=0):
     dev = depth.device
     if dist.get_backend() == "gloo" and dev.type != "cpu":
         dev = torch.device("cpu")          # gloo gathers host tensors (CPU tests, single-GPU dry runs of the N > 1 path)
-    pack = torch.zeros(2, per_rank, H, W, device=dev, dtype=depth.dtype)
     own = depth.shape[0]
+    pack = torch.empty(2, per_rank, H, W, device=dev, dtype=depth.dtype)
     pack[0, :own] = depth
     pack[1, :own] = conf
+    if own < per_rank:
+        pack[:, own:] = 0
     bufs = [torch.empty_like(pack) for _ in range(world)] if rank == dst else None
     dist.gather(pack, bufs, dst=dst)
     if rank != dst:
         return None, None
     out_d = torch.empty(n_tiles, H, W, device=dev, dtype=depth.dtype)
     out_c = torch.empty_like(out_d)
-    for r in range(world):
-        idx = tiles_of_rank(n_tiles, r, world)
-        out_d[idx] = bufs[r][0, :len(idx)]
-        out_c[idx] = bufs[r][1, :len(idx)]
+    for r in range(world):                   # round-robin ownership = a strided slice (one copy kernel per map)
+        n_r = len(range(r, n_tiles, world))
+        out_d[r::world] = bufs[r][0, :n_r]
+        out_c[r::world] = bufs[r][1, :n_r]
     return out_d, out_c
 
 
