@@ -25,6 +25,24 @@ class FuseWeights(ctypes.Structure):
         "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w")]
 
 
+class FConvWeights(ctypes.Structure):
+    """adamvs_fconv_weights"""
+    _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p)]
+
+
+class ContextWeights(ctypes.Structure):
+    """adamvs_context_weights"""
+    _fields_ = [("w1", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("w2", ctypes.c_void_p)]
+
+
+class FeatureWeights(ctypes.Structure):
+    """adamvs_feature_weights"""
+    _fields_ = [(n, FConvWeights) for n in (
+        "conv0_0", "conv0_1", "conv1_0", "conv1_1", "conv1_2", "conv2_0", "conv2_1", "conv2_2",
+        "out1", "deconv1_t", "deconv1_c", "out2", "deconv2_t", "deconv2_c", "out3")] + \
+               [(n, ContextWeights) for n in ("br1_1", "br1_2", "br2_1", "br2_2", "br3_1", "br3_2")]
+
+
 class StageDesc(ctypes.Structure):
     """adamvs_stage_desc"""
     _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision", "precision_fuse")]
@@ -55,6 +73,8 @@ SIGNATURES = {
     "adamvs_depth_stage_workspace_bytes": (c_sz, [ctypes.POINTER(StageDesc)]),
     "adamvs_depth_stage_forward": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(FuseWeights),
                                          c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_feature_net0_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "adamvs_feature_net0": (c_i, [c_f, ctypes.POINTER(FeatureWeights), c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
 }
 
 ABI_VERSION = 1

@@ -1,0 +1,420 @@
+// FeatureNet0 (reference models/adamvs.py:49-152; blocks models/module.py:164-251, 506-524): the 2D U-Net that
+// turns every view into three feature maps (32 / 16 / 8 channels at 1/4, 1/2, 1/1 resolution).  SURVEY.md §8 row f1:
+// immediately upstream of the hot path, and — once the hot path runs at 2.4 ms per tile — its largest neighbour
+// (1.5 ms per tile on the vendor library, which also needs NCHW maps and a transpose for every stage output).
+//
+// Everything is channel-last fp32, [N = B*V images][h*w][C], the layout the plane sweep reads.  The eval-mode
+// BatchNorm of every block is folded into the A fragments (scale) and a bias (shift) on the host (packing.py).
+//   k_fconv    one persistent MFMA kernel for every convolution: 3x3 stride 1, 5x5 stride 2, the four output
+//              parity classes of ConvTranspose2d(k3, s2, p1, op1), and the 1x1 output convolutions; up to two
+//              concatenated sources; epilogue = bias, ReLU, or "+ two bilinearly upsampled context maps".
+//   k_context  the pooled-context branches: AvgPool(P) -> 1x1 conv -> BN -> ReLU, then multiplied by the branch's
+//              slice of the 1x1 output convolution.  (out_k = W . cat(up(b1), up(b2), f); upsampling and the 1x1
+//              convolution are both linear, so W_1 is applied to b1 at pooled resolution and the full-resolution
+//              kernel only adds up(W_1 b1) + up(W_2 b2) to W_f f: the concatenated 2C-channel map never exists.)
+// The kernel structure is that of k_conv_small in slice_red.hip (see the comments there): persistent grid at
+// resident capacity, one 16-pixel run per wave, uniform buffer descriptors + pinned lane offsets, one wait per tile.
+#include "adamvs_hip.h"
+#include "common.h"
+#include "conv_frag.h"
+#include "kernels.h"
+#include "persistent.h"
+
+namespace adamvs {
+
+enum { FM_K3 = 0, FM_K5S2 = 1, FM_K1 = 2, FM_T00 = 3, FM_T01 = 4, FM_T10 = 5, FM_T11 = 6 };
+enum { FE_RELU = 1, FE_CONTEXT = 2 };
+
+struct FConvArgs {
+  const float* srcA;     // [N][hi*wi][CA]
+  const float* srcB;     // [N][hi*wi][CB] (concatenated after A; null when CB == 0)
+  const float* wpk;      // A fragments [NT][NTAPS][(CA+CB)/4][64], BatchNorm scale folded in
+  const float* bias;     // [16*NT] (BatchNorm shift; zeros if none)
+  float* out;            // [N][Ho*Wo][ctot], this launch writes channels co0 .. co0+cout-1
+  const float* ctxA;     // FE_CONTEXT: [N][hA*wA][ctot], added after bilinear upsampling (align_corners=False)
+  const float* ctxB;     //             [N][hB*wB][ctot]
+  int hi, wi;            // input size
+  int ho, wo;            // tile space: output size (input size for the transposed classes, whose output is 2ho x 2wo)
+  int cout, ctot, co0;
+  int hA, wA, hB, wB;
+};
+
+template <int MODE> struct FGeom {
+  static constexpr bool T = MODE >= FM_T00;
+  static constexpr int PY = T ? ((MODE - FM_T00) >> 1) : 0, PX = T ? ((MODE - FM_T00) & 1) : 0;
+  static constexpr int STR = MODE == FM_K5S2 ? 2 : 1;
+  static constexpr int KH = MODE == FM_K3 ? 3 : (MODE == FM_K5S2 ? 5 : (MODE == FM_K1 ? 1 : 1 + PY));
+  static constexpr int KW = MODE == FM_K3 ? 3 : (MODE == FM_K5S2 ? 5 : (MODE == FM_K1 ? 1 : 1 + PX));
+  static constexpr int ORG = MODE == FM_K3 ? -1 : (MODE == FM_K5S2 ? -2 : 0);      // window origin = tile origin * STR + ORG
+  static constexpr int NTAPS = KH * KW;
+  static constexpr int rows(int tr) { return (tr - 1) * STR + KH; }
+  static constexpr int cols(int tc) { return (tc - 1) * STR + KW; }
+};
+
+// ATen area_pixel_compute_source_index, align_corners=False
+__device__ __forceinline__ void up_taps(int dst, int n_in, float scale, int& i0, int& i1, float& l1) {
+  float s = ((float)dst + 0.5f) * scale - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__device__ __forceinline__ f32x4 up_sample4(const float* map, int n, int hm, int wm, int ctot, int c, int y, int x, int ho, int wo) {
+  int y0, y1, x0, x1; float ly, lx;
+  up_taps(y, hm, (float)hm / (float)ho, y0, y1, ly);
+  up_taps(x, wm, (float)wm / (float)wo, x0, x1, lx);
+  const float* p = map + (size_t)n * hm * wm * ctot + c;
+  const f32x4 a = *(const f32x4*)(p + ((size_t)y0 * wm + x0) * ctot), b = *(const f32x4*)(p + ((size_t)y0 * wm + x1) * ctot);
+  const f32x4 cc = *(const f32x4*)(p + ((size_t)y1 * wm + x0) * ctot), d = *(const f32x4*)(p + ((size_t)y1 * wm + x1) * ctot);
+  const f32x4 top = a * (1.f - lx) + b * lx, bot = cc * (1.f - lx) + d * lx;
+  return top * (1.f - ly) + bot * ly;
+}
+
+template <int CA, int CB, int NT, int MODE, int EPI>
+__global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
+  using GM = FGeom<MODE>;
+  constexpr int CIN = CA + CB, KC = CIN / 4, G = CIN / 4, GA = CA / 4, GB = CB / 4;
+  constexpr int TR = 4, TC = 16, STR = GM::STR, NTAPS = GM::NTAPS;
+  constexpr int LR = GM::rows(TR), LC = GM::cols(TC), NPIX = LR * LC;
+  constexpr int PLANE = (STR == 1) ? plane_pitch16(NPIX) : (NPIX | 1);
+  constexpr int GP = group_pitch(PLANE, G);
+  constexpr int NA = (NPIX * GA + 255) / 256, NB = (NPIX * GB + 255) / 256, NL = NA + NB;
+  extern __shared__ float lds[];         // [G][GP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int row = wave;                  // the wave's run: row `wave` of the 4 x 16 tile
+
+  float wf[NT][NTAPS][KC];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) wf[nt][t][kc] = a.wpk[((nt * NTAPS + t) * KC + kc) * 64 + lane];
+  f32x4 bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = *(const f32x4*)(a.bias + nt * 16 + 4 * q);
+
+  // ---- per-lane constants
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    const int gs = isA ? GA : GB, cs = isA ? CA : CB;
+    int j = tid + (isA ? k : k - NA) * 256;
+    j = min(j, NPIX * gs - 1);           // surplus lanes repeat the last item
+    const int g = j % gs, pp = j / gs, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * a.wi + c) * cs + 4 * g) * 4);
+    lbyte[k] = (unsigned)((((isA ? 0 : GA) + g) * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xbyte[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    xbyte[kc] = (unsigned)((kc * GP + q * PLANE + (row * STR) * LC + p * STR) * 4);
+    pin(xbyte[kc]);
+  }
+  // output: lane's pixel (row, p) of the tile, channels co0 + 16 nt + 4q ..; transposed classes write pixel (2y+PY, 2x+PX)
+  const int Wo = GM::T ? 2 * a.wo : a.wo;
+  unsigned ooff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co4 = nt * 16 + 4 * q;
+    const int py = GM::T ? 2 * row + GM::PY : row, px = GM::T ? 2 * p + GM::PX : p;
+    ooff[nt] = co4 < a.cout ? (unsigned)(((py * Wo + px) * a.ctot + a.co0 + co4) * 4) : BUF_OOB;
+    pin(ooff[nt]);
+  }
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int n, int tx, int ty) {
+    const int ix0 = tx * TC * STR + GM::ORG, iy0 = ty * TR * STR + GM::ORG;
+    const long pix0 = ((long)n * a.hi + iy0) * a.wi + ix0;
+    const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
+    const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= a.hi && ix0 + LC <= a.wi) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        stage[k] = buf_load4(k < NA ? ra : rb, ok ? goff[k] : BUF_OOB);              // zero padding
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = GM::T ? ((long)n * 2 * a.ho + 2 * oy0) * Wo + 2 * ox0 : ((long)n * a.ho + oy0) * a.wo + ox0;
+    const buf_rsrc ro = make_rsrc((char*)a.out + opix0 * ((long)a.ctot * 4));
+    const bool valid = oy0 + row < a.ho && ox0 + p < a.wo;
+
+    f32x4 ctx[NT];                       // context terms of this tile's pixels (requested before the chain)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      ctx[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((EPI & FE_CONTEXT) && valid && nt * 16 + 4 * q < a.cout) {
+        const int c = a.co0 + nt * 16 + 4 * q, y = oy0 + row, x = ox0 + p;
+        ctx[nt] = up_sample4(a.ctxA, n, a.hA, a.wA, a.ctot, c, y, x, a.ho, a.wo) +
+                  up_sample4(a.ctxB, n, a.hB, a.wB, a.ctot, c, y, x, a.ho, a.wo);
+      }
+    }
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ty9 = 0; ty9 < GM::KH; ++ty9)
+#pragma unroll
+      for (int tx9 = 0; tx9 < GM::KW; ++tx9)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const float bv = *(const float*)((const char*)lds + xbyte[kc] + (ty9 * LC + tx9) * 4);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[nt][ty9 * GM::KW + tx9][kc], bv, acc[nt]);
+        }
+
+    wait_vmem_all();
+    __syncthreads();                   // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 v = acc[nt] + bias[nt];
+      if (EPI & FE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (EPI & FE_CONTEXT) v += ctx[nt];
+      buf_store4(ro, valid ? ooff[nt] : BUF_OOB, v);
+    }
+    if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; n = nn; tx = txn; ty = tyn;
+  }
+}
+
+template <int CA, int CB, int NT, int MODE, int EPI>
+static int launch_fconv(const FConvArgs& a, int N, hipStream_t st, const char* name) {
+  using GM = FGeom<MODE>;
+  constexpr int G = (CA + CB) / 4, NPIX = GM::rows(4) * GM::cols(16);
+  constexpr int PLANE = (GM::STR == 1) ? plane_pitch16(NPIX) : (NPIX | 1);
+  constexpr size_t lds = (size_t)G * group_pitch(PLANE, G) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
+  auto kern = k_fconv<CA, CB, NT, MODE, EPI>;
+  static int capacity = 0;
+  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(a.wo, 16), cdiv(a.ho, 4), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tg);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "feature_net0 %s: %s", name, hipGetErrorString(e));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Pooled-context branch: AvgPool2d(P) -> 1x1 conv (C -> C/2, BN folded) -> ReLU -> 1x1 (C/2 -> C: the branch's
+// columns of the stage's output convolution).  One thread per (pooled pixel, 4 output channels); the pooled maps
+// are 16 or 64 times smaller than the feature map, so this is a plain streaming kernel.
+//   w1 [C/2][C] (scale folded), b1 [C/2], w2 [C][C/2];  out [N][hp*wp][C]
+template <int C>
+__global__ __launch_bounds__(256) void k_context(const float* __restrict__ feat, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                 float* __restrict__ out, int h, int w, int P, int hp, int wp, size_t total) {
+  constexpr int C2 = C / 2;
+  __shared__ float s_w1[C2 * C], s_b1[C2], s_w2[C * C2];
+  for (int i = threadIdx.x; i < C2 * C; i += 256) { s_w1[i] = w1[i]; s_w2[i] = w2[i]; }
+  for (int i = threadIdx.x; i < C2; i += 256) s_b1[i] = b1[i];
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // pooled pixel
+  if (i >= total) return;
+  const int xp = (int)(i % wp), yp = (int)((i / wp) % hp);
+  const size_t n = i / ((size_t)wp * hp);
+  float pooled[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) pooled[c] = 0.f;
+  const float* base = feat + (((size_t)n * h + (size_t)yp * P) * w + (size_t)xp * P) * C;
+  for (int dy = 0; dy < P; ++dy)
+    for (int dx = 0; dx < P; ++dx) {
+      const f32x4* px = (const f32x4*)(base + ((size_t)dy * w + dx) * C);
+#pragma unroll
+      for (int g = 0; g < C / 4; ++g) {
+        const f32x4 v = px[g];
+        pooled[4 * g] += v.x; pooled[4 * g + 1] += v.y; pooled[4 * g + 2] += v.z; pooled[4 * g + 3] += v.w;
+      }
+    }
+  const float inv = 1.0f / (float)(P * P);
+  float mid[C2];
+#pragma unroll
+  for (int m = 0; m < C2; ++m) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) s += s_w1[m * C + c] * (pooled[c] * inv);
+    mid[m] = fmaxf(s + s_b1[m], 0.f);
+  }
+  float* o = out + i * C;
+#pragma unroll
+  for (int co = 0; co < C; co += 4) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < C2; ++m) {
+      r.x += s_w2[(co + 0) * C2 + m] * mid[m]; r.y += s_w2[(co + 1) * C2 + m] * mid[m];
+      r.z += s_w2[(co + 2) * C2 + m] * mid[m]; r.w += s_w2[(co + 3) * C2 + m] * mid[m];
+    }
+    *(f32x4*)(o + co) = r;
+  }
+}
+
+template <int C>
+static int launch_context(const float* feat, const float* w1, const float* b1, const float* w2, float* out, int N, int h, int w,
+                          int P, hipStream_t st) {
+  const int hp = h / P, wp = w / P;
+  const size_t total = (size_t)N * hp * wp;
+  hipLaunchKernelGGL(k_context<C>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feat, w1, b1, w2, out, h, w, P, hp, wp, total);
+  ADAMVS_CHECK_LAUNCH("feature_net0 context branch");
+  return 0;
+}
+
+// imgs [N][3][H][W] (the reference's layout) -> [N][H*W][4], fourth channel zero
+__global__ void k_pack_rgb(const float* __restrict__ in, float* __restrict__ out, size_t hw, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t n = i / hw, p = i % hw;
+  const float* s = in + n * 3 * hw + p;
+  *(f32x4*)(out + i * 4) = f32x4{s[0], s[hw], s[2 * hw], 0.f};
+}
+
+static inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+}  // namespace adamvs
+
+using namespace adamvs;
+
+// Workspace layout (floats), N images of H x W (both multiples of 32: three /2 levels, AvgPool 8 at the coarsest):
+//   rgb4 [N][HW][4], c0a, c0 [N][HW][8], c1a, c1b, c1 [N][HW/4][16], c2a, c2b, c2 [N][HW/16][32],
+//   d1 [N][HW/4][16] (deconv1.deconv), f1 [N][HW/4][16], d2 [N][HW][8], f2 [N][HW][8], context maps.
+extern "C" size_t adamvs_feature_net0_workspace_bytes(int N, int H, int W) {
+  const size_t hw = (size_t)H * W, n = (size_t)N;
+  size_t f = al64(n * hw * 4) + 2 * al64(n * hw * 8) + 3 * al64(n * hw / 4 * 16) + 3 * al64(n * hw / 16 * 32) +
+             2 * al64(n * hw / 4 * 16) + 2 * al64(n * hw * 8);
+  f += 2 * al64(n * (hw / 16 / 16) * 32) + 2 * al64(n * (hw / 4 / 16) * 16) + 2 * al64(n * (hw / 16) * 8);      // pooled by 4 (x2 for 8: smaller)
+  return f * sizeof(float);
+}
+
+extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weights* wts, float* stage1, float* stage2,
+                                   float* stage3, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(imgs && wts && stage1 && stage2 && stage3 && workspace, "feature_net0: null pointer");
+  ADAMVS_CHECK_ARG(N > 0 && H >= 32 && W >= 32 && (H % 32) == 0 && (W % 32) == 0,
+                   "feature_net0: N=%d H=%d W=%d (H, W multiples of 32)", N, H, W);
+  ADAMVS_CHECK_ARG(workspace_bytes >= adamvs_feature_net0_workspace_bytes(N, H, W), "feature_net0: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const adamvs_feature_weights& fw = *wts;
+  const size_t hw = (size_t)H * W, n = (size_t)N;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+  float* p = (float*)workspace;
+  auto take = [&](size_t floats) { float* r = p; p += al64(floats); return r; };
+  float* rgb4 = take(n * hw * 4);
+  float* c0a = take(n * hw * 8); float* c0 = take(n * hw * 8);
+  float* c1a = take(n * hw / 4 * 16); float* c1b = take(n * hw / 4 * 16); float* c1 = take(n * hw / 4 * 16);
+  float* c2a = take(n * hw / 16 * 32); float* c2b = take(n * hw / 16 * 32); float* c2 = take(n * hw / 16 * 32);
+  float* d1 = take(n * hw / 4 * 16); float* f1 = take(n * hw / 4 * 16);
+  float* d2 = take(n * hw * 8); float* f2 = take(n * hw * 8);
+  float* x1a = take(n * (hw / 16 / 16) * 32); float* x1b = take(n * (hw / 16 / 16) * 32);
+  float* x2a = take(n * (hw / 4 / 16) * 16); float* x2b = take(n * (hw / 4 / 16) * 16);
+  float* x3a = take(n * (hw / 16) * 8); float* x3b = take(n * (hw / 16) * 8);
+  int rc;
+  {
+    const size_t total = n * hw;
+    hipLaunchKernelGGL(k_pack_rgb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, imgs, rgb4, hw, total);
+    ADAMVS_CHECK_LAUNCH("feature_net0 pack_rgb");
+  }
+  auto A = [&](const float* sa, const float* sb, const adamvs_fconv_weights& w, float* out, int hi, int wi, int ho, int wo,
+               int cout, int ctot, int co0) {
+    FConvArgs a{sa, sb, w.w, w.b, out, nullptr, nullptr, hi, wi, ho, wo, cout, ctot, co0, 0, 0, 0, 0};
+    return a;
+  };
+  // conv0: 3(+1) -> 8 -> 8 at full resolution
+  if ((rc = launch_fconv<4, 0, 1, FM_K3, FE_RELU>(A(rgb4, nullptr, fw.conv0_0, c0a, H, W, H, W, 8, 8, 0), N, st, "conv0.0"))) return rc;
+  if ((rc = launch_fconv<8, 0, 1, FM_K3, FE_RELU>(A(c0a, nullptr, fw.conv0_1, c0, H, W, H, W, 8, 8, 0), N, st, "conv0.1"))) return rc;
+  // conv1: 5x5 stride 2 (8 -> 16), two 3x3
+  if ((rc = launch_fconv<8, 0, 1, FM_K5S2, FE_RELU>(A(c0, nullptr, fw.conv1_0, c1a, H, W, H2, W2, 16, 16, 0), N, st, "conv1.0"))) return rc;
+  if ((rc = launch_fconv<16, 0, 1, FM_K3, FE_RELU>(A(c1a, nullptr, fw.conv1_1, c1b, H2, W2, H2, W2, 16, 16, 0), N, st, "conv1.1"))) return rc;
+  if ((rc = launch_fconv<16, 0, 1, FM_K3, FE_RELU>(A(c1b, nullptr, fw.conv1_2, c1, H2, W2, H2, W2, 16, 16, 0), N, st, "conv1.2"))) return rc;
+  // conv2: 5x5 stride 2 (16 -> 32: two launches of 16 output channels, 100 fragment registers each), two 3x3
+  for (int half = 0; half < 2; ++half) {
+    adamvs_fconv_weights wh{fw.conv2_0.w + (size_t)half * 25 * 4 * 64, fw.conv2_0.b + half * 16};
+    if ((rc = launch_fconv<16, 0, 1, FM_K5S2, FE_RELU>(A(c1, nullptr, wh, c2a, H2, W2, H4, W4, 16, 32, 16 * half), N, st, "conv2.0"))) return rc;
+  }
+  if ((rc = launch_fconv<32, 0, 2, FM_K3, FE_RELU>(A(c2a, nullptr, fw.conv2_1, c2b, H4, W4, H4, W4, 32, 32, 0), N, st, "conv2.1"))) return rc;
+  if ((rc = launch_fconv<32, 0, 2, FM_K3, FE_RELU>(A(c2b, nullptr, fw.conv2_2, c2, H4, W4, H4, W4, 32, 32, 0), N, st, "conv2.2"))) return rc;
+  // stage 1 output: out1 . cat(up(branch1_1), up(branch1_2), c2)
+  if ((rc = launch_context<32>(c2, fw.br1_1.w1, fw.br1_1.b1, fw.br1_1.w2, x1a, N, H4, W4, 4, st))) return rc;
+  if ((rc = launch_context<32>(c2, fw.br1_2.w1, fw.br1_2.b1, fw.br1_2.w2, x1b, N, H4, W4, 8, st))) return rc;
+  {
+    FConvArgs a{c2, nullptr, fw.out1.w, fw.out1.b, stage1, x1a, x1b, H4, W4, H4, W4, 32, 32, 0, H4 / 4, W4 / 4, H4 / 8, W4 / 8};
+    if ((rc = launch_fconv<32, 0, 2, FM_K1, FE_CONTEXT>(a, N, st, "out1"))) return rc;
+  }
+  // deconv1: ConvTranspose2d 32 -> 16 (four parity classes) + BN + ReLU, cat with conv1, 3x3 32 -> 16
+  {
+    const size_t tap = (size_t)8 * 64;                // floats per tap fragment set (KC = 8)
+    const float* wt = fw.deconv1_t.w;
+    adamvs_fconv_weights w00{wt, fw.deconv1_t.b}, w01{wt + 1 * tap, fw.deconv1_t.b}, w10{wt + 3 * tap, fw.deconv1_t.b}, w11{wt + 5 * tap, fw.deconv1_t.b};
+    if ((rc = launch_fconv<32, 0, 1, FM_T00, FE_RELU>(A(c2, nullptr, w00, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1 00"))) return rc;
+    if ((rc = launch_fconv<32, 0, 1, FM_T01, FE_RELU>(A(c2, nullptr, w01, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1 01"))) return rc;
+    if ((rc = launch_fconv<32, 0, 1, FM_T10, FE_RELU>(A(c2, nullptr, w10, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1 10"))) return rc;
+    if ((rc = launch_fconv<32, 0, 1, FM_T11, FE_RELU>(A(c2, nullptr, w11, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1 11"))) return rc;
+  }
+  if ((rc = launch_fconv<16, 16, 1, FM_K3, FE_RELU>(A(d1, c1, fw.deconv1_c, f1, H2, W2, H2, W2, 16, 16, 0), N, st, "deconv1.conv"))) return rc;
+  // stage 2 output
+  if ((rc = launch_context<16>(f1, fw.br2_1.w1, fw.br2_1.b1, fw.br2_1.w2, x2a, N, H2, W2, 4, st))) return rc;
+  if ((rc = launch_context<16>(f1, fw.br2_2.w1, fw.br2_2.b1, fw.br2_2.w2, x2b, N, H2, W2, 8, st))) return rc;
+  {
+    FConvArgs a{f1, nullptr, fw.out2.w, fw.out2.b, stage2, x2a, x2b, H2, W2, H2, W2, 16, 16, 0, H2 / 4, W2 / 4, H2 / 8, W2 / 8};
+    if ((rc = launch_fconv<16, 0, 1, FM_K1, FE_CONTEXT>(a, N, st, "out2"))) return rc;
+  }
+  // deconv2: ConvTranspose2d 16 -> 8, cat with conv0, 3x3 16 -> 8
+  {
+    const size_t tap = (size_t)4 * 64;                // KC = 4
+    const float* wt = fw.deconv2_t.w;
+    adamvs_fconv_weights w00{wt, fw.deconv2_t.b}, w01{wt + 1 * tap, fw.deconv2_t.b}, w10{wt + 3 * tap, fw.deconv2_t.b}, w11{wt + 5 * tap, fw.deconv2_t.b};
+    if ((rc = launch_fconv<16, 0, 1, FM_T00, FE_RELU>(A(f1, nullptr, w00, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2 00"))) return rc;
+    if ((rc = launch_fconv<16, 0, 1, FM_T01, FE_RELU>(A(f1, nullptr, w01, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2 01"))) return rc;
+    if ((rc = launch_fconv<16, 0, 1, FM_T10, FE_RELU>(A(f1, nullptr, w10, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2 10"))) return rc;
+    if ((rc = launch_fconv<16, 0, 1, FM_T11, FE_RELU>(A(f1, nullptr, w11, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2 11"))) return rc;
+  }
+  if ((rc = launch_fconv<8, 8, 1, FM_K3, FE_RELU>(A(d2, c0, fw.deconv2_c, f2, H, W, H, W, 8, 8, 0), N, st, "deconv2.conv"))) return rc;
+  // stage 3 output
+  if ((rc = launch_context<8>(f2, fw.br3_1.w1, fw.br3_1.b1, fw.br3_1.w2, x3a, N, H, W, 4, st))) return rc;
+  if ((rc = launch_context<8>(f2, fw.br3_2.w1, fw.br3_2.b1, fw.br3_2.w2, x3b, N, H, W, 8, st))) return rc;
+  {
+    FConvArgs a{f2, nullptr, fw.out3.w, fw.out3.b, stage3, x3a, x3b, H, W, H, W, 8, 8, 0, H / 4, W / 4, H / 8, W / 8};
+    if ((rc = launch_fconv<8, 0, 1, FM_K1, FE_CONTEXT>(a, N, st, "out3"))) return rc;
+  }
+  return 0;
+}

@@ -165,6 +165,46 @@ class PackedFuse:
         return ctypes.c_void_p(getattr(self.struct, name))
 
 
+class PackedFeature:
+    """Device copy of a packed FeatureNet0 + its adamvs_feature_weights struct."""
+
+    def __init__(self, flat, offsets, device):
+        from ._lib import FeatureWeights, FConvWeights, ContextWeights
+        self.buf = flat.to(device)
+        base = self.buf.data_ptr()
+        at = lambda f: base + 4 * offsets[f]
+        kw = {n: FConvWeights(at(n + ".w"), at(n + ".b")) for n in packing_fields()[0]}
+        kw.update({n: ContextWeights(at(n + ".w1"), at(n + ".b1"), at(n + ".w2")) for n in packing_fields()[1]})
+        self.struct = FeatureWeights(**kw)
+
+    def ptr(self):
+        return ctypes.byref(self.struct)
+
+
+def packing_fields():
+    from . import packing
+    return packing.FEATURE_CONVS, packing.FEATURE_BRANCHES
+
+
+def feature_net0(imgs, packed, workspace=None):
+    """FeatureNet0.forward on [N,3,H,W] images -> channel-last (stage1 [N,hw/16,32], stage2 [N,hw/4,16], stage3 [N,hw,8])."""
+    lib = _lib.load()
+    imgs = _dev(imgs, "imgs")
+    N, c, H, W = imgs.shape
+    if c != 3:
+        check(-1, "feature_net0")
+    dev = imgs.device
+    s1 = torch.empty(N, (H // 4) * (W // 4), 32, device=dev, dtype=torch.float32)
+    s2 = torch.empty(N, (H // 2) * (W // 2), 16, device=dev, dtype=torch.float32)
+    s3 = torch.empty(N, H * W, 8, device=dev, dtype=torch.float32)
+    nbytes = lib.adamvs_feature_net0_workspace_bytes(N, H, W)
+    if workspace is None or workspace.numel() * 4 < nbytes:
+        workspace = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+    check(lib.adamvs_feature_net0(_p(imgs), packed.ptr(), _p(s1), _p(s2), _p(s3), N, H, W, _p(workspace), nbytes, _stream()),
+          "feature_net0")
+    return s1, s2, s3
+
+
 def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up, precision=0):
     """SliceCostRegNetRED.forward on channel-last maps; states updated in place. -> reg [B,1,Ho,Wo]"""
     lib = _lib.load()

@@ -29,7 +29,8 @@ def _pooled_context(in_ch, out_ch, pool):
 
 class FeatureNet0(nn.Module):
     """2D U-Net with pooled-context branches, three output scales (C = 32/16/8 at 1/4, 1/2, 1/1);
-    reference models/adamvs.py:49-152.  Plain PyTorch: not part of the hand-written path."""
+    reference models/adamvs.py:49-152.  forward() = adamvs_feature_net0 (csrc/featnet.hip) on GPU tensors whose
+    height and width are multiples of 32 and base_channels = 8; other shapes run the same layers through PyTorch."""
 
     def __init__(self, base_channels, num_stage=3, stride=4):
         super().__init__()
@@ -52,6 +53,31 @@ class FeatureNet0(nn.Module):
         self.out2 = nn.Conv2d(4 * c, 2 * c, 1, bias=False)
         self.out3 = nn.Conv2d(2 * c, c, 1, bias=False)
         self.out_channels = [4 * c, 2 * c, c]
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):             # .cuda()/.to(): repack on next use
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def packed(self, device):
+        if self._packed is None or self._packed.buf.device != device:
+            flat, offsets = packing.pack_feature_net(self.state_dict(), "")
+            self._packed = hip_ops.PackedFeature(flat, offsets, device)
+        return self._packed
+
+    def hip_supported(self, x):
+        return x.is_cuda and self.base_channels == 8 and x.shape[-2] % 32 == 0 and x.shape[-1] % 32 == 0
+
+    def forward_cl(self, x):
+        """[N,3,H,W] -> channel-last stage maps ([N,hw/16,32], [N,hw/4,16], [N,hw,8]) for the plane sweep."""
+        if self.hip_supported(x):
+            return hip_ops.feature_net0(x, self.packed(x.device))
+        f = self.forward_torch(x)
+        return tuple(hip_ops.pack_features(f["stage%d" % (k + 1)]) for k in range(3))
 
     @staticmethod
     def _with_context(feat, branch_a, branch_b):
@@ -61,6 +87,14 @@ class FeatureNet0(nn.Module):
         return torch.cat((a, b, feat), 1)
 
     def forward(self, x):
+        if self.hip_supported(x):
+            H, W = x.shape[-2:]
+            s1, s2, s3 = hip_ops.feature_net0(x, self.packed(x.device))
+            return {"stage1": hip_ops.unpack_features(s1, H // 4, W // 4), "stage2": hip_ops.unpack_features(s2, H // 2, W // 2),
+                    "stage3": hip_ops.unpack_features(s3, H, W)}
+        return self.forward_torch(x)
+
+    def forward_torch(self, x):
         c0 = self.conv0(x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
@@ -265,15 +299,19 @@ class Infer_AdaMVSNet(nn.Module):
     def extract_features(self, imgs):
         """-> (feats_cl, shapes) for infer_from_features; FeatureNet0 on all B*V images in one batch."""
         B, V = imgs.shape[:2]
-        x = imgs.transpose(0, 1).reshape(B * V, *imgs.shape[2:])                  # view-major
-        # MIOpen has tuned solvers for moderate batches only (very large ones fall to its naive kernels): chunk
-        chunks = [self.feature(x[i:i + self.feature_chunk]) for i in range(0, B * V, self.feature_chunk)]
-        f = chunks[0] if len(chunks) == 1 else {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}
+        x = imgs.transpose(0, 1).reshape(B * V, *imgs.shape[2:]).contiguous()     # view-major
+        H, W = x.shape[-2:]
+        if self.feature.hip_supported(x):
+            maps = self.feature.forward_cl(x)                                     # channel-last, no transposes
+        else:
+            # MIOpen has tuned solvers for moderate batches only (very large ones fall to its naive kernels): chunk
+            chunks = [self.feature.forward_cl(x[i:i + self.feature_chunk]) for i in range(0, B * V, self.feature_chunk)]
+            maps = chunks[0] if len(chunks) == 1 else tuple(torch.cat([c[k] for c in chunks], 0) for k in range(3))
         feats_cl, shapes = [], []
         for s in range(self.num_stage):
-            x = f["stage%d" % (s + 1)]
-            feats_cl.append(hip_ops.pack_features(x))
-            shapes.append((B, x.shape[1], x.shape[2], x.shape[3]))
+            scale = (4, 2, 1)[s]
+            feats_cl.append(maps[s])
+            shapes.append((B, maps[s].shape[-1], H // scale, W // scale))
         return feats_cl, shapes
 
     def forward(self, imgs, proj_matrices, depth_values):

@@ -191,3 +191,82 @@ def pack_slice_reg_net(sd, pre, precision="fp32"):
         chunks.append(torch.cat([t, torch.zeros(pad)]))
         o += t.numel() + pad
     return torch.cat(chunks), offsets
+
+
+# --------------------------------------------------------------------------------------------------------------
+# FeatureNet0 (include/adamvs_hip.h: adamvs_feature_weights)
+FEATURE_CONVS = ("conv0_0", "conv0_1", "conv1_0", "conv1_1", "conv1_2", "conv2_0", "conv2_1", "conv2_2",
+                 "out1", "deconv1_t", "deconv1_c", "out2", "deconv2_t", "deconv2_c", "out3")
+FEATURE_BRANCHES = ("br1_1", "br1_2", "br2_1", "br2_2", "br3_1", "br3_2")
+
+
+def _bn_scale_shift(sd, pre):
+    g, b = sd[pre + "weight"].detach().float().cpu(), sd[pre + "bias"].detach().float().cpu()
+    m, v = sd[pre + "running_mean"].detach().float().cpu(), sd[pre + "running_var"].detach().float().cpu()
+    scale = g / torch.sqrt(v + BN_EPS)
+    return scale, b - m * scale
+
+
+def pack_taps(w):
+    """[cout][cin][ntaps] -> A fragments [NT][ntaps][cin/4][64] (cout zero-padded to 16*NT, cin to a multiple of 4)."""
+    cout, cin, nt_ = w.shape
+    cin4 = (cin + 3) // 4 * 4
+    nt = (cout + 15) // 16
+    wp = torch.zeros(nt * 16, cin4, nt_)
+    wp[:cout, :cin] = w
+    # (nt, co16, kc, k4, tap) -> (nt, tap, kc, k4, co16): lane = k4*16 + co16
+    return wp.reshape(nt, 16, cin4 // 4, 4, nt_).permute(0, 4, 2, 3, 1).contiguous().reshape(-1)
+
+
+def pack_feature_net(sd, pre="feature."):
+    """FeatureNet0 of `pre` -> (flat fp32 tensor, {field: offset}); fields 'name.w' / 'name.b' for the convolutions,
+    'name.w1' / 'name.b1' / 'name.w2' for the pooled-context branches."""
+    parts = {}
+
+    def conv_bn(name, key, taps):
+        w = sd[pre + key + "conv.weight"].detach().float().cpu()
+        scale, shift = _bn_scale_shift(sd, pre + key + "bn.")
+        w = (w * scale.reshape(-1, 1, 1, 1)).reshape(w.shape[0], w.shape[1], taps)
+        parts[name + ".w"] = pack_taps(w)
+        parts[name + ".b"] = pad_bias(shift, (w.shape[0] + 15) // 16 * 16)
+
+    conv_bn("conv0_0", "conv0.0.", 9)
+    conv_bn("conv0_1", "conv0.1.", 9)
+    conv_bn("conv1_0", "conv1.0.", 25)
+    conv_bn("conv1_1", "conv1.1.", 9)
+    conv_bn("conv1_2", "conv1.2.", 9)
+    conv_bn("conv2_0", "conv2.0.", 25)
+    conv_bn("conv2_1", "conv2.1.", 9)
+    conv_bn("conv2_2", "conv2.2.", 9)
+    conv_bn("deconv1_c", "deconv1.conv.", 9)
+    conv_bn("deconv2_c", "deconv2.conv.", 9)
+    for name, key in (("deconv1_t", "deconv1.deconv."), ("deconv2_t", "deconv2.deconv.")):
+        w = sd[pre + key + "conv.weight"].detach().float().cpu().permute(1, 0, 2, 3)        # -> [cout][cin][ky][kx]
+        scale, shift = _bn_scale_shift(sd, pre + key + "bn.")
+        w = w * scale.reshape(-1, 1, 1, 1)
+        classes = []
+        for py in (0, 1):
+            for px in (0, 1):
+                taps = [w[:, :, (0 if ty else 2) if py else 1, (0 if tx else 2) if px else 1]
+                        for ty in range(1 + py) for tx in range(1 + px)]
+                classes.append(pack_taps(torch.stack(taps, 2)))
+        parts[name + ".w"] = torch.cat(classes)
+        parts[name + ".b"] = pad_bias(shift, 16)
+    for k, C in ((1, 32), (2, 16), (3, 8)):
+        wo = sd[pre + "out%d.weight" % k].detach().float().cpu().reshape(C, 2 * C)
+        parts["out%d.w" % k] = pack_taps(wo[:, C:].reshape(C, C, 1))
+        parts["out%d.b" % k] = torch.zeros((C + 15) // 16 * 16)
+        for j in (1, 2):
+            key = "branch%d_%d.1." % (k, j)
+            w1 = sd[pre + key + "conv.weight"].detach().float().cpu().reshape(C // 2, C)
+            scale, shift = _bn_scale_shift(sd, pre + key + "bn.")
+            parts["br%d_%d.w1" % (k, j)] = (w1 * scale.reshape(-1, 1)).reshape(-1)
+            parts["br%d_%d.b1" % (k, j)] = shift.clone()
+            parts["br%d_%d.w2" % (k, j)] = wo[:, (j - 1) * (C // 2):j * (C // 2)].contiguous().reshape(-1)
+    offsets, chunks, o = {}, [], 0
+    for f, t in parts.items():
+        pad = (-t.numel()) % 64
+        offsets[f] = o
+        chunks.append(torch.cat([t.reshape(-1), torch.zeros(pad)]))
+        o += t.numel() + pad
+    return torch.cat(chunks), offsets

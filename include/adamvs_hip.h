@@ -128,6 +128,32 @@ typedef struct adamvs_fuse_weights {
   const float* final_w;                         /* [73]: w[tap*8+c], bias   upconv2d */
 } adamvs_fuse_weights;
 
+/* ---- FeatureNet0.forward, reference models/adamvs.py:49-152 (blocks models/module.py:164-251,
+ * 506-524), for N = B*V images at once.  imgs [N][3][H][W] (the reference's layout); outputs channel-last, the layout
+ * every entry point above takes: stage1 [N][(H/4)(W/4)][32], stage2 [N][(H/2)(W/2)][16], stage3 [N][H*W][8].
+ * H and W must be multiples of 32.  base_channels = 8 (the only configuration the reference uses).
+ *
+ * Weights (ada-mvs_amd/packing.py::pack_feature_net): every convolution as fp32 MFMA A fragments with the eval-mode
+ * BatchNorm scale folded in, w = [cout tile][tap][cin/4][64 lanes], lane l = W[16*tile + (l&15)][4*kc + (l>>4)][tap]
+ * (rows beyond cout zero), and b = the BatchNorm shift padded to 16 per tile (zeros for the plain output convs).
+ * conv0_0 takes 4 input channels (RGB + a zero).  The 5x5 stride-2 convolutions hold 25 taps; conv2_0 is stored as two
+ * 16-channel halves.  deconv*_t hold the ConvTranspose2d(k3,s2,p1,op1) weights per output parity class (py,px):
+ * 1 + 2 + 2 + 4 taps in the order 00, 01, 10, 11, tap (ty,tx) = kernel index (py ? (ty ? 0 : 2) : 1, same in x) applied
+ * to input pixel (i+ty, j+tx).  deconv*_c convolve cat(deconv output, skip).  out_k multiply the feature map only;
+ * the pooled-context branches br_k_j = {w1 [C/2][C] (BN folded), b1 [C/2], w2 [C][C/2] = columns of out_k for that
+ * branch} are applied at pooled resolution and their bilinear upsampling (align_corners=False) is added in the
+ * epilogue of out_k (the 1x1 convolution and the upsampling are both linear). */
+typedef struct adamvs_fconv_weights { const float* w; const float* b; } adamvs_fconv_weights;
+typedef struct adamvs_context_weights { const float* w1; const float* b1; const float* w2; } adamvs_context_weights;
+typedef struct adamvs_feature_weights {
+  adamvs_fconv_weights conv0_0, conv0_1, conv1_0, conv1_1, conv1_2, conv2_0, conv2_1, conv2_2;
+  adamvs_fconv_weights out1, deconv1_t, deconv1_c, out2, deconv2_t, deconv2_c, out3;
+  adamvs_context_weights br1_1, br1_2, br2_1, br2_2, br3_1, br3_2;
+} adamvs_feature_weights;
+size_t adamvs_feature_net0_workspace_bytes(int N, int H, int W);
+int adamvs_feature_net0(const float* imgs, const adamvs_feature_weights* weights, float* stage1, float* stage2, float* stage3,
+                        int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
 /* models/adamvs.py:495-512 fused with conv1 of SliceCostRegNetRED (adamvs.py:416), for all
  * D hypotheses at once: c1[d][b][pix][8] = ReLU(conv1(sum_v w_v warp_v ref / (1e-5 + sum_v w_v))).
  * view_weight [S][B][h*w].  Hypothesis loop inside the thread, bilinear taps cached in registers

@@ -93,6 +93,41 @@ def test_pack_unpack_roundtrip(hip):
     assert torch.equal(hip.unpack_features(cl, 10, 14).cpu(), x)
 
 
+# --------------------------------------------------------------------------- FeatureNet0
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (3, 128, 160), (1, 96, 224)])
+def test_feature_net0_against_oracle(hip, O, N, H, W):
+    """adamvs_feature_net0 (MFMA convolutions, folded BatchNorm, context branches applied at pooled resolution)
+    against the CPU restatement of FeatureNet0.forward, stage by stage; also the NCHW dict of the mirror's forward()."""
+    from ada_mvs_amd.models.adamvs import FeatureNet0
+    net = FeatureNet0(8)
+    sd = synth.seeded_state_dict(net, seed=2)
+    net.load_state_dict(sd)
+    x = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(H))
+    ref = O.feature_net(x, sd, "")
+    net = net.cuda().eval()
+    assert net.hip_supported(dev(x))
+    maps = net.forward_cl(dev(x))
+    for k, scale in enumerate((4, 2, 1)):
+        got = hip.unpack_features(maps[k], H // scale, W // scale)
+        assert got.shape == ref["stage%d" % (k + 1)].shape
+        assert rel_l1(got, ref["stage%d" % (k + 1)]) < OP_TOL, "stage%d" % (k + 1)
+    out = net(dev(x))
+    assert rel_l1(out["stage2"], ref["stage2"]) < OP_TOL
+
+
+def test_feature_net0_golden(hip):
+    """Against the reference's own FeatureNet0 outputs (end-to-end fixture, 64x96, 3 views)."""
+    g = load_golden("e2e_tiny")
+    m, _ = _model("tiny")
+    imgs = g["imgs"]
+    B, V = imgs.shape[:2]
+    feats_cl, shapes = m.extract_features(dev(imgs))
+    for k in range(3):
+        ref = g["feat_stage%d" % (k + 1)]                       # [B][V][C][h][w]
+        got = hip.unpack_features(feats_cl[k], shapes[k][2], shapes[k][3]).reshape(V, B, *ref.shape[2:]).transpose(0, 1)
+        assert rel_l1(got, ref) < OP_TOL, "stage%d" % (k + 1)
+
+
 # --------------------------------------------------------------------------- pass A
 @pytest.mark.parametrize("C", [32, 16, 8])
 def test_pair_similarity(hip, O, C):
