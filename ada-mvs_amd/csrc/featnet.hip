@@ -5,10 +5,11 @@
 //
 // Everything is channel-last fp32, [N = B*V images][h*w][C], the layout the plane sweep reads.  The eval-mode
 // BatchNorm of every block is folded into the A fragments (scale) and a bias (shift) on the host (packing.py).
-//   k_fconv    one persistent MFMA kernel for every convolution: 3x3 stride 1, 5x5 stride 2, the four output
-//              parity classes of ConvTranspose2d(k3, s2, p1, op1), and the 1x1 output convolutions; up to two
+//   k_fconv    one persistent MFMA kernel for every convolution: 3x3 stride 1, 5x5 stride 2, ConvTranspose2d(k3, s2,
+//              p1, op1) (four parity-class accumulators per tile), and the 1x1 output convolutions; up to two
 //              concatenated sources; epilogue = bias, ReLU, or "+ two bilinearly upsampled context maps".
-//   k_context  the pooled-context branches: AvgPool(P) -> 1x1 conv -> BN -> ReLU, then multiplied by the branch's
+//   k_context  the two pooled-context branches of a stage (AvgPool 4 and 8, one read of the feature map):
+//              AvgPool(P) -> 1x1 conv -> BN -> ReLU, then multiplied by the branch's
 //              slice of the 1x1 output convolution.  (out_k = W . cat(up(b1), up(b2), f); upsampling and the 1x1
 //              convolution are both linear, so W_1 is applied to b1 at pooled resolution and the full-resolution
 //              kernel only adds up(W_1 b1) + up(W_2 b2) to W_f f: the concatenated 2C-channel map never exists.)
@@ -22,7 +23,7 @@
 
 namespace adamvs {
 
-enum { FM_K3 = 0, FM_K5S2 = 1, FM_K1 = 2, FM_T00 = 3, FM_T01 = 4, FM_T10 = 5, FM_T11 = 6 };
+enum { FM_K3 = 0, FM_K5S2 = 1, FM_K1 = 2, FM_TALL = 3 };      // FM_TALL: ConvTranspose2d(k3, s2, p1, op1), all four parity classes
 enum { FE_RELU = 1, FE_CONTEXT = 2 };
 
 struct FConvArgs {
@@ -37,16 +38,19 @@ struct FConvArgs {
   int ho, wo;            // tile space: output size (input size for the transposed classes, whose output is 2ho x 2wo)
   int cout, ctot, co0;
   int hA, wA, hB, wB;
+  float syA, sxA, syB, sxB;   // FE_CONTEXT: input/output size ratios of the two context maps (filled by the launcher)
 };
 
+// Transposed convolution: output pixel (2i+py, 2j+px) sums input pixels (i+ty, j+tx), ty <= py, tx <= px, with kernel
+// index (py ? (ty ? 0 : 2) : 1, same in x).  One tile = 4 x 16 input pixels = 8 x 32 output pixels; the 2 x 2 input
+// neighbourhood is read once and feeds four accumulators (1 + 2 + 2 + 4 = 9 fragments per k-chunk, stored class by class).
 template <int MODE> struct FGeom {
-  static constexpr bool T = MODE >= FM_T00;
-  static constexpr int PY = T ? ((MODE - FM_T00) >> 1) : 0, PX = T ? ((MODE - FM_T00) & 1) : 0;
+  static constexpr bool T = MODE == FM_TALL;
   static constexpr int STR = MODE == FM_K5S2 ? 2 : 1;
-  static constexpr int KH = MODE == FM_K3 ? 3 : (MODE == FM_K5S2 ? 5 : (MODE == FM_K1 ? 1 : 1 + PY));
-  static constexpr int KW = MODE == FM_K3 ? 3 : (MODE == FM_K5S2 ? 5 : (MODE == FM_K1 ? 1 : 1 + PX));
+  static constexpr int KH = MODE == FM_K3 ? 3 : (MODE == FM_K5S2 ? 5 : (MODE == FM_K1 ? 1 : 2));
+  static constexpr int KW = KH;
   static constexpr int ORG = MODE == FM_K3 ? -1 : (MODE == FM_K5S2 ? -2 : 0);      // window origin = tile origin * STR + ORG
-  static constexpr int NTAPS = KH * KW;
+  static constexpr int NTAPS = T ? 9 : KH * KW;
   static constexpr int rows(int tr) { return (tr - 1) * STR + KH; }
   static constexpr int cols(int tc) { return (tc - 1) * STR + KW; }
 };
@@ -61,10 +65,10 @@ __device__ __forceinline__ void up_taps(int dst, int n_in, float scale, int& i0,
   l1 = s - (float)i0;
 }
 
-__device__ __forceinline__ f32x4 up_sample4(const float* map, int n, int hm, int wm, int ctot, int c, int y, int x, int ho, int wo) {
+__device__ __forceinline__ f32x4 up_sample4(const float* map, int n, int hm, int wm, int ctot, int c, int y, int x, float sy, float sx) {
   int y0, y1, x0, x1; float ly, lx;
-  up_taps(y, hm, (float)hm / (float)ho, y0, y1, ly);
-  up_taps(x, wm, (float)wm / (float)wo, x0, x1, lx);
+  up_taps(y, hm, sy, y0, y1, ly);
+  up_taps(x, wm, sx, x0, x1, lx);
   const float* p = map + (size_t)n * hm * wm * ctot + c;
   const f32x4 a = *(const f32x4*)(p + ((size_t)y0 * wm + x0) * ctot), b = *(const f32x4*)(p + ((size_t)y0 * wm + x1) * ctot);
   const f32x4 cc = *(const f32x4*)(p + ((size_t)y1 * wm + x0) * ctot), d = *(const f32x4*)(p + ((size_t)y1 * wm + x1) * ctot);
@@ -119,12 +123,13 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
     pin(xbyte[kc]);
   }
   // output: lane's pixel (row, p) of the tile, channels co0 + 16 nt + 4q ..; transposed classes write pixel (2y+PY, 2x+PX)
+  static_assert(!GM::T || NT == 1, "transposed layers: at most 16 output channels");
   const int Wo = GM::T ? 2 * a.wo : a.wo;
   unsigned ooff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int co4 = nt * 16 + 4 * q;
-    const int py = GM::T ? 2 * row + GM::PY : row, px = GM::T ? 2 * p + GM::PX : p;
+    const int py = GM::T ? 2 * row : row, px = GM::T ? 2 * p : p;
     ooff[nt] = co4 < a.cout ? (unsigned)(((py * Wo + px) * a.ctot + a.co0 + co4) * 4) : BUF_OOB;
     pin(ooff[nt]);
   }
@@ -176,8 +181,8 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
       ctx[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if ((EPI & FE_CONTEXT) && valid && nt * 16 + 4 * q < a.cout) {
         const int c = a.co0 + nt * 16 + 4 * q, y = oy0 + row, x = ox0 + p;
-        ctx[nt] = up_sample4(a.ctxA, n, a.hA, a.wA, a.ctot, c, y, x, a.ho, a.wo) +
-                  up_sample4(a.ctxB, n, a.hB, a.wB, a.ctot, c, y, x, a.ho, a.wo);
+        ctx[nt] = up_sample4(a.ctxA, n, a.hA, a.wA, a.ctot, c, y, x, a.syA, a.sxA) +
+                  up_sample4(a.ctxB, n, a.hB, a.wB, a.ctot, c, y, x, a.syB, a.sxB);
       }
     }
     const int tn = t + gridDim.x;
@@ -188,9 +193,9 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
       load_tile(stage, nn, txn, tyn);
     }
 
-    f32x4 acc[NT];
+    f32x4 acc[GM::T ? 4 : NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < (GM::T ? 4 : NT); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ty9 = 0; ty9 < GM::KH; ++ty9)
 #pragma unroll
@@ -198,20 +203,39 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
           const float bv = *(const float*)((const char*)lds + xbyte[kc] + (ty9 * LC + tx9) * 4);
+          if (GM::T) {                 // input pixel (i+ty9, j+tx9) feeds the classes with py >= ty9, px >= tx9
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[nt][ty9 * GM::KW + tx9][kc], bv, acc[nt]);
+            for (int cls = 0; cls < 4; ++cls) {
+              const int py = cls >> 1, px = cls & 1;
+              constexpr int cbase[4] = {0, 1, 3, 5};
+              if (py >= ty9 && px >= tx9) acc[cls] = mfma16(wf[0][cbase[cls] + ty9 * (1 + px) + tx9][kc], bv, acc[cls]);
+            }
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[nt][ty9 * GM::KW + tx9][kc], bv, acc[nt]);
+          }
         }
 
     wait_vmem_all();
     __syncthreads();                   // every wave is done reading the tile
     if (more) store_tile(stage);
 
+    if (GM::T) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 v = acc[nt] + bias[nt];
-      if (EPI & FE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (EPI & FE_CONTEXT) v += ctx[nt];
-      buf_store4(ro, valid ? ooff[nt] : BUF_OOB, v);
+      for (int cls = 0; cls < 4; ++cls) {
+        f32x4 v = acc[cls] + bias[0];
+        if (EPI & FE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const unsigned o = ooff[0] + (unsigned)((((cls >> 1) * Wo) + (cls & 1)) * a.ctot * 4);
+        buf_store4(ro, (valid && ooff[0] != BUF_OOB) ? o : BUF_OOB, v);
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 v = acc[nt] + bias[nt];
+        if (EPI & FE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (EPI & FE_CONTEXT) v += ctx[nt];
+        buf_store4(ro, valid ? ooff[nt] : BUF_OOB, v);
+      }
     }
     if (!more) break;
     __syncthreads();                   // next tile visible
@@ -220,8 +244,13 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
 }
 
 template <int CA, int CB, int NT, int MODE, int EPI>
-static int launch_fconv(const FConvArgs& a, int N, hipStream_t st, const char* name) {
+static int launch_fconv(const FConvArgs& a_in, int N, hipStream_t st, const char* name) {
   using GM = FGeom<MODE>;
+  FConvArgs a = a_in;
+  if (EPI & FE_CONTEXT) {
+    a.syA = (float)a.hA / (float)a.ho; a.sxA = (float)a.wA / (float)a.wo;
+    a.syB = (float)a.hB / (float)a.ho; a.sxB = (float)a.wB / (float)a.wo;
+  }
   constexpr int G = (CA + CB) / 4, NPIX = GM::rows(4) * GM::cols(16);
   constexpr int PLANE = (GM::STR == 1) ? plane_pitch16(NPIX) : (NPIX | 1);
   constexpr size_t lds = (size_t)G * group_pitch(PLANE, G) * sizeof(float);
@@ -239,65 +268,83 @@ static int launch_fconv(const FConvArgs& a, int N, hipStream_t st, const char* n
 }
 
 // ---------------------------------------------------------------------------
-// Pooled-context branch: AvgPool2d(P) -> 1x1 conv (C -> C/2, BN folded) -> ReLU -> 1x1 (C/2 -> C: the branch's
-// columns of the stage's output convolution).  One thread per (pooled pixel, 4 output channels); the pooled maps
-// are 16 or 64 times smaller than the feature map, so this is a plain streaming kernel.
-//   w1 [C/2][C] (scale folded), b1 [C/2], w2 [C][C/2];  out [N][hp*wp][C]
+// Pooled-context branches of one stage: AvgPool2d(4) and AvgPool2d(8), each -> 1x1 conv (C -> C/2, BN folded) -> ReLU
+// -> 1x1 (C/2 -> C: the branch's columns of the stage's output convolution).  One thread per 8 x 8 block of the
+// feature map: it is read once, the four 4 x 4 means feed branch a and their mean feeds branch b.  The pooled maps
+// are 16 and 64 times smaller than the feature map, so this is a plain streaming kernel.
+//   w1 [C/2][C] (scale folded), b1 [C/2], w2 [C][C/2];  outA [N][(h/4)(w/4)][C], outB [N][(h/8)(w/8)][C]
 template <int C>
-__global__ __launch_bounds__(256) void k_context(const float* __restrict__ feat, const float* __restrict__ w1,
-                                                 const float* __restrict__ b1, const float* __restrict__ w2,
-                                                 float* __restrict__ out, int h, int w, int P, int hp, int wp, size_t total) {
+__global__ __launch_bounds__(256) void k_context(const float* __restrict__ feat, adamvs_context_weights wa,
+                                                 adamvs_context_weights wb, float* __restrict__ outA,
+                                                 float* __restrict__ outB, int h, int w, size_t total) {
   constexpr int C2 = C / 2;
-  __shared__ float s_w1[C2 * C], s_b1[C2], s_w2[C * C2];
-  for (int i = threadIdx.x; i < C2 * C; i += 256) { s_w1[i] = w1[i]; s_w2[i] = w2[i]; }
-  for (int i = threadIdx.x; i < C2; i += 256) s_b1[i] = b1[i];
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // pooled pixel
-  if (i >= total) return;
-  const int xp = (int)(i % wp), yp = (int)((i / wp) % hp);
-  const size_t n = i / ((size_t)wp * hp);
-  float pooled[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) pooled[c] = 0.f;
-  const float* base = feat + (((size_t)n * h + (size_t)yp * P) * w + (size_t)xp * P) * C;
-  for (int dy = 0; dy < P; ++dy)
-    for (int dx = 0; dx < P; ++dx) {
-      const f32x4* px = (const f32x4*)(base + ((size_t)dy * w + dx) * C);
-#pragma unroll
-      for (int g = 0; g < C / 4; ++g) {
-        const f32x4 v = px[g];
-        pooled[4 * g] += v.x; pooled[4 * g + 1] += v.y; pooled[4 * g + 2] += v.z; pooled[4 * g + 3] += v.w;
-      }
-    }
-  const float inv = 1.0f / (float)(P * P);
-  float mid[C2];
-#pragma unroll
-  for (int m = 0; m < C2; ++m) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) s += s_w1[m * C + c] * (pooled[c] * inv);
-    mid[m] = fmaxf(s + s_b1[m], 0.f);
+  __shared__ float s_w1[2][C2 * C], s_b1[2][C2], s_w2[2][C * C2];
+  for (int i = threadIdx.x; i < C2 * C; i += 256) {
+    s_w1[0][i] = wa.w1[i]; s_w2[0][i] = wa.w2[i];
+    s_w1[1][i] = wb.w1[i]; s_w2[1][i] = wb.w2[i];
   }
-  float* o = out + i * C;
-#pragma unroll
-  for (int co = 0; co < C; co += 4) {
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < C2; i += 256) { s_b1[0][i] = wa.b1[i]; s_b1[1][i] = wb.b1[i]; }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // 8 x 8 block
+  if (i >= total) return;
+  const int w8 = w / 8, h8 = h / 8, w4 = w / 4, h4 = h / 4;
+  const int xb = (int)(i % w8), yb = (int)((i / w8) % h8);
+  const size_t n = i / ((size_t)w8 * h8);
+
+  auto branch = [&](const float (&pooled)[C], int which, float* o) {
+    float mid[C2];
 #pragma unroll
     for (int m = 0; m < C2; ++m) {
-      r.x += s_w2[(co + 0) * C2 + m] * mid[m]; r.y += s_w2[(co + 1) * C2 + m] * mid[m];
-      r.z += s_w2[(co + 2) * C2 + m] * mid[m]; r.w += s_w2[(co + 3) * C2 + m] * mid[m];
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) s += s_w1[which][m * C + c] * pooled[c];
+      mid[m] = fmaxf(s + s_b1[which][m], 0.f);
     }
-    *(f32x4*)(o + co) = r;
-  }
+#pragma unroll
+    for (int co = 0; co < C; co += 4) {
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < C2; ++m) {
+        r.x += s_w2[which][(co + 0) * C2 + m] * mid[m]; r.y += s_w2[which][(co + 1) * C2 + m] * mid[m];
+        r.z += s_w2[which][(co + 2) * C2 + m] * mid[m]; r.w += s_w2[which][(co + 3) * C2 + m] * mid[m];
+      }
+      *(f32x4*)(o + co) = r;
+    }
+  };
+
+  float p8[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) p8[c] = 0.f;
+  for (int sy = 0; sy < 2; ++sy)
+    for (int sx = 0; sx < 2; ++sx) {
+      float p4[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) p4[c] = 0.f;
+      const float* base = feat + (((size_t)n * h + (size_t)yb * 8 + sy * 4) * w + (size_t)xb * 8 + sx * 4) * C;
+      for (int dy = 0; dy < 4; ++dy)
+        for (int dx = 0; dx < 4; ++dx) {
+          const f32x4* px = (const f32x4*)(base + ((size_t)dy * w + dx) * C);
+#pragma unroll
+          for (int g = 0; g < C / 4; ++g) {
+            const f32x4 v = px[g];
+            p4[4 * g] += v.x; p4[4 * g + 1] += v.y; p4[4 * g + 2] += v.z; p4[4 * g + 3] += v.w;
+          }
+        }
+#pragma unroll
+      for (int c = 0; c < C; ++c) { p8[c] += p4[c]; p4[c] *= (1.0f / 16.0f); }
+      branch(p4, 0, outA + (((size_t)n * h4 + (size_t)yb * 2 + sy) * w4 + (size_t)xb * 2 + sx) * C);
+    }
+#pragma unroll
+  for (int c = 0; c < C; ++c) p8[c] *= (1.0f / 64.0f);
+  branch(p8, 1, outB + i * C);
 }
 
 template <int C>
-static int launch_context(const float* feat, const float* w1, const float* b1, const float* w2, float* out, int N, int h, int w,
-                          int P, hipStream_t st) {
-  const int hp = h / P, wp = w / P;
-  const size_t total = (size_t)N * hp * wp;
-  hipLaunchKernelGGL(k_context<C>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feat, w1, b1, w2, out, h, w, P, hp, wp, total);
-  ADAMVS_CHECK_LAUNCH("feature_net0 context branch");
+static int launch_context(const float* feat, const adamvs_context_weights& wa, const adamvs_context_weights& wb, float* outA,
+                          float* outB, int N, int h, int w, hipStream_t st) {
+  const size_t total = (size_t)N * (h / 8) * (w / 8);
+  hipLaunchKernelGGL(k_context<C>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feat, wa, wb, outA, outB, h, w, total);
+  ADAMVS_CHECK_LAUNCH("feature_net0 context branches");
   return 0;
 }
 
@@ -356,7 +403,7 @@ extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weigh
   }
   auto A = [&](const float* sa, const float* sb, const adamvs_fconv_weights& w, float* out, int hi, int wi, int ho, int wo,
                int cout, int ctot, int co0) {
-    FConvArgs a{sa, sb, w.w, w.b, out, nullptr, nullptr, hi, wi, ho, wo, cout, ctot, co0, 0, 0, 0, 0};
+    FConvArgs a{sa, sb, w.w, w.b, out, nullptr, nullptr, hi, wi, ho, wo, cout, ctot, co0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
     return a;
   };
   // conv0: 3(+1) -> 8 -> 8 at full resolution
@@ -374,46 +421,27 @@ extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weigh
   if ((rc = launch_fconv<32, 0, 2, FM_K3, FE_RELU>(A(c2a, nullptr, fw.conv2_1, c2b, H4, W4, H4, W4, 32, 32, 0), N, st, "conv2.1"))) return rc;
   if ((rc = launch_fconv<32, 0, 2, FM_K3, FE_RELU>(A(c2b, nullptr, fw.conv2_2, c2, H4, W4, H4, W4, 32, 32, 0), N, st, "conv2.2"))) return rc;
   // stage 1 output: out1 . cat(up(branch1_1), up(branch1_2), c2)
-  if ((rc = launch_context<32>(c2, fw.br1_1.w1, fw.br1_1.b1, fw.br1_1.w2, x1a, N, H4, W4, 4, st))) return rc;
-  if ((rc = launch_context<32>(c2, fw.br1_2.w1, fw.br1_2.b1, fw.br1_2.w2, x1b, N, H4, W4, 8, st))) return rc;
+  if ((rc = launch_context<32>(c2, fw.br1_1, fw.br1_2, x1a, x1b, N, H4, W4, st))) return rc;
   {
-    FConvArgs a{c2, nullptr, fw.out1.w, fw.out1.b, stage1, x1a, x1b, H4, W4, H4, W4, 32, 32, 0, H4 / 4, W4 / 4, H4 / 8, W4 / 8};
+    FConvArgs a{c2, nullptr, fw.out1.w, fw.out1.b, stage1, x1a, x1b, H4, W4, H4, W4, 32, 32, 0, H4 / 4, W4 / 4, H4 / 8, W4 / 8, 0.f, 0.f, 0.f, 0.f};
     if ((rc = launch_fconv<32, 0, 2, FM_K1, FE_CONTEXT>(a, N, st, "out1"))) return rc;
   }
   // deconv1: ConvTranspose2d 32 -> 16 (four parity classes) + BN + ReLU, cat with conv1, 3x3 32 -> 16
-  {
-    const size_t tap = (size_t)8 * 64;                // floats per tap fragment set (KC = 8)
-    const float* wt = fw.deconv1_t.w;
-    adamvs_fconv_weights w00{wt, fw.deconv1_t.b}, w01{wt + 1 * tap, fw.deconv1_t.b}, w10{wt + 3 * tap, fw.deconv1_t.b}, w11{wt + 5 * tap, fw.deconv1_t.b};
-    if ((rc = launch_fconv<32, 0, 1, FM_T00, FE_RELU>(A(c2, nullptr, w00, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1 00"))) return rc;
-    if ((rc = launch_fconv<32, 0, 1, FM_T01, FE_RELU>(A(c2, nullptr, w01, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1 01"))) return rc;
-    if ((rc = launch_fconv<32, 0, 1, FM_T10, FE_RELU>(A(c2, nullptr, w10, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1 10"))) return rc;
-    if ((rc = launch_fconv<32, 0, 1, FM_T11, FE_RELU>(A(c2, nullptr, w11, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1 11"))) return rc;
-  }
+  if ((rc = launch_fconv<32, 0, 1, FM_TALL, FE_RELU>(A(c2, nullptr, fw.deconv1_t, d1, H4, W4, H4, W4, 16, 16, 0), N, st, "deconv1.deconv"))) return rc;
   if ((rc = launch_fconv<16, 16, 1, FM_K3, FE_RELU>(A(d1, c1, fw.deconv1_c, f1, H2, W2, H2, W2, 16, 16, 0), N, st, "deconv1.conv"))) return rc;
   // stage 2 output
-  if ((rc = launch_context<16>(f1, fw.br2_1.w1, fw.br2_1.b1, fw.br2_1.w2, x2a, N, H2, W2, 4, st))) return rc;
-  if ((rc = launch_context<16>(f1, fw.br2_2.w1, fw.br2_2.b1, fw.br2_2.w2, x2b, N, H2, W2, 8, st))) return rc;
+  if ((rc = launch_context<16>(f1, fw.br2_1, fw.br2_2, x2a, x2b, N, H2, W2, st))) return rc;
   {
-    FConvArgs a{f1, nullptr, fw.out2.w, fw.out2.b, stage2, x2a, x2b, H2, W2, H2, W2, 16, 16, 0, H2 / 4, W2 / 4, H2 / 8, W2 / 8};
+    FConvArgs a{f1, nullptr, fw.out2.w, fw.out2.b, stage2, x2a, x2b, H2, W2, H2, W2, 16, 16, 0, H2 / 4, W2 / 4, H2 / 8, W2 / 8, 0.f, 0.f, 0.f, 0.f};
     if ((rc = launch_fconv<16, 0, 1, FM_K1, FE_CONTEXT>(a, N, st, "out2"))) return rc;
   }
   // deconv2: ConvTranspose2d 16 -> 8, cat with conv0, 3x3 16 -> 8
-  {
-    const size_t tap = (size_t)4 * 64;                // KC = 4
-    const float* wt = fw.deconv2_t.w;
-    adamvs_fconv_weights w00{wt, fw.deconv2_t.b}, w01{wt + 1 * tap, fw.deconv2_t.b}, w10{wt + 3 * tap, fw.deconv2_t.b}, w11{wt + 5 * tap, fw.deconv2_t.b};
-    if ((rc = launch_fconv<16, 0, 1, FM_T00, FE_RELU>(A(f1, nullptr, w00, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2 00"))) return rc;
-    if ((rc = launch_fconv<16, 0, 1, FM_T01, FE_RELU>(A(f1, nullptr, w01, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2 01"))) return rc;
-    if ((rc = launch_fconv<16, 0, 1, FM_T10, FE_RELU>(A(f1, nullptr, w10, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2 10"))) return rc;
-    if ((rc = launch_fconv<16, 0, 1, FM_T11, FE_RELU>(A(f1, nullptr, w11, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2 11"))) return rc;
-  }
+  if ((rc = launch_fconv<16, 0, 1, FM_TALL, FE_RELU>(A(f1, nullptr, fw.deconv2_t, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2.deconv"))) return rc;
   if ((rc = launch_fconv<8, 8, 1, FM_K3, FE_RELU>(A(d2, c0, fw.deconv2_c, f2, H, W, H, W, 8, 8, 0), N, st, "deconv2.conv"))) return rc;
   // stage 3 output
-  if ((rc = launch_context<8>(f2, fw.br3_1.w1, fw.br3_1.b1, fw.br3_1.w2, x3a, N, H, W, 4, st))) return rc;
-  if ((rc = launch_context<8>(f2, fw.br3_2.w1, fw.br3_2.b1, fw.br3_2.w2, x3b, N, H, W, 8, st))) return rc;
+  if ((rc = launch_context<8>(f2, fw.br3_1, fw.br3_2, x3a, x3b, N, H, W, st))) return rc;
   {
-    FConvArgs a{f2, nullptr, fw.out3.w, fw.out3.b, stage3, x3a, x3b, H, W, H, W, 8, 8, 0, H / 4, W / 4, H / 8, W / 8};
+    FConvArgs a{f2, nullptr, fw.out3.w, fw.out3.b, stage3, x3a, x3b, H, W, H, W, 8, 8, 0, H / 4, W / 4, H / 8, W / 8, 0.f, 0.f, 0.f, 0.f};
     if ((rc = launch_fconv<8, 0, 1, FM_K1, FE_CONTEXT>(a, N, st, "out3"))) return rc;
   }
   return 0;

@@ -294,7 +294,9 @@ def main():
                     "tiles_per_gpu_per_step": B, "concurrent_tile_groups": G, "global_tiles_per_step": n_tiles,
                     "parallelism": "tile-sharded x%d, 1 RCCL gather per step" % world,
                     "launch": "eager" if graph is None else "hipGraph replay"},
+                # upstream of the timed region: FeatureNet0 on all views of a tile (csrc/featnet.hip)
                 "feature_net_ms_per_tile": 1e3 * t_feat / B,
+                "end_to_end_maps_per_s_per_gpu": B / (t_feat + elapsed / args.steps),
             }
 
         if rank == 0 and world == 1 and not args.no_roofline:

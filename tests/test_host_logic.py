@@ -129,6 +129,40 @@ def test_packed_network_sizes_match_the_header():
     assert flat3[off3["final_w"] + (0 * 3 + 2) * 8 + 3] == w_fl[0, 3, 0, 2]
 
 
+def test_feature_net_packing_layout():
+    """FeatureNet0 packing (include/adamvs_hip.h: adamvs_feature_weights): BatchNorm folded, fragment order, the
+    transposed layers stored per output parity class, the output convolutions split into feature and context columns."""
+    from ada_mvs_amd.models.adamvs import FeatureNet0
+    net = FeatureNet0(8)
+    sd = synth.seeded_state_dict(net, 3)
+    flat, off = packing.pack_feature_net(sd, "")
+    assert all(o % 64 == 0 for o in off.values())
+    assert set(off) == {n + s for n in packing.FEATURE_CONVS for s in (".w", ".b")} | \
+        {n + s for n in packing.FEATURE_BRANCHES for s in (".w1", ".b1", ".w2")}
+    # conv1.0: 5x5 stride 2, 8 -> 16: fragment (tap, kc), lane l = W[l & 15][4 kc + (l >> 4)][tap] * bn scale
+    w = sd["conv1.0.conv.weight"]
+    scale = sd["conv1.0.bn.weight"] / torch.sqrt(sd["conv1.0.bn.running_var"] + packing.BN_EPS)
+    tap, kc, lane = 7, 1, 37
+    co, ci = lane & 15, 4 * kc + (lane >> 4)
+    got = flat[off["conv1_0.w"] + (tap * 2 + kc) * 64 + lane]
+    assert torch.allclose(got, w[co, ci, tap // 5, tap % 5] * scale[co], rtol=1e-6, atol=0)
+    shift = sd["conv1.0.bn.bias"] - sd["conv1.0.bn.running_mean"] * scale
+    assert torch.allclose(flat[off["conv1_0.b"] + 5], shift[5], rtol=1e-6, atol=1e-8)
+    # conv0.0 pads RGB to 4 input channels: the lanes of the fourth k-row hold zeros
+    assert float(flat[off["conv0_0.w"]:off["conv0_0.w"] + 9 * 64].reshape(9, 4, 16)[:, 3].abs().max()) == 0.0
+    # deconv2.deconv (ConvTranspose2d 16 -> 8): class (1,1) = fragments 5..8, tap (ty,tx) = kernel index (ty ? 0 : 2, tx ? 0 : 2)
+    wt = sd["deconv2.deconv.conv.weight"]                              # [cin 16][cout 8][3][3]
+    sc = sd["deconv2.deconv.bn.weight"] / torch.sqrt(sd["deconv2.deconv.bn.running_var"] + packing.BN_EPS)
+    frag, kc, lane = 5 + (1 * 2 + 0), 2, 19                            # class 11, (ty, tx) = (1, 0) -> (ky, kx) = (0, 2)
+    co, ci = lane & 15, 4 * kc + (lane >> 4)
+    got = flat[off["deconv2_t.w"] + (frag * 4 + kc) * 64 + lane]
+    assert torch.allclose(got, wt[ci, co, 0, 2] * sc[co], rtol=1e-6, atol=0)
+    # out3 = [8][16][1][1]: columns 0-3 branch 1, 4-7 branch 2, 8-15 the feature map
+    wo = sd["out3.weight"].reshape(8, 16)
+    assert torch.equal(flat[off["br3_2.w2"]:off["br3_2.w2"] + 32].reshape(8, 4), wo[:, 4:8])
+    assert flat[off["out3.w"] + (0 * 2 + 1) * 64 + 16 * 2 + 3] == wo[3, 8 + 4 * 1 + 2]
+
+
 def test_synthetic_recipes_are_deterministic():
     a = synth.tile_inputs("tiny", batch=2, seed=3)
     b = synth.tile_inputs("tiny", batch=2, seed=3)
