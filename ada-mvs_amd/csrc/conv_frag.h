@@ -30,27 +30,9 @@ __device__ __forceinline__ void load_wfrag(float (&wf)[NT][9][KC], const float* 
 // them every group of a pixel lands on the same bank: an 8-way conflict for 32 input channels).
 __host__ __device__ constexpr int group_pitch(int plane, int groups) { return 4 * plane + (groups >= 2 ? 32 / groups : 0); }
 
-// One run of 16 output pixels.  `xb` = LDS tile + q*PLANE + p*STRIDE (lane's
-// own k-row and pixel); (row, col) = output coordinates inside the tile; the
-// tile origin is input coordinate (out_row0*STRIDE - 1, out_col0*STRIDE - 1).
-template <int NT, int KC, int STRIDE, int GP, int PITCH>
-__device__ __forceinline__ void conv3x3_run(f32x4 (&acc)[NT], const float (&wf)[NT][9][KC], const float* xb, int row,
-                                            int col) {
-  const float* x0 = xb + (row * STRIDE) * PITCH + col * STRIDE;
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        float bv = x0[kc * GP + ky * PITCH + kx];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[nt][ky * 3 + kx][kc], bv, acc[nt]);
-      }
-}
-
-// Same, with the lane's B-fragment origin given as one pinned LDS byte offset per k-chunk: every read is
-// base register + immediate (tap offsets fit the ds_read2 immediates), no address arithmetic in the chain.
+// One run of 16 output pixels, the lane's B-fragment origin (its own k-row and pixel) given as one pinned LDS byte
+// offset per k-chunk: every read is base register + immediate (tap offsets fit the ds_read2 immediates), no address
+// arithmetic in the chain.
 template <int NT, int KC, int STRIDE, int PITCH>
 __device__ __forceinline__ void conv3x3_run_at(f32x4 (&acc)[NT], const float (&wf)[NT][9][KC], const float* lds,
                                                const unsigned (&xbyte)[KC]) {
