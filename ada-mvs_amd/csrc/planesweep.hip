@@ -51,10 +51,13 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   const float tx = r[9], ty = r[10], tz = r[11];
   const float* pl = planes + (size_t)b * D * hw + pc;
   float* out = sim + (((size_t)s * B + b) * hw + pc) * D;
-  // the 4 bilinear taps stay in registers while consecutive planes fall into the same source cell; the G lanes of
-  // a pixel project G different planes (lane g: plane d0+g) and pass cell + weights around with ds_bpermute
+  // sim = mean_c ref[c] * sum_t w_t tap_t[c] = (1/C) sum_t w_t * dot(ref, tap_t): while consecutive planes fall into
+  // the same source cell (192 planes span ~1.5 px at stage 1) the four tap . ref dot products do not change, so they
+  // are what stays in registers -- reduced over the G lanes of the pixel once per cell -- and a plane costs its own
+  // lane one projection and four FMAs.  The G lanes of a pixel project G different planes (lane g: plane d0+g); the
+  // cells are passed around with ds_bpermute in plane order, so any sequence of cells is handled, one reload each.
   int ccell = -1;
-  f32x4 t00 = {0.f, 0.f, 0.f, 0.f}, t01 = t00, t10 = t00, t11 = t00;
+  float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
   const int gbase = (threadIdx.x & 63) & ~(G - 1);
   for (int d0 = 0; d0 < D; d0 += G) {
     float keep = 0.f;
@@ -62,15 +65,18 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
 #pragma unroll
     for (int j = 0; j < G; ++j) {                                  // planes past D-1 repeat the last one, never stored
       const int cell = __shfl(mine.cell, gbase + j, 64);
-      const float w00 = __shfl(mine.w00, gbase + j, 64), w01 = __shfl(mine.w01, gbase + j, 64);
-      const float w10 = __shfl(mine.w10, gbase + j, 64), w11 = __shfl(mine.w11, gbase + j, 64);
       if (cell != -1 && cell != ccell) {
         ccell = cell;
+        f32x4 t00, t01, t10, t11;
         load_cell_taps(src, C, cell, h, w, t00, t01, t10, t11);
+        const f32x4 m00 = t00 * ref4, m01 = t01 * ref4, m10 = t10 * ref4, m11 = t11 * ref4;
+        d00 = group_sum<G>((m00.x + m00.y) + (m00.z + m00.w));
+        d01 = group_sum<G>((m01.x + m01.y) + (m01.z + m01.w));
+        d10 = group_sum<G>((m10.x + m10.y) + (m10.z + m10.w));
+        d11 = group_sum<G>((m11.x + m11.y) + (m11.z + m11.w));
       }
-      f32x4 m = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * ref4;
-      float part = group_sum<G>((m.x + m.y) + (m.z + m.w));
-      if (j == g) keep = part * (1.0f / (float)C);
+      // padding taps carry weight 0 (and a plane that misses the image has cell -1 and four zero weights)
+      if (j == g) keep = (mine.w00 * d00 + mine.w01 * d01 + mine.w10 * d10 + mine.w11 * d11) * (1.0f / (float)C);
     }
     if (live && d0 + g < D) out[d0 + g] = keep;       // G lanes x 4 B contiguous per pixel
   }

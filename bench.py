@@ -215,10 +215,13 @@ def main():
         groups = [model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]   # upstream of the hot path; untimed, reported
         torch.cuda.synchronize()
         t_feat_first = time.time() - t0
-        t0 = time.time()
-        groups = [model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]
-        torch.cuda.synchronize()
-        t_feat = time.time() - t0
+        t_feat = float("inf")
+        for _ in range(3):                   # steady state: the caching allocator re-uses the workspace of the previous call
+            del groups
+            t0 = time.time()
+            groups = [model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]
+            torch.cuda.synchronize()
+            t_feat = min(t_feat, time.time() - t0)
         del imgs
         projs = [{k: v[g * Bg:(g + 1) * Bg].contiguous() for k, v in proj.items()} for g in range(G)]
         dvs = [dv[g * Bg:(g + 1) * Bg].contiguous() for g in range(G)]
