@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   for (int d0 = 0; d0 < D; d0 += G) {
     float keep = 0.f;
     const PlaneTaps mine = plane_taps(ax, ay, az, tx, ty, tz, pl[(size_t)min(d0 + g, D - 1) * hw], h, w);
+    if (__all(mine.cell == ccell || mine.cell == -1)) {            // whole wave still inside its cached cells
+      keep = (mine.w00 * d00 + mine.w01 * d01 + mine.w10 * d10 + mine.w11 * d11) * (1.0f / (float)C);
+    } else
 #pragma unroll
     for (int j = 0; j < G; ++j) {                                  // planes past D-1 repeat the last one, never stored
       const int cell = __shfl(mine.cell, gbase + j, 64);
