@@ -52,18 +52,29 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
     az[k] = r[6] * x + r[7] * y + r[8];
     tx[k] = r[9]; ty[k] = r[10]; tz[k] = r[11];
   }
-  // per view (all lanes): view weight, cached cell + its 4 taps
+  // per view (all lanes): reference feature x view weight / (1e-5 + sum of view weights), cached cell + its 4 taps.
+  // (adamvs.py:497-512: sum_v w_v (warp_v ref) / (1e-5 + sum_v w_v); the weights do not depend on the plane, so the
+  // normalisation is folded into the per-view reference vector once per pixel)
   float wv[SV];
+  f32x4 refw[SV];
   int ccell[SV];
   f32x4 t00[SV], t01[SV], t10[SV], t11[SV];
-  const float* src[SV];
+  const float* src0 = feat + ((size_t)B + b) * (size_t)hw * C + 4 * g;      // view s: + s * vstride (uniform)
+  const size_t vstride = (size_t)B * hw * C;
 #pragma unroll
   for (int s = 0; s < SV; ++s) {
     const int sc = min(s, S - 1);
     wv[s] = (s < S) ? vw[((size_t)sc * B + b) * hw + pc] : 0.f;
-    src[s] = feat + ((size_t)(sc + 1) * B + b) * (size_t)hw * C + 4 * g;
     ccell[s] = -1;
     t00[s] = t01[s] = t10[s] = t11[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  {
+    float wsum = 1e-5f;                                            // adamvs.py:497
+#pragma unroll
+    for (int s = 0; s < SV; ++s) wsum += wv[s];
+    const float inv = 1.0f / wsum;
+#pragma unroll
+    for (int s = 0; s < SV; ++s) refw[s] = ref4 * (wv[s] * inv);
   }
   const int gbase = (threadIdx.x & 63) & ~(G - 1);   // first lane of this pixel's group
   const float* pl = planes + (size_t)b * D * hw + pc;
@@ -72,6 +83,12 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
 
   // depths: lane g of a pixel fetches plane dg+g, the group reads them back lane by lane -- one load per G planes,
   // so the (rolled) plane loop has no load that would queue behind the previous plane's store (vmcnt is in issue order)
+  // vmcnt retires in order and counts stores too: a tap reload issued after the store of the previous plane waits
+  // for that store to complete (~1.5 us), and with 8 pixels x S views per wave some lane reloads on nearly every
+  // plane.  The results of G planes are therefore parked in LDS (each thread reads back only what it wrote: no
+  // barrier) and flushed as one burst of G stores, so the reloads of G - 1 of every G planes find no store in
+  // front of them.  The plane loop stays rolled (unrolled, the scheduler hoists every plane's projection: spills).
+  __shared__ f32x4 park[G][256];
   for (int dg = d0; dg < d1; dg += G) {
   const float mydepth = pl[(size_t)min(dg + g, d1 - 1) * hw];
 #pragma unroll 1
@@ -83,7 +100,6 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
 #pragma unroll
     for (int k = 0; k < VPL; ++k) mine[k] = plane_taps(ax[k], ay[k], az[k], tx[k], ty[k], tz[k], depth, h, w);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float wsum = 1e-5f;                                          // adamvs.py:497
 #pragma unroll
     for (int s = 0; s < SV; ++s) {
       if (s >= S) break;                                         // uniform
@@ -94,13 +110,17 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
       const float w10 = __shfl(m.w10, from, 64), w11 = __shfl(m.w11, from, 64);
       if (cell != -1 && cell != ccell[s]) {                      // entered another source cell: reload the 4 taps
         ccell[s] = cell;
-        load_cell_taps(src[s], C, cell, h, w, t00[s], t01[s], t10[s], t11[s]);
+        load_cell_taps(src0 + s * vstride, C, cell, h, w, t00[s], t01[s], t10[s], t11[s]);
       }
       f32x4 wrp = t00[s] * w00 + t01[s] * w01 + t10[s] * w10 + t11[s] * w11;     // all-zero weights when padding
-      acc += (wrp * ref4) * wv[s];                               // adamvs.py:504-508
-      wsum += wv[s];
+      acc += wrp * refw[s];                                      // adamvs.py:504-512
     }
-    if (live) *(f32x4*)(out + (size_t)(d - d0) * ostride) = acc * (1.0f / wsum);   // adamvs.py:512
+    park[j][tid] = acc;
+  }
+  if (live) {
+    const int nd = min(G, d1 - dg);
+#pragma unroll 1
+    for (int j = 0; j < nd; ++j) *(f32x4*)(out + (size_t)(dg + j - d0) * ostride) = park[j][tid];
   }
   }
 }
