@@ -232,6 +232,26 @@ def test_slice_reg_step_bf16x3(hip, k):
     assert rel_l1(reg, g["reg"]) < 2e-4, "decoder"
 
 
+@pytest.mark.parametrize("k,h,w", [(0, 22, 38), (1, 30, 18), (2, 26, 50), (0, 4, 6)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_slice_reg_step_ragged_shapes(hip, O, precision, k, h, w):
+    """Sizes that are no multiple of any tile (4 x 16 GRU tiles, 6 x 30 decoder tiles, 8 x 16 conv1 tiles): every
+    kernel takes its edge path on some tiles and its interior path on others."""
+    m, sd = _model("tiny")
+    net = m.DepthNet[k].reg_fuse
+    net.precision = precision
+    B, C = 3, net.in_channels
+    g = torch.Generator().manual_seed(100 * k + h)
+    cost = torch.randn(B, C, h, w, generator=g)
+    s1 = torch.randn(B, 8, h, w, generator=g) * 0.5
+    s2 = torch.randn(B, 16, h // 2, w // 2, generator=g) * 0.5
+    ref, r1, r2 = O.slice_reg_step(cost, s1, s2, sd, "DepthNet.%d.reg_fuse." % k, in_up=(k < 2))
+    reg, n1, n2 = net(dev(cost), dev(s1), dev(s2))
+    tol = OP_TOL if precision == "fp32" else 2e-4
+    assert reg.shape == ref.shape
+    assert rel_l1(n1, r1) < tol and rel_l1(n2, r2) < tol and rel_l1(reg, ref) < tol
+
+
 @pytest.mark.parametrize("k", [0, 1, 2])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_slice_reg_step_many_tiles(hip, precision, k):
