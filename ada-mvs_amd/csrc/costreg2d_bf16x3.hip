@@ -130,12 +130,14 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
         const int o = boff + ((r * STR + ty) * LC + tx) * BX_PIX;
         const bf16x8 bh = *(const bf16x8*)(lhi + o);
         const bf16x8 bl = *(const bf16x8*)(llo + o);
+        // the three products of one accumulator are issued MT instructions apart, not back to back (a dependent
+        // MFMA waits for the full latency of its predecessor)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          acc[mt][r] = mfma_bf16(wh[mt], bh, acc[mt][r]);
-          acc[mt][r] = mfma_bf16(wh[mt], bl, acc[mt][r]);
-          acc[mt][r] = mfma_bf16(wl[mt], bh, acc[mt][r]);
-        }
+        for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bh, acc[mt][r]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bl, acc[mt][r]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wl[mt], bh, acc[mt][r]);
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) { wh[mt] = wh_n[mt]; wl[mt] = wl_n[mt]; }
