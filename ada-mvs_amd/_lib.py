@@ -45,7 +45,7 @@ class FeatureWeights(ctypes.Structure):
 
 class StageDesc(ctypes.Structure):
     """adamvs_stage_desc"""
-    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision", "precision_fuse")]
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision", "precision_fuse", "eps_in_numerator")]
 
 
 # name -> (restype, argtypes); every symbol include/adamvs_hip.h declares
@@ -77,7 +77,7 @@ SIGNATURES = {
     "adamvs_feature_net0": (c_i, [c_f, ctypes.POINTER(FeatureWeights), c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15
 _lib = None

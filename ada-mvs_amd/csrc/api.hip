@@ -61,6 +61,7 @@ static int check_desc(const adamvs_stage_desc* d) {
   ADAMVS_CHECK_ARG((d->h % 2) == 0 && (d->w % 2) == 0, "stage: h=%d w=%d must be even", d->h, d->w);
   ADAMVS_CHECK_ARG((size_t)d->B * d->D <= 65535, "stage: B*D=%d exceeds the grid z limit", d->B * d->D);
   ADAMVS_CHECK_ARG(d->precision == PRECISION_FP32 || d->precision == PRECISION_BF16X3, "stage: precision=%d (0 fp32, 1 bf16x3)", d->precision);
+  ADAMVS_CHECK_ARG(d->eps_in_numerator == 0 || d->eps_in_numerator == 1, "stage: eps_in_numerator=%d (0 or 1)", d->eps_in_numerator);
   ADAMVS_CHECK_ARG(d->precision_fuse == PRECISION_FP32 || d->precision_fuse == PRECISION_BF16X3,
                    "stage: precision_fuse=%d (0 fp32, 1 bf16x3)", d->precision_fuse);
   if (d->first_stage) {
@@ -143,7 +144,7 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   // -- weighted aggregation + conv1 for every hypothesis (state-independent)
   if ((phases & ADAMVS_PHASE_AGGREGATE) &&
       (rc = launch_sweep_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, s.h, s.w,
-                               s.precision_fuse, st)))
+                               s.precision_fuse, s.eps_in_numerator, st)))
     return rc;
 
   // -- recurrence over hypotheses

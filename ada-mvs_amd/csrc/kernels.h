@@ -30,7 +30,8 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
 int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,
                        int in_up, hipStream_t st);
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
-                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, hipStream_t st);
+                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, int eps_in_numerator,
+                       hipStream_t st);
 size_t sweep_workspace_floats(int B, int C, int D, int h, int w);
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
                            int precision, hipStream_t st);

@@ -120,6 +120,6 @@ extern "C" int adamvs_aggregate_conv1(const float* feat, const float* rt, const 
   ADAMVS_CHECK_ARG(workspace && workspace_bytes >= sweep_workspace_floats(B, C, D, h, w) * sizeof(float),
                    "aggregate_conv1: workspace too small (%zu < %zu bytes)", workspace_bytes,
                    sweep_workspace_floats(B, C, D, h, w) * sizeof(float));
-  return launch_sweep_conv1(feat, rt, planes, view_weight, w1pk, c1, (float*)workspace, B, S, C, D, h, w, precision,
+  return launch_sweep_conv1(feat, rt, planes, view_weight, w1pk, c1, (float*)workspace, B, S, C, D, h, w, precision, 0,
                             (hipStream_t)stream);
 }

@@ -27,7 +27,7 @@ template <int C, int SV>
 __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict__ feat, const float* __restrict__ rt,
                                                          const float* __restrict__ planes, const float* __restrict__ vw,
                                                          float* __restrict__ sim, int B, int S, int D, int d0, int d1,
-                                                         int h, int w) {
+                                                         int h, int w, int eps_num) {
   constexpr int G = C / 4, PPB = 256 / G;
   const int hw = h * w;
   const int tid = threadIdx.x, g = tid % G;
@@ -68,11 +68,13 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
     ccell[s] = -1;
     t00[s] = t01[s] = t10[s] = t11[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  float eps_term;       // eps_num (train/test twin, adamvs.py:262-300): (1e-5 + sum) / sum_v w_v instead of sum / (1e-5 + sum_v w_v)
   {
-    float wsum = 1e-5f;                                            // adamvs.py:497
+    float wsum = eps_num ? 0.f : 1e-5f;                            // adamvs.py:497
 #pragma unroll
     for (int s = 0; s < SV; ++s) wsum += wv[s];
     const float inv = 1.0f / wsum;
+    eps_term = eps_num ? 1e-5f * inv : 0.f;
 #pragma unroll
     for (int s = 0; s < SV; ++s) refw[s] = ref4 * (wv[s] * inv);
   }
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
     PlaneTaps mine[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) mine[k] = plane_taps(ax[k], ay[k], az[k], tx[k], ty[k], tz[k], depth, h, w);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {eps_term, eps_term, eps_term, eps_term};
 #pragma unroll
     for (int s = 0; s < SV; ++s) {
       if (s >= S) break;                                         // uniform
@@ -127,12 +129,12 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
 
 template <int C>
 static int launch_sweep_c(const float* feat, const float* rt, const float* planes, const float* vw, float* sim, int B, int S,
-                          int D, int d0, int d1, int h, int w, hipStream_t st) {
+                          int D, int d0, int d1, int h, int w, int eps_num, hipStream_t st) {
   dim3 grid(cdiv(h * w, 256 / (C / 4)), 1, B);
   if (S <= 4)
-    hipLaunchKernelGGL((k_sweep_aggregate<C, 4>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w);
+    hipLaunchKernelGGL((k_sweep_aggregate<C, 4>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
   else
-    hipLaunchKernelGGL((k_sweep_aggregate<C, 8>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w);
+    hipLaunchKernelGGL((k_sweep_aggregate<C, 8>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
   ADAMVS_CHECK_LAUNCH("sweep_aggregate");
   return 0;
 }
@@ -145,15 +147,16 @@ size_t sweep_workspace_floats(int B, int C, int D, int h, int w) {
 }
 
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
-                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, hipStream_t st) {
+                       float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, int eps_num,
+                       hipStream_t st) {
   if (S > 8 || S < 1) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
   const int dc = sweep_chunk_planes(D);
   for (int d0 = 0; d0 < D; d0 += dc) {
     const int d1 = (d0 + dc < D) ? d0 + dc : D;
     int rc;
-    if (C == 32) rc = launch_sweep_c<32>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, st);
-    else if (C == 16) rc = launch_sweep_c<16>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, st);
-    else if (C == 8) rc = launch_sweep_c<8>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, st);
+    if (C == 32) rc = launch_sweep_c<32>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
+    else if (C == 16) rc = launch_sweep_c<16>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
+    else if (C == 8) rc = launch_sweep_c<8>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
     else return set_error(-1, "aggregate_conv1: C=%d unsupported (8, 16 or 32)", C);
     if (rc) return rc;
     // conv1 over the (d1-d0)*B similarity maps of the chunk; image n = dlocal*B + b lands in c1[d0 + dlocal][b]

@@ -217,9 +217,9 @@ def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up, precision=0
     return reg
 
 
-def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0), precision=0, precision_fuse=0):
+def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0), precision=0, precision_fuse=0, eps_in_numerator=0):
     return StageDesc(B, S, C, h, w, D, int(in_up), int(first_stage), int(prev_hw[0]), int(prev_hw[1]), int(precision),
-                     int(precision_fuse))
+                     int(precision_fuse), int(eps_in_numerator))
 
 
 def depth_stage_workspace_bytes(desc):

@@ -200,15 +200,16 @@ class InferDepthNet0(nn.Module):
         _drop_packed(self)
         return super()._load_from_state_dict(*a, **k)
 
-    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0):
+    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0, twin=False):
         """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w];
-        prev_conf None (stage 1) or [S,B,hp,wp].  -> (view_weight [S,B,h,w], pair_depth|None, depth, conf)"""
+        prev_conf None (stage 1) or [S,B,hp,wp].  -> (view_weight [S,B,h,w], pair_depth|None, depth, conf).
+        twin: the train/test model's placement of the 1e-5 in the weighted aggregation (adamvs.py:262-300)."""
         S = feat_cl.shape[0] // B - 1
         D = depth_values.shape[1]
         first = prev_conf is None
         prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
         desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()],
-                                  _PRECISIONS[self.reg_fuse.precision])
+                                  _PRECISIONS[self.reg_fuse.precision], eps_in_numerator=int(twin))
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4
         ws = self._workspace.get(group)
         if ws is None or ws.numel() < need or ws.device != feat_cl.device:
@@ -276,12 +277,14 @@ class Infer_AdaMVSNet(nn.Module):
             net.reg._packed = net.reg_fuse._packed = None
 
     # ---- the hot path on pre-extracted features ---------------------------------------------
-    def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval, group=0):
+    def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval, group=0, twin=False):
         """feats_cl[s]: [V*B, h*w, C] channel-last view-major; shapes[s] = (B, C, h, w).
         Everything below is HIP.  `group` selects the workspace: independent
-        tile groups may run concurrently on different streams (the recurrence is latency-bound per group)."""
+        tile groups may run concurrently on different streams (the recurrence is latency-bound per group).
+        twin: semantics of the train/test model AdaMVSNet (see that class)."""
         outputs = {}
         depth, conf = None, None
+        first_maps = None
         for s in range(self.num_stage):
             name = "stage%d" % (s + 1)
             B, C, h, w = shapes[s]
@@ -289,9 +292,17 @@ class Infer_AdaMVSNet(nn.Module):
             planes = hip_ops.depth_range_samples(cur, self.ndepths[s], self.depth_intervals_ratio[s] * depth_interval, [B, h, w])
             rt = hip_ops.relative_transforms(proj_matrices[name])
             net = self.DepthNet[s]
-            vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, planes, conf, group)
-            conf = vw
-            st = net._as_dict(vw, pd, depth, pconf, self.ndepths[s])
+            vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, planes, conf, group, twin)
+            if twin:
+                # DepthNet0 hands its input confidence list on unchanged (adamvs.py:298): every later stage resamples
+                # the stage-1 maps, and the lists carry S entries
+                conf = vw if s == 0 else conf
+                maps = [conf[i].reshape(B, 1, *conf.shape[-2:]) for i in range(conf.shape[0])]
+                st = {"depth": depth, "photometric_confidence": pconf, "pair_confidence": maps,
+                      "pair_result": [pd[i] for i in range(pd.shape[0])] if pd is not None else []}
+            else:
+                conf = vw
+                st = net._as_dict(vw, pd, depth, pconf, self.ndepths[s])
             outputs[name] = st
             outputs.update(st)
         return outputs
@@ -318,8 +329,37 @@ class Infer_AdaMVSNet(nn.Module):
         if not imgs.is_cuda:
             raise AdaMVSHipError("Infer_AdaMVSNet runs on MI355X only: move the model and its inputs to the GPU "
                                  "(no CPU fallback for the depth-inference path)")
+        return self._forward_infer(imgs, proj_matrices, depth_values)
+
+    def _forward_infer(self, imgs, proj_matrices, depth_values):
         depth_min = float(depth_values[0, 0].cpu().numpy())        # batch item 0 only, host sync (adamvs.py:569-571)
         depth_max = float(depth_values[0, -1].cpu().numpy())
         depth_interval = (depth_max - depth_min) / self.num_depth
         feats_cl, shapes = self.extract_features(imgs)
         return self.infer_from_features(feats_cl, shapes, proj_matrices, depth_values, depth_interval)
+
+
+class AdaMVSNet(Infer_AdaMVSNet):
+    """The reference's train/test model (models/adamvs.py:311-396; DepthNet0 241-305, CostRegNetRED 157-195) in eval
+    mode on the same kernels -- SURVEY.md section 8f row f4: `train_whu.py --mode test` on the fast path.  Same
+    state-dict keys as Infer_AdaMVSNet (the reference loads one checkpoint into both).  What differs from the
+    inference model, and is reproduced: depth_values = [min, max, interval] per tile (adamvs.py:344-347); the 1e-5
+    of the weighted aggregation sits in the numerator (adamvs.py:262, 283-300); every later stage resamples the
+    stage-1 view weights (DepthNet0 returns its confidence_map argument, adamvs.py:298); `pair_confidence` holds S
+    maps.  The softmax / depth_regression / max of adamvs.py:302-305 is the online soft-argmin of the inference
+    model without its +1e-10.  Training (backward) is out of scope: forward() raises in train mode."""
+
+    def __init__(self, ndepths=[48, 32, 8], depth_intervals_ratio=[4, 2, 1], share_cr=False, cr_base_chs=[8, 8, 8],
+                 precision="fp32"):
+        super().__init__(num_depth=ndepths[0], ndepths=ndepths, depth_intervals_ratio=depth_intervals_ratio,
+                         share_cr=share_cr, cr_base_chs=cr_base_chs, precision=precision)
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        if self.training:
+            raise AdaMVSHipError("AdaMVSNet (MI355X build) implements the eval-mode forward only: call .eval()")
+        if not imgs.is_cuda:
+            raise AdaMVSHipError("AdaMVSNet runs on MI355X only: move the model and its inputs to the GPU")
+        depth_interval = float(depth_values[0, -1].cpu().numpy())  # batch item 0 only (adamvs.py:346)
+        depth_range = depth_values[:, 0:-1].contiguous()            # [min, max]
+        feats_cl, shapes = self.extract_features(imgs)
+        return self.infer_from_features(feats_cl, shapes, proj_matrices, depth_range, depth_interval, twin=True)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 1
+#define ADAMVS_ABI_VERSION 2
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -181,6 +181,9 @@ typedef struct adamvs_stage_desc {
   int prev_h, prev_w;     /* size of prev_conf maps when !first_stage */
   int precision;          /* ADAMVS_PRECISION_* for CostRegNet2D (w_reg must be packed accordingly) */
   int precision_fuse;     /* ADAMVS_PRECISION_* for conv1 and the ConvGRU convolutions (w_fuse packed accordingly) */
+  int eps_in_numerator;   /* where the 1e-5 of the weighted aggregation sits: 0 = InferDepthNet0, sum_v w_v x_v / (1e-5 +
+                             sum_v w_v) (adamvs.py:497-512); 1 = the train/test twin DepthNet0, (1e-5 + sum_v w_v x_v) /
+                             sum_v w_v (adamvs.py:262-300) */
 } adamvs_stage_desc;
 
 size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);

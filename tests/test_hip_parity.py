@@ -451,3 +451,27 @@ def test_fails_loudly(hip):
         hip.cost_reg_net_2d(torch.zeros(1, 64, 40, device="cuda"), torch.zeros(10, device="cuda"), 8, 8)   # D=40 unsupported
     with pytest.raises(AdaMVSHipError):
         hip.pack_features(torch.zeros(1, 6, 4, 4, device="cuda"))     # C % 4 != 0
+
+
+def test_train_test_twin_golden(hip):
+    """AdaMVSNet (the reference's train/test model, eval mode) against the reference's own output for it
+    (tools/gen_golden.py: same weights, depth_values = [min, max, interval])."""
+    from ada_mvs_amd.models.adamvs import AdaMVSNet
+    g, tw = load_golden("e2e_tiny"), load_golden("e2e_tiny_twin")
+    c = synth.CONFIGS["tiny"]
+    m = AdaMVSNet(c["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.cuda().eval()
+    dv = g["depth_values"]
+    dv3 = torch.cat([dv, (dv[:, 1:2] - dv[:, 0:1]) / c["num_depth"]], 1)
+    proj = {"stage%d" % k: dev(g["proj_stage%d" % k]) for k in (1, 2, 3)}
+    with torch.no_grad():
+        out = m(dev(g["imgs"]), proj, dev(dv3))
+    assert rel_l1(out["depth"], tw["depth"]) < OP_TOL                       # measured 2e-7
+    assert rel_l1(out["photometric_confidence"], tw["photometric_confidence"]) < OP_TOL     # measured 2e-6
+    assert len(out["stage3"]["pair_confidence"]) == g["imgs"].shape[1] - 1
+    # and it is NOT the inference model: the two agree only to 1e-4 (different eps placement and resampling)
+    assert rel_l1(out["depth"], g["depth"]) > OP_TOL
+    m.train()
+    with pytest.raises(Exception):
+        m(dev(g["imgs"]), proj, dev(dv3))

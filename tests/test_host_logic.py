@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.adamvs_version() == _lib.ABI_VERSION
     assert ctypes.sizeof(_lib.FuseWeights) == 13 * ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_lib.StageDesc) == 12 * ctypes.sizeof(ctypes.c_int)
+    assert ctypes.sizeof(_lib.StageDesc) == 13 * ctypes.sizeof(ctypes.c_int)
 
 
 def test_argument_errors_surface_as_exceptions_without_a_gpu():
@@ -34,10 +34,10 @@ def test_argument_errors_surface_as_exceptions_without_a_gpu():
     assert rc < 0
     with pytest.raises(_lib.AdaMVSHipError, match="pack_features"):
         _lib.check(rc, "pack_features")
-    desc = _lib.StageDesc(1, 2, 12, 8, 8, 16, 1, 1, 0, 0, 0, 0)            # C=12 unsupported
+    desc = _lib.StageDesc(1, 2, 12, 8, 8, 16, 1, 1, 0, 0, 0, 0, 0)         # C=12 unsupported
     assert lib.adamvs_depth_stage_workspace_bytes(ctypes.byref(desc)) == 0
     assert b"C=12" in lib.adamvs_last_error_string()
-    desc = _lib.StageDesc(8, 4, 32, 96, 192, 192, 1, 1, 0, 0, 0, 0)        # cfg2 stage 1, 8 tiles
+    desc = _lib.StageDesc(8, 4, 32, 96, 192, 192, 1, 1, 0, 0, 0, 0, 0)     # cfg2 stage 1, 8 tiles
     assert lib.adamvs_depth_stage_workspace_bytes(ctypes.byref(desc)) > (1 << 30)
 
 
