@@ -186,6 +186,10 @@ def packing_fields():
     return packing.FEATURE_CONVS, packing.FEATURE_BRANCHES
 
 
+def feature_net0_workspace_bytes(N, H, W):
+    return int(_lib.load().adamvs_feature_net0_workspace_bytes(int(N), int(H), int(W)))
+
+
 def feature_net0(imgs, packed, workspace=None):
     """FeatureNet0.forward on [N,3,H,W] images -> channel-last (stage1 [N,hw/16,32], stage2 [N,hw/4,16], stage3 [N,hw,8])."""
     lib = _lib.load()

@@ -54,6 +54,7 @@ class FeatureNet0(nn.Module):
         self.out3 = nn.Conv2d(2 * c, c, 1, bias=False)
         self.out_channels = [4 * c, 2 * c, c]
         self._packed = None
+        self.workspace_limit_bytes = 32 << 30      # forward_cl runs larger batches in chunks
 
     def _apply(self, fn, *a, **k):             # .cuda()/.to(): repack on next use
         self._packed = None
@@ -75,7 +76,13 @@ class FeatureNet0(nn.Module):
     def forward_cl(self, x):
         """[N,3,H,W] -> channel-last stage maps ([N,hw/16,32], [N,hw/4,16], [N,hw,8]) for the plane sweep."""
         if self.hip_supported(x):
-            return hip_ops.feature_net0(x, self.packed(x.device))
+            # intermediate maps take ~77 floats per pixel and image: bound the workspace, not the batch
+            per_image = hip_ops.feature_net0_workspace_bytes(1, x.shape[-2], x.shape[-1])
+            chunk = max(1, int(self.workspace_limit_bytes // per_image))
+            if x.shape[0] <= chunk:
+                return hip_ops.feature_net0(x, self.packed(x.device))
+            parts = [hip_ops.feature_net0(x[i:i + chunk], self.packed(x.device)) for i in range(0, x.shape[0], chunk)]
+            return tuple(torch.cat([p[k] for p in parts], 0) for k in range(3))
         f = self.forward_torch(x)
         return tuple(hip_ops.pack_features(f["stage%d" % (k + 1)]) for k in range(3))
 

@@ -113,6 +113,9 @@ def test_feature_net0_against_oracle(hip, O, N, H, W):
         assert rel_l1(got, ref["stage%d" % (k + 1)]) < OP_TOL, "stage%d" % (k + 1)
     out = net(dev(x))
     assert rel_l1(out["stage2"], ref["stage2"]) < OP_TOL
+    net.workspace_limit_bytes = hip.feature_net0_workspace_bytes(1, H, W)          # one image per call: same maps
+    chunked = net.forward_cl(dev(x))
+    assert all(torch.equal(a, b) for a, b in zip(chunked, maps))
 
 
 def test_feature_net0_golden(hip):
