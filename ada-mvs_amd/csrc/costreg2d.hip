@@ -12,6 +12,8 @@
 // straight from L2 into VGPRs (each wave owns different output channels, so
 // there is nothing to share through LDS); activations go through a planar LDS
 // tile shared by the block's four waves.
+#include <type_traits>
+
 #include "common.h"
 #include "conv_frag.h"
 #include "kernels.h"
@@ -187,18 +189,153 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
   }
 }
 
-// grid: (ceil(cols/16), ceil(rows/8), N [*4 classes for CONV_T2]); block 256
+// ConvTranspose2d(k3, s2, p1, op1), all four output parity classes of one 8 x 16 block of input positions in one
+// workgroup, one after the other.  A class on its own is a short block (1, 2, 2 or 4 taps against the 9 of a
+// stride-1 block) whose prologue -- per-lane constants, the latency of the first fragment and window loads -- and
+// epilogue weigh as much as a third of it; here the constants are shared and the first chunk of the next class is
+// requested during the last chunk of the current one, so its loads and the current class's epilogue overlap.
+template <int MT, int WM, int KB>
+__device__ __forceinline__ void conv_dd_t2_all(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
+  using TG = TileGeom<CONV_T2>;
+  constexpr int LR = TG::LR, LC = TG::LC, PLANE = TG::PLANE, GP = group_pitch(PLANE, KB / 4);
+  constexpr int WN = 4 / WM, NTR = 8 / WN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+  const int wm = wave % WM, wn = wave / WM;
+  const int p = lane & 15, q = lane >> 4;
+  const int D = a.D, KCT = D / 4, NTILES = D / 16;
+  const int r0 = by * 8, c0 = bx * 16;                       // block origin: input positions (i, j)
+  constexpr int NITEMS = LR * LC * (KB / 4), NITA = (NITEMS + 255) / 256;
+
+  const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.hi + r0) * a.wi + c0) * (long)D * 4);
+  unsigned xoff[NITA], xlds[NITA];
+#pragma unroll
+  for (int it = 0; it < NITA; ++it) {
+    const int i = min(tid + it * 256, NITEMS - 1);           // surplus lanes repeat the last item
+    const int g = i % (KB / 4), pp = i / (KB / 4), r = pp / LC, c = pp % LC;
+    const bool ok = r0 + r < a.hi && c0 + c < a.wi;
+    xoff[it] = ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB;
+    xlds[it] = (unsigned)((g * GP + r * LC + c) * 4);
+    pin(xoff[it]); pin(xlds[it]);
+  }
+  const buf_rsrc rw = make_rsrc(a.wpk);
+  unsigned woff = (unsigned)(lane * 4);
+  pin(woff);
+  unsigned xb[KB / 4];
+#pragma unroll
+  for (int kc = 0; kc < KB / 4; ++kc) {
+    xb[kc] = (unsigned)((kc * GP + q * PLANE + (wn * NTR) * LC + p) * 4);
+    pin(xb[kc]);
+  }
+
+  float wfA[4][KB / 4][MT], wfB[4][KB / 4][MT];              // up to 4 taps
+  f32x4 xs[NITA];
+  f32x4 acc[MT][NTR];
+
+  auto load_x = [&](int ch) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it)
+      xs[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+      float* dl = (float*)((char*)lds + xlds[it]);
+      dl[0] = xs[it].x; dl[PLANE] = xs[it].y; dl[2 * PLANE] = xs[it].z; dl[3 * PLANE] = xs[it].w;
+    }
+  };
+  auto load_w = [&](auto pyc, auto pxc, float (&wf)[4][KB / 4][MT], int ch) {
+    constexpr int PY = decltype(pyc)::value, PX = decltype(pxc)::value;
+#pragma unroll
+    for (int ty = 0; ty <= PY; ++ty)
+#pragma unroll
+      for (int tx = 0; tx <= PX; ++tx) {
+        const int ky = PY ? (ty ? 0 : 2) : 1, kx = PX ? (tx ? 0 : 2) : 1;
+#pragma unroll
+        for (int kc = 0; kc < KB / 4; ++kc)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const unsigned frag = (unsigned)(((ky * 3 + kx) * KCT + ch / 4 + kc) * NTILES + wm * MT + mt) * 256u;   // uniform
+            wf[ty * (1 + PX) + tx][kc][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, frag, 0));
+          }
+      }
+  };
+  auto mfma_chunk = [&](auto pyc, auto pxc, const float (&wf)[4][KB / 4][MT]) {
+    constexpr int PY = decltype(pyc)::value, PX = decltype(pxc)::value;
+#pragma unroll
+    for (int ty = 0; ty <= PY; ++ty)
+#pragma unroll
+      for (int tx = 0; tx <= PX; ++tx)
+#pragma unroll
+        for (int kc = 0; kc < KB / 4; ++kc) {
+          float bv[NTR];
+#pragma unroll
+          for (int r = 0; r < NTR; ++r) bv[r] = *(const float*)((const char*)lds + xb[kc] + ((r + ty) * LC + tx) * 4);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < NTR; ++r) acc[mt][r] = mfma16(wf[ty * (1 + PX) + tx][kc][mt], bv[r], acc[mt][r]);
+        }
+  };
+  // one class; wfA and xs hold its first chunk on entry; on exit they hold the first chunk of class (nyc, nxc), if any
+  auto run_class = [&](auto pyc, auto pxc, auto nyc, auto nxc, auto has_next) {
+    constexpr int PY = decltype(pyc)::value, PX = decltype(pxc)::value;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NTR; ++r) acc[mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < D; ch += 2 * KB) {
+      wait_vmem_all();
+      __syncthreads();
+      store_x();
+      __syncthreads();
+      load_w(pyc, pxc, wfB, ch + KB);
+      load_x(ch + KB);
+      mfma_chunk(pyc, pxc, wfA);
+
+      wait_vmem_all();
+      __syncthreads();
+      store_x();
+      __syncthreads();
+      if (ch + 2 * KB < D) {
+        load_w(pyc, pxc, wfA, ch + 2 * KB);
+        load_x(ch + 2 * KB);
+      } else if (decltype(has_next)::value) {
+        load_w(nyc, nxc, wfA, 0);
+        load_x(0);
+      }
+      mfma_chunk(pyc, pxc, wfB);
+    }
+#pragma unroll
+    for (int r = 0; r < NTR; ++r) {
+      const int row = r0 + wn * NTR + r, col = c0 + p;
+      if (!(row < a.hi && col < a.wi)) continue;
+      const size_t opix = ((size_t)n * a.ho + 2 * row + PY) * a.wo + 2 * col + PX;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co4 = (wm * MT + mt) * 16 + 4 * q;
+        f32x4 v = acc[mt][r] + *(const f32x4*)(a.bias + co4);
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.skip) v += *(const f32x4*)(a.skip + opix * D + co4);
+        *(f32x4*)(a.out + opix * D + co4) = v;
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  load_w(I1{}, I1{}, wfA, 0);
+  load_x(0);
+  run_class(I1{}, I1{}, I1{}, I0{}, std::true_type{});
+  run_class(I1{}, I0{}, I0{}, I1{}, std::true_type{});
+  run_class(I0{}, I1{}, I0{}, I0{}, std::true_type{});
+  run_class(I0{}, I0{}, I0{}, I0{}, std::false_type{});
+}
+
+// grid: (ceil(cols/16), ceil(rows/8), N); block 256
 template <int MT, int WM, int MODE, int KB>
 __global__ __launch_bounds__(256, (MT == 4 && WM == 4) ? 1 : 2) void k_conv_dd(ConvDDArgs a) {
   __shared__ float lds[(KB / 4) * group_pitch(TileGeom<MODE>::PLANE, KB / 4)];
   if (MODE == CONV_T2) {
-    int n = blockIdx.z >> 2, cls = blockIdx.z & 3;
-    switch (cls) {        // block-uniform
-      case 0: conv_dd_body<MT, WM, MODE, KB, 0, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
-      case 1: conv_dd_body<MT, WM, MODE, KB, 0, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
-      case 2: conv_dd_body<MT, WM, MODE, KB, 1, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
-      default: conv_dd_body<MT, WM, MODE, KB, 1, 1>(a, lds, n, blockIdx.y, blockIdx.x); break;
-    }
+    conv_dd_t2_all<MT, WM, KB>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
   } else {
     conv_dd_body<MT, WM, MODE, KB, 0, 0>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
   }
@@ -215,7 +352,7 @@ static int launch_conv_dd_cfg(const ConvDDArgs& a, int N, int mode, hipStream_t 
   else if (mode == CONV_S2)
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_T2, KB>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N * 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_T2, KB>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N), dim3(256), 0, st, a);
   ADAMVS_CHECK_LAUNCH("conv_dd");
   return 0;
 }
