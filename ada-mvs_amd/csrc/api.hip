@@ -104,7 +104,13 @@ extern "C" int adamvs_slice_reg_step(const float* cost, float* state1, float* st
   memcpy(&fw, weights, sizeof(fw));
   int rc = launch_conv1(cost, fw.conv1, c1, B, C, h, w, precision, st);
   if (rc) return rc;
-  return launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, precision, st);
+  float* h1_now = state1;
+  if ((rc = launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, precision, st, &h1_now))) return rc;
+  if (h1_now != state1) {              // the split-bf16 level-1 kernel writes the new state to the other buffer
+    hipError_t e = hipMemcpyAsync(state1, h1_now, (size_t)B * h * w * 8 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return set_error((int)e, "slice_reg_step: hipMemcpyAsync: %s", hipGetErrorString(e));
+  }
+  return 0;
 }
 
 extern "C" size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc) {

@@ -256,18 +256,234 @@ int launch_conv1_bf16x3(const float* cost, const float* w, float* c1, int N, int
   return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
 }
 
-// gates1 / cand1 / conv2 / gates2 / cand2 of one recurrent step (the decoder stays on the fp32 path)
-int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBuffers& sb, int B, int h, int w, hipStream_t st) {
+// ---------------------------------------------------------------------------------------------------------------
+// Level-1 ConvGRU in one kernel (reference models/module.py:28-52 at full stage resolution): the gate convolution
+// on cat(x, h), r*h, the candidate convolution on cat(x, r*h) and the state blend, per 8 x 30 tile.  The level-1
+// maps are the widest of the recurrence (8 channels at stage resolution) and the split-bf16 chain is short, so
+// the separate gate / candidate kernels were bound by their memory traffic: x twice, h, r*h out and in, u out and
+// in, h out.  Fused, a tile reads x and h once (12 x 34 window, halo 2) and writes h once; r*h replaces h inside
+// the LDS tile (the candidate convolution only needs it split into bf16 halves anyway) and u stays in LDS.
+// The new state goes to a second buffer (neighbouring tiles still read the old one); the caller alternates them.
+//
+// LDS: window [hi|lo][12*34 pixels][x 8 | h 8 | pad 8] bf16, and u [10*32 region pixels][8] fp32.
+//   gates at region pixel (rr, rc) = window (rr+1, rc+1), region = tile grown by 1: 10 rows x 2 runs of 16
+//   candidate at inner pixel (ir, ic) = window (ir+2, ic+2): 8 rows x 2 runs (columns 30, 31 of a row are surplus)
+// Wave k owns runs k, k+4, ... of both convolutions (its B-fragment offsets differ by compile-time constants).
+struct Gru1Args {
+  const float* x;        // c1 [B][h*w][8]
+  const float* hin;      // state in  [B][h*w][8]
+  float* hout;           // state out [B][h*w][8] (a different buffer)
+  const bf16x8* wg; const float* bg;    // gates1 A fragments [1][hi|lo][5][64], bias [16]
+  const bf16x8* wc; const float* bc;    // cand1  A fragments [1][hi|lo][5][64], bias [16]
+  int h, w;
+};
+
+__global__ __launch_bounds__(256, 2) void k_gru1_fused_bx3(Gru1Args a, TileGrid tg) {
+  constexpr int TR = 8, TC = 30, WR = TR + 4, WC = TC + 4, NPIXW = WR * WC;
+  constexpr int PB = 48;                               // bytes per window pixel (24 bf16)
+  constexpr int LO = NPIXW * PB;                       // lo image
+  constexpr int U0 = 2 * LO;                           // u tile
+  constexpr int NKB = 5, NG = 5, NC = 4;               // k-blocks (9 taps x 16 channels), gate / candidate runs per wave
+  constexpr int NITEM = NPIXW * 2, NS = (NITEM + 255) / 256;      // 4-channel groups per source, loads per thread
+  extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];
+  char* lds = (char*)ldsb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int rr0 = wave >> 1, c0w = (wave & 1) * 16;    // first run of the wave: region row / first column
+
+  bf16x8 gh[NKB], gl[NKB], ch[NKB], cl[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    gh[kb] = a.wg[(0 * NKB + kb) * 64 + lane]; gl[kb] = a.wg[(1 * NKB + kb) * 64 + lane];
+    ch[kb] = a.wc[(0 * NKB + kb) * 64 + lane]; cl[kb] = a.wc[(1 * NKB + kb) * 64 + lane];
+  }
+  const f32x4 bias_g = *(const f32x4*)(a.bg + 4 * q);
+  const f32x4 bias_c = *(const f32x4*)(a.bc + 4 * q);
+
+  unsigned goff[NS], lbyte[NS];
+  int rc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    int j = min(tid + k * 256, NITEM - 1);
+    const int g = j & 1, pp = j >> 1, r = pp / WC, c = pp % WC;
+    goff[k] = (unsigned)(((r * a.w + c) * 8 + 4 * g) * 4);
+    lbyte[k] = (unsigned)(pp * PB + 8 * g);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xoff[NKB];                                  // gate run 0 of the wave; candidate runs add (WC + 1) * PB
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    int kk = 32 * kb + 8 * q;
+    int pos = kk / 16, ch0 = kk % 16;
+    if (pos >= 9) { pos = 0; ch0 = 0; }
+    xoff[kb] = (unsigned)((((rr0 + pos / 3) * WC + c0w + p + pos % 3) * PB) + ch0 * 2);
+    pin(xoff[kb]);
+  }
+  // gate epilogue: lanes q < 2 turn h into r*h in the window tile, lanes q >= 2 keep u
+  const unsigned hbyte = (unsigned)(((rr0 + 1) * WC + c0w + p + 1) * PB + (8 + 4 * (q & 1)) * 2);
+  const unsigned ubyte_w = (unsigned)(U0 + ((rr0 * 32 + c0w + p) * 8 + 4 * (q & 1)) * 4);
+  // candidate epilogue: lanes q < 2, inner pixel (rr0 + 2j, c0w + p): u of region (ir+1, ic+1)
+  const unsigned ubyte_r = (unsigned)(U0 + (((rr0 + 1) * 32 + c0w + p + 1) * 8 + 4 * (q & 1)) * 4);
+  const bool lane_out = q < 2 && c0w + p < TC;
+  unsigned ooff = lane_out ? (unsigned)(((rr0 * a.w + c0w + p) * 8 + 4 * q) * 4) : BUF_OOB;
+  const unsigned orow2 = (unsigned)(a.w * 64);         // two rows of the state maps, bytes
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&sx)[NS], f32x4 (&sh)[NS], int b, int tx, int ty) {
+    const int ix0 = tx * TC - 2, iy0 = ty * TR - 2;
+    const long pix0 = ((long)b * a.h + iy0) * a.w + ix0;
+    const buf_rsrc rx = make_rsrc((const char*)a.x + pix0 * 32);
+    const buf_rsrc rh = make_rsrc((const char*)a.hin + pix0 * 32);
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + WR <= a.h && ix0 + WC <= a.w) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) { sx[k] = buf_load4(rx, goff[k]); sh[k] = buf_load4(rh, goff[k]); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+        const unsigned o = ok ? goff[k] : BUF_OOB;
+        sx[k] = buf_load4(rx, o); sh[k] = buf_load4(rh, o);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&sx)[NS], const f32x4 (&sh)[NS]) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      __bf16* hi = (__bf16*)(lds + lbyte[k]);
+      split_store(hi, (__bf16*)((char*)hi + LO), sx[k]);
+      split_store(hi + 8, (__bf16*)((char*)hi + LO) + 8, sh[k]);
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 sx[NS], sh[NS];
+  load_tile(sx, sh, b, tx, ty);
+  wait_vmem_all();
+  store_tile(sx, sh);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)b * a.h + oy0) * a.w + ox0;
+    const buf_rsrc rin = make_rsrc((const char*)a.hin + opix0 * 32);
+    const buf_rsrc rout = make_rsrc((char*)a.hout + opix0 * 32);
+    const bool full = oy0 + TR <= a.h && ox0 + TC <= a.w;
+    unsigned oo[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      oo[j] = ooff + j * orow2;
+      if (!full && !(oy0 + rr0 + 2 * j < a.h && ox0 + c0w + p < a.w)) oo[j] = BUF_OOB;
+    }
+    f32x4 pre_h[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) pre_h[j] = buf_load4(rin, oo[j]);       // exact fp32 state for the blend
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_tile(sx, sh, bn, txn, tyn);
+    }
+
+    // ---- gates on cat(x, h)
+    f32x4 ag[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      ag[j] = bias_g;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const char* at = lds + xoff[kb] + j * (2 * WC * PB);
+        const bf16x8 bh = *(const bf16x8*)at;
+        const bf16x8 bl = *(const bf16x8*)(at + LO);
+        ag[j] = mfma_bx(gh[kb], bh, ag[j]);
+        ag[j] = mfma_bx(gh[kb], bl, ag[j]);
+        ag[j] = mfma_bx(gl[kb], bh, ag[j]);
+      }
+    }
+    __syncthreads();                   // nobody reads the old h halves any more
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const f32x4 v = ag[j];
+      const f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+      if (q < 2) {
+        __bf16* hi = (__bf16*)(lds + hbyte + j * (2 * WC * PB));
+        __bf16* lo = (__bf16*)((char*)hi + LO);
+        const bf16x4 h4 = *(const bf16x4*)hi, l4 = *(const bf16x4*)lo;
+        const f32x4 hv = {(float)h4.x + (float)l4.x, (float)h4.y + (float)l4.y, (float)h4.z + (float)l4.z, (float)h4.w + (float)l4.w};
+        split_store(hi, lo, sg * hv);
+      } else {
+        *(f32x4*)(lds + ubyte_w + j * (2 * 32 * 32)) = sg;
+      }
+    }
+    __syncthreads();                   // r*h and u visible
+
+    // ---- candidate on cat(x, r*h)
+    f32x4 ac[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      ac[j] = bias_c;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const char* at = lds + xoff[kb] + (WC + 1) * PB + j * (2 * WC * PB);
+        const bf16x8 bh = *(const bf16x8*)at;
+        const bf16x8 bl = *(const bf16x8*)(at + LO);
+        ac[j] = mfma_bx(ch[kb], bh, ac[j]);
+        ac[j] = mfma_bx(ch[kb], bl, ac[j]);
+        ac[j] = mfma_bx(cl[kb], bh, ac[j]);
+      }
+    }
+    f32x4 u4[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) u4[j] = *(const f32x4*)(lds + ubyte_r + j * (2 * 32 * 32));
+
+    wait_vmem_all();                   // the one wait point of the tile
+    __syncthreads();                   // every wave is done with the tile
+    if (more) store_tile(sx, sh);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const f32x4 v = ac[j];
+      const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+      buf_store4(rout, oo[j], u4[j] * pre_h[j] + (1.0f - u4[j]) * cnd);
+    }
+    if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; b = bn; tx = txn; ty = tyn;
+  }
+}
+
+static int launch_gru1_fused(const Gru1Args& a, int B, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * 12 * 34 * 48 + 10 * 32 * 32;
+  static int capacity = 0;
+  if (!capacity) capacity = resident_blocks(k_gru1_fused_bx3, 256, lds);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(a.w, 30), cdiv(a.h, 8), B)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(k_gru1_fused_bx3, dim3(grid), dim3(256), lds, st, a, tg);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "gru1 fused (bf16x3): %s", hipGetErrorString(e));
+  return 0;
+}
+
+// GRU level 1 (fused) / conv2 / gates2 / cand2 of one recurrent step (the decoder stays on the fp32 path).
+// *h1_now receives the buffer that holds the level-1 state after the step.
+int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBuffers& sb, int B, int h, int w, int d,
+                            float** h1_now, hipStream_t st) {
   const int h2 = h / 2, w2 = w / 2;
   int rc;
+  // level 1 fused; its state alternates between the h1 and rh1 buffers (step d reads the one step d-1 wrote)
+  float* hin = (d & 1) ? sb.rh1 : sb.h1;
+  float* hout = (d & 1) ? sb.h1 : sb.rh1;
   {
-    SmallConvArgsBx g{c1, sb.h1, (const bf16x8*)fw.gates1, fw.gates1_b, sb.rh1, sb.u1, sb.h1, h, w, h, w, 16};
-    if ((rc = launch_bx<8, 8, 1, 1, BXE_GATES>(g, B, st, "gates1 (bf16x3)"))) return rc;
-    SmallConvArgsBx c{c1, sb.rh1, (const bf16x8*)fw.cand1, fw.cand1_b, sb.h1, sb.u1, nullptr, h, w, h, w, 8};
-    if ((rc = launch_bx<8, 8, 1, 1, BXE_CAND>(c, B, st, "cand1 (bf16x3)"))) return rc;
+    Gru1Args g{c1, hin, hout, (const bf16x8*)fw.gates1, fw.gates1_b, (const bf16x8*)fw.cand1, fw.cand1_b, h, w};
+    if ((rc = launch_gru1_fused(g, B, st))) return rc;
   }
+  *h1_now = hout;
   {
-    SmallConvArgsBx a{sb.h1, nullptr, (const bf16x8*)fw.conv2, nullptr, sb.c2, nullptr, nullptr, h, w, h2, w2, 16};
+    SmallConvArgsBx a{hout, nullptr, (const bf16x8*)fw.conv2, nullptr, sb.c2, nullptr, nullptr, h, w, h2, w2, 16};
     if ((rc = launch_bx<8, 0, 1, 2, BXE_RELU>(a, B, st, "conv2 (bf16x3)"))) return rc;
   }
   {

@@ -30,6 +30,7 @@ from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_bf16, dense (MI355X_MICROARCH.md)
 
 
 def build_model(cfg, device, precision="fp32"):
@@ -339,10 +340,17 @@ def main():
                             roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
                             roof["traffic_note"] = "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), profiles/r01_traffic.json"
             elif kind == "recurrence":
-                ach = st["recurrence_flops"] / (avg[dom] * 1e-3) / 1e12
-                roof = {"kernel": "recurrent step kernels (%d steps x 6 launches)" % st["D"], "bound": "mfma",
-                        "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                        "launch_ms": avg[dom] / (6 * st["D"]), "traffic": None}
+                # executed flops: the split-bf16 mode issues three bf16 products per fp32 product
+                split = args.precision == "bf16x3"
+                ach = st["recurrence_flops"] * (3 if split else 1) / (avg[dom] * 1e-3) / 1e12
+                peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+                nl = 5 if split else 6
+                roof = {"kernel": "recurrent step kernels (%d steps x %d launches)" % (st["D"], nl), "bound": "mfma",
+                        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                        "launch_ms": avg[dom] / (nl * st["D"]), "traffic": None}
+                if split:
+                    roof["note"] = ("short K (72-288) convolutions on 8-16 channel maps: bound by launch latency, LDS and the "
+                                    "VALU work of the hi/lo split, not by the bf16 matrix pipe")
             else:
                 key = {"pair_similarity": "pair_similarity_bytes", "aggregate_conv1": "aggregate_bytes",
                        "soft_argmin": "softargmin_bytes", "softmax_max_regress": "softmax_bytes",
