@@ -1,0 +1,220 @@
+// MS-REDNet inference pieces that are not 3x3 convolutions (reference models/msrednet.py:373-436,
+// models/module.py:54-106): the variance cost of one hypothesis plane, the
+// GroupNorm(1 group) statistics and the two fused gate / candidate epilogues of ConvGRUCell2, a strided
+// channel-range copy, and the online soft-argmin over the stored log-probabilities.
+// All maps are channel-last [N][pixels][D] with the channel count padded to what adamvs_conv3x3_dd takes;
+// the convolutions themselves run on k_conv_dd (costreg2d.hip).  These kernels stream: HBM-bound by design.
+#include "common.h"
+#include "kernels.h"
+#include "warp_math.h"
+
+namespace adamvs {
+
+// One thread = one reference pixel x one group of 4 channels.  mean and mean of squares over the reference
+// feature and the S warped source features (bilinear, zero padding per tap: module.py:563-564), then
+// E[x^2] - E[x]^2, negated when `negate` (both consumers of the cost take -cost, msrednet.py:351,362).
+__global__ void k_red_variance(const float* __restrict__ feat, const float* __restrict__ rt, const float* __restrict__ plane,
+                               float* __restrict__ out_a, float* __restrict__ out_b, int B, int S, int C, int h, int w, int Da,
+                               int Db, float sign, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = C >> 2;
+  const int g = (int)(i % G);
+  const size_t bp = i / G;                       // b * hw + pixel
+  const size_t hw = (size_t)h * w;
+  const int pix = (int)(bp % hw);
+  const size_t b = bp / hw;
+  const int x = pix % w, y = pix / w;
+  const size_t vstride = (size_t)B * hw * C;
+  const f32x4 r4 = *(const f32x4*)(feat + bp * C + 4 * g);
+  f32x4 sum = r4, sq = r4 * r4;
+  const float d = plane[bp];
+  for (int s = 0; s < S; ++s) {
+    const WarpTaps tp = warp_taps(rt + (b * S + s) * 12, (float)x, (float)y, d, h, w);
+    const float* src = feat + (size_t)(s + 1) * vstride + b * hw * C + 4 * g;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tp.w00 != 0.f) v += tp.w00 * *(const f32x4*)(src + (size_t)tp.o00 * C);
+    if (tp.w01 != 0.f) v += tp.w01 * *(const f32x4*)(src + (size_t)tp.o01 * C);
+    if (tp.w10 != 0.f) v += tp.w10 * *(const f32x4*)(src + (size_t)tp.o10 * C);
+    if (tp.w11 != 0.f) v += tp.w11 * *(const f32x4*)(src + (size_t)tp.o11 * C);
+    sum += v;
+    sq += v * v;
+  }
+  const float inv = 1.0f / (float)(S + 1);
+  const f32x4 m = sum * inv;
+  const f32x4 var = (sq * inv - m * m) * sign;
+  *(f32x4*)(out_a + bp * Da + 4 * g) = var;
+  if (out_b) *(f32x4*)(out_b + bp * Db + 4 * g) = var;
+}
+
+__global__ void k_channel_copy(const float* __restrict__ src, float* __restrict__ dst, int npix, int n, long sbs, int sps, int os,
+                               long dbs, int dps, int od, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % n);
+  const size_t bp = i / n;
+  const int p = (int)(bp % npix);
+  const size_t b = bp / npix;
+  dst[b * dbs + (size_t)p * dps + od + c] = src[b * sbs + (size_t)p * sps + os + c];
+}
+
+// ---- GroupNorm(1 group) statistics, deterministic: fixed partial ranges, double accumulation
+constexpr int GN_PARTS = 64;
+
+__global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x, double* __restrict__ part, int npix, int D,
+                                                     int c0, int n, int ngroups) {
+  // grid (GN_PARTS, ngroups, N): this block sums channels [c0 + g*n, c0 + (g+1)*n) of its pixel range
+  const int g = blockIdx.y, b = blockIdx.z;
+  const int per = (npix + GN_PARTS - 1) / GN_PARTS;
+  const int p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  const int n4 = n >> 2;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < (p1 - p0) * n4; i += 256) {
+    const int p = p0 + i / n4, c = c0 + g * n + 4 * (i % n4);
+    const f32x4 v = *(const f32x4*)(x + ((size_t)b * npix + p) * D + c);
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) { sh[0][threadIdx.x] += sh[0][threadIdx.x + k]; sh[1][threadIdx.x] += sh[1][threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double* o = part + (((size_t)b * ngroups + g) * GN_PARTS + blockIdx.x) * 2;
+    o[0] = sh[0][0]; o[1] = sh[1][0];
+  }
+}
+
+__global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ stats, int count, float eps, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (b, g)
+  if (i >= total) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < GN_PARTS; ++k) { s += part[((size_t)i * GN_PARTS + k) * 2]; q += part[((size_t)i * GN_PARTS + k) * 2 + 1]; }
+  const double mean = s / count;
+  const double var = fmax(q / count - mean * mean, 0.0);    // biased, as torch.nn.GroupNorm
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// gates: r = sigmoid(GN(f[0:HC])), u = sigmoid(GN(f[HC:2HC])); xr[Cx + c] = r * h, u out (module.py:72-92)
+__global__ void k_gru2_gates_apply(const float* __restrict__ f, const float* __restrict__ stats, const float* __restrict__ gn,
+                                   const float* __restrict__ a, float* __restrict__ xr, float* __restrict__ u, int npix, int D,
+                                   int Cx, int HC, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = HC >> 2;
+  const int c = 4 * (int)(i % G);
+  const size_t bp = i / G;
+  const size_t b = bp / npix;
+  const float mr = stats[b * 4 + 0], sr = stats[b * 4 + 1], mu = stats[b * 4 + 2], su = stats[b * 4 + 3];
+  const f32x4 fr = *(const f32x4*)(f + bp * D + c), fu = *(const f32x4*)(f + bp * D + HC + c);
+  const f32x4 gr = *(const f32x4*)(gn + c), br = *(const f32x4*)(gn + HC + c);
+  const f32x4 gu = *(const f32x4*)(gn + 2 * HC + c), bu = *(const f32x4*)(gn + 3 * HC + c);
+  const f32x4 h4 = *(const f32x4*)(a + bp * D + Cx + c);
+  const f32x4 rn = (fr - mr) * sr * gr + br, un = (fu - mu) * su * gu + bu;
+  const f32x4 r = {sigmoidf_(rn.x), sigmoidf_(rn.y), sigmoidf_(rn.z), sigmoidf_(rn.w)};
+  const f32x4 uu = {sigmoidf_(un.x), sigmoidf_(un.y), sigmoidf_(un.z), sigmoidf_(un.w)};
+  *(f32x4*)(xr + bp * D + Cx + c) = r * h4;
+  *(f32x4*)(u + bp * HC + c) = uu;
+}
+
+// candidate + blend: y = tanh(GN(o[0:HC])); h' = u*h + (1-u)*y, into a[Cx + c] (the state lives there) and out2
+__global__ void k_gru2_out_apply(const float* __restrict__ o, const float* __restrict__ stats, const float* __restrict__ gn,
+                                 const float* __restrict__ u, float* __restrict__ a, float* __restrict__ out2, int npix, int D,
+                                 int Cx, int HC, int D2, int o2, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = HC >> 2;
+  const int c = 4 * (int)(i % G);
+  const size_t bp = i / G;
+  const size_t b = bp / npix;
+  const float m = stats[b * 2], s = stats[b * 2 + 1];
+  const f32x4 ov = *(const f32x4*)(o + bp * D + c);
+  const f32x4 ga = *(const f32x4*)(gn + c), be = *(const f32x4*)(gn + HC + c);
+  const f32x4 on = (ov - m) * s * ga + be;
+  const f32x4 y = {tanhf(on.x), tanhf(on.y), tanhf(on.z), tanhf(on.w)};
+  const f32x4 u4 = *(const f32x4*)(u + bp * HC + c);
+  float* hp = a + bp * D + Cx + c;
+  const f32x4 hn = u4 * *(const f32x4*)hp + (1.0f - u4) * y;
+  *(f32x4*)hp = hn;
+  if (out2) *(f32x4*)(out2 + bp * D2 + o2 + c) = hn;
+}
+
+}  // namespace adamvs
+
+// =====================================================================================================================
+using namespace adamvs;
+
+extern "C" int adamvs_red_variance_cost(const float* feat, const float* rt, const float* plane, float* out_a, int Da,
+                                        float* out_b, int Db, int B, int S, int C, int h, int w, int negate, void* stream) {
+  ADAMVS_CHECK_ARG(feat && rt && plane && out_a && B > 0 && S > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && Da >= C &&
+                   (Da % 4) == 0 && (!out_b || (Db >= C && (Db % 4) == 0)),
+                   "red_variance_cost: bad arguments (B=%d S=%d C=%d h=%d w=%d Da=%d Db=%d)", B, S, C, h, w, Da, Db);
+  const size_t total = (size_t)B * h * w * (C / 4);
+  hipLaunchKernelGGL(k_red_variance, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat, rt, plane,
+                     out_a, out_b, B, S, C, h, w, Da, Db, negate ? -1.0f : 1.0f, total);
+  ADAMVS_CHECK_LAUNCH("red_variance_cost");
+  return 0;
+}
+
+extern "C" int adamvs_channel_copy(const float* src, float* dst, int nbatch, int npix, int n, long src_batch_stride,
+                                   int src_pix_stride, int src_c0, long dst_batch_stride, int dst_pix_stride, int dst_c0,
+                                   void* stream) {
+  ADAMVS_CHECK_ARG(src && dst && nbatch > 0 && npix > 0 && n > 0 && src_c0 >= 0 && dst_c0 >= 0, "channel_copy: bad arguments");
+  const size_t total = (size_t)nbatch * npix * n;
+  hipLaunchKernelGGL(k_channel_copy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, npix, n,
+                     src_batch_stride, src_pix_stride, src_c0, dst_batch_stride, dst_pix_stride, dst_c0, total);
+  ADAMVS_CHECK_LAUNCH("channel_copy");
+  return 0;
+}
+
+extern "C" size_t adamvs_group_stats_workspace_bytes(int N, int ngroups) {
+  return (size_t)N * ngroups * GN_PARTS * 2 * sizeof(double);
+}
+
+extern "C" int adamvs_group_stats(const float* x, float* stats, int N, int npix, int D, int c0, int n, int ngroups, float eps,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(x && stats && workspace && N > 0 && npix > 0 && n > 0 && (n % 4) == 0 && (c0 % 4) == 0 && (D % 4) == 0 &&
+                   ngroups > 0 && c0 + n * ngroups <= D, "group_stats: bad arguments (N=%d npix=%d D=%d c0=%d n=%d groups=%d)",
+                   N, npix, D, c0, n, ngroups);
+  ADAMVS_CHECK_ARG(workspace_bytes >= adamvs_group_stats_workspace_bytes(N, ngroups), "group_stats: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gn_partial, dim3(GN_PARTS, ngroups, N), dim3(256), 0, st, x, (double*)workspace, npix, D, c0, n, ngroups);
+  ADAMVS_CHECK_LAUNCH("group_stats (partial)");
+  const int total = N * ngroups;
+  hipLaunchKernelGGL(k_gn_final, dim3(cdiv(total, 64)), dim3(64), 0, st, (const double*)workspace, stats, npix * n, eps, total);
+  ADAMVS_CHECK_LAUNCH("group_stats (final)");
+  return 0;
+}
+
+extern "C" int adamvs_gru2_gates_apply(const float* f, const float* stats, const float* gn, const float* a, float* xr, float* u,
+                                       int N, int npix, int D, int Cx, int HC, void* stream) {
+  ADAMVS_CHECK_ARG(f && stats && gn && a && xr && u && N > 0 && npix > 0 && (HC % 4) == 0 && (Cx % 4) == 0 && (D % 4) == 0 &&
+                   Cx + HC <= D && 2 * HC <= D, "gru2_gates_apply: bad arguments (D=%d Cx=%d HC=%d)", D, Cx, HC);
+  const size_t total = (size_t)N * npix * (HC / 4);
+  hipLaunchKernelGGL(k_gru2_gates_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f, stats, gn, a,
+                     xr, u, npix, D, Cx, HC, total);
+  ADAMVS_CHECK_LAUNCH("gru2_gates_apply");
+  return 0;
+}
+
+extern "C" int adamvs_gru2_out_apply(const float* o, const float* stats, const float* gn, const float* u, float* a, float* out2,
+                                     int N, int npix, int D, int Cx, int HC, int D2, int c2, void* stream) {
+  ADAMVS_CHECK_ARG(o && stats && gn && u && a && N > 0 && npix > 0 && (HC % 4) == 0 && (Cx % 4) == 0 && (D % 4) == 0 &&
+                   Cx + HC <= D && (!out2 || ((D2 % 4) == 0 && (c2 % 4) == 0 && c2 + HC <= D2)),
+                   "gru2_out_apply: bad arguments (D=%d Cx=%d HC=%d D2=%d c2=%d)", D, Cx, HC, D2, c2);
+  const size_t total = (size_t)N * npix * (HC / 4);
+  hipLaunchKernelGGL(k_gru2_out_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, o, stats, gn, u, a,
+                     out2, npix, D, Cx, HC, D2, c2, total);
+  ADAMVS_CHECK_LAUNCH("gru2_out_apply");
+  return 0;
+}
+
+extern "C" int adamvs_soft_argmin(const float* vol, const float* planes, float* depth, float* confidence, int B, int D, int h,
+                                  int w, void* stream) {
+  ADAMVS_CHECK_ARG(vol && planes && depth && confidence && B > 0 && D > 0 && h > 0 && w > 0, "soft_argmin: bad arguments");
+  return launch_soft_argmin(vol, planes, depth, confidence, B, D, h, w, 0, (hipStream_t)stream);
+}

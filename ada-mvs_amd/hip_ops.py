@@ -267,3 +267,58 @@ def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspac
         _p(vw), _p(pd) if pd is not None else null, _p(depth), _p(conf), int(phases), _p(workspace), nbytes, _stream()),
         "depth_stage_forward")
     return vw, pd, depth, conf
+
+
+# ---- MS-REDNet pieces (csrc/msred.hip; reference models/msrednet.py:373-436, models/module.py:54-106) ---------------
+def red_variance_cost(feat, rt, plane, out_a, out_b, B, S, C, h, w, negate=True):
+    """-variance of (reference, warped sources) for one plane into channels [0,C) of out_a (and out_b)."""
+    check(_lib.load().adamvs_red_variance_cost(_p(_dev(feat, "feat")), _p(rt), _p(_dev(plane, "plane")), _p(out_a), out_a.shape[-1],
+                                               _p(out_b) if out_b is not None else ctypes.c_void_p(0),
+                                               out_b.shape[-1] if out_b is not None else 0, B, S, C, h, w, int(negate),
+                                               _stream()), "red_variance_cost")
+
+
+def channel_copy(src, src_c0, dst, dst_c0, n):
+    """dst[b, p, dst_c0:dst_c0+n] = src[b, p, src_c0:src_c0+n] for channel-last maps [N, npix, D]."""
+    N, npix = src.shape[0], src.shape[1]
+    check(_lib.load().adamvs_channel_copy(_p(src), _p(dst), N, npix, n, src.stride(0), src.stride(1), src_c0, dst.stride(0),
+                                          dst.stride(1), dst_c0, _stream()), "channel_copy")
+
+
+def plane_to_volume(src, vol, d):
+    """vol[b, d, p] = src[b, p, 0]: the single real channel of the last decoder layer into the slice volume."""
+    N, npix = src.shape[0], src.shape[1]
+    check(_lib.load().adamvs_channel_copy(_p(src), ctypes.c_void_p(vol.data_ptr() + 4 * d * vol.stride(1)), N, npix, 1,
+                                          src.stride(0), src.stride(1), 0, vol.stride(0), 1, 0, _stream()), "channel_copy")
+
+
+def group_stats(x, c0, n, ngroups, stats, workspace, eps=1e-5):
+    N, npix, D = x.shape
+    check(_lib.load().adamvs_group_stats(_p(x), _p(stats), N, npix, D, c0, n, ngroups, eps, _p(workspace),
+                                         workspace.numel() * workspace.element_size(), _stream()), "group_stats")
+    return stats
+
+
+def group_stats_workspace(N, ngroups, device):
+    return torch.empty(_lib.load().adamvs_group_stats_workspace_bytes(N, ngroups) // 8, device=device, dtype=torch.float64)
+
+
+def gru2_gates_apply(f, stats, gn, a, xr, u, Cx, HC):
+    N, npix, D = f.shape
+    check(_lib.load().adamvs_gru2_gates_apply(_p(f), _p(stats), _p(gn), _p(a), _p(xr), _p(u), N, npix, D, Cx, HC, _stream()),
+          "gru2_gates_apply")
+
+
+def gru2_out_apply(o, stats, gn, u, a, out2, c2, Cx, HC):
+    N, npix, D = o.shape
+    check(_lib.load().adamvs_gru2_out_apply(_p(o), _p(stats), _p(gn), _p(u), _p(a), _p(out2) if out2 is not None else
+                                            ctypes.c_void_p(0), N, npix, D, Cx, HC, out2.shape[-1] if out2 is not None else 0, c2,
+                                            _stream()), "gru2_out_apply")
+
+
+def soft_argmin(vol, planes, B, D, h, w):
+    depth = torch.empty(B, h, w, device=vol.device, dtype=torch.float32)
+    conf = torch.empty(B, h, w, device=vol.device, dtype=torch.float32)
+    check(_lib.load().adamvs_soft_argmin(_p(vol), _p(_dev(planes, "planes")), _p(depth), _p(conf), B, D, h, w, _stream()),
+          "soft_argmin")
+    return depth, conf

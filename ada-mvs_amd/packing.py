@@ -218,9 +218,11 @@ def pack_taps(w):
     return wp.reshape(nt, 16, cin4 // 4, 4, nt_).permute(0, 4, 2, 3, 1).contiguous().reshape(-1)
 
 
-def pack_feature_net(sd, pre="feature."):
+def pack_feature_net(sd, pre="feature.", context=True):
     """FeatureNet0 of `pre` -> (flat fp32 tensor, {field: offset}); fields 'name.w' / 'name.b' for the convolutions,
-    'name.w1' / 'name.b1' / 'name.w2' for the pooled-context branches."""
+    'name.w1' / 'name.b1' / 'name.w2' for the pooled-context branches.  context=False: the plain U-Net `FeatureNet`
+    of MS-REDNet (reference models/msrednet.py:29-127) -- same layers, out_k are [C][C] and there are no branches, so
+    the branch weights are zeros (their contribution to out_k vanishes)."""
     parts = {}
 
     def conv_bn(name, key, taps):
@@ -253,6 +255,15 @@ def pack_feature_net(sd, pre="feature."):
         parts[name + ".w"] = torch.cat(classes)
         parts[name + ".b"] = pad_bias(shift, 16)
     for k, C in ((1, 32), (2, 16), (3, 8)):
+        if not context:
+            wo = sd[pre + "out%d.weight" % k].detach().float().cpu().reshape(C, C)
+            parts["out%d.w" % k] = pack_taps(wo.reshape(C, C, 1))
+            parts["out%d.b" % k] = torch.zeros((C + 15) // 16 * 16)
+            for j in (1, 2):
+                parts["br%d_%d.w1" % (k, j)] = torch.zeros(C // 2 * C)
+                parts["br%d_%d.b1" % (k, j)] = torch.zeros(C // 2)
+                parts["br%d_%d.w2" % (k, j)] = torch.zeros(C * (C // 2))
+            continue
         wo = sd[pre + "out%d.weight" % k].detach().float().cpu().reshape(C, 2 * C)
         parts["out%d.w" % k] = pack_taps(wo[:, C:].reshape(C, C, 1))
         parts["out%d.b" % k] = torch.zeros((C + 15) // 16 * 16)
@@ -267,6 +278,63 @@ def pack_feature_net(sd, pre="feature."):
     for f, t in parts.items():
         pad = (-t.numel()) % 64
         offsets[f] = o
+        chunks.append(torch.cat([t.reshape(-1), torch.zeros(pad)]))
+        o += t.numel() + pad
+    return torch.cat(chunks), offsets
+
+
+# ---- MS-REDNet regulariser (reference models/msrednet.py:330-366) on adamvs_conv3x3_dd -------------------------------
+def pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def pack_padded_dd(w, bias, D, transposed=False, flip=False, cin_at=0):
+    """A 3x3 convolution [cout][cin][3][3] (ConvTranspose2d: [cin][cout][3][3]) zero-padded to D x D for
+    adamvs_conv3x3_dd: 9*D*D fragment floats + D bias floats.  The real input channels sit at [cin_at, cin_at + cin)
+    of the D-wide map, the real outputs at [0, cout).  flip: a stride-1 ConvTranspose2d (k3 p1) as the equivalent
+    convolution -- taps mirrored, channels swapped (reference msrednet.py:345, 364)."""
+    w = w.detach().to(torch.float32).cpu()
+    if flip:
+        w = w.permute(1, 0, 2, 3).flip(2, 3)
+    elif transposed:
+        w = w.permute(1, 0, 2, 3)              # -> [cout][cin][ky][kx]; the kernel's transposed mode takes it from here
+    cout, cin = w.shape[:2]
+    assert cout <= D and cin_at + cin <= D and D % 16 == 0
+    full = torch.zeros(D, D, 3, 3)
+    full[:cout, cin_at:cin_at + cin] = w
+    shift = torch.zeros(D)
+    if bias is not None:
+        shift[:cout] = bias.detach().to(torch.float32).cpu()
+    if transposed and not flip:                # pack_reg_layer permutes [cin][cout] -> [cout][cin] itself
+        full = full.permute(1, 0, 2, 3).contiguous()
+    return pack_reg_layer(full, torch.ones(D), shift, transposed and not flip)
+
+
+def pack_red_regularization(sd, pre, C):
+    """slice_RED_Regularization of `pre` for stage feature width C -> (flat fp32 tensor, {name: (offset, D)}).
+    Level k = 1..4 works on cat(x_k, h_k) with x widths (C, 16, 32, 64), state widths (8, 16, 32, 64) and map width
+    D_k = pad16(x + h); the encoder convolutions read the same cat buffers (zero weights on the state channels)."""
+    xw, hw = (C, 16, 32, 64), (8, 16, 32, 64)
+    Dk = [pad16(x + h) for x, h in zip(xw, hw)]
+    parts = {}
+    for k in range(4):
+        g = pre + "conv_gru%d." % (k + 1)
+        parts["gates%d" % (k + 1)] = (pack_padded_dd(sd[g + "gate_conv.weight"], sd[g + "gate_conv.bias"], Dk[k]), Dk[k])
+        parts["cand%d" % (k + 1)] = (pack_padded_dd(sd[g + "output_conv.weight"], sd[g + "output_conv.bias"], Dk[k]), Dk[k])
+        gn = torch.cat([sd[g + n].detach().float().cpu().reshape(-1) for n in (
+            "reset_gate_norm.weight", "reset_gate_norm.bias", "update_gate_norm.weight", "update_gate_norm.bias",
+            "output_norm.weight", "output_norm.bias")])
+        parts["gn%d" % (k + 1)] = (gn, hw[k])
+    for k in range(3):                          # conv_{k+1}: level k+1 -> level k+2, stride 2, on the cat buffer of its input
+        parts["conv%d" % (k + 1)] = (pack_padded_dd(sd[pre + "conv%d.conv.weight" % (k + 1)], None, Dk[k]), Dk[k])
+    # decoder: upconv3 64 -> 32 (width 64), upconv2 32 -> 16 (width 32), upconv1 16 -> 8 (width 16), upconv2d 8 -> 1 (width 16)
+    for name, D in (("upconv3", 64), ("upconv2", 32), ("upconv1", 16)):
+        parts[name] = (pack_padded_dd(sd[pre + name + ".conv.weight"], None, D, transposed=True), D)
+    parts["upconv2d"] = (pack_padded_dd(sd[pre + "upconv2d.weight"], sd[pre + "upconv2d.bias"], 16, flip=True), 16)
+    offsets, chunks, o = {}, [], 0
+    for name, (t, D) in parts.items():
+        pad = (-t.numel()) % 64
+        offsets[name] = (o, D)
         chunks.append(torch.cat([t.reshape(-1), torch.zeros(pad)]))
         o += t.numel() + pad
     return torch.cat(chunks), offsets

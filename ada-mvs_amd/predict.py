@@ -6,7 +6,7 @@ Same options, same input formats and the same files in the output folder as refe
 (`<view>/<name>_init.pfm`, `_prob.pfm`, `<name>.jpg`, `<name>.txt`, `color/*.png` with --display).  Differences by
 design: one process per GPU instead of nn.DataParallel (under torch.distributed.run the samples are dealt
 round-robin to the ranks, every rank writes its own files, no collective); `--precision bf16x3` selects the
-split-bf16 mode; `--model msrednet` is not implemented and says so.
+split-bf16 mode of `--model adamvs`; `--model msrednet` is ada_mvs_amd/models/msrednet.py (fp32).
 """
 import argparse
 import os
@@ -57,15 +57,19 @@ def build_parser():
 
 
 def build_model(args, device):
+    ndepths = [int(nd) for nd in args.ndepths.split(",") if nd]
+    ratios = [float(r) for r in args.depth_inter_r.split(",") if r]
+    chs = [int(ch) for ch in args.cr_base_chs.split(",") if ch]
     if args.model == "msrednet":
-        raise Exception("msrednet: not implemented in this build (SURVEY.md section 8f row f3); use --model adamvs")
-    if args.model != "adamvs":
+        from .models.msrednet import Infer_CascadeREDNet
+        model = Infer_CascadeREDNet(num_depth=args.numdepth, ndepths=ndepths, depth_interals_ratio=ratios,
+                                    share_cr=args.share_cr, cr_base_chs=chs)
+    elif args.model == "adamvs":
+        from .models.adamvs import Infer_AdaMVSNet
+        model = Infer_AdaMVSNet(num_depth=args.numdepth, ndepths=ndepths, depth_intervals_ratio=ratios,
+                                share_cr=args.share_cr, cr_base_chs=chs, precision=args.precision)
+    else:
         raise Exception("{}? Not implemented yet!".format(args.model))
-    from .models.adamvs import Infer_AdaMVSNet
-    model = Infer_AdaMVSNet(num_depth=args.numdepth, ndepths=[int(nd) for nd in args.ndepths.split(",") if nd],
-                            depth_intervals_ratio=[float(r) for r in args.depth_inter_r.split(",") if r],
-                            share_cr=args.share_cr, cr_base_chs=[int(ch) for ch in args.cr_base_chs.split(",") if ch],
-                            precision=args.precision)
     if args.loadckpt:
         print("loading model {}".format(args.loadckpt))
         state = torch.load(args.loadckpt, map_location="cpu")["model"]

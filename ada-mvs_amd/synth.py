@@ -70,8 +70,14 @@ def seeded_state_dict(model, seed=0):
             sd[pre + "running_var"] = torch.from_numpy(
                 _rng(pre + "running_var", seed).uniform(0.5, 1.5, n).astype(np.float32))
             sd[pre + "num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+        elif isinstance(mod, torch.nn.GroupNorm):
+            n = mod.num_channels
+            sd[pre + "weight"] = torch.from_numpy(
+                _rng(pre + "weight", seed).uniform(0.5, 1.5, n).astype(np.float32))
+            sd[pre + "bias"] = torch.from_numpy(
+                (_rng(pre + "bias", seed).standard_normal(n) * 0.1).astype(np.float32))
     for key in list(sd):
-        if key.endswith("reg_fuse.upconv2d.weight") or key.endswith("reg.prob.weight"):
+        if key.endswith("upconv2d.weight") or key.endswith("reg.prob.weight"):
             sd[key] = sd[key] * 3.0
     missing = set(model.state_dict().keys()) - set(sd.keys())
     if missing:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 2
+#define ADAMVS_ABI_VERSION 3
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -205,6 +205,48 @@ int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat,
                                const float* prev_conf, const float* w_reg, const adamvs_fuse_weights* w_fuse,
                                float* view_weight, float* pair_depth, float* depth, float* confidence,
                                int phases, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- MS-REDNet inference (models/msrednet.py:330-436) ------------------------
+ * The sibling model of predict_whu.py --model msrednet.  Its 3x3 convolutions run on adamvs_conv3x3_dd with the
+ * channel counts zero-padded to a supported width; what follows are the pieces around them.  Maps are
+ * channel-last [N][pixels][D]. */
+
+/* Variance cost of ONE hypothesis plane, msrednet.py:396-412: over the reference feature and the S source features
+ * warped onto the plane (homo_warping_float, module.py:527-568): E[x^2] - E[x]^2 per channel, negated when `negate`
+ * (both consumers take -cost, msrednet.py:351,362).  feat [V=S+1][B][h*w][C], rt [B][S][12], plane [B][h*w] ->
+ * channels [0,C) of out_a [B][h*w][Da] and, when out_b != NULL, of out_b [B][h*w][Db]; other channels untouched. */
+int adamvs_red_variance_cost(const float* feat, const float* rt, const float* plane, float* out_a, int Da, float* out_b,
+                             int Db, int B, int S, int C, int h, int w, int negate, void* stream);
+
+/* dst[b][p][dst_c0 + c] = src[b][p][src_c0 + c], c < n (strides in floats): narrows / widens / concatenates maps. */
+int adamvs_channel_copy(const float* src, float* dst, int nbatch, int npix, int n, long src_batch_stride,
+                        int src_pix_stride, int src_c0, long dst_batch_stride, int dst_pix_stride, int dst_c0, void* stream);
+
+/* nn.GroupNorm(1, n) statistics (module.py:63-68): for g < ngroups, over channels [c0 + g*n, c0 + (g+1)*n) and all
+ * pixels of sample b: stats[b][g] = {mean, 1/sqrt(biased var + eps)}.  Deterministic (fixed partial ranges, double
+ * accumulation). */
+size_t adamvs_group_stats_workspace_bytes(int N, int ngroups);
+int adamvs_group_stats(const float* x, float* stats, int N, int npix, int D, int c0, int n, int ngroups, float eps,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ConvGRUCell2.gates + the reset product, module.py:72-92.  f [N][npix][D] = gate_conv(cat(x, h)) with reset rows
+ * [0,HC) and update rows [HC,2HC); stats [N][2][2] from adamvs_group_stats(f, c0 = 0, n = HC, ngroups = 2);
+ * gn [4][HC] = reset_gate_norm weight, bias, update_gate_norm weight, bias; a [N][npix][D] = cat(x, h) (h at channels
+ * [Cx, Cx+HC)).  Writes r*h into channels [Cx, Cx+HC) of xr [N][npix][D] (whose x part the caller filled) and
+ * u [N][npix][HC]. */
+int adamvs_gru2_gates_apply(const float* f, const float* stats, const float* gn, const float* a, float* xr, float* u,
+                            int N, int npix, int D, int Cx, int HC, void* stream);
+
+/* ConvGRUCell2.output + forward, module.py:91-106.  o [N][npix][D] = output_conv(cat(x, r*h)) rows [0,HC);
+ * stats [N][2]; gn [2][HC] = output_norm weight, bias.  h' = u*h + (1-u)*tanh(GN(o)) replaces h inside a (channels
+ * [Cx, Cx+HC)) and is also written to channels [c2, c2+HC) of out2 [N][npix][D2] when out2 != NULL. */
+int adamvs_gru2_out_apply(const float* o, const float* stats, const float* gn, const float* u, float* a, float* out2,
+                          int N, int npix, int D, int Cx, int HC, int D2, int c2, void* stream);
+
+/* The running exp-sum / max / weighted-depth update of msrednet.py:415-436 (same as adamvs.py:512-531) in one pass over
+ * the stored slices: vol [B][D][h*w] = reg_cost of every plane, planes [B][D][h*w] -> depth, confidence [B][h*w]. */
+int adamvs_soft_argmin(const float* vol, const float* planes, float* depth, float* confidence, int B, int D, int h, int w,
+                       void* stream);
 
 #ifdef __cplusplus
 }

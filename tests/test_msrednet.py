@@ -1,0 +1,218 @@
+"""MS-REDNet inference: oracle/msrednet_oracle.py against fixtures the reference's own
+models/msrednet.py produced (tools/gen_golden_msred.py), and -- on the GPU -- the HIP path against both."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ada_mvs_amd  # noqa: F401
+from ada_mvs_amd import synth
+from oracle import msrednet_oracle as mo
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+OP_TOL = 2e-5          # relative L1 per op / network (fp32 on both sides)
+E2E_TOL = 1e-3         # BASELINE.json: depth and confidence maps within 1e-3 relative L1
+
+
+def gold(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, name + ".npz")).items()}
+
+
+def rel_l1(a, b):
+    return float((a - b).abs().sum() / b.abs().sum().clamp_min(1e-12))
+
+
+class _Cell(torch.nn.Module):
+    def __init__(self, cin, hc):
+        super().__init__()
+        self.gate_conv = torch.nn.Conv2d(cin + hc, 2 * hc, 3, padding=1)
+        self.reset_gate_norm = torch.nn.GroupNorm(1, hc, 1e-5, True)
+        self.update_gate_norm = torch.nn.GroupNorm(1, hc, 1e-5, True)
+        self.output_conv = torch.nn.Conv2d(cin + hc, hc, 3, padding=1)
+        self.output_norm = torch.nn.GroupNorm(1, hc, 1e-5, True)
+
+
+def cell_state_dict(seed=2):
+    return synth.seeded_state_dict(_Cell(16, 16), seed=seed)
+
+
+def test_oracle_gru_cell2_matches_reference():
+    g = gold("msred_gru_cell")
+    out = mo.conv_gru_cell2(g["x"], g["h"], cell_state_dict(), "")
+    assert rel_l1(out, g["out"]) < 1e-6
+
+
+def slice_state_dict(C=32, seed=3):
+    from ada_mvs_amd.models.msrednet import slice_RED_Regularization
+    return synth.seeded_state_dict(slice_RED_Regularization(C, 8), seed=seed)
+
+
+def test_oracle_slice_step_matches_reference():
+    g = gold("msred_slice_step")
+    sd = slice_state_dict()
+    B, _, h, w = g["cost0"].shape
+    states = [torch.zeros(B, 8 << k, h >> k, w >> k) for k in range(4)]
+    for step in range(2):
+        reg, states = mo.slice_red_step(g["cost%d" % step], states, sd, "")
+        assert rel_l1(reg, g["reg%d" % step]) < 1e-5
+        for k in range(4):
+            assert rel_l1(states[k], g["state%d_%d" % (k + 1, step)]) < 1e-5
+
+
+def tiny_model_state():
+    from ada_mvs_amd.models.msrednet import Infer_CascadeREDNet
+    c = synth.CONFIGS["tiny"]
+    m = Infer_CascadeREDNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    return m, synth.seeded_state_dict(m, seed=0)
+
+
+def test_oracle_end_to_end_matches_reference():
+    g = gold("msred_e2e_tiny")
+    _, sd = tiny_model_state()
+    imgs, proj, dv = synth.tile_inputs("tiny", batch=1, seed=0)
+    c = synth.CONFIGS["tiny"]
+    with mo.ao.use_grid_sample():
+        out = mo.infer_cascade_rednet_forward(imgs, proj, dv, sd, c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    assert rel_l1(out["stage1"]["depth"], g["depth_stage1"]) < 1e-5
+    assert rel_l1(out["stage2"]["depth"], g["depth_stage2"]) < 1e-5
+    assert rel_l1(out["depth"], g["depth"]) < 1e-5
+    assert rel_l1(out["photometric_confidence"], g["photometric_confidence"]) < 1e-4
+
+
+def test_state_dict_keys_match_reference_layout():
+    m, sd = tiny_model_state()
+    keys = set(m.state_dict())
+    assert set(sd) == keys
+    for k in ("feature.conv0.0.conv.weight", "feature.deconv1.deconv.conv.weight", "feature.out3.weight",
+              "cost_regularization.0.conv_gru4.gate_conv.bias", "cost_regularization.2.conv_gru1.output_norm.weight",
+              "cost_regularization.1.upconv3.conv.weight", "cost_regularization.2.upconv2d.bias"):
+        assert k in keys
+    assert m.state_dict()["cost_regularization.0.conv_gru1.gate_conv.weight"].shape == (16, 40, 3, 3)
+    assert m.state_dict()["cost_regularization.2.conv_gru1.gate_conv.weight"].shape == (16, 16, 3, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path (csrc/msred.hip + k_conv_dd) against the reference's fixtures and the oracle
+# ---------------------------------------------------------------------------------------------------------------
+def _cl(x):
+    """[B,C,h,w] -> channel-last [B,h*w,C] on the GPU"""
+    B, C, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B, h * w, C).contiguous().cuda()
+
+
+def _nchw(x_cl, h, w):
+    B, _, C = x_cl.shape
+    return x_cl.reshape(B, h, w, C).permute(0, 3, 1, 2).cpu()
+
+
+@pytest.mark.gpu
+def test_group_stats_against_torch():
+    from ada_mvs_amd import hip_ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, 37 * 11, 48, generator=g) * 2 + 0.7).cuda()
+    stats = torch.zeros(3, 2, 2, device="cuda")
+    hip_ops.group_stats(x, 16, 12, 2, stats, hip_ops.group_stats_workspace(3, 2, x.device))
+    for gi in range(2):
+        part = x[:, :, 16 + 12 * gi:16 + 12 * (gi + 1)].double()
+        mean = part.mean(dim=(1, 2))
+        rstd = 1.0 / torch.sqrt(part.var(dim=(1, 2), unbiased=False) + 1e-5)
+        assert torch.allclose(stats[:, gi, 0].double(), mean, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(stats[:, gi, 1].double(), rstd, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("baseline", [8.0, 150.0])            # in bounds / with out-of-bounds taps
+def test_variance_cost_against_oracle(baseline):
+    from ada_mvs_amd import hip_ops
+    B, C, h, w, V = 2, 16, 24, 40, 4
+    feats = [synth.smooth_features(B, C, h, w, seed=10 + v) for v in range(V)]
+    proj = synth.rig_projections(V, 4 * h, 4 * w, batch=B, baseline=baseline)["stage1"]
+    plane = 400 + 200 * torch.rand(B, 1, h, w, generator=torch.Generator().manual_seed(1))
+    rel = [mo.ao.relative_transform(proj[:, v], proj[:, 0]) for v in range(1, V)]
+    want = mo.variance_cost(feats[0], feats[1:], [r[0] for r in rel], [r[1] for r in rel], plane)
+    feat_cl = torch.cat([_cl(f) for f in feats], 0)
+    rt = hip_ops.relative_transforms(proj.cuda())
+    a = torch.full((B, h * w, 32), 7.0, device="cuda")
+    b = torch.full((B, h * w, 16), 7.0, device="cuda")
+    hip_ops.red_variance_cost(feat_cl, rt, plane.reshape(B, h * w).cuda(), a, b, B, V - 1, C, h, w, negate=True)
+    assert rel_l1(-_nchw(a[:, :, :C], h, w), want) < OP_TOL and rel_l1(-_nchw(b, h, w), want) < OP_TOL
+    assert bool((a[:, :, C:] == 7.0).all())                      # the other channels are not touched
+
+
+@pytest.mark.gpu
+def test_slice_red_steps_against_reference_golden():
+    from ada_mvs_amd.models.msrednet import slice_RED_Regularization
+    g = gold("msred_slice_step")
+    net = slice_RED_Regularization(32, 8)
+    net.load_state_dict(slice_state_dict())
+    net = net.cuda()
+    B, C, h, w = g["cost0"].shape
+    net.begin(B, h, w, torch.device("cuda:0"))
+    vol = torch.zeros(B, 2, h * w, device="cuda")
+    a, xr = net.cost_targets()
+    for step in range(2):
+        neg = -_cl(g["cost%d" % step])
+        a[:, :, :C] = neg
+        xr[:, :, :C] = neg
+        net.step(vol, step)
+        torch.cuda.synchronize()
+        assert rel_l1(vol[:, step].reshape(B, 1, h, w).cpu(), g["reg%d" % step]) < OP_TOL
+        for k in range(4):
+            L = net.lv[k]
+            state = _nchw(L.a[:, :, L.Cx:L.Cx + L.HC].contiguous(), h >> k, w >> k)
+            assert rel_l1(state, g["state%d_%d" % (k + 1, step)]) < OP_TOL, "state %d step %d" % (k + 1, step)
+
+
+@pytest.mark.gpu
+def test_feature_net_unet_against_oracle():
+    m, sd = tiny_model_state()
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(4))
+    want = mo.feature_net_unet(x, {k[len("feature."):]: v for k, v in sd.items() if k.startswith("feature.")}, "")
+    with torch.no_grad():
+        got = m.feature(x.cuda())
+    for k in ("stage1", "stage2", "stage3"):
+        assert rel_l1(got[k].cpu(), want[k]) < 5e-5, k
+
+
+@pytest.mark.gpu
+def test_end_to_end_against_reference_golden_and_oracle():
+    g = gold("msred_e2e_tiny")
+    m, sd = tiny_model_state()
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs("tiny", batch=1, seed=0)
+    with torch.no_grad():
+        out = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+    assert rel_l1(out["stage1"]["depth"].cpu(), g["depth_stage1"]) < E2E_TOL
+    assert rel_l1(out["stage2"]["depth"].cpu(), g["depth_stage2"]) < E2E_TOL
+    assert rel_l1(out["depth"].cpu(), g["depth"]) < E2E_TOL
+    assert rel_l1(out["photometric_confidence"].cpu(), g["photometric_confidence"]) < E2E_TOL
+    assert out["depth"].shape == (1, 64, 96) and out["stage1"]["depth"].shape == (1, 16, 24)
+
+
+@pytest.mark.gpu
+def test_end_to_end_batch_of_two_against_oracle():
+    """B = 2 with different depth ranges per sample (the interval comes from sample 0, as in the reference)."""
+    m, sd = tiny_model_state()
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs("tiny", batch=2, seed=3)
+    dv[1] = torch.tensor([380.0, 640.0])
+    c = synth.CONFIGS["tiny"]
+    with mo.ao.use_grid_sample():
+        want = mo.infer_cascade_rednet_forward(imgs, proj, dv, sd, c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    with torch.no_grad():
+        out = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+    assert rel_l1(out["depth"].cpu(), want["depth"]) < E2E_TOL
+    assert rel_l1(out["photometric_confidence"].cpu(), want["photometric_confidence"]) < E2E_TOL
+
+
+def test_cpu_tensors_raise():
+    m, _ = tiny_model_state()
+    imgs, proj, dv = synth.tile_inputs("tiny", batch=1, seed=0)
+    from ada_mvs_amd._lib import AdaMVSHipError
+    with pytest.raises(AdaMVSHipError, match="MI355X"):
+        m(imgs, proj, dv)

@@ -224,15 +224,13 @@ def test_predict_cli_options_and_model_errors():
     assert (a.model, a.dataset, a.view_num, a.numdepth, a.max_w, a.max_h) == ("adamvs", "predict_oblique", 5, 192, 3712, 5504)
     assert (a.resize_scale, a.sample_scale, a.ndepths, a.depth_inter_r, a.cr_base_chs) == (0.5, 1, "48,32,8", "4,2,1", "8,8,8")
     assert a.display is True and a.batch_size == 1
-    a.model = "msrednet"
-    with pytest.raises(Exception, match="msrednet"):
-        predict.build_model(a, "cpu")
     a.model = "other"
     with pytest.raises(Exception, match="Not implemented"):
         predict.build_model(a, "cpu")
-    a.model = "adamvs"
-    with pytest.raises(Exception, match="loadckpt"):
-        predict.build_model(a, "cpu")
+    for name in ("adamvs", "msrednet"):
+        a.model = name
+        with pytest.raises(Exception, match="loadckpt"):
+            predict.build_model(a, "cpu")
     with pytest.raises(RuntimeError, match="MI355X"):          # no GPU in the CPU test run: loud, no fallback
         import torch
         if torch.cuda.is_available():
