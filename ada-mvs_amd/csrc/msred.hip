@@ -10,25 +10,28 @@
 
 namespace adamvs {
 
-// One thread = one reference pixel x one group of 4 channels.  mean and mean of squares over the reference
-// feature and the S warped source features (bilinear, zero padding per tap: module.py:563-564), then
+// One thread = one plane x one reference pixel x one group of 4 channels.  mean and mean of squares over the
+// reference feature and the S warped source features (bilinear, zero padding per tap: module.py:563-564), then
 // E[x^2] - E[x]^2, negated when `negate` (both consumers of the cost take -cost, msrednet.py:351,362).
-__global__ void k_red_variance(const float* __restrict__ feat, const float* __restrict__ rt, const float* __restrict__ plane,
-                               float* __restrict__ out_a, float* __restrict__ out_b, int B, int S, int C, int h, int w, int Da,
-                               int Db, float sign, size_t total) {
+// Output map index = d * B + b (plane-major: the planes of one step are contiguous).
+__global__ void k_red_variance(const float* __restrict__ feat, const float* __restrict__ rt, const float* __restrict__ planes,
+                               float* __restrict__ out_a, float* __restrict__ out_b, int B, int S, int C, int D, int h, int w,
+                               int Da, int Db, float sign, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int G = C >> 2;
   const int g = (int)(i % G);
-  const size_t bp = i / G;                       // b * hw + pixel
   const size_t hw = (size_t)h * w;
-  const int pix = (int)(bp % hw);
-  const size_t b = bp / hw;
+  const size_t dbp = i / G;                      // (d * B + b) * hw + pixel
+  const int pix = (int)(dbp % hw);
+  const size_t db = dbp / hw;
+  const size_t b = db % B, dd = db / B;
+  const size_t bp = b * hw + pix;
   const int x = pix % w, y = pix / w;
   const size_t vstride = (size_t)B * hw * C;
   const f32x4 r4 = *(const f32x4*)(feat + bp * C + 4 * g);
   f32x4 sum = r4, sq = r4 * r4;
-  const float d = plane[bp];
+  const float d = planes[(b * D + dd) * hw + pix];
   for (int s = 0; s < S; ++s) {
     const WarpTaps tp = warp_taps(rt + (b * S + s) * 12, (float)x, (float)y, d, h, w);
     const float* src = feat + (size_t)(s + 1) * vstride + b * hw * C + 4 * g;
@@ -43,8 +46,8 @@ __global__ void k_red_variance(const float* __restrict__ feat, const float* __re
   const float inv = 1.0f / (float)(S + 1);
   const f32x4 m = sum * inv;
   const f32x4 var = (sq * inv - m * m) * sign;
-  *(f32x4*)(out_a + bp * Da + 4 * g) = var;
-  if (out_b) *(f32x4*)(out_b + bp * Db + 4 * g) = var;
+  *(f32x4*)(out_a + dbp * Da + 4 * g) = var;
+  if (out_b) *(f32x4*)(out_b + dbp * Db + 4 * g) = var;
 }
 
 __global__ void k_channel_copy(const float* __restrict__ src, float* __restrict__ dst, int npix, int n, long sbs, int sps, int os,
@@ -101,7 +104,7 @@ __global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ 
 
 // gates: r = sigmoid(GN(f[0:HC])), u = sigmoid(GN(f[HC:2HC])); xr[Cx + c] = r * h, u out (module.py:72-92)
 __global__ void k_gru2_gates_apply(const float* __restrict__ f, const float* __restrict__ stats, const float* __restrict__ gn,
-                                   const float* __restrict__ a, float* __restrict__ xr, float* __restrict__ u, int npix, int D,
+                                   const float* a, float* xr, float* __restrict__ u, int npix, int D,
                                    int Cx, int HC, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -121,10 +124,11 @@ __global__ void k_gru2_gates_apply(const float* __restrict__ f, const float* __r
   *(f32x4*)(u + bp * HC + c) = uu;
 }
 
-// candidate + blend: y = tanh(GN(o[0:HC])); h' = u*h + (1-u)*y, into a[Cx + c] (the state lives there) and out2
+// candidate + blend: y = tanh(GN(o[0:HC])); h' = u*h + (1-u)*y on the compact state hst [N][npix][HC] (in place), and
+// copies of h' into channels [c2, c2+HC) of out2 (the next plane's cat buffer) and [c3, c3+HC) of out3 (the decoder's input)
 __global__ void k_gru2_out_apply(const float* __restrict__ o, const float* __restrict__ stats, const float* __restrict__ gn,
-                                 const float* __restrict__ u, float* __restrict__ a, float* __restrict__ out2, int npix, int D,
-                                 int Cx, int HC, int D2, int o2, size_t total) {
+                                 const float* __restrict__ u, float* __restrict__ hst, float* __restrict__ out2,
+                                 float* __restrict__ out3, int npix, int D, int HC, int D2, int c2, int D3, int c3, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int G = HC >> 2;
@@ -137,10 +141,11 @@ __global__ void k_gru2_out_apply(const float* __restrict__ o, const float* __res
   const f32x4 on = (ov - m) * s * ga + be;
   const f32x4 y = {tanhf(on.x), tanhf(on.y), tanhf(on.z), tanhf(on.w)};
   const f32x4 u4 = *(const f32x4*)(u + bp * HC + c);
-  float* hp = a + bp * D + Cx + c;
+  float* hp = hst + bp * HC + c;
   const f32x4 hn = u4 * *(const f32x4*)hp + (1.0f - u4) * y;
   *(f32x4*)hp = hn;
-  if (out2) *(f32x4*)(out2 + bp * D2 + o2 + c) = hn;
+  if (out2) *(f32x4*)(out2 + bp * D2 + c2 + c) = hn;
+  if (out3) *(f32x4*)(out3 + bp * D3 + c3 + c) = hn;
 }
 
 }  // namespace adamvs
@@ -148,14 +153,16 @@ __global__ void k_gru2_out_apply(const float* __restrict__ o, const float* __res
 // =====================================================================================================================
 using namespace adamvs;
 
-extern "C" int adamvs_red_variance_cost(const float* feat, const float* rt, const float* plane, float* out_a, int Da,
-                                        float* out_b, int Db, int B, int S, int C, int h, int w, int negate, void* stream) {
-  ADAMVS_CHECK_ARG(feat && rt && plane && out_a && B > 0 && S > 0 && C > 0 && (C % 4) == 0 && h > 0 && w > 0 && Da >= C &&
-                   (Da % 4) == 0 && (!out_b || (Db >= C && (Db % 4) == 0)),
-                   "red_variance_cost: bad arguments (B=%d S=%d C=%d h=%d w=%d Da=%d Db=%d)", B, S, C, h, w, Da, Db);
-  const size_t total = (size_t)B * h * w * (C / 4);
-  hipLaunchKernelGGL(k_red_variance, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat, rt, plane,
-                     out_a, out_b, B, S, C, h, w, Da, Db, negate ? -1.0f : 1.0f, total);
+extern "C" int adamvs_red_variance_cost(const float* feat, const float* rt, const float* planes, float* out_a, int Da,
+                                        float* out_b, int Db, int B, int S, int C, int D, int h, int w, int negate,
+                                        void* stream) {
+  ADAMVS_CHECK_ARG(feat && rt && planes && out_a && B > 0 && S > 0 && C > 0 && (C % 4) == 0 && D > 0 && h > 0 && w > 0 &&
+                   Da >= C && (Da % 4) == 0 && (!out_b || (Db >= C && (Db % 4) == 0)),
+                   "red_variance_cost: bad arguments (B=%d S=%d C=%d D=%d h=%d w=%d Da=%d Db=%d)", B, S, C, D, h, w, Da, Db);
+  const size_t total = (size_t)D * B * h * w * (C / 4);
+  ADAMVS_CHECK_ARG(total / 256 < 0x7fffffffu, "red_variance_cost: too many planes x pixels for one launch");
+  hipLaunchKernelGGL(k_red_variance, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat, rt, planes,
+                     out_a, out_b, B, S, C, D, h, w, Da, Db, negate ? -1.0f : 1.0f, total);
   ADAMVS_CHECK_LAUNCH("red_variance_cost");
   return 0;
 }
@@ -201,14 +208,15 @@ extern "C" int adamvs_gru2_gates_apply(const float* f, const float* stats, const
   return 0;
 }
 
-extern "C" int adamvs_gru2_out_apply(const float* o, const float* stats, const float* gn, const float* u, float* a, float* out2,
-                                     int N, int npix, int D, int Cx, int HC, int D2, int c2, void* stream) {
-  ADAMVS_CHECK_ARG(o && stats && gn && u && a && N > 0 && npix > 0 && (HC % 4) == 0 && (Cx % 4) == 0 && (D % 4) == 0 &&
-                   Cx + HC <= D && (!out2 || ((D2 % 4) == 0 && (c2 % 4) == 0 && c2 + HC <= D2)),
-                   "gru2_out_apply: bad arguments (D=%d Cx=%d HC=%d D2=%d c2=%d)", D, Cx, HC, D2, c2);
+extern "C" int adamvs_gru2_out_apply(const float* o, const float* stats, const float* gn, const float* u, float* h, float* out2,
+                                     int D2, int c2, float* out3, int D3, int c3, int N, int npix, int D, int HC, void* stream) {
+  ADAMVS_CHECK_ARG(o && stats && gn && u && h && N > 0 && npix > 0 && (HC % 4) == 0 && (D % 4) == 0 && HC <= D &&
+                   (!out2 || ((D2 % 4) == 0 && (c2 % 4) == 0 && c2 + HC <= D2)) &&
+                   (!out3 || ((D3 % 4) == 0 && (c3 % 4) == 0 && c3 + HC <= D3)),
+                   "gru2_out_apply: bad arguments (D=%d HC=%d D2=%d c2=%d D3=%d c3=%d)", D, HC, D2, c2, D3, c3);
   const size_t total = (size_t)N * npix * (HC / 4);
-  hipLaunchKernelGGL(k_gru2_out_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, o, stats, gn, u, a,
-                     out2, npix, D, Cx, HC, D2, c2, total);
+  hipLaunchKernelGGL(k_gru2_out_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, o, stats, gn, u, h,
+                     out2, out3, npix, D, HC, D2, c2, D3, c3, total);
   ADAMVS_CHECK_LAUNCH("gru2_out_apply");
   return 0;
 }

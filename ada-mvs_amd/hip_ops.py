@@ -270,11 +270,12 @@ def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspac
 
 
 # ---- MS-REDNet pieces (csrc/msred.hip; reference models/msrednet.py:373-436, models/module.py:54-106) ---------------
-def red_variance_cost(feat, rt, plane, out_a, out_b, B, S, C, h, w, negate=True):
-    """-variance of (reference, warped sources) for one plane into channels [0,C) of out_a (and out_b)."""
-    check(_lib.load().adamvs_red_variance_cost(_p(_dev(feat, "feat")), _p(rt), _p(_dev(plane, "plane")), _p(out_a), out_a.shape[-1],
+def red_variance_cost(feat, rt, planes, out_a, out_b, B, S, C, D, h, w, negate=True):
+    """-variance of (reference, warped sources) for the D planes [B,D,h*w] into channels [0,C) of out_a [D*B,h*w,Da]
+    (plane-major) and out_b."""
+    check(_lib.load().adamvs_red_variance_cost(_p(_dev(feat, "feat")), _p(rt), _p(_dev(planes, "planes")), _p(out_a), out_a.shape[-1],
                                                _p(out_b) if out_b is not None else ctypes.c_void_p(0),
-                                               out_b.shape[-1] if out_b is not None else 0, B, S, C, h, w, int(negate),
+                                               out_b.shape[-1] if out_b is not None else 0, B, S, C, D, h, w, int(negate),
                                                _stream()), "red_variance_cost")
 
 
@@ -285,11 +286,14 @@ def channel_copy(src, src_c0, dst, dst_c0, n):
                                           dst.stride(1), dst_c0, _stream()), "channel_copy")
 
 
-def plane_to_volume(src, vol, d):
-    """vol[b, d, p] = src[b, p, 0]: the single real channel of the last decoder layer into the slice volume."""
+def planes_to_volume(src, vol, B):
+    """vol[b, d, p] = src[d * B + b, p, 0]: the single real channel of the last decoder layer into the slice volume."""
     N, npix = src.shape[0], src.shape[1]
-    check(_lib.load().adamvs_channel_copy(_p(src), ctypes.c_void_p(vol.data_ptr() + 4 * d * vol.stride(1)), N, npix, 1,
-                                          src.stride(0), src.stride(1), 0, vol.stride(0), 1, 0, _stream()), "channel_copy")
+    D = N // B
+    for b in range(B):
+        check(_lib.load().adamvs_channel_copy(ctypes.c_void_p(src.data_ptr() + 4 * b * src.stride(0)),
+                                              ctypes.c_void_p(vol.data_ptr() + 4 * b * vol.stride(0)), D, npix, 1,
+                                              B * src.stride(0), src.stride(1), 0, vol.stride(1), 1, 0, _stream()), "channel_copy")
 
 
 def group_stats(x, c0, n, ngroups, stats, workspace, eps=1e-5):
@@ -309,11 +313,13 @@ def gru2_gates_apply(f, stats, gn, a, xr, u, Cx, HC):
           "gru2_gates_apply")
 
 
-def gru2_out_apply(o, stats, gn, u, a, out2, c2, Cx, HC):
+def gru2_out_apply(o, stats, gn, u, h, out2, c2, out3, c3, HC):
     N, npix, D = o.shape
-    check(_lib.load().adamvs_gru2_out_apply(_p(o), _p(stats), _p(gn), _p(u), _p(a), _p(out2) if out2 is not None else
-                                            ctypes.c_void_p(0), N, npix, D, Cx, HC, out2.shape[-1] if out2 is not None else 0, c2,
-                                            _stream()), "gru2_out_apply")
+    null = ctypes.c_void_p(0)
+    check(_lib.load().adamvs_gru2_out_apply(_p(o), _p(stats), _p(gn), _p(u), _p(h),
+                                            _p(out2) if out2 is not None else null, out2.shape[-1] if out2 is not None else 0, c2,
+                                            _p(out3) if out3 is not None else null, out3.shape[-1] if out3 is not None else 0, c3,
+                                            N, npix, D, HC, _stream()), "gru2_out_apply")
 
 
 def soft_argmin(vol, planes, B, D, h, w):

@@ -81,20 +81,21 @@ class ConvGRUCell2(_FusedLayer):
         self.output_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
 
 
-class _Level:
-    """Buffers of one resolution level: a = cat(x, h), xr = cat(x, r*h), f / o = convolution outputs, u."""
-
-    def __init__(self, B, npix, D, Cx, HC, dev):
-        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)      # noqa: E731
-        self.D, self.Cx, self.HC, self.npix = D, Cx, HC, npix
-        self.a, self.xr, self.f, self.o = z(B, npix, D), z(B, npix, D), z(B, npix, D), z(B, npix, D)
-        self.u = z(B, npix, HC)
-        self.stats = z(B, 2, 2)
-        self.stats_o = z(B, 2)
-
-
 class slice_RED_Regularization(nn.Module):
-    """reference models/msrednet.py:330-366; the state lives in the level buffers of `begin()`."""
+    """reference models/msrednet.py:330-366, restructured around what is and is not recurrent.
+
+    In the reference step, conv1-3 (the encoder) depend only on the cost of the plane, every ConvGRUCell2 only on its
+    own state and its encoder map, and the decoder (upconv3/2/1, upconv2d) only on the four GRU outputs.  So per stage:
+      A  the encoder for ALL planes in one batched launch per layer (maps indexed d * B + b),
+      B  four independent recurrences over the planes (one per level), each on its own stream,
+      C  the decoder for all planes in one batched launch per layer.
+    Level k works on cat(x_k, h_k) buffers of width D_k = pad16(x + h) (x widths C/16/32/64, states 8/16/32/64): the
+    encoder writes the x part for every plane, the recurrence keeps h there (the candidate epilogue of plane d writes
+    h' into plane d+1's buffer) and turns it into r*h in place for the candidate convolution."""
+
+    XW = (None, 16, 32, 64)        # x widths of levels 2-4 (level 1: in_channels)
+    HW = (8, 16, 32, 64)           # state widths
+    RW = (16, 32, 64, 64)          # width of the stored GRU outputs = what the decoder layer reading them takes
 
     def __init__(self, in_channels, base_channels=8):
         super().__init__()
@@ -113,6 +114,8 @@ class slice_RED_Regularization(nn.Module):
         self.upconv1 = ConvTransReLU(2 * c, c, 3, 2, 1, 1)
         self.upconv2d = nn.ConvTranspose2d(c, 1, kernel_size=3, stride=1, padding=1, output_padding=0)
         self._packed = None
+        self._streams = None
+        self.concurrent_levels = True
 
     def _apply(self, fn, *a, **k):
         self._packed = None
@@ -133,75 +136,101 @@ class slice_RED_Regularization(nn.Module):
         o, D = offsets[name]
         return flat[o:o + 9 * D * D], flat[o + 9 * D * D:o + 9 * D * D + D]
 
-    def begin(self, B, h, w, device):
-        """Zero states and buffers for a stage of h x w maps (h, w multiples of 8)."""
-        if h % 8 or w % 8:
-            raise AdaMVSHipError("slice_RED_Regularization: map size %dx%d must be a multiple of 8 (three stride-2 levels)" % (h, w))
-        self.packed(device)
-        C = self.in_channels
-        self.B, self.h, self.w = B, h, w
-        xw, hw = (C, 16, 32, 64), (8, 16, 32, 64)
-        self.lv = [_Level(B, (h >> k) * (w >> k), packing.pad16(xw[k] + hw[k]), xw[k], hw[k], device) for k in range(4)]
-        z = lambda *s: torch.zeros(*s, device=device, dtype=torch.float32)      # noqa: E731
-        n = [l.npix for l in self.lv]
-        self.enc = [None] + [z(B, n[k], self.lv[k - 1].D) for k in (1, 2, 3)]    # conv_k output at level k+1, width D_k
-        self.r4 = z(B, n[3], 64)                    # reg_cost4 -> upconv3
-        self.skip = [z(B, n[0], 16), z(B, n[1], 32), z(B, n[2], 64)]             # reg_cost1..3 as decoder skips
-        self.up3, self.up3n = z(B, n[2], 64), z(B, n[2], 32)
-        self.up2, self.up2n = z(B, n[1], 32), z(B, n[1], 16)
-        self.up1, self.fin = z(B, n[0], 16), z(B, n[0], 16)
-        self.gn_ws = hip_ops.group_stats_workspace(B, 2, device)
-        self.gn = [self._gn(k) for k in range(4)]
-
     def _gn(self, k):
         flat, offsets = self._packed
         o, hc = offsets["gn%d" % (k + 1)]
         return flat[o:o + 6 * hc]
 
-    def cost_targets(self):
-        """Where the (negated) cost of the next plane goes: the x part of level 1's two cat buffers."""
-        return self.lv[0].a, self.lv[0].xr
+    def widths(self):
+        xw = (self.in_channels,) + self.XW[1:]
+        return xw, [packing.pad16(x + h) for x, h in zip(xw, self.HW)]
 
-    def _gru(self, k, out2, c2):
-        """ConvGRUCell2 of level k (0-based) on a = cat(x, h); h' replaces h in a and goes to out2[..., c2:c2+HC]."""
-        L, B = self.lv[k], self.B
-        hk, wk = self.h >> k, self.w >> k
+    # ---- A: cost + encoder for all planes -------------------------------------------------------------------------
+    def encode(self, feat_cl, rt, planes, B, S, h, w):
+        """-> X[k] [D*B, npix_k, D_k]: cat buffers of the four levels with the x part filled, state part zero."""
+        dev = feat_cl.device
+        D = planes.shape[1]
+        N = D * B
+        xw, dk = self.widths()
+        X = [torch.zeros(N, (h >> k) * (w >> k), dk[k], device=dev, dtype=torch.float32) for k in range(4)]
+        hip_ops.red_variance_cost(feat_cl, rt, planes, X[0], None, B, S, self.in_channels, D, h, w, negate=True)
+        for k in (1, 2, 3):             # conv_k reads the cat buffer of level k (zero weights on the state channels)
+            wk, bk = self._w("conv%d" % k)
+            e = hip_ops.conv3x3_dd(X[k - 1], wk, bk, None, N, dk[k - 1], h >> (k - 1), w >> (k - 1), 1, True)
+            hip_ops.channel_copy(e, 0, X[k], 0, xw[k])
+        return X
+
+    # ---- B: one level's recurrence over the planes ----------------------------------------------------------------
+    def recur_level(self, k, Xk, Rk, B, h, w):
+        """ConvGRUCell2 of level k (0-based) over the planes of Xk [D*B, npix, D_k]; outputs into Rk[..., :HC]."""
+        dev = Xk.device
+        xw, dk = self.widths()
+        Dk, Cx, HC = dk[k], xw[k], self.HW[k]
+        npix, hk, wk = Xk.shape[1], h >> k, w >> k
+        D = Xk.shape[0] // B
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)      # noqa: E731
+        f, o, u, state = z(B, npix, Dk), z(B, npix, Dk), z(B, npix, HC), z(B, npix, HC)
+        stats, stats_o = z(B, 2, 2), z(B, 2)
+        ws = hip_ops.group_stats_workspace(B, 2, dev)
+        gn = self._gn(k)
         wg, bg = self._w("gates%d" % (k + 1))
-        hip_ops.conv3x3_dd(L.a, wg, bg, None, B, L.D, hk, wk, 0, False, out=L.f)
-        hip_ops.group_stats(L.f, 0, L.HC, 2, L.stats, self.gn_ws)
-        hip_ops.gru2_gates_apply(L.f, L.stats, self.gn[k], L.a, L.xr, L.u, L.Cx, L.HC)
         wc, bc = self._w("cand%d" % (k + 1))
-        hip_ops.conv3x3_dd(L.xr, wc, bc, None, B, L.D, hk, wk, 0, False, out=L.o)
-        hip_ops.group_stats(L.o, 0, L.HC, 1, L.stats_o, self.gn_ws)
-        hip_ops.gru2_out_apply(L.o, L.stats_o, self.gn[k][4 * L.HC:], L.u, L.a, out2, c2, L.Cx, L.HC)
+        for d in range(D):
+            a = Xk[d * B:(d + 1) * B]                  # cat(x_d, h): h written by the previous plane's epilogue (zeros at d = 0)
+            hip_ops.conv3x3_dd(a, wg, bg, None, B, Dk, hk, wk, 0, False, out=f)
+            hip_ops.group_stats(f, 0, HC, 2, stats, ws)
+            hip_ops.gru2_gates_apply(f, stats, gn, a, a, u, Cx, HC)        # cat(x, h) -> cat(x, r*h) in place
+            hip_ops.conv3x3_dd(a, wc, bc, None, B, Dk, hk, wk, 0, False, out=o)
+            hip_ops.group_stats(o, 0, HC, 1, stats_o, ws)
+            nxt = Xk[(d + 1) * B:(d + 2) * B] if d + 1 < D else None
+            hip_ops.gru2_out_apply(o, stats_o, gn[4 * HC:], u, state, nxt, Cx, Rk[d * B:(d + 1) * B], 0, HC)
 
-    def step(self, vol, d):
-        """One plane: the -cost is already in the level-1 buffers (cost_targets); writes reg_cost into vol[:, d]."""
-        B, h, w, lv = self.B, self.h, self.w, self.lv
-        # encoder: conv_k reads the cat buffer of level k (zero weights on the state channels), stride 2, ReLU
-        for k in (1, 2, 3):
-            wk_, bk_ = self._w("conv%d" % k)
-            hip_ops.conv3x3_dd(lv[k - 1].a, wk_, bk_, None, B, lv[k - 1].D, h >> (k - 1), w >> (k - 1), 1, True, out=self.enc[k])
-            hip_ops.channel_copy(self.enc[k], 0, lv[k].a, 0, lv[k].Cx)
-            hip_ops.channel_copy(self.enc[k], 0, lv[k].xr, 0, lv[k].Cx)
-        self._gru(3, self.r4, 0)
-        self._gru(2, self.skip[2], 0)
+    # ---- C: decoder for all planes --------------------------------------------------------------------------------
+    def decode(self, R, B, h, w):
+        """R[k] [D*B, npix_k, RW[k]] (GRU outputs in the leading channels) -> reg_cost of every plane [D*B, h*w, 16] (channel 0)."""
+        N = R[0].shape[0]
         w3, b3 = self._w("upconv3")
-        hip_ops.conv3x3_dd(self.r4, w3, b3, self.skip[2], B, 64, h >> 3, w >> 3, 2, True, out=self.up3)      # relu(upconv3) + reg3
-        hip_ops.channel_copy(self.up3, 0, self.up3n, 0, 32)
-        self._gru(1, self.skip[1], 0)
+        up3 = hip_ops.conv3x3_dd(R[3], w3, b3, R[2], N, 64, h >> 3, w >> 3, 2, True)          # relu(upconv3(reg4)) + reg3
+        up3n = torch.empty(N, up3.shape[1], 32, device=up3.device, dtype=torch.float32)
+        hip_ops.channel_copy(up3, 0, up3n, 0, 32)
         w2, b2 = self._w("upconv2")
-        hip_ops.conv3x3_dd(self.up3n, w2, b2, self.skip[1], B, 32, h >> 2, w >> 2, 2, True, out=self.up2)
-        hip_ops.channel_copy(self.up2, 0, self.up2n, 0, 16)
-        self._gru(0, self.skip[0], 0)
+        up2 = hip_ops.conv3x3_dd(up3n, w2, b2, R[1], N, 32, h >> 2, w >> 2, 2, True)
+        up2n = torch.empty(N, up2.shape[1], 16, device=up2.device, dtype=torch.float32)
+        hip_ops.channel_copy(up2, 0, up2n, 0, 16)
         w1, b1 = self._w("upconv1")
-        hip_ops.conv3x3_dd(self.up2n, w1, b1, self.skip[0], B, 16, h >> 1, w >> 1, 2, True, out=self.up1)
+        up1 = hip_ops.conv3x3_dd(up2n, w1, b1, R[0], N, 16, h >> 1, w >> 1, 2, True)
         wf, bf = self._w("upconv2d")
-        hip_ops.conv3x3_dd(self.up1, wf, bf, None, B, 16, h, w, 0, False, out=self.fin)
-        hip_ops.plane_to_volume(self.fin, vol, d)
+        return hip_ops.conv3x3_dd(up1, wf, bf, None, N, 16, h, w, 0, False)
+
+    def regularize(self, feat_cl, rt, planes, B, S, h, w):
+        """All planes of a stage: -> vol [B, D, h*w] of reg_cost (the argument of exp in msrednet.py:415)."""
+        if h % 8 or w % 8:
+            raise AdaMVSHipError("slice_RED_Regularization: map size %dx%d must be a multiple of 8 (three stride-2 levels)" % (h, w))
+        dev = feat_cl.device
+        self.packed(dev)
+        D = planes.shape[1]
+        X = self.encode(feat_cl, rt, planes, B, S, h, w)
+        R = [torch.zeros(D * B, X[k].shape[1], self.RW[k], device=dev, dtype=torch.float32) for k in range(4)]
+        if self.concurrent_levels:
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+            main = torch.cuda.current_stream()
+            for k in (3, 2, 1, 0):
+                self._streams[k].wait_stream(main)
+                with torch.cuda.stream(self._streams[k]):
+                    self.recur_level(k, X[k], R[k], B, h, w)
+            for k in range(4):
+                main.wait_stream(self._streams[k])
+        else:
+            for k in (3, 2, 1, 0):
+                self.recur_level(k, X[k], R[k], B, h, w)
+        fin = self.decode(R, B, h, w)
+        vol = torch.empty(B, D, h * w, device=dev, dtype=torch.float32)
+        hip_ops.planes_to_volume(fin, vol, B)
+        return vol, X
 
     def forward(self, *args, **kwargs):
-        raise RuntimeError("slice_RED_Regularization runs plane by plane inside InferDepthNet (begin / step)")
+        raise RuntimeError("slice_RED_Regularization runs a whole stage at a time (regularize); InferDepthNet drives it")
 
 
 class InferDepthNet(nn.Module):
@@ -209,17 +238,9 @@ class InferDepthNet(nn.Module):
 
     def run(self, feat_cl, B, C, h, w, rt, planes, cost_regularization):
         """feat_cl [V*B, h*w, C] view-major; rt [B,S,12]; planes [B,D,h,w] -> depth, photometric_confidence [B,h,w]."""
-        dev = feat_cl.device
         S = feat_cl.shape[0] // B - 1
         D = planes.shape[1]
-        reg = cost_regularization
-        reg.begin(B, h, w, dev)
-        vol = torch.empty(B, D, h * w, device=dev, dtype=torch.float32)
-        a, xr = reg.cost_targets()
-        for d in range(D):
-            plane = planes[:, d].contiguous()
-            hip_ops.red_variance_cost(feat_cl, rt, plane, a, xr, B, S, C, h, w, negate=True)
-            reg.step(vol, d)
+        vol, _ = cost_regularization.regularize(feat_cl, rt, planes, B, S, h, w)
         return hip_ops.soft_argmin(vol, planes, B, D, h, w)
 
     def forward(self, *args, **kwargs):
@@ -255,27 +276,35 @@ class Infer_CascadeREDNet(nn.Module):
         depth_min = float(depth_values[0, 0].cpu().numpy())         # batch item 0 only, as in the reference
         depth_max = float(depth_values[0, -1].cpu().numpy())
         depth_interval = (depth_max - depth_min) / self.num_depth
+        maps, shapes = self.extract_features(imgs)
+        return self.infer_from_features(maps, shapes, proj_matrices, depth_values, depth_interval)
+
+    def extract_features(self, imgs):
+        """-> channel-last stage maps [V*B, h*w, C] (view-major) and their (B, C, h, w)."""
         B, V = imgs.shape[:2]
         H, W = imgs.shape[-2:]
         x = imgs.transpose(0, 1).reshape(B * V, *imgs.shape[2:]).contiguous()
         maps = self.feature.forward_cl(x)
+        return maps, [(B, maps[s].shape[-1], H // sc, W // sc) for s, sc in enumerate((4, 2, 1))]
+
+    def infer_from_features(self, maps, shapes, proj_matrices, depth_values, depth_interval):
+        """The three stages on pre-extracted features; no host synchronisation (capturable in a hipGraph)."""
         outputs, depth = {}, None
+        H, W = shapes[2][2], shapes[2][3]
         for s in range(self.num_stage):
             name = "stage%d" % (s + 1)
-            scale = STAGE_SCALE[name]
-            h, w = H // scale, W // scale
+            B, C, h, w = shapes[s]
             if depth is None:
-                planes = hip_ops.depth_range_samples(depth_values, self.ndepths[s], self.depth_interals_ratio[s] * depth_interval,
-                                                     [B, h, w])
+                cur = depth_values
             else:
                 # msrednet.py:495-514: previous depth to full resolution, window samples there, then down to the stage's
                 # resolution.  The samples are affine in the depth map, so resampling the map first is the same thing.
                 cur = hip_ops.resize_bilinear(depth, (H, W))
-                if scale != 1:
+                if (h, w) != (H, W):
                     cur = hip_ops.resize_bilinear(cur, (h, w))
-                planes = hip_ops.depth_range_samples(cur, self.ndepths[s], self.depth_interals_ratio[s] * depth_interval, [B, h, w])
+            planes = hip_ops.depth_range_samples(cur, self.ndepths[s], self.depth_interals_ratio[s] * depth_interval, [B, h, w])
             rt = hip_ops.relative_transforms(proj_matrices[name])
-            depth, conf = self.DepthNet.run(maps[s], B, maps[s].shape[-1], h, w, rt, planes, self.cost_regularization[s])
+            depth, conf = self.DepthNet.run(maps[s], B, C, h, w, rt, planes, self.cost_regularization[s])
             st = {"depth": depth, "photometric_confidence": conf}
             outputs[name] = st
             outputs.update(st)

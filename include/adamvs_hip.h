@@ -211,12 +211,13 @@ int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat,
  * channel counts zero-padded to a supported width; what follows are the pieces around them.  Maps are
  * channel-last [N][pixels][D]. */
 
-/* Variance cost of ONE hypothesis plane, msrednet.py:396-412: over the reference feature and the S source features
- * warped onto the plane (homo_warping_float, module.py:527-568): E[x^2] - E[x]^2 per channel, negated when `negate`
- * (both consumers take -cost, msrednet.py:351,362).  feat [V=S+1][B][h*w][C], rt [B][S][12], plane [B][h*w] ->
- * channels [0,C) of out_a [B][h*w][Da] and, when out_b != NULL, of out_b [B][h*w][Db]; other channels untouched. */
-int adamvs_red_variance_cost(const float* feat, const float* rt, const float* plane, float* out_a, int Da, float* out_b,
-                             int Db, int B, int S, int C, int h, int w, int negate, void* stream);
+/* Variance cost of the D hypothesis planes of a stage, msrednet.py:396-412: over the reference feature and the S source
+ * features warped onto the plane (homo_warping_float, module.py:527-568): E[x^2] - E[x]^2 per channel, negated when
+ * `negate` (both consumers take -cost, msrednet.py:351,362).  feat [V=S+1][B][h*w][C], rt [B][S][12],
+ * planes [B][D][h*w] -> channels [0,C) of out_a [D][B][h*w][Da] (plane-major) and, when out_b != NULL, of
+ * out_b [D][B][h*w][Db]; other channels untouched. */
+int adamvs_red_variance_cost(const float* feat, const float* rt, const float* planes, float* out_a, int Da, float* out_b,
+                             int Db, int B, int S, int C, int D, int h, int w, int negate, void* stream);
 
 /* dst[b][p][dst_c0 + c] = src[b][p][src_c0 + c], c < n (strides in floats): narrows / widens / concatenates maps. */
 int adamvs_channel_copy(const float* src, float* dst, int nbatch, int npix, int n, long src_batch_stride,
@@ -232,16 +233,17 @@ int adamvs_group_stats(const float* x, float* stats, int N, int npix, int D, int
 /* ConvGRUCell2.gates + the reset product, module.py:72-92.  f [N][npix][D] = gate_conv(cat(x, h)) with reset rows
  * [0,HC) and update rows [HC,2HC); stats [N][2][2] from adamvs_group_stats(f, c0 = 0, n = HC, ngroups = 2);
  * gn [4][HC] = reset_gate_norm weight, bias, update_gate_norm weight, bias; a [N][npix][D] = cat(x, h) (h at channels
- * [Cx, Cx+HC)).  Writes r*h into channels [Cx, Cx+HC) of xr [N][npix][D] (whose x part the caller filled) and
- * u [N][npix][HC]. */
+ * [Cx, Cx+HC)).  Writes r*h into channels [Cx, Cx+HC) of xr [N][npix][D] -- xr may be a itself: cat(x, h) then
+ * becomes cat(x, r*h) in place -- and u [N][npix][HC]. */
 int adamvs_gru2_gates_apply(const float* f, const float* stats, const float* gn, const float* a, float* xr, float* u,
                             int N, int npix, int D, int Cx, int HC, void* stream);
 
 /* ConvGRUCell2.output + forward, module.py:91-106.  o [N][npix][D] = output_conv(cat(x, r*h)) rows [0,HC);
- * stats [N][2]; gn [2][HC] = output_norm weight, bias.  h' = u*h + (1-u)*tanh(GN(o)) replaces h inside a (channels
- * [Cx, Cx+HC)) and is also written to channels [c2, c2+HC) of out2 [N][npix][D2] when out2 != NULL. */
-int adamvs_gru2_out_apply(const float* o, const float* stats, const float* gn, const float* u, float* a, float* out2,
-                          int N, int npix, int D, int Cx, int HC, int D2, int c2, void* stream);
+ * stats [N][2]; gn [2][HC] = output_norm weight, bias; h [N][npix][HC] the state, replaced by
+ * h' = u*h + (1-u)*tanh(GN(o)).  h' is also written to channels [c2, c2+HC) of out2 [N][npix][D2] and
+ * [c3, c3+HC) of out3 [N][npix][D3] when those are not NULL (the next plane's cat buffer; the decoder's input). */
+int adamvs_gru2_out_apply(const float* o, const float* stats, const float* gn, const float* u, float* h, float* out2,
+                          int D2, int c2, float* out3, int D3, int c3, int N, int npix, int D, int HC, void* stream);
 
 /* The running exp-sum / max / weighted-depth update of msrednet.py:415-436 (same as adamvs.py:512-531) in one pass over
  * the stored slices: vol [B][D][h*w] = reg_cost of every plane, planes [B][D][h*w] -> depth, confidence [B][h*w]. */

@@ -128,39 +128,54 @@ def test_variance_cost_against_oracle(baseline):
     B, C, h, w, V = 2, 16, 24, 40, 4
     feats = [synth.smooth_features(B, C, h, w, seed=10 + v) for v in range(V)]
     proj = synth.rig_projections(V, 4 * h, 4 * w, batch=B, baseline=baseline)["stage1"]
-    plane = 400 + 200 * torch.rand(B, 1, h, w, generator=torch.Generator().manual_seed(1))
+    planes = 400 + 200 * torch.rand(B, 3, h, w, generator=torch.Generator().manual_seed(1))
     rel = [mo.ao.relative_transform(proj[:, v], proj[:, 0]) for v in range(1, V)]
-    want = mo.variance_cost(feats[0], feats[1:], [r[0] for r in rel], [r[1] for r in rel], plane)
     feat_cl = torch.cat([_cl(f) for f in feats], 0)
     rt = hip_ops.relative_transforms(proj.cuda())
-    a = torch.full((B, h * w, 32), 7.0, device="cuda")
-    b = torch.full((B, h * w, 16), 7.0, device="cuda")
-    hip_ops.red_variance_cost(feat_cl, rt, plane.reshape(B, h * w).cuda(), a, b, B, V - 1, C, h, w, negate=True)
-    assert rel_l1(-_nchw(a[:, :, :C], h, w), want) < OP_TOL and rel_l1(-_nchw(b, h, w), want) < OP_TOL
+    a = torch.full((3 * B, h * w, 32), 7.0, device="cuda")
+    b = torch.full((3 * B, h * w, 16), 7.0, device="cuda")
+    hip_ops.red_variance_cost(feat_cl, rt, planes.reshape(B, 3, h * w).cuda(), a, b, B, V - 1, C, 3, h, w, negate=True)
+    for d in range(3):                                             # maps are plane-major: index d * B + b
+        want = mo.variance_cost(feats[0], feats[1:], [r[0] for r in rel], [r[1] for r in rel], planes[:, d:d + 1])
+        assert rel_l1(-_nchw(a[d * B:(d + 1) * B, :, :C], h, w), want) < OP_TOL
+        assert rel_l1(-_nchw(b[d * B:(d + 1) * B], h, w), want) < OP_TOL
     assert bool((a[:, :, C:] == 7.0).all())                      # the other channels are not touched
 
 
 @pytest.mark.gpu
-def test_slice_red_steps_against_reference_golden():
+@pytest.mark.parametrize("concurrent", [False, True])
+def test_slice_red_steps_against_reference_golden(concurrent):
+    """Two consecutive planes through encoder / four recurrences / decoder: reg_cost and all four states."""
+    from ada_mvs_amd import packing
     from ada_mvs_amd.models.msrednet import slice_RED_Regularization
     g = gold("msred_slice_step")
     net = slice_RED_Regularization(32, 8)
     net.load_state_dict(slice_state_dict())
     net = net.cuda()
+    net.concurrent_levels = concurrent
+    dev = torch.device("cuda:0")
+    net.packed(dev)
     B, C, h, w = g["cost0"].shape
-    net.begin(B, h, w, torch.device("cuda:0"))
-    vol = torch.zeros(B, 2, h * w, device="cuda")
-    a, xr = net.cost_targets()
+    xw, dk = net.widths()
+    # encode() minus the variance kernel: the fixture holds the cost itself
+    X = [torch.zeros(2 * B, (h >> k) * (w >> k), dk[k], device=dev) for k in range(4)]
     for step in range(2):
-        neg = -_cl(g["cost%d" % step])
-        a[:, :, :C] = neg
-        xr[:, :, :C] = neg
-        net.step(vol, step)
-        torch.cuda.synchronize()
-        assert rel_l1(vol[:, step].reshape(B, 1, h, w).cpu(), g["reg%d" % step]) < OP_TOL
+        X[0][step * B:(step + 1) * B, :, :C] = -_cl(g["cost%d" % step])
+    from ada_mvs_amd import hip_ops
+    for k in (1, 2, 3):
+        wk, bk = net._w("conv%d" % k)
+        e = hip_ops.conv3x3_dd(X[k - 1], wk, bk, None, 2 * B, dk[k - 1], h >> (k - 1), w >> (k - 1), 1, True)
+        hip_ops.channel_copy(e, 0, X[k], 0, xw[k])
+    R = [torch.zeros(2 * B, X[k].shape[1], net.RW[k], device=dev) for k in range(4)]
+    for k in range(4):
+        net.recur_level(k, X[k], R[k], B, h, w)
+    fin = net.decode(R, B, h, w)
+    torch.cuda.synchronize()
+    for step in range(2):
+        reg = fin[step * B:(step + 1) * B, :, 0].reshape(B, 1, h, w).cpu()
+        assert rel_l1(reg, g["reg%d" % step]) < OP_TOL
         for k in range(4):
-            L = net.lv[k]
-            state = _nchw(L.a[:, :, L.Cx:L.Cx + L.HC].contiguous(), h >> k, w >> k)
+            state = _nchw(R[k][step * B:(step + 1) * B, :, :net.HW[k]].contiguous(), h >> k, w >> k)
             assert rel_l1(state, g["state%d_%d" % (k + 1, step)]) < OP_TOL, "state %d step %d" % (k + 1, step)
 
 
