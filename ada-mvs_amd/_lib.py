@@ -78,9 +78,10 @@ SIGNATURES = {
     "adamvs_red_variance_cost": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_channel_copy": (c_i, [c_f, c_f, c_i, c_i, c_i, ctypes.c_long, c_i, c_i, ctypes.c_long, c_i, c_i, c_st]),
     "adamvs_group_stats_workspace_bytes": (c_sz, [c_i, c_i]),
-    "adamvs_group_stats": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_void_p, c_sz, c_st]),
-    "adamvs_gru2_gates_apply": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
-    "adamvs_gru2_out_apply": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_group_stats_partial": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_group_stats_finish": (c_i, [ctypes.c_void_p, c_f, c_i, c_i, c_i, ctypes.c_float, c_st]),
+    "adamvs_gru2_gates_apply": (c_i, [c_f, c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, c_st]),
+    "adamvs_gru2_out_apply": (c_i, [c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_st]),
     "adamvs_soft_argmin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
 }
 

@@ -61,19 +61,21 @@ __global__ void k_channel_copy(const float* __restrict__ src, float* __restrict_
   dst[b * dbs + (size_t)p * dps + od + c] = src[b * sbs + (size_t)p * sps + os + c];
 }
 
-// ---- GroupNorm(1 group) statistics, deterministic: fixed partial ranges, double accumulation
+// ---- GroupNorm(1 group) statistics, deterministic: fixed partial ranges, double accumulation.
+// k_gn_partial: grid (GN_PARTS, ngroups, N); group g = map x0 / x1, channels [0, n) of a D-wide map.  The consumers
+// (the two epilogue kernels below) finish the reduction themselves: one fewer dependent launch per normalisation.
 constexpr int GN_PARTS = 64;
 
-__global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x, double* __restrict__ part, int npix, int D,
-                                                     int c0, int n, int ngroups) {
-  // grid (GN_PARTS, ngroups, N): this block sums channels [c0 + g*n, c0 + (g+1)*n) of its pixel range
-  const int g = blockIdx.y, b = blockIdx.z;
+__global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                     double* __restrict__ part, int npix, int D, int n) {
+  const int g = blockIdx.y, b = blockIdx.z, ngroups = gridDim.y;
+  const float* x = g ? x1 : x0;
   const int per = (npix + GN_PARTS - 1) / GN_PARTS;
   const int p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
   const int n4 = n >> 2;
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < (p1 - p0) * n4; i += 256) {
-    const int p = p0 + i / n4, c = c0 + g * n + 4 * (i % n4);
+    const int p = p0 + i / n4, c = 4 * (i % n4);
     const f32x4 v = *(const f32x4*)(x + ((size_t)b * npix + p) * D + c);
     s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
     q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -91,61 +93,76 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x,
   }
 }
 
-__global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ stats, int count, float eps, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (b, g)
-  if (i >= total) return;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < GN_PARTS; ++k) { s += part[((size_t)i * GN_PARTS + k) * 2]; q += part[((size_t)i * GN_PARTS + k) * 2 + 1]; }
-  const double mean = s / count;
-  const double var = fmax(q / count - mean * mean, 0.0);    // biased, as torch.nn.GroupNorm
-  stats[2 * i] = (float)mean;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+// mean and 1/sqrt(biased var + eps) of group g of sample b from the partial sums, into shared memory (threads < ngroups)
+__device__ __forceinline__ void gn_finish(const double* __restrict__ part, int b, int ngroups, int count, float eps,
+                                          float (*st)[2]) {
+  if ((int)threadIdx.x < ngroups) {
+    const double* p = part + ((size_t)b * ngroups + threadIdx.x) * GN_PARTS * 2;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < GN_PARTS; ++k) { s += p[2 * k]; q += p[2 * k + 1]; }
+    const double mean = s / count;
+    const double var = fmax(q / count - mean * mean, 0.0);    // biased, as torch.nn.GroupNorm
+    st[threadIdx.x][0] = (float)mean;
+    st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
 }
 
-// gates: r = sigmoid(GN(f[0:HC])), u = sigmoid(GN(f[HC:2HC])); xr[Cx + c] = r * h, u out (module.py:72-92)
-__global__ void k_gru2_gates_apply(const float* __restrict__ f, const float* __restrict__ stats, const float* __restrict__ gn,
-                                   const float* a, float* xr, float* __restrict__ u, int npix, int D,
-                                   int Cx, int HC, size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+__global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ stats, int ngroups, int count, float eps) {
+  __shared__ float st[2][2];
+  gn_finish(part, blockIdx.x, ngroups, count, eps, st);
+  if ((int)threadIdx.x < ngroups) {
+    stats[(blockIdx.x * ngroups + threadIdx.x) * 2] = st[threadIdx.x][0];
+    stats[(blockIdx.x * ngroups + threadIdx.x) * 2 + 1] = st[threadIdx.x][1];
+  }
+}
+
+// gates (module.py:72-92): fr / fu = the reset / update halves of gate_conv(cat(x, h)), both W-wide maps with HC real
+// channels; r = sigmoid(GN(fr)), u = sigmoid(GN(fu)); rh = r * h (W-wide, HC real), u out [N][npix][HC].
+// grid (blocks over npix * HC/4, N).
+__global__ void k_gru2_gates_apply(const float* __restrict__ fr, const float* __restrict__ fu, const double* __restrict__ part,
+                                   const float* __restrict__ gn, const float* __restrict__ h, float* __restrict__ rh,
+                                   float* __restrict__ u, int npix, int W, int HC, float eps) {
+  __shared__ float st[2][2];
+  const int b = blockIdx.y;
+  gn_finish(part, b, 2, npix * HC, eps, st);
   const int G = HC >> 2;
-  const int c = 4 * (int)(i % G);
-  const size_t bp = i / G;
-  const size_t b = bp / npix;
-  const float mr = stats[b * 4 + 0], sr = stats[b * 4 + 1], mu = stats[b * 4 + 2], su = stats[b * 4 + 3];
-  const f32x4 fr = *(const f32x4*)(f + bp * D + c), fu = *(const f32x4*)(f + bp * D + HC + c);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * G) return;
+  const int c = 4 * (i % G);
+  const size_t bp = (size_t)b * npix + i / G;
+  const f32x4 a = *(const f32x4*)(fr + bp * W + c), v = *(const f32x4*)(fu + bp * W + c);
   const f32x4 gr = *(const f32x4*)(gn + c), br = *(const f32x4*)(gn + HC + c);
   const f32x4 gu = *(const f32x4*)(gn + 2 * HC + c), bu = *(const f32x4*)(gn + 3 * HC + c);
-  const f32x4 h4 = *(const f32x4*)(a + bp * D + Cx + c);
-  const f32x4 rn = (fr - mr) * sr * gr + br, un = (fu - mu) * su * gu + bu;
+  const f32x4 rn = (a - st[0][0]) * st[0][1] * gr + br, un = (v - st[1][0]) * st[1][1] * gu + bu;
   const f32x4 r = {sigmoidf_(rn.x), sigmoidf_(rn.y), sigmoidf_(rn.z), sigmoidf_(rn.w)};
   const f32x4 uu = {sigmoidf_(un.x), sigmoidf_(un.y), sigmoidf_(un.z), sigmoidf_(un.w)};
-  *(f32x4*)(xr + bp * D + Cx + c) = r * h4;
+  *(f32x4*)(rh + bp * W + c) = r * *(const f32x4*)(h + bp * W + c);
   *(f32x4*)(u + bp * HC + c) = uu;
 }
 
-// candidate + blend: y = tanh(GN(o[0:HC])); h' = u*h + (1-u)*y on the compact state hst [N][npix][HC] (in place), and
-// copies of h' into channels [c2, c2+HC) of out2 (the next plane's cat buffer) and [c3, c3+HC) of out3 (the decoder's input)
-__global__ void k_gru2_out_apply(const float* __restrict__ o, const float* __restrict__ stats, const float* __restrict__ gn,
-                                 const float* __restrict__ u, float* __restrict__ hst, float* __restrict__ out2,
-                                 float* __restrict__ out3, int npix, int D, int HC, int D2, int c2, int D3, int c3, size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+// candidate + blend (module.py:91-106): y = tanh(GN(o)); h' = u*h + (1-u)*y, in place on the W-wide state map and
+// into channels [0, HC) of out [N][npix][Wo] (the decoder's input).  grid (blocks over npix * HC/4, N).
+__global__ void k_gru2_out_apply(const float* __restrict__ o, const double* __restrict__ part, const float* __restrict__ gn,
+                                 const float* __restrict__ u, float* __restrict__ h, float* __restrict__ out, int npix, int W,
+                                 int HC, int Wo, float eps) {
+  __shared__ float st[2][2];
+  const int b = blockIdx.y;
+  gn_finish(part, b, 1, npix * HC, eps, st);
   const int G = HC >> 2;
-  const int c = 4 * (int)(i % G);
-  const size_t bp = i / G;
-  const size_t b = bp / npix;
-  const float m = stats[b * 2], s = stats[b * 2 + 1];
-  const f32x4 ov = *(const f32x4*)(o + bp * D + c);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * G) return;
+  const int c = 4 * (i % G);
+  const size_t bp = (size_t)b * npix + i / G;
+  const f32x4 ov = *(const f32x4*)(o + bp * W + c);
   const f32x4 ga = *(const f32x4*)(gn + c), be = *(const f32x4*)(gn + HC + c);
-  const f32x4 on = (ov - m) * s * ga + be;
+  const f32x4 on = (ov - st[0][0]) * st[0][1] * ga + be;
   const f32x4 y = {tanhf(on.x), tanhf(on.y), tanhf(on.z), tanhf(on.w)};
   const f32x4 u4 = *(const f32x4*)(u + bp * HC + c);
-  float* hp = hst + bp * HC + c;
+  float* hp = h + bp * W + c;
   const f32x4 hn = u4 * *(const f32x4*)hp + (1.0f - u4) * y;
   *(f32x4*)hp = hn;
-  if (out2) *(f32x4*)(out2 + bp * D2 + c2 + c) = hn;
-  if (out3) *(f32x4*)(out3 + bp * D3 + c3 + c) = hn;
+  if (out) *(f32x4*)(out + bp * Wo + c) = hn;
 }
 
 }  // namespace adamvs
@@ -182,41 +199,42 @@ extern "C" size_t adamvs_group_stats_workspace_bytes(int N, int ngroups) {
   return (size_t)N * ngroups * GN_PARTS * 2 * sizeof(double);
 }
 
-extern "C" int adamvs_group_stats(const float* x, float* stats, int N, int npix, int D, int c0, int n, int ngroups, float eps,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
-  ADAMVS_CHECK_ARG(x && stats && workspace && N > 0 && npix > 0 && n > 0 && (n % 4) == 0 && (c0 % 4) == 0 && (D % 4) == 0 &&
-                   ngroups > 0 && c0 + n * ngroups <= D, "group_stats: bad arguments (N=%d npix=%d D=%d c0=%d n=%d groups=%d)",
-                   N, npix, D, c0, n, ngroups);
-  ADAMVS_CHECK_ARG(workspace_bytes >= adamvs_group_stats_workspace_bytes(N, ngroups), "group_stats: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gn_partial, dim3(GN_PARTS, ngroups, N), dim3(256), 0, st, x, (double*)workspace, npix, D, c0, n, ngroups);
-  ADAMVS_CHECK_LAUNCH("group_stats (partial)");
-  const int total = N * ngroups;
-  hipLaunchKernelGGL(k_gn_final, dim3(cdiv(total, 64)), dim3(64), 0, st, (const double*)workspace, stats, npix * n, eps, total);
-  ADAMVS_CHECK_LAUNCH("group_stats (final)");
+extern "C" int adamvs_group_stats_partial(const float* x0, const float* x1, int N, int npix, int D, int n, void* partials,
+                                          size_t partials_bytes, void* stream) {
+  const int ngroups = x1 ? 2 : 1;
+  ADAMVS_CHECK_ARG(x0 && partials && N > 0 && npix > 0 && n > 0 && (n % 4) == 0 && (D % 4) == 0 && n <= D,
+                   "group_stats_partial: bad arguments (N=%d npix=%d D=%d n=%d)", N, npix, D, n);
+  ADAMVS_CHECK_ARG(partials_bytes >= adamvs_group_stats_workspace_bytes(N, ngroups), "group_stats_partial: buffer too small");
+  hipLaunchKernelGGL(k_gn_partial, dim3(GN_PARTS, ngroups, N), dim3(256), 0, (hipStream_t)stream, x0, x1, (double*)partials, npix,
+                     D, n);
+  ADAMVS_CHECK_LAUNCH("group_stats_partial");
   return 0;
 }
 
-extern "C" int adamvs_gru2_gates_apply(const float* f, const float* stats, const float* gn, const float* a, float* xr, float* u,
-                                       int N, int npix, int D, int Cx, int HC, void* stream) {
-  ADAMVS_CHECK_ARG(f && stats && gn && a && xr && u && N > 0 && npix > 0 && (HC % 4) == 0 && (Cx % 4) == 0 && (D % 4) == 0 &&
-                   Cx + HC <= D && 2 * HC <= D, "gru2_gates_apply: bad arguments (D=%d Cx=%d HC=%d)", D, Cx, HC);
-  const size_t total = (size_t)N * npix * (HC / 4);
-  hipLaunchKernelGGL(k_gru2_gates_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f, stats, gn, a,
-                     xr, u, npix, D, Cx, HC, total);
+extern "C" int adamvs_group_stats_finish(const void* partials, float* stats, int N, int ngroups, int count, float eps,
+                                         void* stream) {
+  ADAMVS_CHECK_ARG(partials && stats && N > 0 && (ngroups == 1 || ngroups == 2) && count > 0, "group_stats_finish: bad arguments");
+  hipLaunchKernelGGL(k_gn_final, dim3(N), dim3(64), 0, (hipStream_t)stream, (const double*)partials, stats, ngroups, count, eps);
+  ADAMVS_CHECK_LAUNCH("group_stats_finish");
+  return 0;
+}
+
+extern "C" int adamvs_gru2_gates_apply(const float* fr, const float* fu, const void* partials, const float* gn, const float* h,
+                                       float* rh, float* u, int N, int npix, int W, int HC, float eps, void* stream) {
+  ADAMVS_CHECK_ARG(fr && fu && partials && gn && h && rh && u && N > 0 && npix > 0 && (HC % 4) == 0 && (W % 4) == 0 && HC <= W,
+                   "gru2_gates_apply: bad arguments (W=%d HC=%d)", W, HC);
+  hipLaunchKernelGGL(k_gru2_gates_apply, dim3(cdiv(npix * (HC / 4), 256), N), dim3(256), 0, (hipStream_t)stream, fr, fu,
+                     (const double*)partials, gn, h, rh, u, npix, W, HC, eps);
   ADAMVS_CHECK_LAUNCH("gru2_gates_apply");
   return 0;
 }
 
-extern "C" int adamvs_gru2_out_apply(const float* o, const float* stats, const float* gn, const float* u, float* h, float* out2,
-                                     int D2, int c2, float* out3, int D3, int c3, int N, int npix, int D, int HC, void* stream) {
-  ADAMVS_CHECK_ARG(o && stats && gn && u && h && N > 0 && npix > 0 && (HC % 4) == 0 && (D % 4) == 0 && HC <= D &&
-                   (!out2 || ((D2 % 4) == 0 && (c2 % 4) == 0 && c2 + HC <= D2)) &&
-                   (!out3 || ((D3 % 4) == 0 && (c3 % 4) == 0 && c3 + HC <= D3)),
-                   "gru2_out_apply: bad arguments (D=%d HC=%d D2=%d c2=%d D3=%d c3=%d)", D, HC, D2, c2, D3, c3);
-  const size_t total = (size_t)N * npix * (HC / 4);
-  hipLaunchKernelGGL(k_gru2_out_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, o, stats, gn, u, h,
-                     out2, out3, npix, D, HC, D2, c2, D3, c3, total);
+extern "C" int adamvs_gru2_out_apply(const float* o, const void* partials, const float* gn, const float* u, float* h, float* out,
+                                     int Wo, int N, int npix, int W, int HC, float eps, void* stream) {
+  ADAMVS_CHECK_ARG(o && partials && gn && u && h && N > 0 && npix > 0 && (HC % 4) == 0 && (W % 4) == 0 && HC <= W &&
+                   (!out || ((Wo % 4) == 0 && HC <= Wo)), "gru2_out_apply: bad arguments (W=%d HC=%d Wo=%d)", W, HC, Wo);
+  hipLaunchKernelGGL(k_gru2_out_apply, dim3(cdiv(npix * (HC / 4), 256), N), dim3(256), 0, (hipStream_t)stream, o,
+                     (const double*)partials, gn, u, h, out, npix, W, HC, Wo, eps);
   ADAMVS_CHECK_LAUNCH("gru2_out_apply");
   return 0;
 }

@@ -296,30 +296,35 @@ def planes_to_volume(src, vol, B):
                                               B * src.stride(0), src.stride(1), 0, vol.stride(1), 1, 0, _stream()), "channel_copy")
 
 
-def group_stats(x, c0, n, ngroups, stats, workspace, eps=1e-5):
-    N, npix, D = x.shape
-    check(_lib.load().adamvs_group_stats(_p(x), _p(stats), N, npix, D, c0, n, ngroups, eps, _p(workspace),
-                                         workspace.numel() * workspace.element_size(), _stream()), "group_stats")
-    return stats
-
-
 def group_stats_workspace(N, ngroups, device):
     return torch.empty(_lib.load().adamvs_group_stats_workspace_bytes(N, ngroups) // 8, device=device, dtype=torch.float64)
 
 
-def gru2_gates_apply(f, stats, gn, a, xr, u, Cx, HC):
-    N, npix, D = f.shape
-    check(_lib.load().adamvs_gru2_gates_apply(_p(f), _p(stats), _p(gn), _p(a), _p(xr), _p(u), N, npix, D, Cx, HC, _stream()),
-          "gru2_gates_apply")
+def group_stats_partial(x0, x1, n, partials):
+    """Partial sums for GroupNorm(1 group) over channels [0, n) of x0 (and x1): consumed by the gru2_* epilogues."""
+    N, npix, D = x0.shape
+    check(_lib.load().adamvs_group_stats_partial(_p(x0), _p(x1) if x1 is not None else ctypes.c_void_p(0), N, npix, D, n,
+                                                 _p(partials), partials.numel() * 8, _stream()), "group_stats_partial")
 
 
-def gru2_out_apply(o, stats, gn, u, h, out2, c2, out3, c3, HC):
-    N, npix, D = o.shape
-    null = ctypes.c_void_p(0)
-    check(_lib.load().adamvs_gru2_out_apply(_p(o), _p(stats), _p(gn), _p(u), _p(h),
-                                            _p(out2) if out2 is not None else null, out2.shape[-1] if out2 is not None else 0, c2,
-                                            _p(out3) if out3 is not None else null, out3.shape[-1] if out3 is not None else 0, c3,
-                                            N, npix, D, HC, _stream()), "gru2_out_apply")
+def group_stats_finish(partials, N, ngroups, count, eps=1e-5):
+    stats = torch.empty(N, ngroups, 2, device=partials.device, dtype=torch.float32)
+    check(_lib.load().adamvs_group_stats_finish(_p(partials), _p(stats), N, ngroups, count, eps, _stream()), "group_stats_finish")
+    return stats
+
+
+def gru2_gates_apply(fr, fu, partials, gn, h, rh, u, HC, eps=1e-5):
+    N, npix, W = fr.shape
+    check(_lib.load().adamvs_gru2_gates_apply(_p(fr), _p(fu), _p(partials), _p(gn), _p(h), _p(rh), _p(u), N, npix, W, HC, eps,
+                                              _stream()), "gru2_gates_apply")
+
+
+def gru2_out_apply(o, partials, gn, u, h, out, HC, eps=1e-5):
+    N, npix, W = o.shape
+    check(_lib.load().adamvs_gru2_out_apply(_p(o), _p(partials), _p(gn), _p(u), _p(h),
+                                            _p(out) if out is not None else ctypes.c_void_p(0),
+                                            out.shape[-1] if out is not None else 0, N, npix, W, HC, eps, _stream()),
+          "gru2_out_apply")
 
 
 def soft_argmin(vol, planes, B, D, h, w):

@@ -85,16 +85,20 @@ class slice_RED_Regularization(nn.Module):
     """reference models/msrednet.py:330-366, restructured around what is and is not recurrent.
 
     In the reference step, conv1-3 (the encoder) depend only on the cost of the plane, every ConvGRUCell2 only on its
-    own state and its encoder map, and the decoder (upconv3/2/1, upconv2d) only on the four GRU outputs.  So per stage:
-      A  the encoder for ALL planes in one batched launch per layer (maps indexed d * B + b),
-      B  four independent recurrences over the planes (one per level), each on its own stream,
-      C  the decoder for all planes in one batched launch per layer.
-    Level k works on cat(x_k, h_k) buffers of width D_k = pad16(x + h) (x widths C/16/32/64, states 8/16/32/64): the
-    encoder writes the x part for every plane, the recurrence keeps h there (the candidate epilogue of plane d writes
-    h' into plane d+1's buffer) and turns it into r*h in place for the candidate convolution."""
+    own state and its encoder map, and the decoder (upconv3/2/1, upconv2d) only on the four GRU outputs.  Inside a
+    cell both convolutions act on cat(x, .) and are linear, conv(cat(x, h)) = Wx.x + Wh.h + b, so their x halves are
+    state-independent as well.  Per stage:
+      A  cost, encoder and the x halves of all gate / candidate convolutions for ALL planes, one batched launch per
+         layer (maps indexed d * B + b),
+      B  four independent recurrences over the planes (one per level, each on its own stream); per plane the h halves
+         of the three convolutions (the x halves enter through the `skip` operand), two GroupNorm reductions and the
+         two fused epilogues,
+      C  the decoder for all planes, one batched launch per layer.
+    Channel counts are zero-padded to widths adamvs_conv3x3_dd takes: x maps XW, state maps HW, GRU outputs RW."""
 
-    XW = (None, 16, 32, 64)        # x widths of levels 2-4 (level 1: in_channels)
-    HW = (8, 16, 32, 64)           # state widths
+    XC = (None, 16, 32, 64)        # x channels of levels 2-4 (level 1: in_channels)
+    HC = (8, 16, 32, 64)           # state channels
+    HW = (16, 16, 32, 64)          # state map widths
     RW = (16, 32, 64, 64)          # width of the stored GRU outputs = what the decoder layer reading them takes
 
     def __init__(self, in_channels, base_channels=8):
@@ -141,49 +145,68 @@ class slice_RED_Regularization(nn.Module):
         o, hc = offsets["gn%d" % (k + 1)]
         return flat[o:o + 6 * hc]
 
-    def widths(self):
-        xw = (self.in_channels,) + self.XW[1:]
-        return xw, [packing.pad16(x + h) for x, h in zip(xw, self.HW)]
+    def x_widths(self):
+        return (max(packing.pad16(self.in_channels), 16), 32, 64, 64)
 
-    # ---- A: cost + encoder for all planes -------------------------------------------------------------------------
-    def encode(self, feat_cl, rt, planes, B, S, h, w):
-        """-> X[k] [D*B, npix_k, D_k]: cat buffers of the four levels with the x part filled, state part zero."""
-        dev = feat_cl.device
+    @staticmethod
+    def _to_width(x, n, width):
+        """The first n channels of x as a `width`-wide map (zero padded); x itself when it already has that width."""
+        if x.shape[-1] == width:
+            return x
+        out = torch.zeros(x.shape[0], x.shape[1], width, device=x.device, dtype=torch.float32)
+        hip_ops.channel_copy(x, 0, out, 0, n)
+        return out
+
+    # ---- A: cost, encoder and the x halves of the GRU convolutions for all planes -----------------------------------
+    def cost_maps(self, feat_cl, rt, planes, B, S, h, w):
+        """-> X0 [D*B, h*w, XW0]: the negated variance cost of every plane (plane-major)."""
         D = planes.shape[1]
-        N = D * B
-        xw, dk = self.widths()
-        X = [torch.zeros(N, (h >> k) * (w >> k), dk[k], device=dev, dtype=torch.float32) for k in range(4)]
-        hip_ops.red_variance_cost(feat_cl, rt, planes, X[0], None, B, S, self.in_channels, D, h, w, negate=True)
-        for k in (1, 2, 3):             # conv_k reads the cat buffer of level k (zero weights on the state channels)
-            wk, bk = self._w("conv%d" % k)
-            e = hip_ops.conv3x3_dd(X[k - 1], wk, bk, None, N, dk[k - 1], h >> (k - 1), w >> (k - 1), 1, True)
-            hip_ops.channel_copy(e, 0, X[k], 0, xw[k])
-        return X
+        X0 = torch.zeros(D * B, h * w, self.x_widths()[0], device=feat_cl.device, dtype=torch.float32)
+        hip_ops.red_variance_cost(feat_cl, rt, planes, X0, None, B, S, self.in_channels, D, h, w, negate=True)
+        return X0
+
+    def encode(self, X0, h, w):
+        """X0 -> per level k: (gxr, gxu, cx) [D*B, npix_k, HW_k], the x halves (+ bias) of the reset / update / candidate
+        convolutions of ConvGRUCell2 k for every plane."""
+        N = X0.shape[0]
+        xw = self.x_widths()
+        xc = (self.in_channels,) + self.XC[1:]
+        X, halves = X0, []
+        for k in range(4):
+            hk, wk = h >> k, w >> k
+            lev = []
+            for name in ("gxr", "gxu", "cx"):
+                wt, bs = self._w("%s%d" % (name, k + 1))
+                lev.append(self._to_width(hip_ops.conv3x3_dd(X, wt, bs, None, N, xw[k], hk, wk, 0, False), self.HC[k], self.HW[k]))
+            halves.append(lev)
+            if k < 3:                  # conv_{k+1}: stride 2, ReLU; its output is the next level's x
+                wt, bs = self._w("conv%d" % (k + 1))
+                X = self._to_width(hip_ops.conv3x3_dd(X, wt, bs, None, N, xw[k], hk, wk, 1, True), xc[k + 1], xw[k + 1])
+        return halves
 
     # ---- B: one level's recurrence over the planes ----------------------------------------------------------------
-    def recur_level(self, k, Xk, Rk, B, h, w):
-        """ConvGRUCell2 of level k (0-based) over the planes of Xk [D*B, npix, D_k]; outputs into Rk[..., :HC]."""
-        dev = Xk.device
-        xw, dk = self.widths()
-        Dk, Cx, HC = dk[k], xw[k], self.HW[k]
-        npix, hk, wk = Xk.shape[1], h >> k, w >> k
-        D = Xk.shape[0] // B
+    def recur_level(self, k, halves_k, Rk, B, h, w):
+        """ConvGRUCell2 of level k (0-based) over the planes; h' of plane d into Rk[d*B:(d+1)*B, :, :HC]."""
+        gxr, gxu, cx = halves_k
+        dev = gxr.device
+        W, HC = self.HW[k], self.HC[k]
+        npix, hk, wk = gxr.shape[1], h >> k, w >> k
+        D = gxr.shape[0] // B
         z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)      # noqa: E731
-        f, o, u, state = z(B, npix, Dk), z(B, npix, Dk), z(B, npix, HC), z(B, npix, HC)
-        stats, stats_o = z(B, 2, 2), z(B, 2)
-        ws = hip_ops.group_stats_workspace(B, 2, dev)
+        state, rh, fr, fu, o = z(B, npix, W), z(B, npix, W), z(B, npix, W), z(B, npix, W), z(B, npix, W)
+        u = z(B, npix, HC)
+        part = hip_ops.group_stats_workspace(B, 2, dev)
         gn = self._gn(k)
-        wg, bg = self._w("gates%d" % (k + 1))
-        wc, bc = self._w("cand%d" % (k + 1))
+        (wr, br), (wu, bu), (wc, bc) = (self._w("%s%d" % (n, k + 1)) for n in ("ghr", "ghu", "ch"))
         for d in range(D):
-            a = Xk[d * B:(d + 1) * B]                  # cat(x_d, h): h written by the previous plane's epilogue (zeros at d = 0)
-            hip_ops.conv3x3_dd(a, wg, bg, None, B, Dk, hk, wk, 0, False, out=f)
-            hip_ops.group_stats(f, 0, HC, 2, stats, ws)
-            hip_ops.gru2_gates_apply(f, stats, gn, a, a, u, Cx, HC)        # cat(x, h) -> cat(x, r*h) in place
-            hip_ops.conv3x3_dd(a, wc, bc, None, B, Dk, hk, wk, 0, False, out=o)
-            hip_ops.group_stats(o, 0, HC, 1, stats_o, ws)
-            nxt = Xk[(d + 1) * B:(d + 2) * B] if d + 1 < D else None
-            hip_ops.gru2_out_apply(o, stats_o, gn[4 * HC:], u, state, nxt, Cx, Rk[d * B:(d + 1) * B], 0, HC)
+            sl = slice(d * B, (d + 1) * B)
+            hip_ops.conv3x3_dd(state, wr, br, gxr[sl], B, W, hk, wk, 0, False, out=fr)        # Wh.h + (Wx.x + b)
+            hip_ops.conv3x3_dd(state, wu, bu, gxu[sl], B, W, hk, wk, 0, False, out=fu)
+            hip_ops.group_stats_partial(fr, fu, HC, part)
+            hip_ops.gru2_gates_apply(fr, fu, part, gn, state, rh, u, HC)
+            hip_ops.conv3x3_dd(rh, wc, bc, cx[sl], B, W, hk, wk, 0, False, out=o)
+            hip_ops.group_stats_partial(o, None, HC, part)
+            hip_ops.gru2_out_apply(o, part, gn[4 * HC:], u, state, Rk[sl], HC)
 
     # ---- C: decoder for all planes --------------------------------------------------------------------------------
     def decode(self, R, B, h, w):
@@ -191,26 +214,22 @@ class slice_RED_Regularization(nn.Module):
         N = R[0].shape[0]
         w3, b3 = self._w("upconv3")
         up3 = hip_ops.conv3x3_dd(R[3], w3, b3, R[2], N, 64, h >> 3, w >> 3, 2, True)          # relu(upconv3(reg4)) + reg3
-        up3n = torch.empty(N, up3.shape[1], 32, device=up3.device, dtype=torch.float32)
-        hip_ops.channel_copy(up3, 0, up3n, 0, 32)
         w2, b2 = self._w("upconv2")
-        up2 = hip_ops.conv3x3_dd(up3n, w2, b2, R[1], N, 32, h >> 2, w >> 2, 2, True)
-        up2n = torch.empty(N, up2.shape[1], 16, device=up2.device, dtype=torch.float32)
-        hip_ops.channel_copy(up2, 0, up2n, 0, 16)
+        up2 = hip_ops.conv3x3_dd(self._to_width(up3, 32, 32), w2, b2, R[1], N, 32, h >> 2, w >> 2, 2, True)
         w1, b1 = self._w("upconv1")
-        up1 = hip_ops.conv3x3_dd(up2n, w1, b1, R[0], N, 16, h >> 1, w >> 1, 2, True)
+        up1 = hip_ops.conv3x3_dd(self._to_width(up2, 16, 16), w1, b1, R[0], N, 16, h >> 1, w >> 1, 2, True)
         wf, bf = self._w("upconv2d")
         return hip_ops.conv3x3_dd(up1, wf, bf, None, N, 16, h, w, 0, False)
 
-    def regularize(self, feat_cl, rt, planes, B, S, h, w):
-        """All planes of a stage: -> vol [B, D, h*w] of reg_cost (the argument of exp in msrednet.py:415)."""
+    def regularize_maps(self, X0, B, h, w):
+        """X0 [D*B, h*w, XW0] (-cost of every plane) -> (reg_cost maps [D*B, h*w, 16] (channel 0), R: the GRU outputs)."""
         if h % 8 or w % 8:
             raise AdaMVSHipError("slice_RED_Regularization: map size %dx%d must be a multiple of 8 (three stride-2 levels)" % (h, w))
-        dev = feat_cl.device
+        dev = X0.device
         self.packed(dev)
-        D = planes.shape[1]
-        X = self.encode(feat_cl, rt, planes, B, S, h, w)
-        R = [torch.zeros(D * B, X[k].shape[1], self.RW[k], device=dev, dtype=torch.float32) for k in range(4)]
+        N = X0.shape[0]
+        halves = self.encode(X0, h, w)
+        R = [torch.zeros(N, (h >> k) * (w >> k), self.RW[k], device=dev, dtype=torch.float32) for k in range(4)]
         if self.concurrent_levels:
             if self._streams is None:
                 self._streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
@@ -218,16 +237,21 @@ class slice_RED_Regularization(nn.Module):
             for k in (3, 2, 1, 0):
                 self._streams[k].wait_stream(main)
                 with torch.cuda.stream(self._streams[k]):
-                    self.recur_level(k, X[k], R[k], B, h, w)
+                    self.recur_level(k, halves[k], R[k], B, h, w)
             for k in range(4):
                 main.wait_stream(self._streams[k])
         else:
             for k in (3, 2, 1, 0):
-                self.recur_level(k, X[k], R[k], B, h, w)
-        fin = self.decode(R, B, h, w)
-        vol = torch.empty(B, D, h * w, device=dev, dtype=torch.float32)
+                self.recur_level(k, halves[k], R[k], B, h, w)
+        return self.decode(R, B, h, w), R
+
+    def regularize(self, feat_cl, rt, planes, B, S, h, w):
+        """All planes of a stage: -> vol [B, D, h*w] of reg_cost (the argument of exp in msrednet.py:415)."""
+        self.packed(feat_cl.device)
+        fin, _ = self.regularize_maps(self.cost_maps(feat_cl, rt, planes, B, S, h, w), B, h, w)
+        vol = torch.empty(B, planes.shape[1], h * w, device=feat_cl.device, dtype=torch.float32)
         hip_ops.planes_to_volume(fin, vol, B)
-        return vol, X
+        return vol
 
     def forward(self, *args, **kwargs):
         raise RuntimeError("slice_RED_Regularization runs a whole stage at a time (regularize); InferDepthNet drives it")
@@ -240,7 +264,7 @@ class InferDepthNet(nn.Module):
         """feat_cl [V*B, h*w, C] view-major; rt [B,S,12]; planes [B,D,h,w] -> depth, photometric_confidence [B,h,w]."""
         S = feat_cl.shape[0] // B - 1
         D = planes.shape[1]
-        vol, _ = cost_regularization.regularize(feat_cl, rt, planes, B, S, h, w)
+        vol = cost_regularization.regularize(feat_cl, rt, planes, B, S, h, w)
         return hip_ops.soft_argmin(vol, planes, B, D, h, w)
 
     def forward(self, *args, **kwargs):

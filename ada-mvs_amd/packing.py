@@ -312,22 +312,33 @@ def pack_padded_dd(w, bias, D, transposed=False, flip=False, cin_at=0):
 
 def pack_red_regularization(sd, pre, C):
     """slice_RED_Regularization of `pre` for stage feature width C -> (flat fp32 tensor, {name: (offset, D)}).
-    Level k = 1..4 works on cat(x_k, h_k) with x widths (C, 16, 32, 64), state widths (8, 16, 32, 64) and map width
-    D_k = pad16(x + h); the encoder convolutions read the same cat buffers (zero weights on the state channels)."""
-    xw, hw = (C, 16, 32, 64), (8, 16, 32, 64)
-    Dk = [pad16(x + h) for x, h in zip(xw, hw)]
+
+    Level k = 1..4: x widths (C, 16, 32, 64) held in maps of width XW = (max(pad16(C), 16), 32, 64, 64), states
+    (8, 16, 32, 64) in maps of width HW = (16, 16, 32, 64).  gate_conv / output_conv act on cat(x, h) and are split by
+    linearity into an x half (+ bias; applied to all planes at once) and an h half (applied per plane):
+    gxr / gxu / cx (width XW) and ghr / ghu / ch (width HW), r = reset rows, u = update rows of gate_conv.
+    conv1-3 at the width of their input map; decoder: upconv3 64, upconv2 32, upconv1 16, upconv2d 16."""
+    xc, hc = (C, 16, 32, 64), (8, 16, 32, 64)
+    XW, HW = (max(pad16(C), 16), 32, 64, 64), (16, 16, 32, 64)
     parts = {}
     for k in range(4):
         g = pre + "conv_gru%d." % (k + 1)
-        parts["gates%d" % (k + 1)] = (pack_padded_dd(sd[g + "gate_conv.weight"], sd[g + "gate_conv.bias"], Dk[k]), Dk[k])
-        parts["cand%d" % (k + 1)] = (pack_padded_dd(sd[g + "output_conv.weight"], sd[g + "output_conv.bias"], Dk[k]), Dk[k])
-        gn = torch.cat([sd[g + n].detach().float().cpu().reshape(-1) for n in (
+        wg, bg = sd[g + "gate_conv.weight"], sd[g + "gate_conv.bias"]
+        wc, bc = sd[g + "output_conv.weight"], sd[g + "output_conv.bias"]
+        cx, h = xc[k], hc[k]
+        n = str(k + 1)
+        parts["gxr" + n] = (pack_padded_dd(wg[:h, :cx], bg[:h], XW[k]), XW[k])
+        parts["gxu" + n] = (pack_padded_dd(wg[h:, :cx], bg[h:], XW[k]), XW[k])
+        parts["cx" + n] = (pack_padded_dd(wc[:, :cx], bc, XW[k]), XW[k])
+        parts["ghr" + n] = (pack_padded_dd(wg[:h, cx:], None, HW[k]), HW[k])
+        parts["ghu" + n] = (pack_padded_dd(wg[h:, cx:], None, HW[k]), HW[k])
+        parts["ch" + n] = (pack_padded_dd(wc[:, cx:], None, HW[k]), HW[k])
+        gn = torch.cat([sd[g + m].detach().float().cpu().reshape(-1) for m in (
             "reset_gate_norm.weight", "reset_gate_norm.bias", "update_gate_norm.weight", "update_gate_norm.bias",
             "output_norm.weight", "output_norm.bias")])
-        parts["gn%d" % (k + 1)] = (gn, hw[k])
-    for k in range(3):                          # conv_{k+1}: level k+1 -> level k+2, stride 2, on the cat buffer of its input
-        parts["conv%d" % (k + 1)] = (pack_padded_dd(sd[pre + "conv%d.conv.weight" % (k + 1)], None, Dk[k]), Dk[k])
-    # decoder: upconv3 64 -> 32 (width 64), upconv2 32 -> 16 (width 32), upconv1 16 -> 8 (width 16), upconv2d 8 -> 1 (width 16)
+        parts["gn" + n] = (gn, h)
+    for k in range(3):                          # conv_{k+1}: level k+1 -> level k+2, stride 2
+        parts["conv%d" % (k + 1)] = (pack_padded_dd(sd[pre + "conv%d.conv.weight" % (k + 1)], None, XW[k]), XW[k])
     for name, D in (("upconv3", 64), ("upconv2", 32), ("upconv1", 16)):
         parts[name] = (pack_padded_dd(sd[pre + name + ".conv.weight"], None, D, transposed=True), D)
     parts["upconv2d"] = (pack_padded_dd(sd[pre + "upconv2d.weight"], sd[pre + "upconv2d.bias"], 16, flip=True), 16)

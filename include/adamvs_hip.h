@@ -223,27 +223,29 @@ int adamvs_red_variance_cost(const float* feat, const float* rt, const float* pl
 int adamvs_channel_copy(const float* src, float* dst, int nbatch, int npix, int n, long src_batch_stride,
                         int src_pix_stride, int src_c0, long dst_batch_stride, int dst_pix_stride, int dst_c0, void* stream);
 
-/* nn.GroupNorm(1, n) statistics (module.py:63-68): for g < ngroups, over channels [c0 + g*n, c0 + (g+1)*n) and all
- * pixels of sample b: stats[b][g] = {mean, 1/sqrt(biased var + eps)}.  Deterministic (fixed partial ranges, double
- * accumulation). */
+/* nn.GroupNorm(1, HC) statistics (module.py:63-68), in two deterministic halves.  _partial: for map g in {x0, x1}
+ * (x1 may be NULL), over channels [0, n) and fixed pixel ranges of sample b: double-precision partial sums into
+ * `partials` (adamvs_group_stats_workspace_bytes(N, ngroups)).  The two epilogues below finish the reduction
+ * themselves; _finish does it standalone: stats[b][g] = {mean, 1/sqrt(biased var + eps)}, count = npix * n. */
 size_t adamvs_group_stats_workspace_bytes(int N, int ngroups);
-int adamvs_group_stats(const float* x, float* stats, int N, int npix, int D, int c0, int n, int ngroups, float eps,
-                       void* workspace, size_t workspace_bytes, void* stream);
+int adamvs_group_stats_partial(const float* x0, const float* x1, int N, int npix, int D, int n, void* partials,
+                               size_t partials_bytes, void* stream);
+int adamvs_group_stats_finish(const void* partials, float* stats, int N, int ngroups, int count, float eps, void* stream);
 
-/* ConvGRUCell2.gates + the reset product, module.py:72-92.  f [N][npix][D] = gate_conv(cat(x, h)) with reset rows
- * [0,HC) and update rows [HC,2HC); stats [N][2][2] from adamvs_group_stats(f, c0 = 0, n = HC, ngroups = 2);
- * gn [4][HC] = reset_gate_norm weight, bias, update_gate_norm weight, bias; a [N][npix][D] = cat(x, h) (h at channels
- * [Cx, Cx+HC)).  Writes r*h into channels [Cx, Cx+HC) of xr [N][npix][D] -- xr may be a itself: cat(x, h) then
- * becomes cat(x, r*h) in place -- and u [N][npix][HC]. */
-int adamvs_gru2_gates_apply(const float* f, const float* stats, const float* gn, const float* a, float* xr, float* u,
-                            int N, int npix, int D, int Cx, int HC, void* stream);
+/* ConvGRUCell2.gates + the reset product, module.py:72-92.  The gate convolution is linear in cat(x, h):
+ * gate_conv(cat(x, h)) = Wx.x + Wh.h + b, and so is the output convolution.  The x halves do not depend on the state
+ * and are computed for all planes at once; per plane only the h halves remain, with the x halves added through the
+ * `skip` operand of adamvs_conv3x3_dd.  fr, fu [N][npix][W]: reset / update halves (HC real channels each);
+ * partials from adamvs_group_stats_partial(fr, fu); gn [4][HC] = reset_gate_norm weight, bias, update_gate_norm
+ * weight, bias; h [N][npix][W] the state.  -> rh = sigmoid(GN(fr)) * h [N][npix][W], u = sigmoid(GN(fu)) [N][npix][HC]. */
+int adamvs_gru2_gates_apply(const float* fr, const float* fu, const void* partials, const float* gn, const float* h,
+                            float* rh, float* u, int N, int npix, int W, int HC, float eps, void* stream);
 
-/* ConvGRUCell2.output + forward, module.py:91-106.  o [N][npix][D] = output_conv(cat(x, r*h)) rows [0,HC);
- * stats [N][2]; gn [2][HC] = output_norm weight, bias; h [N][npix][HC] the state, replaced by
- * h' = u*h + (1-u)*tanh(GN(o)).  h' is also written to channels [c2, c2+HC) of out2 [N][npix][D2] and
- * [c3, c3+HC) of out3 [N][npix][D3] when those are not NULL (the next plane's cat buffer; the decoder's input). */
-int adamvs_gru2_out_apply(const float* o, const float* stats, const float* gn, const float* u, float* h, float* out2,
-                          int D2, int c2, float* out3, int D3, int c3, int N, int npix, int D, int HC, void* stream);
+/* ConvGRUCell2.output + forward, module.py:91-106.  o [N][npix][W] = output_conv(cat(x, r*h)) (HC real channels);
+ * partials from adamvs_group_stats_partial(o, NULL); gn [2][HC] = output_norm weight, bias.
+ * h' = u*h + (1-u)*tanh(GN(o)) replaces h [N][npix][W] and goes to channels [0, HC) of out [N][npix][Wo] (may be NULL). */
+int adamvs_gru2_out_apply(const float* o, const void* partials, const float* gn, const float* u, float* h, float* out,
+                          int Wo, int N, int npix, int W, int HC, float eps, void* stream);
 
 /* The running exp-sum / max / weighted-depth update of msrednet.py:415-436 (same as adamvs.py:512-531) in one pass over
  * the stored slices: vol [B][D][h*w] = reg_cost of every plane, planes [B][D][h*w] -> depth, confidence [B][h*w]. */

@@ -110,15 +110,46 @@ def _nchw(x_cl, h, w):
 def test_group_stats_against_torch():
     from ada_mvs_amd import hip_ops
     g = torch.Generator().manual_seed(5)
-    x = (torch.randn(3, 37 * 11, 48, generator=g) * 2 + 0.7).cuda()
-    stats = torch.zeros(3, 2, 2, device="cuda")
-    hip_ops.group_stats(x, 16, 12, 2, stats, hip_ops.group_stats_workspace(3, 2, x.device))
-    for gi in range(2):
-        part = x[:, :, 16 + 12 * gi:16 + 12 * (gi + 1)].double()
-        mean = part.mean(dim=(1, 2))
-        rstd = 1.0 / torch.sqrt(part.var(dim=(1, 2), unbiased=False) + 1e-5)
+    x0 = (torch.randn(3, 37 * 11, 48, generator=g) * 2 + 0.7).cuda()
+    x1 = (torch.randn(3, 37 * 11, 48, generator=g) * 0.3 - 1.1).cuda()
+    part = hip_ops.group_stats_workspace(3, 2, x0.device)
+    hip_ops.group_stats_partial(x0, x1, 12, part)
+    stats = hip_ops.group_stats_finish(part, 3, 2, 37 * 11 * 12)
+    for gi, x in enumerate((x0, x1)):
+        sel = x[:, :, :12].double()
+        mean = sel.mean(dim=(1, 2))
+        rstd = 1.0 / torch.sqrt(sel.var(dim=(1, 2), unbiased=False) + 1e-5)
         assert torch.allclose(stats[:, gi, 0].double(), mean, rtol=1e-6, atol=1e-6)
         assert torch.allclose(stats[:, gi, 1].double(), rstd, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gru_cell2_against_reference_golden():
+    """One ConvGRUCell2 (x 16, h 16 channels) through the split convolutions and the two fused epilogues."""
+    from ada_mvs_amd import hip_ops, packing
+    g = gold("msred_gru_cell")
+    sd = cell_state_dict()
+    x, h0 = g["x"], g["h"]
+    B, _, hh, ww = x.shape
+    dev = torch.device("cuda:0")
+    wg, bg, wc, bc = sd["gate_conv.weight"], sd["gate_conv.bias"], sd["output_conv.weight"], sd["output_conv.bias"]
+    pk = lambda w, b: packing.pack_padded_dd(w, b, 16).to(dev)          # noqa: E731
+    conv = lambda inp, p, skip: hip_ops.conv3x3_dd(inp, p[:9 * 256], p[9 * 256:], skip, B, 16, hh, ww, 0, False)   # noqa: E731
+    xm, state = _cl(x), _cl(h0)
+    fr = conv(state, pk(wg[:16, 16:], None), conv(xm, pk(wg[:16, :16], bg[:16]), None))
+    fu = conv(state, pk(wg[16:, 16:], None), conv(xm, pk(wg[16:, :16], bg[16:]), None))
+    part = hip_ops.group_stats_workspace(B, 2, dev)
+    hip_ops.group_stats_partial(fr, fu, 16, part)
+    gn = torch.cat([sd[k].reshape(-1) for k in ("reset_gate_norm.weight", "reset_gate_norm.bias", "update_gate_norm.weight",
+                                                "update_gate_norm.bias", "output_norm.weight", "output_norm.bias")]).to(dev)
+    rh, u = torch.zeros_like(state), torch.zeros(B, hh * ww, 16, device=dev)
+    hip_ops.gru2_gates_apply(fr, fu, part, gn, state, rh, u, 16)
+    o = conv(rh, pk(wc[:, 16:], None), conv(xm, pk(wc[:, :16], bc), None))
+    hip_ops.group_stats_partial(o, None, 16, part)
+    out = torch.zeros(B, hh * ww, 32, device=dev)
+    hip_ops.gru2_out_apply(o, part, gn[64:], u, state, out, 16)
+    assert rel_l1(_nchw(state, hh, ww), g["out"]) < OP_TOL
+    assert rel_l1(_nchw(out[:, :, :16].contiguous(), hh, ww), g["out"]) < OP_TOL and bool((out[:, :, 16:] == 0).all())
 
 
 @pytest.mark.gpu
@@ -146,7 +177,6 @@ def test_variance_cost_against_oracle(baseline):
 @pytest.mark.parametrize("concurrent", [False, True])
 def test_slice_red_steps_against_reference_golden(concurrent):
     """Two consecutive planes through encoder / four recurrences / decoder: reg_cost and all four states."""
-    from ada_mvs_amd import packing
     from ada_mvs_amd.models.msrednet import slice_RED_Regularization
     g = gold("msred_slice_step")
     net = slice_RED_Regularization(32, 8)
@@ -156,26 +186,16 @@ def test_slice_red_steps_against_reference_golden(concurrent):
     dev = torch.device("cuda:0")
     net.packed(dev)
     B, C, h, w = g["cost0"].shape
-    xw, dk = net.widths()
-    # encode() minus the variance kernel: the fixture holds the cost itself
-    X = [torch.zeros(2 * B, (h >> k) * (w >> k), dk[k], device=dev) for k in range(4)]
+    X0 = torch.zeros(2 * B, h * w, net.x_widths()[0], device=dev)       # what cost_maps() produces, from the fixture's cost
     for step in range(2):
-        X[0][step * B:(step + 1) * B, :, :C] = -_cl(g["cost%d" % step])
-    from ada_mvs_amd import hip_ops
-    for k in (1, 2, 3):
-        wk, bk = net._w("conv%d" % k)
-        e = hip_ops.conv3x3_dd(X[k - 1], wk, bk, None, 2 * B, dk[k - 1], h >> (k - 1), w >> (k - 1), 1, True)
-        hip_ops.channel_copy(e, 0, X[k], 0, xw[k])
-    R = [torch.zeros(2 * B, X[k].shape[1], net.RW[k], device=dev) for k in range(4)]
-    for k in range(4):
-        net.recur_level(k, X[k], R[k], B, h, w)
-    fin = net.decode(R, B, h, w)
+        X0[step * B:(step + 1) * B, :, :C] = -_cl(g["cost%d" % step])
+    fin, R = net.regularize_maps(X0, B, h, w)
     torch.cuda.synchronize()
     for step in range(2):
         reg = fin[step * B:(step + 1) * B, :, 0].reshape(B, 1, h, w).cpu()
         assert rel_l1(reg, g["reg%d" % step]) < OP_TOL
         for k in range(4):
-            state = _nchw(R[k][step * B:(step + 1) * B, :, :net.HW[k]].contiguous(), h >> k, w >> k)
+            state = _nchw(R[k][step * B:(step + 1) * B, :, :net.HC[k]].contiguous(), h >> k, w >> k)
             assert rel_l1(state, g["state%d_%d" % (k + 1, step)]) < OP_TOL, "state %d step %d" % (k + 1, step)
 
 
