@@ -12,6 +12,7 @@
 // straight from L2 into VGPRs (each wave owns different output channels, so
 // there is nothing to share through LDS); activations go through a planar LDS
 // tile shared by the block's four waves.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -361,7 +362,113 @@ bool costreg_depth_supported(int D) {
   return D == 16 || D == 32 || D == 48 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-1 layer on a SMALL grid (the deep GRU levels of MS-REDNet: 64 channels on 12x24 ... 48x96 maps, one
+// convolution at a time in a recurrence).  An 8 x 16 output tile of k_conv_dd at D = 64 is 9.4 MFLOP = 37k cycles
+// of fp32 MFMA on one CU (measured 27 us per launch whatever the map size) while a 12 x 24 map has three such tiles:
+// 250 CUs idle.  Here a workgroup takes TR = 1..8 output rows x 16 columns, TR chosen at launch so that the grid
+// covers the chip, and everything is requested once: each wave owns one tile of 16 output channels and keeps all its
+// A fragments in registers (9 * D/4 <= 144 VGPRs), the (TR+2) x 18 window of all D input channels goes to LDS in one
+// round of loads, and what follows is MFMAs fed from LDS.  Same fragment layout, planar LDS layout and epilogue as
+// k_conv_dd.  D = 32: two waves per channel tile (NTR rows each, TR = 2 NTR); D = 64: one (TR = NTR).
+template <int D, int NTR>
+__global__ __launch_bounds__(256) void k_conv_dd_resident(ConvDDArgs a) {
+  constexpr int WM = D / 16, WN = 4 / WM, TR = NTR * WN, KCT = D / 4, NTILES = D / 16;
+  constexpr int LR = TR + 2, LC = 18, PLANE = plane_pitch16(LR * LC);
+  constexpr int NITEMS = LR * LC * KCT, NIT = (NITEMS + 255) / 256;
+  __shared__ float lds[D * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int p = lane & 15, q = lane >> 4;
+  const int n = blockIdx.z, r0 = blockIdx.y * TR, c0 = blockIdx.x * 16;
+  const int iy0 = r0 - 1, ix0 = c0 - 1;
+
+  // all loads of the block, back to back: A fragments of the wave's channel tile, then the input window
+  const buf_rsrc rw = make_rsrc(a.wpk);
+  float wf[9][KCT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kc = 0; kc < KCT; ++kc)
+      wf[t][kc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+          rw, (unsigned)(lane * 4), (unsigned)(((t * KCT + kc) * NTILES + wm) * 256), 0));
+  const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
+  f32x4 xs[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = min(tid + it * 256, NITEMS - 1);
+    const int g = i % KCT, pp = i / KCT, r = pp / LC, c = pp % LC;
+    const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi;
+    xs[it] = buf_load4(rx, ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = min(tid + it * 256, NITEMS - 1);
+    const int g = i % KCT, pp = i / KCT;
+    float* d = lds + 4 * g * PLANE + pp;
+    d[0] = xs[it].x; d[PLANE] = xs[it].y; d[2 * PLANE] = xs[it].z; d[3 * PLANE] = xs[it].w;
+  }
+  __syncthreads();
+
+  f32x4 acc[NTR];
+#pragma unroll
+  for (int r = 0; r < NTR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* xb = lds + q * PLANE + (wn * NTR) * LC + p;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kc = 0; kc < KCT; ++kc)
+#pragma unroll
+      for (int r = 0; r < NTR; ++r)
+        acc[r] = mfma16(wf[t][kc], xb[4 * kc * PLANE + (r + t / 3) * LC + t % 3], acc[r]);
+
+  const int co4 = wm * 16 + 4 * q;
+  const f32x4 bias = *(const f32x4*)(a.bias + co4);
+#pragma unroll
+  for (int r = 0; r < NTR; ++r) {
+    const int oy = r0 + wn * NTR + r, ox = c0 + p;
+    if (oy >= a.ho || ox >= a.wo) continue;
+    const size_t opix = ((size_t)n * a.ho + oy) * a.wo + ox;
+    f32x4 v = acc[r] + bias;
+    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (a.skip) v += *(const f32x4*)(a.skip + opix * D + co4);
+    *(f32x4*)(a.out + opix * D + co4) = v;
+  }
+}
+
+static int small_grid_limit() {          // workgroups up to which the resident form is used (0 disables it)
+  static int limit = -1;
+  if (limit < 0) {
+    const char* e = getenv("ADAMVS_CONV_SMALL_GRID");
+    limit = e ? atoi(e) : 1024;
+  }
+  return limit;
+}
+
+template <int D, int NTR>
+static int launch_conv_dd_resident_rows(const ConvDDArgs& a, int N, hipStream_t st) {
+  constexpr int TR = NTR * (4 / (D / 16));
+  hipLaunchKernelGGL((k_conv_dd_resident<D, NTR>), dim3(cdiv(a.wo, 16), cdiv(a.ho, TR), N), dim3(256), 0, st, a);
+  ADAMVS_CHECK_LAUNCH("conv_dd (resident)");
+  return 0;
+}
+
+// the fewest rows per workgroup (most workgroups) that stays within the limit; -1: grid too large for this form
+template <int D>
+static int launch_conv_dd_resident(const ConvDDArgs& a, int N, hipStream_t st) {
+  constexpr int WN = 4 / (D / 16);
+  const long cols = (long)cdiv(a.wo, 16) * N, limit = small_grid_limit();
+  if (cols * cdiv(a.ho, 1 * WN) <= limit) return launch_conv_dd_resident_rows<D, 1>(a, N, st);
+  if (cols * cdiv(a.ho, 2 * WN) <= limit) return launch_conv_dd_resident_rows<D, 2>(a, N, st);
+  if (cols * cdiv(a.ho, 4 * WN) <= limit) return launch_conv_dd_resident_rows<D, 4>(a, N, st);
+  return -1;
+}
+
 static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
+  if (mode == CONV_S1 && (a.D == 32 || a.D == 64)) {
+    const int rc = a.D == 32 ? launch_conv_dd_resident<32>(a, N, st) : launch_conv_dd_resident<64>(a, N, st);
+    if (rc >= 0) return rc;
+  }
   switch (a.D) {
     case 16: return launch_conv_dd_cfg<1, 1>(a, N, mode, st);
     case 32: return launch_conv_dd_cfg<2, 1>(a, N, mode, st);

@@ -251,3 +251,22 @@ def test_cpu_tensors_raise():
     from ada_mvs_amd._lib import AdaMVSHipError
     with pytest.raises(AdaMVSHipError, match="MI355X"):
         m(imgs, proj, dv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,h,w,relu", [(64, 12, 24, False), (64, 20, 36, True), (32, 6, 10, False), (32, 48, 96, True),
+                                        (64, 48, 96, False)])
+def test_conv3x3_dd_small_grid_form_against_torch(D, h, w, relu):
+    """adamvs_conv3x3_dd on few workgroups takes the register/LDS-resident kernel: same results as the streaming one."""
+    from ada_mvs_amd import hip_ops, packing
+    g = torch.Generator().manual_seed(D + h)
+    N = 2
+    wt = torch.randn(D, D, 3, 3, generator=g) * (2.0 / (9 * D)) ** 0.5
+    bias = torch.randn(D, generator=g) * 0.1
+    x = torch.randn(N, D, h, w, generator=g)
+    skip = torch.randn(N, D, h, w, generator=g)
+    want = torch.nn.functional.conv2d(x, wt, bias, padding=1)
+    want = (torch.relu(want) if relu else want) + skip
+    pk = packing.pack_reg_layer(wt, torch.ones(D), bias, False).cuda()
+    got = hip_ops.conv3x3_dd(_cl(x), pk[:9 * D * D], pk[9 * D * D:], _cl(skip), N, D, h, w, 0, relu)
+    assert rel_l1(_nchw(got, h, w), want) < 1e-5
