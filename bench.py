@@ -173,6 +173,89 @@ def cpu_baseline(cfg, sd):
                       "(grid_sample form of the warp, as the reference issues it)" % (cfg, dt)}
 
 
+# ---- the sibling model: not the headline, selected with --model msrednet ---------------
+def msrednet_flops(views, H, W, ndepths):
+    """Convolution flops of one map through slice_RED_Regularization (reference models/msrednet.py:330-366), real channels."""
+    total = 0.0
+    for s, (scale, C) in enumerate(((4, 32), (2, 16), (1, 8))):
+        hw = (H // scale) * (W // scale)
+        x, hc = (C, 16, 32, 64), (8, 16, 32, 64)
+        per_plane = 0.0
+        for k in range(4):
+            px = hw / 4 ** k
+            per_plane += 2 * 9 * (x[k] + hc[k]) * 3 * hc[k] * px                 # gate_conv (2 hc rows) + output_conv
+            if k < 3:
+                per_plane += 2 * 9 * x[k] * x[k + 1] * px / 4                     # conv_{k+1}, stride 2
+                per_plane += 2 * 9 * hc[k + 1] * hc[k] * px / 4                   # upconv_{k+1}, per input position
+        per_plane += 2 * 9 * 8 * 1 * hw                                           # upconv2d
+        total += ndepths[s] * per_plane
+    return total
+
+
+def bench_msrednet(args):
+    """One JSON line for Infer_CascadeREDNet on --red-batch synthetic tiles per step (same line format, single GPU)."""
+    from ada_mvs_amd.models.msrednet import Infer_CascadeREDNet
+    c = synth.CONFIGS[args.workload]
+    nd = c["ndepths"] if len(c["ndepths"]) == 3 else [48, 32, 8]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    m = Infer_CascadeREDNet(c["num_depth"], nd, synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    B = args.red_batch
+    imgs, proj, dv = synth.tile_inputs(dict(c, ndepths=nd), batch=B, seed=0)
+    imgs, dv = imgs.to(dev), dv.to(dev)
+    proj = {k: v.to(dev) for k, v in proj.items()}
+    interval = (synth.DEPTH_RANGE[1] - synth.DEPTH_RANGE[0]) / c["num_depth"]
+    with torch.no_grad():
+        maps, shapes = m.extract_features(imgs)
+        m.infer_from_features(maps, shapes, proj, dv, interval)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.infer_from_features(maps, shapes, proj, dv, interval)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(g):
+            m.infer_from_features(maps, shapes, proj, dv, interval)
+        for _ in range(args.warmup):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+    flops = B * msrednet_flops(c["views"], c["H"], c["W"], nd)
+    ach = flops / dt / 1e12
+    result = {"metric": "depth maps/s", "value": B / dt, "unit": "depth maps/s", "n_gpus": 1, "steps": args.steps,
+              "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "msrednet (Infer_CascadeREDNet), %s shape: %d views, %dx%d, hypotheses %s, fp32" % (
+                  args.workload, c["views"], c["W"], c["H"], "/".join(map(str, nd))), "tiles_per_gpu_per_step": B,
+                  "launch": "hipGraph replay, four level recurrences as parallel branches"},
+              "roofline": {"kernel": "all convolutions of slice_RED_Regularization (k_conv_dd / k_conv_dd_resident)",
+                           "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "note": "%d planes x 4 levels x 7 dependent launches on maps down to %dx%d: latency-bound, see DESIGN.md"
+                                   % (sum(nd), c["H"] // 32, c["W"] // 32)}}
+    if not args.no_cpu_baseline:
+        from oracle import msrednet_oracle as MO       # checker / baseline only
+        sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
+        threads = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(threads)
+        ci, cp, cd = synth.tile_inputs(dict(c, ndepths=nd), batch=1, seed=0)
+        with torch.no_grad(), MO.ao.use_grid_sample():
+            t0 = time.time()
+            MO.infer_cascade_rednet_forward(ci, cp, cd, sd_cpu, c["num_depth"], nd, synth.DEPTH_INTERVALS_RATIO)
+            cdt = time.time() - t0
+        result["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "depth maps/s", "cores": threads, "kind": "port",
+                                  "sample": "1 tile, images to maps, %.1f s, oracle/msrednet_oracle.py" % cdt}
+    print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +269,13 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--red-batch", type=int, default=1, help="--model msrednet: tiles per step")
+    ap.add_argument("--model", default="adamvs", choices=["adamvs", "msrednet"],
+                    help="adamvs: the headline path; msrednet: the sibling model (SURVEY.md 8f row f3), --red-batch tiles per step, 1 GPU")
     args = ap.parse_args()
+    if args.model == "msrednet":
+        _lib.load()
+        return bench_msrednet(args)
 
     rank, world, local = adist.init_from_env()
     if world != args.gpus and rank == 0:
