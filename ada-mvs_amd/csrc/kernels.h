@@ -30,6 +30,8 @@ int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBu
 // after an even step of the split-bf16 path, whose fused level-1 kernel alternates the two)
 int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers& sb, float* vol, int B, int h, int w, int D,
                       int d, int in_up, int precision, hipStream_t st, float** h1_now = nullptr);
+int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias, float* out,
+                     int cout, int B, int h, int w, hipStream_t st);
 int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,
                        int in_up, hipStream_t st);
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,

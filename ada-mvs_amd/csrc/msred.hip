@@ -117,12 +117,13 @@ __global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ 
   }
 }
 
-// gates (module.py:72-92): fr / fu = the reset / update halves of gate_conv(cat(x, h)), both W-wide maps with HC real
-// channels; r = sigmoid(GN(fr)), u = sigmoid(GN(fu)); rh = r * h (W-wide, HC real), u out [N][npix][HC].
+// gates (module.py:72-92): fr / fu = the reset / update halves of gate_conv(cat(x, h)), Wf-wide maps with HC real
+// channels (two maps, or the two halves of one); r = sigmoid(GN(fr)), u = sigmoid(GN(fu)); rh = r * h (h, rh W-wide,
+// HC real), u out [N][npix][HC].
 // grid (blocks over npix * HC/4, N).
 __global__ void k_gru2_gates_apply(const float* __restrict__ fr, const float* __restrict__ fu, const double* __restrict__ part,
                                    const float* __restrict__ gn, const float* __restrict__ h, float* __restrict__ rh,
-                                   float* __restrict__ u, int npix, int W, int HC, float eps) {
+                                   float* __restrict__ u, int npix, int Wf, int W, int HC, float eps) {
   __shared__ float st[2][2];
   const int b = blockIdx.y;
   gn_finish(part, b, 2, npix * HC, eps, st);
@@ -131,7 +132,7 @@ __global__ void k_gru2_gates_apply(const float* __restrict__ fr, const float* __
   if (i >= npix * G) return;
   const int c = 4 * (i % G);
   const size_t bp = (size_t)b * npix + i / G;
-  const f32x4 a = *(const f32x4*)(fr + bp * W + c), v = *(const f32x4*)(fu + bp * W + c);
+  const f32x4 a = *(const f32x4*)(fr + bp * Wf + c), v = *(const f32x4*)(fu + bp * Wf + c);
   const f32x4 gr = *(const f32x4*)(gn + c), br = *(const f32x4*)(gn + HC + c);
   const f32x4 gu = *(const f32x4*)(gn + 2 * HC + c), bu = *(const f32x4*)(gn + 3 * HC + c);
   const f32x4 rn = (a - st[0][0]) * st[0][1] * gr + br, un = (v - st[1][0]) * st[1][1] * gu + bu;
@@ -219,12 +220,13 @@ extern "C" int adamvs_group_stats_finish(const void* partials, float* stats, int
   return 0;
 }
 
-extern "C" int adamvs_gru2_gates_apply(const float* fr, const float* fu, const void* partials, const float* gn, const float* h,
-                                       float* rh, float* u, int N, int npix, int W, int HC, float eps, void* stream) {
-  ADAMVS_CHECK_ARG(fr && fu && partials && gn && h && rh && u && N > 0 && npix > 0 && (HC % 4) == 0 && (W % 4) == 0 && HC <= W,
-                   "gru2_gates_apply: bad arguments (W=%d HC=%d)", W, HC);
+extern "C" int adamvs_gru2_gates_apply(const float* fr, const float* fu, int Wf, const void* partials, const float* gn,
+                                       const float* h, float* rh, float* u, int N, int npix, int W, int HC, float eps,
+                                       void* stream) {
+  ADAMVS_CHECK_ARG(fr && fu && partials && gn && h && rh && u && N > 0 && npix > 0 && (HC % 4) == 0 && (W % 4) == 0 && HC <= W &&
+                   (Wf % 4) == 0 && HC <= Wf, "gru2_gates_apply: bad arguments (Wf=%d W=%d HC=%d)", Wf, W, HC);
   hipLaunchKernelGGL(k_gru2_gates_apply, dim3(cdiv(npix * (HC / 4), 256), N), dim3(256), 0, (hipStream_t)stream, fr, fu,
-                     (const double*)partials, gn, h, rh, u, npix, W, HC, eps);
+                     (const double*)partials, gn, h, rh, u, npix, Wf, W, HC, eps);
   ADAMVS_CHECK_LAUNCH("gru2_gates_apply");
   return 0;
 }
@@ -237,6 +239,13 @@ extern "C" int adamvs_gru2_out_apply(const float* o, const void* partials, const
                      (const double*)partials, gn, u, h, out, npix, W, HC, Wo, eps);
   ADAMVS_CHECK_LAUNCH("gru2_out_apply");
   return 0;
+}
+
+extern "C" int adamvs_conv3x3_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias,
+                                   float* out, int cout, int B, int h, int w, void* stream) {
+  ADAMVS_CHECK_ARG(srcA && srcB && wpk && bias && out && B > 0 && h > 0 && w > 0 && cout > 0 && (cout % 4) == 0,
+                   "conv3x3_pair: bad arguments (B=%d h=%d w=%d cout=%d)", B, h, w, cout);
+  return launch_conv_pair(srcA, CA, srcB, CB, wpk, bias, out, cout, B, h, w, (hipStream_t)stream);
 }
 
 extern "C" int adamvs_soft_argmin(const float* vol, const float* planes, float* depth, float* confidence, int B, int D, int h,

@@ -14,7 +14,7 @@
 
 namespace adamvs {
 
-enum { EPI_RELU = 0, EPI_GATES = 1, EPI_CAND = 2 };
+enum { EPI_RELU = 0, EPI_GATES = 1, EPI_CAND = 2, EPI_LINEAR = 3 };   // LINEAR: out = conv + bias (MS-REDNet cells)
 
 struct SmallConvArgs {
   const float* srcA;   // [B][hi*wi][CA]
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a, TileGrid tg
     pin(hbyte[nt]);
   }
   // output offsets (bytes) of the lane's pixel inside the tile, per 16-channel slice
-  const int CO = (EPI == EPI_RELU) ? a.cout : HC;
+  const int CO = (EPI == EPI_RELU || EPI == EPI_LINEAR) ? a.cout : HC;
   // ooff: destination 0 (RELU out, GATES r*h, CAND h); ooff1: destination 1 (GATES u).  Rows that do not
   // belong to a destination carry BUF_OOB, so every store is issued by all lanes with one uniform descriptor.
   unsigned ooff[NT], ooff1[NT];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a, TileGrid tg
   for (int nt = 0; nt < NT; ++nt) {
     const int co4 = nt * 16 + 4 * q;
     const unsigned at = (unsigned)(((row * a.wo + col + p) * CO + (EPI == EPI_GATES && co4 >= HC ? co4 - HC : co4)) * 4);
-    const bool to0 = (EPI == EPI_RELU) ? co4 < a.cout : co4 < HC;
+    const bool to0 = (EPI == EPI_RELU || EPI == EPI_LINEAR) ? co4 < a.cout : co4 < HC;
     const bool to1 = EPI == EPI_GATES && co4 >= HC && co4 < 2 * HC;
     ooff[nt] = to0 ? at : BUF_OOB;
     ooff1[nt] = to1 ? at : BUF_OOB;
@@ -203,6 +203,8 @@ __global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a, TileGrid tg
       f32x4 v = acc[nt] + bias[nt];
       if (EPI == EPI_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        buf_store4(r0, oo[nt], v);
+      } else if (EPI == EPI_LINEAR) {
         buf_store4(r0, oo[nt], v);
       } else if (EPI == EPI_GATES) {
         f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
@@ -811,6 +813,21 @@ static int launch_conv1_c(const float* cost, const float* w, float* c1, int N, i
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, cost, w, c1, h, w_, tg);
   ADAMVS_CHECK_LAUNCH("conv1");
   return 0;
+}
+
+// out = conv3x3(cat(srcA, srcB)) + bias on compact channel-last maps (the ConvGRUCell2 convolutions of MS-REDNet's two
+// shallow levels: gate_conv / output_conv of reference models/module.py:62-67 before their GroupNorm)
+int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias, float* out,
+                     int cout, int B, int h, int w, hipStream_t st) {
+  SmallConvArgs a{srcA, srcB, wpk, bias, out, nullptr, h, w, h, w, cout};
+  if (CB == 8 && cout <= 16) {
+    if (CA == 32) return launch_small<32, 8, 1, 1, EPI_LINEAR>(a, B, st, "conv_pair");
+    if (CA == 16) return launch_small<16, 8, 1, 1, EPI_LINEAR>(a, B, st, "conv_pair");
+    if (CA == 8) return launch_small<8, 8, 1, 1, EPI_LINEAR>(a, B, st, "conv_pair");
+  }
+  if (CA == 16 && CB == 16 && cout <= 16) return launch_small<16, 16, 1, 1, EPI_LINEAR>(a, B, st, "conv_pair");
+  if (CA == 16 && CB == 16 && cout <= 32) return launch_small<16, 16, 2, 1, EPI_LINEAR>(a, B, st, "conv_pair");
+  return set_error(-1, "conv3x3_pair: (CA=%d, CB=%d, cout=%d) unsupported: (32|16|8, 8, <=16) or (16, 16, <=32)", CA, CB, cout);
 }
 
 int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int precision, hipStream_t st) {

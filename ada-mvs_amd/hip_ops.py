@@ -301,8 +301,9 @@ def group_stats_workspace(N, ngroups, device):
 
 
 def group_stats_partial(x0, x1, n, partials):
-    """Partial sums for GroupNorm(1 group) over channels [0, n) of x0 (and x1): consumed by the gru2_* epilogues."""
-    N, npix, D = x0.shape
+    """Partial sums for GroupNorm(1 group) over channels [0, n) of x0 (and x1; views into a wider map are fine: the
+    pixel stride is what counts): consumed by the gru2_* epilogues."""
+    N, npix, D = x0.shape[0], x0.shape[1], x0.stride(1)
     check(_lib.load().adamvs_group_stats_partial(_p(x0), _p(x1) if x1 is not None else ctypes.c_void_p(0), N, npix, D, n,
                                                  _p(partials), partials.numel() * 8, _stream()), "group_stats_partial")
 
@@ -314,9 +315,20 @@ def group_stats_finish(partials, N, ngroups, count, eps=1e-5):
 
 
 def gru2_gates_apply(fr, fu, partials, gn, h, rh, u, HC, eps=1e-5):
-    N, npix, W = fr.shape
-    check(_lib.load().adamvs_gru2_gates_apply(_p(fr), _p(fu), _p(partials), _p(gn), _p(h), _p(rh), _p(u), N, npix, W, HC, eps,
-                                              _stream()), "gru2_gates_apply")
+    """fr / fu: two maps of one width, or views of the two halves of one map (their last-but-one stride is the width)."""
+    N, npix, W = h.shape
+    check(_lib.load().adamvs_gru2_gates_apply(_p(fr), _p(fu), fr.stride(1), _p(partials), _p(gn), _p(h), _p(rh), _p(u), N, npix, W,
+                                              HC, eps, _stream()), "gru2_gates_apply")
+
+
+def conv3x3_pair(a, b, wpk, bias, cout, h, w, out=None):
+    """conv3x3(cat(a, b)) + bias on compact channel-last maps [B, h*w, CA], [B, h*w, CB] -> [B, h*w, cout]."""
+    B = a.shape[0]
+    if out is None:
+        out = torch.empty(B, h * w, cout, device=a.device, dtype=torch.float32)
+    check(_lib.load().adamvs_conv3x3_pair(_p(_dev(a, "a")), a.shape[-1], _p(_dev(b, "b")), b.shape[-1], _p(wpk), _p(bias), _p(out),
+                                          cout, B, h, w, _stream()), "conv3x3_pair")
+    return out
 
 
 def gru2_out_apply(o, partials, gn, u, h, out, HC, eps=1e-5):

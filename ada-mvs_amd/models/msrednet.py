@@ -88,11 +88,12 @@ class slice_RED_Regularization(nn.Module):
     own state and its encoder map, and the decoder (upconv3/2/1, upconv2d) only on the four GRU outputs.  Inside a
     cell both convolutions act on cat(x, .) and are linear, conv(cat(x, h)) = Wx.x + Wh.h + b, so their x halves are
     state-independent as well.  Per stage:
-      A  cost, encoder and the x halves of all gate / candidate convolutions for ALL planes, one batched launch per
-         layer (maps indexed d * B + b),
-      B  four independent recurrences over the planes (one per level, each on its own stream); per plane the h halves
-         of the three convolutions (the x halves enter through the `skip` operand), two GroupNorm reductions and the
-         two fused epilogues,
+      A  cost, encoder and (levels 3, 4) the x halves of the gate / candidate convolutions for ALL planes, one batched
+         launch per layer (maps indexed d * B + b),
+      B  four independent recurrences over the planes (one per level, each on its own stream); per plane: levels 3, 4
+         the h halves of the three convolutions (the x halves enter through the `skip` operand) on the small-grid
+         form of k_conv_dd, levels 1, 2 both convolutions whole on cat(x, h) with register-resident weights
+         (adamvs_conv3x3_pair); two GroupNorm reductions and the two fused epilogues,
       C  the decoder for all planes, one batched launch per layer.
     Channel counts are zero-padded to widths adamvs_conv3x3_dd takes: x maps XW, state maps HW, GRU outputs RW."""
 
@@ -140,6 +141,13 @@ class slice_RED_Regularization(nn.Module):
         o, D = offsets[name]
         return flat[o:o + 9 * D * D], flat[o + 9 * D * D:o + 9 * D * D + D]
 
+    def _wp(self, name, cin):
+        """(A fragments, bias) of a register-resident pair convolution (levels 1 and 2)."""
+        flat, offsets = self._packed
+        o, rows = offsets[name]
+        n = rows * 9 * cin
+        return flat[o:o + n], flat[o + n:o + n + rows]
+
     def _gn(self, k):
         flat, offsets = self._packed
         o, hc = offsets["gn%d" % (k + 1)]
@@ -157,37 +165,51 @@ class slice_RED_Regularization(nn.Module):
         hip_ops.channel_copy(x, 0, out, 0, n)
         return out
 
-    # ---- A: cost, encoder and the x halves of the GRU convolutions for all planes -----------------------------------
+    # ---- A: cost, encoder and the x halves of the deep levels' GRU convolutions for all planes --------------------------
     def cost_maps(self, feat_cl, rt, planes, B, S, h, w):
-        """-> X0 [D*B, h*w, XW0]: the negated variance cost of every plane (plane-major)."""
-        D = planes.shape[1]
-        X0 = torch.zeros(D * B, h * w, self.x_widths()[0], device=feat_cl.device, dtype=torch.float32)
-        hip_ops.red_variance_cost(feat_cl, rt, planes, X0, None, B, S, self.in_channels, D, h, w, negate=True)
-        return X0
+        """-> (X0 [D*B, h*w, XW0], the negated variance cost of every plane (plane-major) at the encoder's width,
+        and the same map compact [D*B, h*w, C] for the level-1 cell -- X0 itself when XW0 == C)."""
+        D, C, xw0 = planes.shape[1], self.in_channels, self.x_widths()[0]
+        X0 = torch.zeros(D * B, h * w, xw0, device=feat_cl.device, dtype=torch.float32)
+        xc = X0 if xw0 == C else torch.empty(D * B, h * w, C, device=feat_cl.device, dtype=torch.float32)
+        hip_ops.red_variance_cost(feat_cl, rt, planes, X0, None if xc is X0 else xc, B, S, C, D, h, w, negate=True)
+        return X0, xc
 
-    def encode(self, X0, h, w):
-        """X0 -> per level k: (gxr, gxu, cx) [D*B, npix_k, HW_k], the x halves (+ bias) of the reset / update / candidate
-        convolutions of ConvGRUCell2 k for every plane."""
+    def encode(self, X0, xc, h, w):
+        """-> per level what its recurrence consumes.  Levels 1, 2 (8/16-channel states at the two largest resolutions):
+        the compact x map [D*B, npix, Cx]; their cells run both convolutions on cat(x, h) with register-resident weights
+        (adamvs_conv3x3_pair).  Levels 3, 4: (gxr, gxu, cx) [D*B, npix, HW_k], the x halves (+ bias) of the reset /
+        update / candidate convolutions for every plane."""
         N = X0.shape[0]
         xw = self.x_widths()
-        xc = (self.in_channels,) + self.XC[1:]
-        X, halves = X0, []
+        xcn = (self.in_channels,) + self.XC[1:]
+        X, feeds = X0, []
         for k in range(4):
             hk, wk = h >> k, w >> k
-            lev = []
-            for name in ("gxr", "gxu", "cx"):
-                wt, bs = self._w("%s%d" % (name, k + 1))
-                lev.append(self._to_width(hip_ops.conv3x3_dd(X, wt, bs, None, N, xw[k], hk, wk, 0, False), self.HC[k], self.HW[k]))
-            halves.append(lev)
+            if k < 2:
+                feeds.append(xc if k == 0 else self._to_width(X, 16, 16))
+            else:
+                lev = []
+                for name in ("gxr", "gxu", "cx"):
+                    wt, bs = self._w("%s%d" % (name, k + 1))
+                    lev.append(self._to_width(hip_ops.conv3x3_dd(X, wt, bs, None, N, xw[k], hk, wk, 0, False), self.HC[k], self.HW[k]))
+                feeds.append(lev)
             if k < 3:                  # conv_{k+1}: stride 2, ReLU; its output is the next level's x
                 wt, bs = self._w("conv%d" % (k + 1))
-                X = self._to_width(hip_ops.conv3x3_dd(X, wt, bs, None, N, xw[k], hk, wk, 1, True), xc[k + 1], xw[k + 1])
-        return halves
+                e = hip_ops.conv3x3_dd(X, wt, bs, None, N, xw[k], hk, wk, 1, True)
+                if k == 0:
+                    feeds_x1 = e       # 16 real channels at width XW0: level 2 reads them compact
+                X = self._to_width(e, xcn[k + 1], xw[k + 1])
+            if k == 1:
+                feeds[1] = self._to_width(feeds_x1, 16, 16)
+        return feeds
 
     # ---- B: one level's recurrence over the planes ----------------------------------------------------------------
-    def recur_level(self, k, halves_k, Rk, B, h, w):
+    def recur_level(self, k, feed, Rk, B, h, w):
         """ConvGRUCell2 of level k (0-based) over the planes; h' of plane d into Rk[d*B:(d+1)*B, :, :HC]."""
-        gxr, gxu, cx = halves_k
+        if k < 2:
+            return self._recur_pair(k, feed, Rk, B, h, w)
+        gxr, gxu, cx = feed
         dev = gxr.device
         W, HC = self.HW[k], self.HC[k]
         npix, hk, wk = gxr.shape[1], h >> k, w >> k
@@ -208,6 +230,29 @@ class slice_RED_Regularization(nn.Module):
             hip_ops.group_stats_partial(o, None, HC, part)
             hip_ops.gru2_out_apply(o, part, gn[4 * HC:], u, state, Rk[sl], HC)
 
+    def _recur_pair(self, k, x, Rk, B, h, w):
+        """Levels 1, 2: gate_conv / output_conv on cat(x_d, h) / cat(x_d, r*h) in one launch each (compact maps)."""
+        dev = x.device
+        HC, Cx = self.HC[k], x.shape[-1]
+        npix, hk, wk = x.shape[1], h >> k, w >> k
+        D = x.shape[0] // B
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)      # noqa: E731
+        state, rh, u, o = z(B, npix, HC), z(B, npix, HC), z(B, npix, HC), z(B, npix, HC)
+        f = z(B, npix, 2 * HC)
+        fu = f[:, :, HC:]                                                   # update rows: a view, pixel stride 2 HC
+        part = hip_ops.group_stats_workspace(B, 2, dev)
+        gn = self._gn(k)
+        wg, bg = self._wp("gp%d" % (k + 1), Cx + HC)
+        wc, bc = self._wp("cp%d" % (k + 1), Cx + HC)
+        for d in range(D):
+            sl = slice(d * B, (d + 1) * B)
+            hip_ops.conv3x3_pair(x[sl], state, wg, bg, 2 * HC, hk, wk, out=f)
+            hip_ops.group_stats_partial(f, fu, HC, part)
+            hip_ops.gru2_gates_apply(f, fu, part, gn, state, rh, u, HC)
+            hip_ops.conv3x3_pair(x[sl], rh, wc, bc, HC, hk, wk, out=o)
+            hip_ops.group_stats_partial(o, None, HC, part)
+            hip_ops.gru2_out_apply(o, part, gn[4 * HC:], u, state, Rk[sl], HC)
+
     # ---- C: decoder for all planes --------------------------------------------------------------------------------
     def decode(self, R, B, h, w):
         """R[k] [D*B, npix_k, RW[k]] (GRU outputs in the leading channels) -> reg_cost of every plane [D*B, h*w, 16] (channel 0)."""
@@ -221,14 +266,15 @@ class slice_RED_Regularization(nn.Module):
         wf, bf = self._w("upconv2d")
         return hip_ops.conv3x3_dd(up1, wf, bf, None, N, 16, h, w, 0, False)
 
-    def regularize_maps(self, X0, B, h, w):
-        """X0 [D*B, h*w, XW0] (-cost of every plane) -> (reg_cost maps [D*B, h*w, 16] (channel 0), R: the GRU outputs)."""
+    def regularize_maps(self, X0, B, h, w, xc=None):
+        """X0 [D*B, h*w, XW0] (-cost of every plane; xc: the same compact, when XW0 != C) -> (reg_cost maps
+        [D*B, h*w, 16] (channel 0), R: the GRU outputs)."""
         if h % 8 or w % 8:
             raise AdaMVSHipError("slice_RED_Regularization: map size %dx%d must be a multiple of 8 (three stride-2 levels)" % (h, w))
         dev = X0.device
         self.packed(dev)
         N = X0.shape[0]
-        halves = self.encode(X0, h, w)
+        halves = self.encode(X0, X0 if xc is None else xc, h, w)
         R = [torch.zeros(N, (h >> k) * (w >> k), self.RW[k], device=dev, dtype=torch.float32) for k in range(4)]
         if self.concurrent_levels:
             if self._streams is None:
@@ -248,7 +294,8 @@ class slice_RED_Regularization(nn.Module):
     def regularize(self, feat_cl, rt, planes, B, S, h, w):
         """All planes of a stage: -> vol [B, D, h*w] of reg_cost (the argument of exp in msrednet.py:415)."""
         self.packed(feat_cl.device)
-        fin, _ = self.regularize_maps(self.cost_maps(feat_cl, rt, planes, B, S, h, w), B, h, w)
+        X0, xc = self.cost_maps(feat_cl, rt, planes, B, S, h, w)
+        fin, _ = self.regularize_maps(X0, B, h, w, xc)
         vol = torch.empty(B, planes.shape[1], h * w, device=feat_cl.device, dtype=torch.float32)
         hip_ops.planes_to_volume(fin, vol, B)
         return vol

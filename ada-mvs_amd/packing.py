@@ -317,7 +317,9 @@ def pack_red_regularization(sd, pre, C):
     (8, 16, 32, 64) in maps of width HW = (16, 16, 32, 64).  gate_conv / output_conv act on cat(x, h) and are split by
     linearity into an x half (+ bias; applied to all planes at once) and an h half (applied per plane):
     gxr / gxu / cx (width XW) and ghr / ghu / ch (width HW), r = reset rows, u = update rows of gate_conv.
-    conv1-3 at the width of their input map; decoder: upconv3 64, upconv2 32, upconv1 16, upconv2d 16."""
+    conv1-3 at the width of their input map; decoder: upconv3 64, upconv2 32, upconv1 16, upconv2d 16.
+    gp / cp (levels 1, 2): gate_conv / output_conv whole, as register-resident A fragments for adamvs_conv3x3_pair,
+    followed by the bias padded to 16 * tiles (the dict's second entry is that padded output count)."""
     xc, hc = (C, 16, 32, 64), (8, 16, 32, 64)
     XW, HW = (max(pad16(C), 16), 32, 64, 64), (16, 16, 32, 64)
     parts = {}
@@ -337,6 +339,12 @@ def pack_red_regularization(sd, pre, C):
             "reset_gate_norm.weight", "reset_gate_norm.bias", "update_gate_norm.weight", "update_gate_norm.bias",
             "output_norm.weight", "output_norm.bias")])
         parts["gn" + n] = (gn, h)
+    for k in range(2):                          # the two shallow levels: both convolutions of the cell on cat(x, h) directly
+        g = pre + "conv_gru%d." % (k + 1)
+        for name, key in (("gp", "gate_conv"), ("cp", "output_conv")):
+            wt = sd[g + key + ".weight"]
+            nt16 = pad16(wt.shape[0])
+            parts["%s%d" % (name, k + 1)] = (torch.cat([pack_small_conv(wt), pad_bias(sd[g + key + ".bias"], nt16)]), nt16)
     for k in range(3):                          # conv_{k+1}: level k+1 -> level k+2, stride 2
         parts["conv%d" % (k + 1)] = (pack_padded_dd(sd[pre + "conv%d.conv.weight" % (k + 1)], None, XW[k]), XW[k])
     for name, D in (("upconv3", 64), ("upconv2", 32), ("upconv1", 16)):

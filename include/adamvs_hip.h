@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 3
+#define ADAMVS_ABI_VERSION 4
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -235,10 +235,11 @@ int adamvs_group_stats_finish(const void* partials, float* stats, int N, int ngr
 /* ConvGRUCell2.gates + the reset product, module.py:72-92.  The gate convolution is linear in cat(x, h):
  * gate_conv(cat(x, h)) = Wx.x + Wh.h + b, and so is the output convolution.  The x halves do not depend on the state
  * and are computed for all planes at once; per plane only the h halves remain, with the x halves added through the
- * `skip` operand of adamvs_conv3x3_dd.  fr, fu [N][npix][W]: reset / update halves (HC real channels each);
+ * `skip` operand of adamvs_conv3x3_dd.  fr, fu [N][npix][Wf]: reset / update halves (HC real channels each; two maps,
+ * or fu = fr + HC inside one 2HC-wide map as adamvs_conv3x3_pair writes it);
  * partials from adamvs_group_stats_partial(fr, fu); gn [4][HC] = reset_gate_norm weight, bias, update_gate_norm
  * weight, bias; h [N][npix][W] the state.  -> rh = sigmoid(GN(fr)) * h [N][npix][W], u = sigmoid(GN(fu)) [N][npix][HC]. */
-int adamvs_gru2_gates_apply(const float* fr, const float* fu, const void* partials, const float* gn, const float* h,
+int adamvs_gru2_gates_apply(const float* fr, const float* fu, int Wf, const void* partials, const float* gn, const float* h,
                             float* rh, float* u, int N, int npix, int W, int HC, float eps, void* stream);
 
 /* ConvGRUCell2.output + forward, module.py:91-106.  o [N][npix][W] = output_conv(cat(x, r*h)) (HC real channels);
@@ -246,6 +247,14 @@ int adamvs_gru2_gates_apply(const float* fr, const float* fu, const void* partia
  * h' = u*h + (1-u)*tanh(GN(o)) replaces h [N][npix][W] and goes to channels [0, HC) of out [N][npix][Wo] (may be NULL). */
 int adamvs_gru2_out_apply(const float* o, const void* partials, const float* gn, const float* u, float* h, float* out,
                           int Wo, int N, int npix, int W, int HC, float eps, void* stream);
+
+/* out = conv3x3(cat(srcA, srcB)) + bias, stride 1, zero padding, on COMPACT channel-last maps: srcA [B][h*w][CA],
+ * srcB [B][h*w][CB] -> out [B][h*w][cout].  gate_conv / output_conv of ConvGRUCell2 (module.py:62-67) for the two shallow
+ * levels of MS-REDNet, whose 8/16-channel states would waste a 16-wide k_conv_dd tile: weights stay in registers as
+ * A fragments wpk [ceil(cout/16)][9][(CA+CB)/4][64] (value W[cout = 16*tile + (lane&15)][cin = 4*kc + (lane>>4)][tap]),
+ * bias [16*ceil(cout/16)] zero padded.  (CA, CB, cout) in (32|16|8, 8, <=16) or (16, 16, <=32). */
+int adamvs_conv3x3_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias,
+                        float* out, int cout, int B, int h, int w, void* stream);
 
 /* The running exp-sum / max / weighted-depth update of msrednet.py:415-436 (same as adamvs.py:512-531) in one pass over
  * the stored slices: vol [B][D][h*w] = reg_cost of every plane, planes [B][D][h*w] -> depth, confidence [B][h*w]. */

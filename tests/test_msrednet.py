@@ -270,3 +270,20 @@ def test_conv3x3_dd_small_grid_form_against_torch(D, h, w, relu):
     pk = packing.pack_reg_layer(wt, torch.ones(D), bias, False).cuda()
     got = hip_ops.conv3x3_dd(_cl(x), pk[:9 * D * D], pk[9 * D * D:], _cl(skip), N, D, h, w, 0, relu)
     assert rel_l1(_nchw(got, h, w), want) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("CA,CB,cout,h,w", [(32, 8, 16, 16, 24), (16, 8, 8, 22, 38), (8, 8, 16, 64, 96), (16, 16, 32, 12, 20),
+                                             (16, 16, 16, 30, 50)])
+def test_conv3x3_pair_against_torch(CA, CB, cout, h, w):
+    """conv3x3(cat(a, b)) + bias with register-resident weights (levels 1, 2 of the MS-REDNet cells), ragged sizes too."""
+    from ada_mvs_amd import hip_ops, packing
+    g = torch.Generator().manual_seed(CA + cout + h)
+    B = 2
+    wt = torch.randn(cout, CA + CB, 3, 3, generator=g) * (2.0 / (9 * (CA + CB))) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    a, b = torch.randn(B, CA, h, w, generator=g), torch.randn(B, CB, h, w, generator=g)
+    want = torch.nn.functional.conv2d(torch.cat((a, b), 1), wt, bias, padding=1)
+    rows = packing.pad16(cout)
+    got = hip_ops.conv3x3_pair(_cl(a), _cl(b), packing.pack_small_conv(wt).cuda(), packing.pad_bias(bias, rows).cuda(), cout, h, w)
+    assert got.shape == (B, h * w, cout) and rel_l1(_nchw(got, h, w), want) < 1e-5
