@@ -239,18 +239,21 @@ def test_predict_cli_options_and_model_errors():
 
 
 @pytest.mark.gpu
-def test_predict_end_to_end_writes_reference_layout(tmp_path):
+@pytest.mark.parametrize("model_name", ["adamvs", "msrednet"])
+def test_predict_end_to_end_writes_reference_layout(tmp_path, model_name):
     """The whole predict_whu.py chain on a synthetic folder: files, formats, and values equal to a direct model call."""
     import torch
     from ada_mvs_amd import predict, synth
     from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    from ada_mvs_amd.models.msrednet import Infer_CascadeREDNet
     src, out = tmp_path / "src", tmp_path / "out"
     _write_scene(str(src))
-    argv = ["--data_folder", str(src), "--output_folder", str(out), "--view_num", "3", "--numdepth", "16",
+    argv = ["--data_folder", str(src), "--output_folder", str(out), "--view_num", "3", "--numdepth", "16", "--model", model_name,
             "--ndepths", "16,8,4", "--seeded_weights", "0", "--batch_size", "2", "--num_workers", "0"]
     assert predict.main(argv) == 4
     ds = find_dataset_def("predict_oblique")(str(src), 3, predict.build_parser().parse_args(argv))
-    model = Infer_AdaMVSNet(16, [16, 8, 4], [4.0, 2.0, 1.0], False, [8, 8, 8])
+    cls = Infer_AdaMVSNet if model_name == "adamvs" else Infer_CascadeREDNet
+    model = cls(16, [16, 8, 4], [4.0, 2.0, 1.0], False, [8, 8, 8])
     model.load_state_dict(synth.seeded_state_dict(model, seed=0))
     model = model.cuda().eval()
     for i in range(4):
