@@ -29,7 +29,10 @@ struct ConvDDArgs16 {
 
 enum { BX_S1 = 0, BX_S2 = 1, BX_T2 = 2 };
 constexpr int BX_KB = 32;            // input channels per chunk = one MFMA k-step
-constexpr int BX_PIX = 40;           // bf16 per pixel row in LDS: 32 + 8 pad (80 B: 16-B aligned, spreads the banks)
+constexpr int BX_PIX = 40;           // bf16 per pixel row in LDS: 32 + 8 pad (80 B).  ds_read_b128's four 16-lane groups are
+                                     // not contiguous (MI355X_MICROARCH.md, LDS): this pitch is 2-way on the stride-1 layers
+                                     // (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE), 96 B is conflict-free -- and not
+                                     // faster: the LDS array is 13 % busy either way, the kernel is not bound by it
 
 // Block rows: 8.  (16-row blocks reuse each streamed A fragment twice as often, but their 192 accumulator
 // registers leave one wave per SIMD; two waves feeding the matrix pipe from LDS are worth more: 4.0 -> 3.5 ms on
@@ -99,48 +102,75 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
       }
     }
   };
-  auto load_w = [&](bf16x8 (&wh)[MT], bf16x8 (&wl)[MT], int kb, int ty, int tx) {
+  // A fragments: uniform descriptor + pinned lane offset; the fragment index is the scalar offset operand
+  const buf_rsrc rw = make_rsrc(a.wpk);
+  unsigned wlane = (unsigned)(lane * 16);
+  pin(wlane);
+  const unsigned lo_bytes = (unsigned)(lo_off * 16);
+  auto load_w = [&](bf16x8 (&wh)[MT], bf16x8 (&wl)[MT], int kb, int t) {
+    const int ty = t / NTX, tx = t % NTX;
     const int ky = (MODE == BX_T2) ? (PY ? (ty ? 0 : 2) : 1) : ty;
     const int kx = (MODE == BX_T2) ? (PX ? (tx ? 0 : 2) : 1) : tx;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      size_t f = ((size_t)((ky * 3 + kx) * KBT + kb) * NTILES + wm * MT + mt) * 64 + lane;
-      wh[mt] = a.wpk[f];
-      wl[mt] = a.wpk[lo_off + f];
+      const unsigned f = (unsigned)((((ky * 3 + kx) * KBT + kb) * NTILES + wm * MT + mt) * 1024);       // uniform, bytes
+      wh[mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, f, 0));
+      wl[mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, f + lo_bytes, 0));
     }
   };
 
   // lane's B-fragment base: pixel column p of the wave's first row, k-group q (8 channels = 16 bytes)
-  const int boff = ((wn * NTR * STR) * LC + p * STR) * BX_PIX + 8 * q;
+  unsigned boff = (unsigned)((((wn * NTR * STR) * LC + p * STR) * BX_PIX + 8 * q) * 2);     // bytes
+  pin(boff);
+  constexpr int LOB = NPIX * BX_PIX * 2;              // byte distance hi -> lo image
+  constexpr int NTAP = NTY * NTX;
   f32x4 xs[NIT];
   load_x(xs, 0);
+  bf16x8 w0h[MT], w0l[MT], w1h[MT], w1l[MT];          // two named fragment sets: tap t uses set t & 1 (no copies)
+  auto tap = [&](const bf16x8 (&wh)[MT], const bf16x8 (&wl)[MT], int t) {
+    const int ty = t / NTX, tx = t % NTX;
+    // B fragments one row ahead of the MFMAs that consume them (LDS latency under the previous row's chain)
+    bf16x8 bh[NTR], bl[NTR];
+    {
+      const char* at = (const char*)lds + boff + (ty * LC + tx) * (BX_PIX * 2);
+      bh[0] = *(const bf16x8*)at;
+      bl[0] = *(const bf16x8*)(at + LOB);
+    }
+#pragma unroll
+    for (int r = 0; r < NTR; ++r) {
+      if (r + 1 < NTR) {
+        const char* at = (const char*)lds + boff + (((r + 1) * STR + ty) * LC + tx) * (BX_PIX * 2);
+        bh[r + 1] = *(const bf16x8*)at;
+        bl[r + 1] = *(const bf16x8*)(at + LOB);
+      }
+      // the three products of one accumulator are issued MT instructions apart, not back to back
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bh[r], acc[mt][r]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bl[r], acc[mt][r]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wl[mt], bh[r], acc[mt][r]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   for (int kb = 0; kb < KBT; ++kb) {
     __syncthreads();                     // previous chunk's readers are done
     store_x(xs);
+    load_w(w0h, w0l, kb, 0);
     __syncthreads();
     if (kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);               // in flight during the MFMAs, stored at the next top
-    bf16x8 wh[MT], wl[MT], wh_n[MT], wl_n[MT];
-    load_w(wh, wl, kb, 0, 0);
-#pragma unroll 1                     // rolled: a full unroll lets the scheduler hoist every LDS fragment of the chunk (spills)
-    for (int t = 0; t < NTY * NTX; ++t) {
-      const int ty = t / NTX, tx = t % NTX;
-      if (t + 1 < NTY * NTX) load_w(wh_n, wl_n, kb, (t + 1) / NTX, (t + 1) % NTX);      // next tap's fragments
-#pragma unroll                       // static accumulator indices (a runtime index would send acc to scratch)
-      for (int r = 0; r < NTR; ++r) {
-        const int o = boff + ((r * STR + ty) * LC + tx) * BX_PIX;
-        const bf16x8 bh = *(const bf16x8*)(lhi + o);
-        const bf16x8 bl = *(const bf16x8*)(llo + o);
-        // the three products of one accumulator are issued MT instructions apart, not back to back (a dependent
-        // MFMA waits for the full latency of its predecessor)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bh, acc[mt][r]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bl, acc[mt][r]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wl[mt], bh, acc[mt][r]);
+    for (int t = 0; t < NTAP; ++t) {
+      // next tap's fragments are requested before this tap's MFMAs; the scheduling barriers keep the taps apart
+      // (a free scheduler hoists every LDS fragment of the chunk and spills)
+      if (t & 1) {
+        if (t + 1 < NTAP) load_w(w0h, w0l, kb, t + 1);
+        tap(w1h, w1l, t);
+      } else {
+        if (t + 1 < NTAP) load_w(w1h, w1l, kb, t + 1);
+        tap(w0h, w0l, t);
       }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) { wh[mt] = wh_n[mt]; wl[mt] = wl_n[mt]; }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
