@@ -50,15 +50,18 @@ __global__ void k_red_variance(const float* __restrict__ feat, const float* __re
   if (out_b) *(f32x4*)(out_b + dbp * Db + 4 * g) = var;
 }
 
+template <typename T>       // float, or f32x4 when the channel count, both offsets and both pixel strides are multiples of 4
 __global__ void k_channel_copy(const float* __restrict__ src, float* __restrict__ dst, int npix, int n, long sbs, int sps, int os,
                                long dbs, int dps, int od, size_t total) {
+  constexpr int V = sizeof(T) / sizeof(float);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % n);
-  const size_t bp = i / n;
+  const int nv = n / V;
+  const int c = (int)(i % nv) * V;
+  const size_t bp = i / nv;
   const int p = (int)(bp % npix);
   const size_t b = bp / npix;
-  dst[b * dbs + (size_t)p * dps + od + c] = src[b * sbs + (size_t)p * sps + os + c];
+  *(T*)(dst + b * dbs + (size_t)p * dps + od + c) = *(const T*)(src + b * sbs + (size_t)p * sps + os + c);
 }
 
 // ---- GroupNorm(1 group) statistics, deterministic: fixed partial ranges, double accumulation.
@@ -189,9 +192,15 @@ extern "C" int adamvs_channel_copy(const float* src, float* dst, int nbatch, int
                                    int src_pix_stride, int src_c0, long dst_batch_stride, int dst_pix_stride, int dst_c0,
                                    void* stream) {
   ADAMVS_CHECK_ARG(src && dst && nbatch > 0 && npix > 0 && n > 0 && src_c0 >= 0 && dst_c0 >= 0, "channel_copy: bad arguments");
-  const size_t total = (size_t)nbatch * npix * n;
-  hipLaunchKernelGGL(k_channel_copy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, npix, n,
-                     src_batch_stride, src_pix_stride, src_c0, dst_batch_stride, dst_pix_stride, dst_c0, total);
+  const bool vec = (n % 4) == 0 && (src_c0 % 4) == 0 && (dst_c0 % 4) == 0 && (src_pix_stride % 4) == 0 && (dst_pix_stride % 4) == 0 &&
+                   (src_batch_stride % 4) == 0 && (dst_batch_stride % 4) == 0 && ((size_t)src % 16) == 0 && ((size_t)dst % 16) == 0;
+  const size_t total = (size_t)nbatch * npix * (vec ? n / 4 : n);
+  if (vec)
+    hipLaunchKernelGGL(k_channel_copy<f32x4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, npix,
+                       n, src_batch_stride, src_pix_stride, src_c0, dst_batch_stride, dst_pix_stride, dst_c0, total);
+  else
+    hipLaunchKernelGGL(k_channel_copy<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, npix,
+                       n, src_batch_stride, src_pix_stride, src_c0, dst_batch_stride, dst_pix_stride, dst_c0, total);
   ADAMVS_CHECK_LAUNCH("channel_copy");
   return 0;
 }

@@ -170,7 +170,7 @@ class slice_RED_Regularization(nn.Module):
         """-> (X0 [D*B, h*w, XW0], the negated variance cost of every plane (plane-major) at the encoder's width,
         and the same map compact [D*B, h*w, C] for the level-1 cell -- X0 itself when XW0 == C)."""
         D, C, xw0 = planes.shape[1], self.in_channels, self.x_widths()[0]
-        X0 = torch.zeros(D * B, h * w, xw0, device=feat_cl.device, dtype=torch.float32)
+        X0 = (torch.empty if xw0 == C else torch.zeros)(D * B, h * w, xw0, device=feat_cl.device, dtype=torch.float32)
         xc = X0 if xw0 == C else torch.empty(D * B, h * w, C, device=feat_cl.device, dtype=torch.float32)
         hip_ops.red_variance_cost(feat_cl, rt, planes, X0, None if xc is X0 else xc, B, S, C, D, h, w, negate=True)
         return X0, xc
@@ -190,15 +190,19 @@ class slice_RED_Regularization(nn.Module):
                 feeds.append(xc if k == 0 else self._to_width(X, 16, 16))
             else:
                 lev = []
+                src = narrow if k == 2 else X      # level 3: conv2's own 32-wide output (x is exactly 32 channels)
                 for name in ("gxr", "gxu", "cx"):
                     wt, bs = self._w("%s%d" % (name, k + 1))
-                    lev.append(self._to_width(hip_ops.conv3x3_dd(X, wt, bs, None, N, xw[k], hk, wk, 0, False), self.HC[k], self.HW[k]))
+                    lev.append(self._to_width(hip_ops.conv3x3_dd(src, wt, bs, None, N, src.shape[-1], hk, wk, 0, False),
+                                              self.HC[k], self.HW[k]))
                 feeds.append(lev)
             if k < 3:                  # conv_{k+1}: stride 2, ReLU; its output is the next level's x
                 wt, bs = self._w("conv%d" % (k + 1))
                 e = hip_ops.conv3x3_dd(X, wt, bs, None, N, xw[k], hk, wk, 1, True)
                 if k == 0:
                     feeds_x1 = e       # 16 real channels at width XW0: level 2 reads them compact
+                if k == 1:
+                    narrow = e         # 32 channels, 32 wide: what level 3's x halves read
                 X = self._to_width(e, xcn[k + 1], xw[k + 1])
             if k == 1:
                 feeds[1] = self._to_width(feeds_x1, 16, 16)
@@ -275,7 +279,8 @@ class slice_RED_Regularization(nn.Module):
         self.packed(dev)
         N = X0.shape[0]
         halves = self.encode(X0, X0 if xc is None else xc, h, w)
-        R = [torch.zeros(N, (h >> k) * (w >> k), self.RW[k], device=dev, dtype=torch.float32) for k in range(4)]
+        alloc = lambda k: (torch.empty if self.RW[k] == self.HC[k] else torch.zeros)       # noqa: E731  (pad channels must be 0)
+        R = [alloc(k)(N, (h >> k) * (w >> k), self.RW[k], device=dev, dtype=torch.float32) for k in range(4)]
         if self.concurrent_levels:
             if self._streams is None:
                 self._streams = [torch.cuda.Stream(device=dev) for _ in range(4)]

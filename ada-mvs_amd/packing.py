@@ -322,6 +322,7 @@ def pack_red_regularization(sd, pre, C):
     followed by the bias padded to 16 * tiles (the dict's second entry is that padded output count)."""
     xc, hc = (C, 16, 32, 64), (8, 16, 32, 64)
     XW, HW = (max(pad16(C), 16), 32, 64, 64), (16, 16, 32, 64)
+    GW = (XW[0], XW[1], 32, 64)               # width of the x halves' input: level 3 reads conv2's own 32-wide output
     parts = {}
     for k in range(4):
         g = pre + "conv_gru%d." % (k + 1)
@@ -329,9 +330,9 @@ def pack_red_regularization(sd, pre, C):
         wc, bc = sd[g + "output_conv.weight"], sd[g + "output_conv.bias"]
         cx, h = xc[k], hc[k]
         n = str(k + 1)
-        parts["gxr" + n] = (pack_padded_dd(wg[:h, :cx], bg[:h], XW[k]), XW[k])
-        parts["gxu" + n] = (pack_padded_dd(wg[h:, :cx], bg[h:], XW[k]), XW[k])
-        parts["cx" + n] = (pack_padded_dd(wc[:, :cx], bc, XW[k]), XW[k])
+        parts["gxr" + n] = (pack_padded_dd(wg[:h, :cx], bg[:h], GW[k]), GW[k])
+        parts["gxu" + n] = (pack_padded_dd(wg[h:, :cx], bg[h:], GW[k]), GW[k])
+        parts["cx" + n] = (pack_padded_dd(wc[:, :cx], bc, GW[k]), GW[k])
         parts["ghr" + n] = (pack_padded_dd(wg[:h, cx:], None, HW[k]), HW[k])
         parts["ghu" + n] = (pack_padded_dd(wg[h:, cx:], None, HW[k]), HW[k])
         parts["ch" + n] = (pack_padded_dd(wc[:, cx:], None, HW[k]), HW[k])
