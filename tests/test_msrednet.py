@@ -287,3 +287,47 @@ def test_conv3x3_pair_against_torch(CA, CB, cout, h, w):
     rows = packing.pad16(cout)
     got = hip_ops.conv3x3_pair(_cl(a), _cl(b), packing.pack_small_conv(wt).cuda(), packing.pad_bias(bias, rows).cuda(), cout, h, w)
     assert got.shape == (B, h * w, cout) and rel_l1(_nchw(got, h, w), want) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("views", [2, 6])
+def test_end_to_end_other_view_counts_against_oracle(views):
+    """One source view (variance of two samples) and five: the cost kernel's view loop, against the oracle."""
+    c = dict(synth.CONFIGS["tiny"], views=views)
+    from ada_mvs_amd.models.msrednet import Infer_CascadeREDNet
+    m = Infer_CascadeREDNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=1)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs(c, batch=1, seed=2)
+    with mo.ao.use_grid_sample():
+        want = mo.infer_cascade_rednet_forward(imgs, proj, dv, sd, c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    with torch.no_grad():
+        out = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+    assert rel_l1(out["depth"].cpu(), want["depth"]) < E2E_TOL
+    assert rel_l1(out["photometric_confidence"].cpu(), want["photometric_confidence"]) < E2E_TOL
+
+
+@pytest.mark.gpu
+def test_error_behaviour_of_the_new_entry_points():
+    from ada_mvs_amd import hip_ops
+    from ada_mvs_amd._lib import AdaMVSHipError
+    from ada_mvs_amd.models.msrednet import slice_RED_Regularization
+    dev = torch.device("cuda:0")
+    net = slice_RED_Regularization(32, 8)
+    net.load_state_dict(slice_state_dict())
+    net = net.cuda()
+    with pytest.raises(AdaMVSHipError, match="multiple of 8"):           # three stride-2 levels
+        net.regularize_maps(torch.zeros(1, 12 * 20, 32, device=dev), 1, 12, 20)
+    a, b = torch.zeros(1, 64, 24, device=dev), torch.zeros(1, 64, 8, device=dev)
+    with pytest.raises(AdaMVSHipError, match="conv3x3_pair"):             # 24 + 8 channels: not a supported pairing
+        hip_ops.conv3x3_pair(a, b, torch.zeros(9 * 32 * 16, device=dev), torch.zeros(16, device=dev), 16, 8, 8)
+    x = torch.zeros(2, 16, 30, device=dev)
+    with pytest.raises(AdaMVSHipError, match="group_stats_partial"):      # 30-wide rows are not float4-addressable
+        hip_ops.group_stats_partial(x, None, 8, hip_ops.group_stats_workspace(2, 1, dev))
+    with pytest.raises(AdaMVSHipError, match="GPU tensor"):
+        hip_ops.red_variance_cost(torch.zeros(2, 4, 8), torch.zeros(1, 1, 12, device=dev), torch.zeros(1, 1, 4, device=dev),
+                                  torch.zeros(1, 4, 8, device=dev), None, 1, 1, 8, 1, 2, 2)
+    from ada_mvs_amd.models.msrednet import Infer_CascadeREDNet
+    with pytest.raises(AdaMVSHipError, match="share_cr"):
+        Infer_CascadeREDNet(16, [16, 8, 4], [4, 2, 1], share_cr=True)
