@@ -65,16 +65,22 @@ __global__ void k_channel_copy(const float* __restrict__ src, float* __restrict_
 }
 
 // ---- GroupNorm(1 group) statistics, deterministic: fixed partial ranges, double accumulation.
-// k_gn_partial: grid (GN_PARTS, ngroups, N); group g = map x0 / x1, channels [0, n) of a D-wide map.  The consumers
-// (the two epilogue kernels below) finish the reduction themselves: one fewer dependent launch per normalisation.
-constexpr int GN_PARTS = 64;
+// k_gn_partial: grid (parts, ngroups, N); group g = map x0 / x1, channels [0, n) of a D-wide map; parts = gn_parts(npix)
+// pixel ranges per (sample, group): 64 for the small maps of the deep levels, up to 1024 so that a full-resolution
+// map (5 M pixels at the reference's predict size) is not reduced by 64 workgroups.  The consumers (the two epilogue
+// kernels below) finish the reduction themselves: one fewer dependent launch per normalisation.
+constexpr int GN_PARTS_MAX = 1024;
+__host__ __device__ inline int gn_parts(int npix) {
+  const int want = (npix + 2047) / 2048;
+  return want < 64 ? 64 : (want > GN_PARTS_MAX ? GN_PARTS_MAX : want);
+}
 
 __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x0, const float* __restrict__ x1,
                                                      double* __restrict__ part, int npix, int D, int n) {
-  const int g = blockIdx.y, b = blockIdx.z, ngroups = gridDim.y;
+  const int g = blockIdx.y, b = blockIdx.z, ngroups = gridDim.y, parts = gridDim.x;
   const float* x = g ? x1 : x0;
-  const int per = (npix + GN_PARTS - 1) / GN_PARTS;
-  const int p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  const int per = (npix + parts - 1) / parts;
+  const int p0 = min(npix, (int)blockIdx.x * per), p1 = min(npix, p0 + per);
   const int n4 = n >> 2;
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < (p1 - p0) * n4; i += 256) {
@@ -91,29 +97,36 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x0
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    double* o = part + (((size_t)b * ngroups + g) * GN_PARTS + blockIdx.x) * 2;
+    double* o = part + (((size_t)b * ngroups + g) * parts + blockIdx.x) * 2;
     o[0] = sh[0][0]; o[1] = sh[1][0];
   }
 }
 
-// mean and 1/sqrt(biased var + eps) of group g of sample b from the partial sums, into shared memory (threads < ngroups)
-__device__ __forceinline__ void gn_finish(const double* __restrict__ part, int b, int ngroups, int count, float eps,
+// mean and 1/sqrt(biased var + eps) of the groups of sample b from the partial sums, into shared memory.  Wave 0 does
+// it: lane l sums partials l, l + 64, ... in order, then a fixed shuffle tree -- the same association every time.
+__device__ __forceinline__ void gn_finish(const double* __restrict__ part, int b, int ngroups, int parts, int count, float eps,
                                           float (*st)[2]) {
-  if ((int)threadIdx.x < ngroups) {
-    const double* p = part + ((size_t)b * ngroups + threadIdx.x) * GN_PARTS * 2;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < GN_PARTS; ++k) { s += p[2 * k]; q += p[2 * k + 1]; }
-    const double mean = s / count;
-    const double var = fmax(q / count - mean * mean, 0.0);    // biased, as torch.nn.GroupNorm
-    st[threadIdx.x][0] = (float)mean;
-    st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x < 64) {
+    for (int g = 0; g < ngroups; ++g) {
+      const double* p = part + ((size_t)b * ngroups + g) * parts * 2;
+      double s = 0.0, q = 0.0;
+      for (int k = threadIdx.x; k < parts; k += 64) { s += p[2 * k]; q += p[2 * k + 1]; }
+      for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); q += __shfl_down(q, o); }
+      if (threadIdx.x == 0) {
+        const double mean = s / count;
+        const double var = fmax(q / count - mean * mean, 0.0);    // biased, as torch.nn.GroupNorm
+        st[g][0] = (float)mean;
+        st[g][1] = (float)(1.0 / sqrt(var + (double)eps));
+      }
+    }
   }
   __syncthreads();
 }
 
-__global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ stats, int ngroups, int count, float eps) {
+__global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ stats, int ngroups, int parts, int count,
+                           float eps) {
   __shared__ float st[2][2];
-  gn_finish(part, blockIdx.x, ngroups, count, eps, st);
+  gn_finish(part, blockIdx.x, ngroups, parts, count, eps, st);
   if ((int)threadIdx.x < ngroups) {
     stats[(blockIdx.x * ngroups + threadIdx.x) * 2] = st[threadIdx.x][0];
     stats[(blockIdx.x * ngroups + threadIdx.x) * 2 + 1] = st[threadIdx.x][1];
@@ -129,7 +142,7 @@ __global__ void k_gru2_gates_apply(const float* __restrict__ fr, const float* __
                                    float* __restrict__ u, int npix, int Wf, int W, int HC, float eps) {
   __shared__ float st[2][2];
   const int b = blockIdx.y;
-  gn_finish(part, b, 2, npix * HC, eps, st);
+  gn_finish(part, b, 2, gn_parts(npix), npix * HC, eps, st);
   const int G = HC >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix * G) return;
@@ -152,7 +165,7 @@ __global__ void k_gru2_out_apply(const float* __restrict__ o, const double* __re
                                  int HC, int Wo, float eps) {
   __shared__ float st[2][2];
   const int b = blockIdx.y;
-  gn_finish(part, b, 1, npix * HC, eps, st);
+  gn_finish(part, b, 1, gn_parts(npix), npix * HC, eps, st);
   const int G = HC >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix * G) return;
@@ -206,7 +219,7 @@ extern "C" int adamvs_channel_copy(const float* src, float* dst, int nbatch, int
 }
 
 extern "C" size_t adamvs_group_stats_workspace_bytes(int N, int ngroups) {
-  return (size_t)N * ngroups * GN_PARTS * 2 * sizeof(double);
+  return (size_t)N * ngroups * GN_PARTS_MAX * 2 * sizeof(double);
 }
 
 extern "C" int adamvs_group_stats_partial(const float* x0, const float* x1, int N, int npix, int D, int n, void* partials,
@@ -215,16 +228,18 @@ extern "C" int adamvs_group_stats_partial(const float* x0, const float* x1, int 
   ADAMVS_CHECK_ARG(x0 && partials && N > 0 && npix > 0 && n > 0 && (n % 4) == 0 && (D % 4) == 0 && n <= D,
                    "group_stats_partial: bad arguments (N=%d npix=%d D=%d n=%d)", N, npix, D, n);
   ADAMVS_CHECK_ARG(partials_bytes >= adamvs_group_stats_workspace_bytes(N, ngroups), "group_stats_partial: buffer too small");
-  hipLaunchKernelGGL(k_gn_partial, dim3(GN_PARTS, ngroups, N), dim3(256), 0, (hipStream_t)stream, x0, x1, (double*)partials, npix,
-                     D, n);
+  hipLaunchKernelGGL(k_gn_partial, dim3(gn_parts(npix), ngroups, N), dim3(256), 0, (hipStream_t)stream, x0, x1,
+                     (double*)partials, npix, D, n);
   ADAMVS_CHECK_LAUNCH("group_stats_partial");
   return 0;
 }
 
-extern "C" int adamvs_group_stats_finish(const void* partials, float* stats, int N, int ngroups, int count, float eps,
+extern "C" int adamvs_group_stats_finish(const void* partials, float* stats, int N, int ngroups, int npix, int n, float eps,
                                          void* stream) {
-  ADAMVS_CHECK_ARG(partials && stats && N > 0 && (ngroups == 1 || ngroups == 2) && count > 0, "group_stats_finish: bad arguments");
-  hipLaunchKernelGGL(k_gn_final, dim3(N), dim3(64), 0, (hipStream_t)stream, (const double*)partials, stats, ngroups, count, eps);
+  ADAMVS_CHECK_ARG(partials && stats && N > 0 && (ngroups == 1 || ngroups == 2) && npix > 0 && n > 0,
+                   "group_stats_finish: bad arguments");
+  hipLaunchKernelGGL(k_gn_final, dim3(N), dim3(64), 0, (hipStream_t)stream, (const double*)partials, stats, ngroups,
+                     gn_parts(npix), npix * n, eps);
   ADAMVS_CHECK_LAUNCH("group_stats_finish");
   return 0;
 }

@@ -308,9 +308,9 @@ def group_stats_partial(x0, x1, n, partials):
                                                  _p(partials), partials.numel() * 8, _stream()), "group_stats_partial")
 
 
-def group_stats_finish(partials, N, ngroups, count, eps=1e-5):
+def group_stats_finish(partials, N, ngroups, npix, n, eps=1e-5):
     stats = torch.empty(N, ngroups, 2, device=partials.device, dtype=torch.float32)
-    check(_lib.load().adamvs_group_stats_finish(_p(partials), _p(stats), N, ngroups, count, eps, _stream()), "group_stats_finish")
+    check(_lib.load().adamvs_group_stats_finish(_p(partials), _p(stats), N, ngroups, npix, n, eps, _stream()), "group_stats_finish")
     return stats
 
 

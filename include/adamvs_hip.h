@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 4
+#define ADAMVS_ABI_VERSION 5
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -226,11 +226,12 @@ int adamvs_channel_copy(const float* src, float* dst, int nbatch, int npix, int 
 /* nn.GroupNorm(1, HC) statistics (module.py:63-68), in two deterministic halves.  _partial: for map g in {x0, x1}
  * (x1 may be NULL), over channels [0, n) and fixed pixel ranges of sample b: double-precision partial sums into
  * `partials` (adamvs_group_stats_workspace_bytes(N, ngroups)).  The two epilogues below finish the reduction
- * themselves; _finish does it standalone: stats[b][g] = {mean, 1/sqrt(biased var + eps)}, count = npix * n. */
+ * themselves; _finish does it standalone (same npix and n as _partial): stats[b][g] = {mean, 1/sqrt(biased var + eps)}. */
 size_t adamvs_group_stats_workspace_bytes(int N, int ngroups);
 int adamvs_group_stats_partial(const float* x0, const float* x1, int N, int npix, int D, int n, void* partials,
                                size_t partials_bytes, void* stream);
-int adamvs_group_stats_finish(const void* partials, float* stats, int N, int ngroups, int count, float eps, void* stream);
+int adamvs_group_stats_finish(const void* partials, float* stats, int N, int ngroups, int npix, int n, float eps,
+                              void* stream);
 
 /* ConvGRUCell2.gates + the reset product, module.py:72-92.  The gate convolution is linear in cat(x, h):
  * gate_conv(cat(x, h)) = Wx.x + Wh.h + b, and so is the output convolution.  The x halves do not depend on the state

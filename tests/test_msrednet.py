@@ -107,14 +107,17 @@ def _nchw(x_cl, h, w):
 
 
 @pytest.mark.gpu
-def test_group_stats_against_torch():
+@pytest.mark.parametrize("npix", [37 * 11, 640 * 480])         # 64 partial ranges / 150 of them
+def test_group_stats_against_torch(npix):
     from ada_mvs_amd import hip_ops
     g = torch.Generator().manual_seed(5)
-    x0 = (torch.randn(3, 37 * 11, 48, generator=g) * 2 + 0.7).cuda()
-    x1 = (torch.randn(3, 37 * 11, 48, generator=g) * 0.3 - 1.1).cuda()
+    x0 = (torch.randn(3, npix, 48, generator=g) * 2 + 0.7).cuda()
+    x1 = (torch.randn(3, npix, 48, generator=g) * 0.3 - 1.1).cuda()
     part = hip_ops.group_stats_workspace(3, 2, x0.device)
     hip_ops.group_stats_partial(x0, x1, 12, part)
-    stats = hip_ops.group_stats_finish(part, 3, 2, 37 * 11 * 12)
+    stats = hip_ops.group_stats_finish(part, 3, 2, npix, 12)
+    again = hip_ops.group_stats_finish(part, 3, 2, npix, 12)
+    assert torch.equal(stats, again)                            # fixed association: bit-identical
     for gi, x in enumerate((x0, x1)):
         sel = x[:, :, :12].double()
         mean = sel.mean(dim=(1, 2))
