@@ -334,3 +334,37 @@ def test_error_behaviour_of_the_new_entry_points():
     from ada_mvs_amd.models.msrednet import Infer_CascadeREDNet
     with pytest.raises(AdaMVSHipError, match="share_cr"):
         Infer_CascadeREDNet(16, [16, 8, 4], [4, 2, 1], share_cr=True)
+
+
+def test_regulariser_packing_layout():
+    """pack_red_regularization: every block at a 64-float offset; the padded D x D blocks hold the real weights at the
+    documented fragment positions and zeros elsewhere; the stride-1 ConvTranspose2d enters as its mirrored convolution."""
+    from ada_mvs_amd import packing
+    sd = slice_state_dict(C=16, seed=5)
+    flat, off = packing.pack_red_regularization(sd, "", 16)
+    assert all(o % 64 == 0 for o, _ in off.values())
+    for name in ("gxr3", "ghu4", "cx3", "conv2", "upconv3", "upconv2d", "gp1", "cp2", "gn4"):
+        assert name in off
+
+    def frag(name, tap, co, ci):                       # value of W[co][ci][tap] in a padded block
+        o, D = off[name]
+        tile, r, kc, k4 = co // 16, co % 16, ci // 4, ci % 4
+        return float(flat[o + ((tap * (D // 4) + kc) * (D // 16) + tile) * 64 + k4 * 16 + r])
+
+    wg = sd["conv_gru3.gate_conv.weight"]              # [64][32 + 32][3][3]: reset rows 0-31, x columns 0-31
+    assert off["gxr3"][1] == 32 and off["ghr3"][1] == 32
+    assert frag("gxr3", 4, 5, 7) == float(wg[5, 7, 1, 1]) and frag("ghr3", 2, 30, 3) == float(wg[30, 32 + 3, 0, 2])
+    assert frag("gxu3", 0, 1, 2) == float(wg[32 + 1, 2, 0, 0])
+    o, D = off["gxr3"]
+    assert torch.equal(flat[o + 9 * D * D:o + 9 * D * D + D], sd["conv_gru3.gate_conv.bias"][:32])        # bias with the x half
+    o, D = off["ghr3"]
+    assert bool((flat[o + 9 * D * D:o + 9 * D * D + D] == 0).all())                                      # none with the h half
+    w1 = sd["conv1.conv.weight"]                       # [16][16][3][3] at width 16
+    assert off["conv1"][1] == 16 and frag("conv1", 8, 15, 15) == float(w1[15, 15, 2, 2])
+    wt = sd["upconv2d.weight"]                         # ConvTranspose2d [cin 8][cout 1][3][3] -> conv [1][8] with mirrored taps
+    assert frag("upconv2d", 0, 0, 3) == float(wt[3, 0, 2, 2]) and frag("upconv2d", 5, 0, 7) == float(wt[7, 0, 1, 0])
+    assert frag("upconv2d", 4, 1, 0) == 0.0 and frag("upconv2d", 4, 0, 8) == 0.0                          # padding
+    o, D = off["upconv2d"]
+    assert float(flat[o + 9 * D * D]) == float(sd["upconv2d.bias"][0])
+    gn_o, hc = off["gn2"]
+    assert hc == 16 and torch.equal(flat[gn_o + 4 * hc:gn_o + 5 * hc], sd["conv_gru2.output_norm.weight"])
