@@ -83,10 +83,15 @@ SIGNATURES = {
     "adamvs_gru2_gates_apply": (c_i, [c_f, c_f, c_i, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, c_st]),
     "adamvs_conv3x3_pair": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_gru2_out_apply": (c_i, [c_f, ctypes.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_st]),
+    "adamvs_red_recur_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "adamvs_red_recur_pair": (c_i, [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float,
+                                    ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_red_recur_split": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float,
+                                     ctypes.c_void_p, c_sz, c_st]),
     "adamvs_soft_argmin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15
 _lib = None

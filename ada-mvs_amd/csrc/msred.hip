@@ -4,6 +4,7 @@
 // channel-range copy, and the online soft-argmin over the stored log-probabilities.
 // All maps are channel-last [N][pixels][D] with the channel count padded to what adamvs_conv3x3_dd takes;
 // the convolutions themselves run on k_conv_dd (costreg2d.hip).  These kernels stream: HBM-bound by design.
+#include "../../include/adamvs_hip.h"
 #include "common.h"
 #include "kernels.h"
 #include "warp_math.h"
@@ -270,6 +271,93 @@ extern "C" int adamvs_conv3x3_pair(const float* srcA, int CA, const float* srcB,
   ADAMVS_CHECK_ARG(srcA && srcB && wpk && bias && out && B > 0 && h > 0 && w > 0 && cout > 0 && (cout % 4) == 0,
                    "conv3x3_pair: bad arguments (B=%d h=%d w=%d cout=%d)", B, h, w, cout);
   return launch_conv_pair(srcA, CA, srcB, CB, wpk, bias, out, cout, B, h, w, (hipStream_t)stream);
+}
+
+// ---- one level's recurrence over the planes of a stage, launched from native code (a Python loop of 6-7 ctypes calls
+// per plane and level costs more than the kernels it launches)
+namespace {
+struct RecurBuffers { float *state, *rh, *f, *fu, *o, *u; double* part; };
+
+size_t recur_floats(int B, int npix, int W, int Wf, int HC) {      // state, rh, o: W wide; f (and fu): Wf wide; u: HC
+  auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+  return 3 * al((size_t)B * npix * W) + 2 * al((size_t)B * npix * Wf) + al((size_t)B * npix * HC);
+}
+
+int carve_recur(RecurBuffers& r, void* workspace, size_t bytes, int B, int npix, int W, int Wf, int HC, hipStream_t st) {
+  auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+  const size_t need = recur_floats(B, npix, W, Wf, HC) * sizeof(float) + adamvs_group_stats_workspace_bytes(B, 2);
+  if (!workspace || bytes < need) return set_error(-1, "red_recur: workspace too small (%zu < %zu bytes)", bytes, need);
+  float* p = (float*)workspace;
+  r.state = p; p += al((size_t)B * npix * W);
+  r.rh = p;    p += al((size_t)B * npix * W);
+  r.o = p;     p += al((size_t)B * npix * W);
+  r.f = p;     p += al((size_t)B * npix * Wf);
+  r.fu = p;    p += al((size_t)B * npix * Wf);
+  r.u = p;     p += al((size_t)B * npix * HC);
+  r.part = (double*)p;
+  // the state starts at zero; rh keeps zeros in its padding channels (only HC channels are ever written)
+  hipError_t e = hipMemsetAsync(r.state, 0, 2 * al((size_t)B * npix * W) * sizeof(float), st);
+  if (e != hipSuccess) return set_error((int)e, "red_recur: hipMemsetAsync: %s", hipGetErrorString(e));
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t adamvs_red_recur_workspace_bytes(int B, int h, int w, int W, int Wf, int HC) {
+  if (B <= 0 || h <= 0 || w <= 0 || W <= 0 || Wf <= 0 || HC <= 0) return 0;
+  return recur_floats(B, h * w, W, Wf, HC) * sizeof(float) + adamvs_group_stats_workspace_bytes(B, 2);
+}
+
+extern "C" int adamvs_red_recur_pair(const float* x, int Cx, const float* wg, const float* bg, const float* wc, const float* bc,
+                                     const float* gn, float* R, int RW, int B, int D, int h, int w, int HC, float eps,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(x && wg && bg && wc && bc && gn && R && B > 0 && D > 0 && h > 0 && w > 0 && HC > 0 && (HC % 4) == 0 && RW >= HC,
+                   "red_recur_pair: bad arguments (B=%d D=%d h=%d w=%d Cx=%d HC=%d RW=%d)", B, D, h, w, Cx, HC, RW);
+  hipStream_t st = (hipStream_t)stream;
+  const int npix = h * w;
+  RecurBuffers r;
+  if (int rc = carve_recur(r, workspace, workspace_bytes, B, npix, HC, 2 * HC, HC, st)) return rc;
+  const size_t pbytes = adamvs_group_stats_workspace_bytes(B, 2);
+  for (int d = 0; d < D; ++d) {
+    const float* xd = x + (size_t)d * B * npix * Cx;
+    int rc;
+    if ((rc = adamvs_conv3x3_pair(xd, Cx, r.state, HC, wg, bg, r.f, 2 * HC, B, h, w, stream))) return rc;
+    if ((rc = adamvs_group_stats_partial(r.f, r.f + HC, B, npix, 2 * HC, HC, r.part, pbytes, stream))) return rc;
+    if ((rc = adamvs_gru2_gates_apply(r.f, r.f + HC, 2 * HC, r.part, gn, r.state, r.rh, r.u, B, npix, HC, HC, eps, stream))) return rc;
+    if ((rc = adamvs_conv3x3_pair(xd, Cx, r.rh, HC, wc, bc, r.o, HC, B, h, w, stream))) return rc;
+    if ((rc = adamvs_group_stats_partial(r.o, nullptr, B, npix, HC, HC, r.part, pbytes, stream))) return rc;
+    if ((rc = adamvs_gru2_out_apply(r.o, r.part, gn + 4 * HC, r.u, r.state, R + (size_t)d * B * npix * RW, RW, B, npix, HC, HC, eps,
+                                    stream)))
+      return rc;
+  }
+  return 0;
+}
+
+extern "C" int adamvs_red_recur_split(const float* gxr, const float* gxu, const float* cx, const float* w_ghr, const float* w_ghu,
+                                      const float* w_ch, const float* gn, float* R, int RW, int B, int D, int h, int w, int W,
+                                      int HC, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(gxr && gxu && cx && w_ghr && w_ghu && w_ch && gn && R && B > 0 && D > 0 && h > 0 && w > 0 && HC > 0 &&
+                   (HC % 4) == 0 && W >= HC && RW >= HC, "red_recur_split: bad arguments (B=%d D=%d h=%d w=%d W=%d HC=%d RW=%d)",
+                   B, D, h, w, W, HC, RW);
+  hipStream_t st = (hipStream_t)stream;
+  const int npix = h * w;
+  RecurBuffers r;
+  if (int rc = carve_recur(r, workspace, workspace_bytes, B, npix, W, W, HC, st)) return rc;
+  const size_t pbytes = adamvs_group_stats_workspace_bytes(B, 2);
+  const size_t wsz = (size_t)9 * W * W, plane = (size_t)B * npix * W;
+  for (int d = 0; d < D; ++d) {
+    int rc;
+    // Wh.h + (Wx.x + b): the x halves of all planes were computed before the recurrence and enter as `skip`
+    if ((rc = adamvs_conv3x3_dd(r.state, w_ghr, w_ghr + wsz, gxr + d * plane, r.f, B, W, h, w, 0, 0, 0, stream))) return rc;
+    if ((rc = adamvs_conv3x3_dd(r.state, w_ghu, w_ghu + wsz, gxu + d * plane, r.fu, B, W, h, w, 0, 0, 0, stream))) return rc;
+    if ((rc = adamvs_group_stats_partial(r.f, r.fu, B, npix, W, HC, r.part, pbytes, stream))) return rc;
+    if ((rc = adamvs_gru2_gates_apply(r.f, r.fu, W, r.part, gn, r.state, r.rh, r.u, B, npix, W, HC, eps, stream))) return rc;
+    if ((rc = adamvs_conv3x3_dd(r.rh, w_ch, w_ch + wsz, cx + d * plane, r.o, B, W, h, w, 0, 0, 0, stream))) return rc;
+    if ((rc = adamvs_group_stats_partial(r.o, nullptr, B, npix, W, HC, r.part, pbytes, stream))) return rc;
+    if ((rc = adamvs_gru2_out_apply(r.o, r.part, gn + 4 * HC, r.u, r.state, R + (size_t)d * B * npix * RW, RW, B, npix, W, HC, eps,
+                                    stream)))
+      return rc;
+  }
+  return 0;
 }
 
 extern "C" int adamvs_soft_argmin(const float* vol, const float* planes, float* depth, float* confidence, int B, int D, int h,

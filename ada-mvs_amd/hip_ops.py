@@ -339,6 +339,27 @@ def gru2_out_apply(o, partials, gn, u, h, out, HC, eps=1e-5):
           "gru2_out_apply")
 
 
+def red_recur_pair(x, wg, bg, wc, bc, gn, R, B, h, w, HC, eps=1e-5):
+    """ConvGRUCell2 of a shallow level over all planes: x [D*B, h*w, Cx] compact -> R[:, :, :HC]."""
+    D, Cx = x.shape[0] // B, x.shape[-1]
+    lib = _lib.load()
+    nbytes = lib.adamvs_red_recur_workspace_bytes(B, h, w, HC, 2 * HC, HC)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    check(lib.adamvs_red_recur_pair(_p(_dev(x, "x")), Cx, _p(wg), _p(bg), _p(wc), _p(bc), _p(gn), _p(R), R.shape[-1], B, D, h, w, HC,
+                                    eps, _p(ws), nbytes, _stream()), "red_recur_pair")
+
+
+def red_recur_split(gxr, gxu, cx, w_ghr, w_ghu, w_ch, gn, R, B, h, w, HC, eps=1e-5):
+    """ConvGRUCell2 of a deep level over all planes from the precomputed x halves [D*B, h*w, W] -> R[:, :, :HC].
+    w_*: the h halves as contiguous (9 W W + W)-float blocks."""
+    D, W = gxr.shape[0] // B, gxr.shape[-1]
+    lib = _lib.load()
+    nbytes = lib.adamvs_red_recur_workspace_bytes(B, h, w, W, W, HC)
+    ws = torch.empty(nbytes // 4, device=gxr.device, dtype=torch.float32)
+    check(lib.adamvs_red_recur_split(_p(_dev(gxr, "gxr")), _p(gxu), _p(cx), _p(w_ghr), _p(w_ghu), _p(w_ch), _p(gn), _p(R),
+                                     R.shape[-1], B, D, h, w, W, HC, eps, _p(ws), nbytes, _stream()), "red_recur_split")
+
+
 def soft_argmin(vol, planes, B, D, h, w):
     depth = torch.empty(B, h, w, device=vol.device, dtype=torch.float32)
     conf = torch.empty(B, h, w, device=vol.device, dtype=torch.float32)

@@ -141,6 +141,12 @@ class slice_RED_Regularization(nn.Module):
         o, D = offsets[name]
         return flat[o:o + 9 * D * D], flat[o + 9 * D * D:o + 9 * D * D + D]
 
+    def _wblock(self, name):
+        """A padded D x D layer as one contiguous block: 9 D D fragment floats followed by D bias floats."""
+        flat, offsets = self._packed
+        o, D = offsets[name]
+        return flat[o:o + 9 * D * D + D]
+
     def _wp(self, name, cin):
         """(A fragments, bias) of a register-resident pair convolution (levels 1 and 2)."""
         flat, offsets = self._packed
@@ -210,52 +216,19 @@ class slice_RED_Regularization(nn.Module):
 
     # ---- B: one level's recurrence over the planes ----------------------------------------------------------------
     def recur_level(self, k, feed, Rk, B, h, w):
-        """ConvGRUCell2 of level k (0-based) over the planes; h' of plane d into Rk[d*B:(d+1)*B, :, :HC]."""
-        if k < 2:
-            return self._recur_pair(k, feed, Rk, B, h, w)
-        gxr, gxu, cx = feed
-        dev = gxr.device
-        W, HC = self.HW[k], self.HC[k]
-        npix, hk, wk = gxr.shape[1], h >> k, w >> k
-        D = gxr.shape[0] // B
-        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)      # noqa: E731
-        state, rh, fr, fu, o = z(B, npix, W), z(B, npix, W), z(B, npix, W), z(B, npix, W), z(B, npix, W)
-        u = z(B, npix, HC)
-        part = hip_ops.group_stats_workspace(B, 2, dev)
+        """ConvGRUCell2 of level k (0-based) over the planes; h' of plane d into Rk[d*B:(d+1)*B, :, :HC].  One native
+        call per level: the per-plane launches (6-7 kernels) are issued from C++ (adamvs_red_recur_pair / _split)."""
+        hk, wk, HC = h >> k, w >> k, self.HC[k]
         gn = self._gn(k)
-        (wr, br), (wu, bu), (wc, bc) = (self._w("%s%d" % (n, k + 1)) for n in ("ghr", "ghu", "ch"))
-        for d in range(D):
-            sl = slice(d * B, (d + 1) * B)
-            hip_ops.conv3x3_dd(state, wr, br, gxr[sl], B, W, hk, wk, 0, False, out=fr)        # Wh.h + (Wx.x + b)
-            hip_ops.conv3x3_dd(state, wu, bu, gxu[sl], B, W, hk, wk, 0, False, out=fu)
-            hip_ops.group_stats_partial(fr, fu, HC, part)
-            hip_ops.gru2_gates_apply(fr, fu, part, gn, state, rh, u, HC)
-            hip_ops.conv3x3_dd(rh, wc, bc, cx[sl], B, W, hk, wk, 0, False, out=o)
-            hip_ops.group_stats_partial(o, None, HC, part)
-            hip_ops.gru2_out_apply(o, part, gn[4 * HC:], u, state, Rk[sl], HC)
-
-    def _recur_pair(self, k, x, Rk, B, h, w):
-        """Levels 1, 2: gate_conv / output_conv on cat(x_d, h) / cat(x_d, r*h) in one launch each (compact maps)."""
-        dev = x.device
-        HC, Cx = self.HC[k], x.shape[-1]
-        npix, hk, wk = x.shape[1], h >> k, w >> k
-        D = x.shape[0] // B
-        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)      # noqa: E731
-        state, rh, u, o = z(B, npix, HC), z(B, npix, HC), z(B, npix, HC), z(B, npix, HC)
-        f = z(B, npix, 2 * HC)
-        fu = f[:, :, HC:]                                                   # update rows: a view, pixel stride 2 HC
-        part = hip_ops.group_stats_workspace(B, 2, dev)
-        gn = self._gn(k)
-        wg, bg = self._wp("gp%d" % (k + 1), Cx + HC)
-        wc, bc = self._wp("cp%d" % (k + 1), Cx + HC)
-        for d in range(D):
-            sl = slice(d * B, (d + 1) * B)
-            hip_ops.conv3x3_pair(x[sl], state, wg, bg, 2 * HC, hk, wk, out=f)
-            hip_ops.group_stats_partial(f, fu, HC, part)
-            hip_ops.gru2_gates_apply(f, fu, part, gn, state, rh, u, HC)
-            hip_ops.conv3x3_pair(x[sl], rh, wc, bc, HC, hk, wk, out=o)
-            hip_ops.group_stats_partial(o, None, HC, part)
-            hip_ops.gru2_out_apply(o, part, gn[4 * HC:], u, state, Rk[sl], HC)
+        if k < 2:      # levels 1, 2: gate_conv / output_conv whole, on cat(x_d, h) / cat(x_d, r*h) (compact maps)
+            Cx = feed.shape[-1]
+            wg, bg = self._wp("gp%d" % (k + 1), Cx + HC)
+            wc, bc = self._wp("cp%d" % (k + 1), Cx + HC)
+            hip_ops.red_recur_pair(feed, wg, bg, wc, bc, gn, Rk, B, hk, wk, HC)
+        else:          # levels 3, 4: the h halves per plane; the x halves (feed) enter as the convolutions' skip operand
+            gxr, gxu, cx = feed
+            blocks = [self._wblock("%s%d" % (n, k + 1)) for n in ("ghr", "ghu", "ch")]
+            hip_ops.red_recur_split(gxr, gxu, cx, blocks[0], blocks[1], blocks[2], gn, Rk, B, hk, wk, HC)
 
     # ---- C: decoder for all planes --------------------------------------------------------------------------------
     def decode(self, R, B, h, w):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 5
+#define ADAMVS_ABI_VERSION 6
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -256,6 +256,23 @@ int adamvs_gru2_out_apply(const float* o, const void* partials, const float* gn,
  * bias [16*ceil(cout/16)] zero padded.  (CA, CB, cout) in (32|16|8, 8, <=16) or (16, 16, <=32). */
 int adamvs_conv3x3_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias,
                         float* out, int cout, int B, int h, int w, void* stream);
+
+/* One level's whole recurrence over the D planes of a stage (the loop of slice_RED_Regularization.forward restricted to
+ * one ConvGRUCell2, msrednet.py:349-366), launched from native code: per plane the convolutions, the two GroupNorm
+ * reductions and the two epilogues above; the state starts at zero; h' of plane d goes to channels [0, HC) of
+ * R [D][B][h*w][RW] (plane-major).  gn [6][HC] = reset / update / output norm weight, bias.
+ * _pair (levels 1, 2): x [D][B][h*w][Cx] compact, wg / wc + bg / bc as for adamvs_conv3x3_pair (gate_conv with 2 HC
+ * rows, output_conv).  _split (levels 3, 4): gxr, gxu, cx [D][B][h*w][W] = the x halves (+ bias) of the reset / update /
+ * candidate convolutions, w_ghr / w_ghu / w_ch = the h halves as adamvs_conv3x3_dd blocks (9 W W fragment floats + W
+ * zero bias floats each).  workspace: adamvs_red_recur_workspace_bytes(B, h, w, W, Wf, HC) with (W, Wf) = (HC, 2 HC)
+ * for _pair and (W, W) for _split. */
+size_t adamvs_red_recur_workspace_bytes(int B, int h, int w, int W, int Wf, int HC);
+int adamvs_red_recur_pair(const float* x, int Cx, const float* wg, const float* bg, const float* wc, const float* bc,
+                          const float* gn, float* R, int RW, int B, int D, int h, int w, int HC, float eps, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int adamvs_red_recur_split(const float* gxr, const float* gxu, const float* cx, const float* w_ghr, const float* w_ghu,
+                           const float* w_ch, const float* gn, float* R, int RW, int B, int D, int h, int w, int W, int HC,
+                           float eps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The running exp-sum / max / weighted-depth update of msrednet.py:415-436 (same as adamvs.py:512-531) in one pass over
  * the stored slices: vol [B][D][h*w] = reg_cost of every plane, planes [B][D][h*w] -> depth, confidence [B][h*w]. */
