@@ -37,6 +37,8 @@ int launch_soft_argmin(const float* vol, const float* planes, float* depth, floa
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
                        float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, int eps_in_numerator,
                        hipStream_t st);
+int launch_sweep_variance(const float* feat, const float* rt, const float* planes, float* out_a, int Da, float* out_b, int Db,
+                          int B, int S, int C, int D, int h, int w, hipStream_t st);
 size_t sweep_workspace_floats(int B, int C, int D, int h, int w);
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
                            int precision, hipStream_t st);

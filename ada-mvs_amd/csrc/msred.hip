@@ -194,6 +194,12 @@ extern "C" int adamvs_red_variance_cost(const float* feat, const float* rt, cons
   ADAMVS_CHECK_ARG(feat && rt && planes && out_a && B > 0 && S > 0 && C > 0 && (C % 4) == 0 && D > 0 && h > 0 && w > 0 &&
                    Da >= C && (Da % 4) == 0 && (!out_b || (Db >= C && (Db % 4) == 0)),
                    "red_variance_cost: bad arguments (B=%d S=%d C=%d D=%d h=%d w=%d Da=%d Db=%d)", B, S, C, D, h, w, Da, Db);
+  // the register-resident-tap sweep of the Ada-MVS aggregation in its variance mode (sweep.hip): the feature maps are read
+  // about once per pixel instead of once per pixel and plane (this kernel below gathered 116 GB through L2 for 16
+  // tiles of stage 1).  It writes the negated variance; other view counts / widths / sign take the plain kernel.
+  // Its plane loop is sequential inside a thread: worth it once the pixels alone fill the chip (one small tile: 9.3 vs 8.7 ms).
+  if (negate && S <= 8 && (C == 8 || C == 16 || C == 32) && (size_t)B * h * w >= 65536)
+    return launch_sweep_variance(feat, rt, planes, out_a, Da, out_b, Db, B, S, C, D, h, w, (hipStream_t)stream);
   const size_t total = (size_t)D * B * h * w * (C / 4);
   ADAMVS_CHECK_ARG(total / 256 < 0x7fffffffu, "red_variance_cost: too many planes x pixels for one launch");
   hipLaunchKernelGGL(k_red_variance, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat, rt, planes,

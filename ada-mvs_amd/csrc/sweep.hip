@@ -23,11 +23,16 @@
 namespace adamvs {
 
 // grid: (ceil(hw / (256/G)), 1, B); block 256.  sim [d1-d0][B][hw][C].
-template <int C, int SV>
+// MODE 1 (MS-REDNet, reference models/msrednet.py:396-412): the same sweep with the variance over the reference and
+// the S warped views instead of the weighted sum -- two accumulators (sum, sum of squares) per plane, result
+// -(E[x^2] - E[x]^2) into channels [0, C) of sim [d1-d0][B][hw][Da] and, when sim_b != null, of sim_b [..][Db]
+// (vw and eps_num unused).
+template <int C, int SV, int MODE = 0>
 __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict__ feat, const float* __restrict__ rt,
                                                          const float* __restrict__ planes, const float* __restrict__ vw,
                                                          float* __restrict__ sim, int B, int S, int D, int d0, int d1,
-                                                         int h, int w, int eps_num) {
+                                                         int h, int w, int eps_num, float* __restrict__ sim_b = nullptr,
+                                                         int Da = C, int Db = C) {
   constexpr int G = C / 4, PPB = 256 / G;
   const int hw = h * w;
   const int tid = threadIdx.x, g = tid % G;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
 #pragma unroll
   for (int s = 0; s < SV; ++s) {
     const int sc = min(s, S - 1);
-    wv[s] = (s < S) ? vw[((size_t)sc * B + b) * hw + pc] : 0.f;
+    wv[s] = (MODE == 0 && s < S) ? vw[((size_t)sc * B + b) * hw + pc] : 0.f;
     ccell[s] = -1;
     t00[s] = t01[s] = t10[s] = t11[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -80,8 +85,12 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
   }
   const int gbase = (threadIdx.x & 63) & ~(G - 1);   // first lane of this pixel's group
   const float* pl = planes + (size_t)b * D * hw + pc;
-  float* out = sim + ((size_t)b * hw + pc) * C + 4 * g;
-  const size_t ostride = (size_t)B * hw * C;
+  const int OA = (MODE == 1) ? Da : C;
+  float* out = sim + ((size_t)b * hw + pc) * OA + 4 * g;
+  const size_t ostride = (size_t)B * hw * OA;
+  float* outb = (MODE == 1 && sim_b) ? sim_b + ((size_t)b * hw + pc) * Db + 4 * g : nullptr;
+  const size_t ostride_b = (size_t)B * hw * Db;
+  const float inv_n = 1.0f / (float)(S + 1);
 
   // depths: lane g of a pixel fetches plane dg+g, the group reads them back lane by lane -- one load per G planes,
   // so the (rolled) plane loop has no load that would queue behind the previous plane's store (vmcnt is in issue order)
@@ -102,6 +111,8 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
 #pragma unroll
     for (int k = 0; k < VPL; ++k) mine[k] = plane_taps(ax[k], ay[k], az[k], tx[k], ty[k], tz[k], depth, h, w);
     f32x4 acc = {eps_term, eps_term, eps_term, eps_term};
+    f32x4 acc2 = ref4 * ref4;
+    if (MODE == 1) acc = ref4;
 #pragma unroll
     for (int s = 0; s < SV; ++s) {
       if (s >= S) break;                                         // uniform
@@ -115,16 +126,44 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
         load_cell_taps(src0 + s * vstride, C, cell, h, w, t00[s], t01[s], t10[s], t11[s]);
       }
       f32x4 wrp = t00[s] * w00 + t01[s] * w01 + t10[s] * w10 + t11[s] * w11;     // all-zero weights when padding
-      acc += wrp * refw[s];                                      // adamvs.py:504-512
+      if (MODE == 1) { acc += wrp; acc2 += wrp * wrp; }          // msrednet.py:404-407
+      else acc += wrp * refw[s];                                 // adamvs.py:504-512
     }
+    if (MODE == 1) { const f32x4 m = acc * inv_n; acc = m * m - acc2 * inv_n; }     // -(E[x^2] - E[x]^2), msrednet.py:411
     park[j][tid] = acc;
   }
   if (live) {
     const int nd = min(G, d1 - dg);
 #pragma unroll 1
-    for (int j = 0; j < nd; ++j) *(f32x4*)(out + (size_t)(dg + j - d0) * ostride) = park[j][tid];
+    for (int j = 0; j < nd; ++j) {
+      *(f32x4*)(out + (size_t)(dg + j - d0) * ostride) = park[j][tid];
+      if (MODE == 1 && outb) *(f32x4*)(outb + (size_t)(dg + j - d0) * ostride_b) = park[j][tid];
+    }
   }
   }
+}
+
+template <int C>
+static int launch_sweep_variance_c(const float* feat, const float* rt, const float* planes, float* out_a, int Da, float* out_b,
+                                   int Db, int B, int S, int D, int h, int w, hipStream_t st) {
+  dim3 grid(cdiv(h * w, 256 / (C / 4)), 1, B);
+  if (S <= 4)
+    hipLaunchKernelGGL((k_sweep_aggregate<C, 4, 1>), grid, dim3(256), 0, st, feat, rt, planes, nullptr, out_a, B, S, D, 0, D, h, w, 0,
+                       out_b, Da, Db);
+  else
+    hipLaunchKernelGGL((k_sweep_aggregate<C, 8, 1>), grid, dim3(256), 0, st, feat, rt, planes, nullptr, out_a, B, S, D, 0, D, h, w, 0,
+                       out_b, Da, Db);
+  ADAMVS_CHECK_LAUNCH("sweep_variance");
+  return 0;
+}
+
+// -variance of (reference, S warped views) for all D planes with register-resident taps; S <= 8, C in {8, 16, 32}
+int launch_sweep_variance(const float* feat, const float* rt, const float* planes, float* out_a, int Da, float* out_b, int Db,
+                          int B, int S, int C, int D, int h, int w, hipStream_t st) {
+  if (C == 32) return launch_sweep_variance_c<32>(feat, rt, planes, out_a, Da, out_b, Db, B, S, D, h, w, st);
+  if (C == 16) return launch_sweep_variance_c<16>(feat, rt, planes, out_a, Da, out_b, Db, B, S, D, h, w, st);
+  if (C == 8) return launch_sweep_variance_c<8>(feat, rt, planes, out_a, Da, out_b, Db, B, S, D, h, w, st);
+  return set_error(-1, "sweep_variance: C=%d unsupported (8, 16 or 32)", C);
 }
 
 template <int C>

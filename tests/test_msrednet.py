@@ -156,10 +156,11 @@ def test_gru_cell2_against_reference_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("baseline", [8.0, 150.0])            # in bounds / with out-of-bounds taps
-def test_variance_cost_against_oracle(baseline):
+@pytest.mark.parametrize("baseline,B,h,w", [(8.0, 2, 24, 40), (150.0, 2, 24, 40),      # in bounds / out-of-bounds taps: plain kernel
+                                            (8.0, 2, 176, 192), (150.0, 2, 176, 192)])   # >= 65536 pixels: the sweep form
+def test_variance_cost_against_oracle(baseline, B, h, w):
     from ada_mvs_amd import hip_ops
-    B, C, h, w, V = 2, 16, 24, 40, 4
+    C, V = 16, 4
     feats = [synth.smooth_features(B, C, h, w, seed=10 + v) for v in range(V)]
     proj = synth.rig_projections(V, 4 * h, 4 * w, batch=B, baseline=baseline)["stage1"]
     planes = 400 + 200 * torch.rand(B, 3, h, w, generator=torch.Generator().manual_seed(1))
@@ -174,6 +175,10 @@ def test_variance_cost_against_oracle(baseline):
         assert rel_l1(-_nchw(a[d * B:(d + 1) * B, :, :C], h, w), want) < OP_TOL
         assert rel_l1(-_nchw(b[d * B:(d + 1) * B], h, w), want) < OP_TOL
     assert bool((a[:, :, C:] == 7.0).all())                      # the other channels are not touched
+    # positive sign: the plain one-thread-per-plane kernel (the negated form above runs on the register-resident-tap sweep)
+    hip_ops.red_variance_cost(feat_cl, rt, planes.reshape(B, 3, h * w).cuda(), a, None, B, V - 1, C, 3, h, w, negate=False)
+    want = mo.variance_cost(feats[0], feats[1:], [r[0] for r in rel], [r[1] for r in rel], planes[:, 1:2])
+    assert rel_l1(_nchw(a[B:2 * B, :, :C], h, w), want) < OP_TOL
 
 
 @pytest.mark.gpu
