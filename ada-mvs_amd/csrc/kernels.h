@@ -9,7 +9,7 @@ enum { PRECISION_FP32 = 0, PRECISION_BF16X3 = 1 };
 struct FuseWeights {          // mirrors adamvs_fuse_weights in include/adamvs_hip.h
   const float* conv1;         // [1][9][C/4][64]
   const float* gates1; const float* gates1_b;   // [1][9][4][64], [16]
-  const float* cand1;  const float* cand1_b;    // [1][9][4][64], [16]
+  const float* cand1;  const float* cand1_b;    // [12][4][64] (two-row form, fp32), [16]
   const float* conv2;                           // [1][9][2][64]
   const float* gates2; const float* gates2_b;   // [2][9][8][64], [32]
   const float* cand2;  const float* cand2_b;    // [1][9][8][64], [16]

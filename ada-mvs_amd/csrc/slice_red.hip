@@ -649,6 +649,132 @@ __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__
   }
 }
 
+// Candidate convolution of the level-1 ConvGRU (reference models/module.py:44-50: tanh(conv(cat(x, r*h))), blend with
+// u) in the same two-row form: its 8 output channels fill half an MFMA tile in the one-row form of k_conv_small (36
+// MFMAs per 16-pixel run, half of the rows zero); with rows 8-15 = the same channels of the next output row it is
+// 24 per run.  Two sources like k_conv_small (x = c1, r*h: 2 + 2 channel groups), its fused epilogue (u and h of the
+// lane's own pixel requested before the chain; h updated in place), the tile and pipeline of k_conv1_two_row.
+__global__ __launch_bounds__(256) void k_cand1_two_row(SmallConvArgs a, TileGrid tg) {
+  constexpr int CA = 8, CB = 8, C = 16, KC = C / 4, G = C / 4, GA = CA / 4, TR = 8, TC = 16, LR = TR + 2, LC = TC + 2;
+  constexpr int NPIX = LR * LC, PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
+  constexpr int NA = (NPIX * GA + 255) / 256, NL = 2 * NA;     // loads per source: a load's base must be uniform
+  extern __shared__ float lds[];           // [G][GP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int h = a.hi, w = a.wi;
+  float wf[12][KC];
+#pragma unroll
+  for (int t = 0; t < 12; ++t)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) wf[t][kc] = a.wpk[(t * KC + kc) * 64 + lane];
+  const f32x4 bias = *(const f32x4*)(a.bias + 4 * (q & 1));
+
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    const int j = min(tid + (isA ? k : k - NA) * 256, NPIX * GA - 1);          // surplus lanes repeat the last item
+    const int g = j % GA, pp = j / GA, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * w + c) * CA + 4 * g) * 4);
+    lbyte[k] = (unsigned)((((isA ? 0 : GA) + g) * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xbyte[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    xbyte[kc] = (unsigned)((kc * GP + q * PLANE + (2 * wave) * LC + p) * 4);
+    pin(xbyte[kc]);
+  }
+  const int orow = 2 * wave + (q >> 1);                       // lane's output pixel (orow, p), channels 4*(q&1)..
+  unsigned ooff = (unsigned)(((orow * w + p) * 8 + 4 * (q & 1)) * 4);
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int n, int tx, int ty) {
+    const int ix0 = tx * TC - 1, iy0 = ty * TR - 1;
+    const long pix0 = ((long)n * h + iy0) * w + ix0;
+    const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
+    const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= h && ix0 + LC <= w) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        stage[k] = buf_load4(k < NA ? ra : rb, ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? goff[k] : BUF_OOB);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int y0 = ty * TR, x0 = tx * TC;
+    const long opix0 = ((long)n * h + y0) * w + x0;
+    const buf_rsrc rh = make_rsrc((char*)a.dst0 + opix0 * 32);          // h, updated in place
+    const buf_rsrc ru = make_rsrc((const char*)a.dst1 + opix0 * 32);    // u
+    unsigned oo = ooff;
+    if (!(y0 + TR <= h && x0 + TC <= w)) oo = (y0 + orow < h && x0 + p < w) ? ooff : BUF_OOB;
+    const f32x4 pre_u = buf_load4(ru, oo), pre_h = buf_load4(rh, oo);  // epilogue operands first, then the next tile
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+          acc = mfma16(wf[rr * 3 + kx][kc], *(const float*)((const char*)lds + xbyte[kc] + (rr * LC + kx) * 4), acc);
+
+    wait_vmem_all();
+    __syncthreads();                                // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+    const f32x4 v = acc + bias;
+    const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+    buf_store4(rh, oo, pre_u * pre_h + (1.0f - pre_u) * cnd);
+    if (!more) break;
+    __syncthreads();                                // next tile visible
+    t = tn; n = nn; tx = txn; ty = tyn;
+  }
+}
+
+static int launch_cand1_two_row(const SmallConvArgs& a, int B, hipStream_t st) {
+  constexpr int G = 4;
+  constexpr size_t lds = (size_t)G * group_pitch(plane_pitch16(10 * 18), G) * sizeof(float);
+  static int capacity = 0;
+  if (!capacity) capacity = resident_blocks(k_cand1_two_row, 256, lds);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(a.wo, 16), cdiv(a.ho, 8), B)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(k_cand1_two_row, dim3(grid), dim3(256), lds, st, a, tg);
+  ADAMVS_CHECK_LAUNCH("cand1 (two-row)");
+  return 0;
+}
+
 // The same convolution for wide inputs (C = 32) with the contraction split over the waves.  Held in full, the
 // A fragments are 12 * C/4 = 96 registers per lane and leave room for two waves per SIMD, too few to cover the
 // load / LDS-fill / epilogue phases of each other.  Here wave k owns input channels 8k..8k+7 (24 fragment
@@ -849,8 +975,8 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   {  // GRU level 1: gates on cat(c1, h1), candidate on cat(c1, r*h1)
     SmallConvArgs g{c1, sb.h1, fw.gates1, fw.gates1_b, sb.rh1, sb.u1, h, w, h, w, 16};
     if ((rc = launch_small<8, 8, 1, 1, EPI_GATES>(g, B, st, "gates1"))) return rc;
-    SmallConvArgs c{c1, sb.rh1, fw.cand1, fw.cand1_b, sb.h1, sb.u1, h, w, h, w, 8};
-    if ((rc = launch_small<8, 8, 1, 1, EPI_CAND>(c, B, st, "cand1"))) return rc;
+    SmallConvArgs c{c1, sb.rh1, fw.cand1, fw.cand1_b, sb.h1, sb.u1, h, w, h, w, 8};     // cand1: two-row fragments
+    if ((rc = launch_cand1_two_row(c, B, st))) return rc;
   }
   {  // conv2: 8 -> 16, stride 2, ReLU
     SmallConvArgs a{sb.h1, nullptr, fw.conv2, nullptr, sb.c2, nullptr, h, w, h2, w2, 16};

@@ -169,7 +169,8 @@ def pack_slice_reg_net(sd, pre, precision="fp32"):
         "conv1": pack_c1(sd[pre + "conv1.conv.weight"]),
         "gates1": pack_small(sd[pre + "conv_gru1.conv_gates.0.weight"]),
         "gates1_b": pad_bias(sd[pre + "conv_gru1.conv_gates.0.bias"], 16),
-        "cand1": pack_small(sd[pre + "conv_gru1.convc.0.weight"]),
+        # fp32: 8 outputs fill half an MFMA tile, so the kernel takes them in the two-row form of conv1
+        "cand1": (pack_conv1_two_row if precision == "fp32" else pack_small)(sd[pre + "conv_gru1.convc.0.weight"]),
         "cand1_b": pad_bias(sd[pre + "conv_gru1.convc.0.bias"], 16),
         "conv2": pack_small(sd[pre + "conv2.conv.weight"]),
         "gates2": pack_small(sd[pre + "conv_gru2.conv_gates.0.weight"]),

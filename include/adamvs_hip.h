@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 6
+#define ADAMVS_ABI_VERSION 7
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -120,7 +120,7 @@ int adamvs_softmax_max_regress(const float* score, const float* planes, float* v
 typedef struct adamvs_fuse_weights {
   const float* conv1;                           /* [12][C/4][64] two-row form reg_fuse.conv1.conv.weight */
   const float* gates1; const float* gates1_b;   /* [1][9][4][64], [16]      conv_gru1.conv_gates.0 */
-  const float* cand1;  const float* cand1_b;    /* [1][9][4][64], [16]      conv_gru1.convc.0 */
+  const float* cand1;  const float* cand1_b;    /* [12][4][64] two-row form like conv1 (fp32), [16]   conv_gru1.convc.0 */
   const float* conv2;                           /* [1][9][2][64]            conv2.conv.weight */
   const float* gates2; const float* gates2_b;   /* [2][9][8][64], [32]      conv_gru2.conv_gates.0 */
   const float* cand2;  const float* cand2_b;    /* [1][9][8][64], [16]      conv_gru2.convc.0 */
