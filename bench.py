@@ -262,7 +262,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=list(synth.CONFIGS))
-    ap.add_argument("--batch", type=int, default=128, help="reference tiles per GPU per step (32: 405, 64: 438, 128: 446, 192: 449 maps/s)")
+    ap.add_argument("--batch", type=int, default=128, help="reference tiles per GPU per step")
     ap.add_argument("--groups", type=int, default=1, help="independent tile groups run concurrently on separate HIP streams")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32: exact fp32 MFMA (the cfg2 headline); bf16x3: split-bf16 MFMA for the convolutions (~1e-5 of fp32)")
