@@ -50,6 +50,14 @@ def scale_image(image, scale=1, interpolation="linear"):
         return image[ys][:, xs]
     if interpolation != "linear":
         return None
+    if scale == 0.5 and h % 2 == 0 and w % 2 == 0 and np.issubdtype(image.dtype, np.integer) and image.dtype.itemsize <= 2:
+        # the default predict setting: every sample centre falls between four pixels with weights 1/4 -- the 2 x 2 box,
+        # in integer arithmetic (same rounding as the general path below: half up)
+        acc = image[0::2, 0::2].astype(np.uint32)
+        acc += image[0::2, 1::2]
+        acc += image[1::2, 0::2]
+        acc += image[1::2, 1::2]
+        return ((acc + 2) >> 2).astype(image.dtype)
     y0, y1, fy = _axis_taps(h, nh, 1.0 / scale)
     x0, x1, fx = _axis_taps(w, nw, 1.0 / scale)
     src = image.astype(np.float64)

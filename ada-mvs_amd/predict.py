@@ -50,7 +50,7 @@ def build_parser():
     ap.add_argument("--cr_base_chs", type=str, default="8,8,8", help="cost regularization base channels")
     # not in the reference
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"], help="arithmetic of the convolutions")
-    ap.add_argument("--num_workers", type=int, default=2, help="loader processes (the reference uses 1)")
+    ap.add_argument("--num_workers", type=int, default=4, help="loader processes (the reference uses 1); decoding and resizing a view takes ~1 s of CPU")
     ap.add_argument("--seeded_weights", type=int, default=None,
                     help="no checkpoint: seeded random weights (ada_mvs_amd.synth), for dry runs and tests")
     return ap
