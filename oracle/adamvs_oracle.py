@@ -16,7 +16,6 @@ tests/test_oracle_golden.py checks every function below against them.
 All `file:line` citations are relative to the reference repository root.
 Weights arrive as a flat state dict using the reference's key names.
 """
-import math
 
 import torch
 import torch.nn.functional as F
