@@ -499,6 +499,19 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
   size_t b = n % B;
   const float* sc = score + pix * D;
   const float* pl = planes + b * D * hw + pp;
+  // The 16 pixels of a block are consecutive; read per lane, a plane value costs a whole 64-byte sector for 16 bytes
+  // (lanes of a wave hold 16 different planes of 4 pixels: 4x the plane volume through L2).  When the block lies inside
+  // one map the [D][16] patch is staged through LDS with full sectors instead (row pitch 17: 2-way at worst).
+  constexpr int DMAX = NQ > 0 ? 64 * NQ : 1;
+  __shared__ float lp[NQ > 0 ? DMAX * 17 : 1];
+  const size_t gp0 = (size_t)blockIdx.x * 16;
+  const bool staged = NQ > 0 && gp0 + 16 <= npix && (gp0 % hw) + 16 <= (size_t)hw;     // uniform
+  if (staged) {
+    const float* src = planes + ((gp0 / hw) % B) * D * hw + gp0 % hw;
+    for (int i = threadIdx.x; i < D * 16; i += 256) lp[(i >> 4) * 17 + (i & 15)] = src[(size_t)(i >> 4) * hw + (i & 15)];
+    __syncthreads();
+  }
+  const float* lpp = lp + (threadIdx.x >> 4);
   float m = -INFINITY;
   f32x4 keep[NQ > 0 ? NQ : 1];
   if (NQ > 0) {
@@ -520,7 +533,8 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
   auto term = [&](f32x4 v, int d) {
     float e0 = __expf(v.x - m), e1 = __expf(v.y - m), e2 = __expf(v.z - m), e3 = __expf(v.w - m);
     se += (e0 + e1) + (e2 + e3);
-    sd += e0 * pl[(size_t)d * hw] + e1 * pl[(size_t)(d + 1) * hw] + e2 * pl[(size_t)(d + 2) * hw] + e3 * pl[(size_t)(d + 3) * hw];
+    if (staged) sd += e0 * lpp[d * 17] + e1 * lpp[(d + 1) * 17] + e2 * lpp[(d + 2) * 17] + e3 * lpp[(d + 3) * 17];
+    else sd += e0 * pl[(size_t)d * hw] + e1 * pl[(size_t)(d + 1) * hw] + e2 * pl[(size_t)(d + 2) * hw] + e3 * pl[(size_t)(d + 3) * hw];
   };
   if (NQ > 0) {
 #pragma unroll
