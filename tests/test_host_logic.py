@@ -182,3 +182,14 @@ def test_reference_style_import_path():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().endswith("339")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No libadamvs_hip.so -> AdaMVSHipError naming the build command; nothing falls back to PyTorch or the oracle."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libadamvs_hip.so"))
+    with pytest.raises(_lib.AdaMVSHipError, match="not built"):
+        _lib.load()
+    from ada_mvs_amd import hip_ops
+    with pytest.raises(_lib.AdaMVSHipError):                    # every op goes through load(): same failure
+        hip_ops.feature_net0_workspace_bytes(1, 64, 96)
