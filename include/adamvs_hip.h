@@ -108,7 +108,7 @@ int adamvs_softmax_max_regress(const float* score, const float* planes, float* v
 /* SliceCostRegNetRED weights (models/adamvs.py:400-413), packed by the host:
  * conv weights as MFMA A fragments [cout tile][tap][cin/4][64 lanes] holding
  * W[cout = 16*tile + (lane&15)][cin = 4*kc + (lane>>4)][tap] (0 beyond cout),
- * biases zero-padded to 16 per tile.  conv1 (8 output channels) uses the two-row form: fragment
+ * biases zero-padded to 16 per tile.  conv1 and cand1 (8 output channels each) use the two-row form: fragment
  * (rr, kx, kc), rr = 0..3, holds for lanes with (lane&15) < 8 the weights of output row y,
  * W[lane&15][cin][ky = rr][kx] (0 if rr = 3), and for the other lanes those of output row y+1,
  * W[(lane&15)-8][cin][ky = rr-1][kx] (0 if rr = 0), so one MFMA feeds two output rows.
