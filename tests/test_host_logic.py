@@ -120,6 +120,15 @@ def test_packed_network_sizes_match_the_header():
     assert all(o % 64 == 0 for o in off.values())
     assert off["gates1"] - off["conv1"] == 12 * 8 * 64               # two-row conv1, C=32 -> KC=8
     assert flat.numel() >= off["final_w"] + 73
+    # cand1 (8 outputs from cat(c1, r*h) = 16 channels) in the same two-row form: [12 = (rr, kx)][KC = 4][64]
+    assert off["cand1_b"] - off["cand1"] == 12 * 4 * 64
+    wc = sd["DepthNet.0.reg_fuse.conv_gru1.convc.0.weight"]          # [8][16][3][3]
+    frag = flat[off["cand1"]:off["cand1"] + 12 * 4 * 64].reshape(4, 3, 4, 4, 16)      # [rr][kx][kc][k4][row]
+    assert frag[1, 2, 3, 1, 5] == wc[5, 13, 1, 2]                     # rows 0-7: output row y, ky = rr
+    assert frag[1, 2, 3, 1, 8 + 5] == wc[5, 13, 0, 2]                 # rows 8-15: output row y+1, ky = rr - 1
+    assert frag[3, 0, 0, 0, 2] == 0 and frag[0, 0, 0, 0, 8 + 2] == 0  # no tap for (row y, rr = 3) and (row y+1, rr = 0)
+    flat_b, off_b = packing.pack_slice_reg_net(sd, "DepthNet.0.reg_fuse.", "bf16x3")
+    assert off_b["cand1_b"] - off_b["cand1"] != 12 * 4 * 64           # the split-bf16 kernel keeps its own k-flattened form
     # last layer: tap-major (a channel pair of one tap is one 64-bit scalar operand of the packed FMA), bias at [72]
     w_up = sd["DepthNet.0.reg_fuse.upconv2d.weight"]                  # ConvTranspose2d: [8][1][3][3]
     fw = flat[off["final_w"]:off["final_w"] + 73]
