@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must be imported before the library is loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadamvs_hip.so")
+LIB_PATH = os.environ.get("ADAMVS_LIB_PATH") or os.path.join(_HERE, "libadamvs_hip.so")     # override: A/B of two builds
 
 c_f = ctypes.c_void_p          # device pointer to float
 c_i = ctypes.c_int

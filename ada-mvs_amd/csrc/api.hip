@@ -22,8 +22,13 @@ static_assert(sizeof(FuseWeights) == sizeof(adamvs_fuse_weights), "adamvs_fuse_w
 
 static size_t align_up(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats: 256-byte slots
 
+// Workspace of one stage.  The hypothesis axis is processed in chunks of DC = sweep_chunk_planes(D) planes (aggregation
+// -> conv1 -> recurrence -> soft-argmin accumulation per chunk, reference models/adamvs.py:495-531 runs the same
+// chain per plane), so nothing below grows with D except the stage-1 similarity / score volumes, whose hypothesis axis
+// is CostRegNet2D's channel axis (models/adamvs.py:464-486).
 struct StageCarve {
-  size_t c1, h1, rh1, u1, c2, h2, rh2, u2, vol, agg, sim, score, creg, total;   // offsets in floats
+  size_t c1, h1[4], rh1, u1, c2[2], h2[2], rh2, u2, vol[2], acc, agg, sim, score, creg, total;   // offsets in floats
+  int dc;
 };
 
 static StageCarve carve(const adamvs_stage_desc& s) {
@@ -32,15 +37,17 @@ static StageCarve carve(const adamvs_stage_desc& s) {
   size_t HW = s.in_up ? 4 * hw : hw;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += align_up(n); return r; };
-  c.c1 = take((size_t)s.D * s.B * hw * 8);
-  c.h1 = take((size_t)s.B * hw * 8);
+  c.dc = sweep_chunk_planes(s.D);
+  c.c1 = take((size_t)c.dc * s.B * hw * 8);
+  for (int i = 0; i < 4; ++i) c.h1[i] = take((size_t)s.B * hw * 8);
   c.rh1 = take((size_t)s.B * hw * 8);
   c.u1 = take((size_t)s.B * hw * 8);
-  c.c2 = take((size_t)s.B * hw4 * 16);
-  c.h2 = take((size_t)s.B * hw4 * 16);
+  for (int i = 0; i < 2; ++i) c.c2[i] = take((size_t)s.B * hw4 * 16);
+  for (int i = 0; i < 2; ++i) c.h2[i] = take((size_t)s.B * hw4 * 16);
   c.rh2 = take((size_t)s.B * hw4 * 16);
   c.u2 = take((size_t)s.B * hw4 * 16);
-  c.vol = take((size_t)s.B * s.D * HW);
+  for (int i = 0; i < 2; ++i) c.vol[i] = take((size_t)s.B * c.dc * HW);      // the decoder runs two or three hypotheses behind level 1
+  c.acc = take(3 * (size_t)s.B * HW);
   c.agg = take(sweep_workspace_floats(s.B, s.C, s.D, s.h, s.w));
   c.sim = c.score = c.creg = o;
   if (s.first_stage) {
@@ -147,24 +154,65 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
     if ((rc = adamvs_resize_bilinear(prev_conf, view_weight, s.S * s.B, s.prev_h, s.prev_w, s.h, s.w, stream))) return rc;
   }
 
-  // -- weighted aggregation + conv1 for every hypothesis (state-independent)
-  if ((phases & ADAMVS_PHASE_AGGREGATE) &&
-      (rc = launch_sweep_conv1(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, s.h, s.w,
-                               s.precision_fuse, s.eps_in_numerator, st)))
-    return rc;
-
-  // -- recurrence over hypotheses
-  if (phases & ADAMVS_PHASE_RECURRENCE) {
-  hipError_t e = hipMemsetAsync(ws + c.h1, 0, (size_t)s.B * s.h * s.w * 8 * sizeof(float), st);
-  if (e == hipSuccess) e = hipMemsetAsync(ws + c.h2, 0, (size_t)s.B * (s.h / 2) * (s.w / 2) * 16 * sizeof(float), st);
-  if (e != hipSuccess) return set_error((int)e, "stage: hipMemsetAsync: %s", hipGetErrorString(e));
-  StepBuffers sb{ws + c.h1, ws + c.rh1, ws + c.u1, ws + c.c2, ws + c.h2, ws + c.rh2, ws + c.u2};
-  const size_t c1_stride = (size_t)s.B * s.h * s.w * 8;
-  for (int d = 0; d < s.D; ++d) {
-    if ((rc = launch_slice_step(ws + c.c1 + d * c1_stride, fw, sb, ws + c.vol, s.B, s.h, s.w, s.D, d, s.in_up, s.precision_fuse, st)))
+  // -- per chunk of hypotheses: weighted aggregation + conv1 (state-independent), the recurrence, soft-argmin accumulation.
+  // With the full mask the three are interleaved chunk by chunk and the recurrence runs as a pipeline across chunk
+  // boundaries.  A partial mask (phase-by-phase timing, bench.py) runs the selected phase alone over all chunks on the
+  // same buffers: its duration is that of the phase, only the full mask produces the maps.
+  const bool do_agg = phases & ADAMVS_PHASE_AGGREGATE, do_rec = phases & ADAMVS_PHASE_RECURRENCE, do_arg = phases & ADAMVS_PHASE_SOFT_ARGMIN;
+  if (!do_agg && !do_rec && !do_arg) return 0;
+  const size_t hw = (size_t)s.h * s.w, hw4 = (size_t)(s.h / 2) * (s.w / 2);
+  const int dc = c.dc, nchunks = (s.D + dc - 1) / dc;
+  const size_t c1_stride = (size_t)s.B * hw * 8;
+  GruStateRing rb{{ws + c.h1[0], ws + c.h1[1], ws + c.h1[2], ws + c.h1[3]}, ws + c.rh1, ws + c.u1, {ws + c.c2[0], ws + c.c2[1]},
+                  {ws + c.h2[0], ws + c.h2[1]}, ws + c.rh2, ws + c.u2};
+  const int mode = recurrence_mode(s.precision_fuse, (long)s.B * s.h * s.w);
+  const bool pipelined = mode != 0;
+  const int lag = recurrence_lags(mode, s.precision_fuse).dec;       // the decoder runs `lag` hypotheses behind level 1
+  if (do_rec) {      // zero initial states (adamvs.py:448-449): h1[-1] = ring slot 3, h2[-1] = ring slot 1 (slot 0 when sequential)
+    hipError_t e = hipMemsetAsync(pipelined ? rb.h1[3] : rb.h1[0], 0, (size_t)s.B * hw * 8 * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(pipelined ? rb.h2[1] : rb.h2[0], 0, (size_t)s.B * hw4 * 16 * sizeof(float), st);
+    if (e != hipSuccess) return set_error((int)e, "stage: hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  auto vol_of = [&](int d) { return ws + c.vol[(d / dc) & 1]; };
+  auto argmin_chunk = [&](int k) {
+    const int d0 = k * dc, nd = (d0 + dc < s.D ? d0 + dc : s.D) - d0;
+    return launch_soft_argmin_chunk(ws + c.vol[k & 1], dc, planes, s.D, d0, nd, ws + c.acc, k == 0, k == nchunks - 1, depth, confidence,
+                                    s.B, s.h, s.w, s.in_up, st);
+  };
+  StepBuffers sb{rb.h1[0], rb.rh1, rb.u1, rb.c2[0], rb.h2[0], rb.rh2, rb.u2};     // sequential mode: states updated in place
+  for (int k = 0; k < nchunks; ++k) {
+    const int d0 = k * dc, d1 = d0 + dc < s.D ? d0 + dc : s.D;
+    if (do_agg && (rc = launch_sweep_conv1_chunk(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, d0,
+                                                 d1, s.h, s.w, s.precision_fuse, s.eps_in_numerator, st)))
       return rc;
+    if (do_rec) {
+      for (int t = d0; t < d1; ++t) {
+        const float* c1_t = ws + c.c1 + (size_t)(t - d0) * c1_stride;
+        if (pipelined) {
+          // level 1 of hypothesis t, level 2 of t-1 (t-2), decoder of t-lag (which may belong to the previous chunk)
+          const int sd = t - lag;
+          if ((rc = launch_recur_pipeline_step(rb, fw, s.B, s.h, s.w, s.D, t, c1_t, sd >= 0 ? vol_of(sd) : nullptr, dc, sd >= 0 ? sd % dc : 0,
+                                               s.in_up, s.precision_fuse, mode, st)))
+            return rc;
+          if (do_arg && sd >= 0 && sd % dc == dc - 1 && (rc = argmin_chunk(sd / dc))) return rc;   // a chunk of the volume is complete
+        } else if ((rc = launch_slice_step(c1_t, fw, sb, vol_of(t), s.B, s.h, s.w, dc, t % dc, s.in_up, s.precision_fuse, st))) {
+          return rc;
+        }
+      }
+      if (!pipelined && do_arg && (rc = argmin_chunk(k))) return rc;
+    } else if (do_arg && (rc = argmin_chunk(k))) {
+      return rc;
+    }
   }
+  if (do_rec && pipelined) {
+    for (int t = s.D; t < s.D + lag; ++t) {     // drain: the levels and decoders still behind
+      const int sd = t - lag;
+      if ((rc = launch_recur_pipeline_step(rb, fw, s.B, s.h, s.w, s.D, t, nullptr, sd >= 0 ? vol_of(sd) : nullptr, dc, sd >= 0 ? sd % dc : 0,
+                                           s.in_up, s.precision_fuse, mode, st)))
+        return rc;
+      if (do_arg && sd >= 0 && sd % dc == dc - 1 && sd / dc < nchunks - 1 && (rc = argmin_chunk(sd / dc))) return rc;
+    }
+    if (do_arg && (rc = argmin_chunk(nchunks - 1))) return rc;
   }
-  if (!(phases & ADAMVS_PHASE_SOFT_ARGMIN)) return 0;
-  return launch_soft_argmin(ws + c.vol, planes, depth, confidence, s.B, s.D, s.h, s.w, s.in_up, st);
+  return 0;
 }

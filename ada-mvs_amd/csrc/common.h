@@ -56,6 +56,15 @@ __device__ __forceinline__ f32x4 buf_load4(buf_rsrc r, unsigned byte_off) {
 __device__ __forceinline__ void buf_store4(buf_rsrc r, unsigned byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
 }
+// An MFMA result may be read only after the matrix pipe has written it back (8 passes for the 16x16 shapes used here: 11
+// wait states); the hardware does not interlock, the compiler inserts s_nop.  Its hazard recognizer (ROCm 7.2, clang 22)
+// counts wait states along ONE predecessor path when the first read sits behind a branch: for
+//     chain; barrier; if (more) refill_lds(); epilogue(acc)
+// it emitted `s_nop 0` on the path that skips the refill, and the last tile of every workgroup lost the final MFMA in
+// accumulator rows 8-15.  drain() makes the accumulator a VGPR value in the basic block of the chain itself, where the
+// count is linear and right; tools/mfma_hazard_lint.py checks the built library for the pattern.
+__device__ __forceinline__ void drain(f32x4& acc) { asm volatile("" : "+v"(acc)); }
+
 // Pin a per-lane constant in a register: computed once, never rematerialised or sunk into a branch.
 template <typename T> __device__ __forceinline__ void pin(T& x) { asm volatile("" : "+v"(x)); }
 

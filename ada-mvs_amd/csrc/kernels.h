@@ -22,6 +22,24 @@ struct StepBuffers {          // all channel-last
   float* c2; float* h2; float* rh2; float* u2;   // [B][hw/4][16]
 };
 
+// State of the software-pipelined recurrence (recurrence.hip): h1 of step t in h1[t % 4]; h2 and conv2's output of step t
+// in h2[t % 2], c2[t % 2]
+struct GruStateRing {
+  float* h1[4]; float* rh1; float* u1;              // [B][hw][8]
+  float* c2[2]; float* h2[2]; float* rh2; float* u2;   // [B][hw/4][16]
+};
+struct RecurLags { int c2, dec; };       // hypotheses by which cand2 / the decoder run behind level 1
+int recurrence_mode(int precision, long pixels);
+RecurLags recurrence_lags(int schedule, int precision);
+int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, int B, int h, int w, int D, int t, const float* c1_t,
+                               float* vol_dec, int D_vol, int d_dec, int in_up, int precision, int schedule, hipStream_t st);
+int launch_soft_argmin_chunk(const float* vol, int vol_D, const float* planes, int D, int d0, int nd, float* acc, int first, int last,
+                             float* depth, float* conf, int B, int h, int w, int in_up, hipStream_t st);
+int sweep_chunk_planes(int D);
+int launch_sweep_conv1_chunk(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+                             float* c1_chunk, float* sim_ws, int B, int S, int C, int D, int d0, int d1, int h, int w, int precision,
+                             int eps_in_numerator, hipStream_t st);
+
 int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, int precision, hipStream_t st);
 int launch_conv1_bf16x3(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st);
 int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBuffers& sb, int B, int h, int w, int d,

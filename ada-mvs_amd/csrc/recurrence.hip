@@ -1,0 +1,383 @@
+// Software-pipelined recurrence of one cascade stage.
+//
+//   for d in range(D): reg_cost, state1, state2 = SliceCostRegNetRED(cost_d, state1, state2)
+//   reference models/adamvs.py:495-527 (the loop), 415-424 (one step), models/module.py:24-52 (ConvGRUCell)
+//
+// One step is a chain  gates1 -> cand1 -> conv2 -> gates2 -> cand2 -> decoder  of six dependent tile loops.  Only two
+// of the dependencies cross steps -- level 1 of step t+1 needs h1[t], level 2 of step t+1 needs h2[t] -- so the steps
+// are skewed: while level 1 works on hypothesis t, level 2 works on t-1 and the decoder on t-2, and roles that do
+// not depend on each other share a launch ("slot"): workgroups [0, n0) of the grid walk the tiles of one role,
+// [n0, n0+n1) those of the next, ... (k_slot).  Three dependent launches per hypothesis instead of six, each with
+// matrix-bound and memory-bound tile loops resident side by side on every CU:
+//
+//   fp32     slot A(t): gates1(t) | conv2(t-1)      slot B(t): cand1(t) | gates2(t-1)     slot C(t): cand2(t-1) | decoder(t-2)
+//   bf16x3   slot A(t): gru1(t)   | conv2(t-1)      slot B(t): gru1(t)' | gates2(t-1) | decoder(t-2)'    slot C(t): gru1(t)'' | cand2(t-1) | decoder(t-2)''
+//            (the fused level-1 kernel has no dependant inside its step: its tiles are spread over the three slots)
+//
+// State rings: h1 of step t lives in h1[t % 4] (the decoder still reads h1[t-2] or h1[t-3] while cand1 writes h1[t]),
+// h2 and conv2's output of step t in h2[t % 2], c2[t % 2].  The arithmetic of every tile is that of the one-role kernels (slice_roles.h): the pipelined stage
+// is bit-identical to the sequential one, which tests/test_hip_parity.py asserts.
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+#include "persistent.h"
+#include "slice_roles.h"
+#include "slice_roles_bx3.h"
+
+namespace adamvs {
+
+struct NopRole {
+  struct Args {};
+  static constexpr size_t LDS_BYTES = 0;
+  static int tiles_x(const Args&) { return 1; }
+  static int tiles_y(const Args&) { return 1; }
+  static __device__ __forceinline__ void run(const Args&, const TileGrid&, TileRange, int, int, float*) {}
+};
+
+template <class R0, class R1, class R2>
+struct SlotArgs {
+  typename R0::Args a0; TileGrid g0; TileRange r0; int n0;     // role 0: workgroups [0, n0)
+  typename R1::Args a1; TileGrid g1; TileRange r1; int n1;     // role 1: workgroups [n0, n0 + n1)
+  typename R2::Args a2; TileGrid g2; TileRange r2;             // role 2: the rest of the grid
+};
+
+// POLICY 0: the grid is divided between the roles (workgroups [0, n0) run role 0, ...), in proportion to their estimated
+// work: roles with different bottlenecks are resident side by side for the whole launch, at the price of a cost model.
+// POLICY 1: every workgroup walks its share of EVERY role, one role after the other, the order rotated by the workgroup
+// index: no cost model (each workgroup gets the same number of tiles of each role), the mixture on a CU comes from
+// neighbouring workgroups being in different roles.
+template <class R0, class R1, class R2, int POLICY>
+__global__ __launch_bounds__(256) void k_slot(SlotArgs<R0, R1, R2> s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wg = blockIdx.x;                  // workgroup-uniform: the role dispatch is a scalar branch
+  if (POLICY == 0) {
+    if (wg < s.n0) R0::run(s.a0, s.g0, s.r0, wg, s.n0, lds);
+    else if (wg < s.n0 + s.n1) R1::run(s.a1, s.g1, s.r1, wg - s.n0, s.n1, lds);
+    else R2::run(s.a2, s.g2, s.r2, wg - s.n0 - s.n1, (int)gridDim.x - s.n0 - s.n1, lds);
+  } else {
+    const int nwg = (int)gridDim.x;
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+      int r = p + wg % 3;
+      r = r >= 3 ? r - 3 : r;
+      // a workgroup without a tile of a role (absent role: empty range, null arguments) must not even run its prologue
+      if (r == 0) { if (s.r0.begin + wg < s.r0.end) R0::run(s.a0, s.g0, s.r0, wg, nwg, lds); }
+      else if (r == 1) { if (s.r1.begin + wg < s.r1.end) R1::run(s.a1, s.g1, s.r1, wg, nwg, lds); }
+      else if (s.r2.begin + wg < s.r2.end) R2::run(s.a2, s.g2, s.r2, wg, nwg, lds);
+      __syncthreads();                        // the next role refills the LDS tile
+    }
+  }
+}
+
+constexpr size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+// A role instance of a slot: its arguments (null = absent), the fraction [f0, f1) of its tiles this slot takes and its
+// cost per tile relative to the other roles (what the grid is divided by).
+template <class R>
+struct RoleUse {
+  const typename R::Args* args;
+  float cost;
+  float f0, f1;
+};
+
+// Divide `total` workgroups over the roles in proportion to their work, at least one and at most one per tile.
+static void split_grid(int total, const long (&tiles)[3], const double (&work)[3], int (&n)[3]) {
+  double W = 0;
+  for (int i = 0; i < 3; ++i) W += tiles[i] ? work[i] : 0;
+  int sum = 0;
+  for (int i = 0; i < 3; ++i) {
+    n[i] = 0;
+    if (!tiles[i]) continue;
+    long v = (long)(total * (work[i] / W) + 0.5);
+    n[i] = (int)(v < 1 ? 1 : (v > tiles[i] ? tiles[i] : v));
+    sum += n[i];
+  }
+  while (sum > total) {                       // rounding: take from the role with the most workgroups
+    int k = -1;
+    for (int i = 0; i < 3; ++i) if (n[i] > 1 && (k < 0 || n[i] > n[k])) k = i;
+    if (k < 0) break;
+    --n[k]; --sum;
+  }
+  while (sum < total) {                       // give to the role with the most work per workgroup that can still grow
+    int k = -1;
+    for (int i = 0; i < 3; ++i)
+      if (tiles[i] && n[i] < tiles[i] && (k < 0 || work[i] / n[i] > work[k] / n[k])) k = i;
+    if (k < 0) break;
+    ++n[k]; ++sum;
+  }
+}
+
+int slot_policy() {                           // ADAMVS_SLOT_POLICY: 0 (default) = grid divided between the roles, 1 = every workgroup runs every role
+  const char* e = getenv("ADAMVS_SLOT_POLICY");
+  return e ? atoi(e) : 0;
+}
+
+template <class R0, class R1, class R2, int POLICY>
+static int launch_slot_p(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleUse<R2>& u2, int B, hipStream_t st, const char* name) {
+  constexpr size_t lds = max3(R0::LDS_BYTES, R1::LDS_BYTES, R2::LDS_BYTES);
+  static_assert(lds <= 64 * 1024, "slot exceeds the default dynamic LDS limit");
+  auto kern = k_slot<R0, R1, R2, POLICY>;
+  static int capacity = 0;                    // per instantiation; a pure function of the kernel and the device
+  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  SlotArgs<R0, R1, R2> s;
+  memset(&s, 0, sizeof(s));
+  long tiles[3] = {0, 0, 0};
+  double work[3] = {0, 0, 0};
+  int rc;
+  auto prep = [&](auto* args, auto& dst_args, TileGrid& g, TileRange& r, float cost, float f0, float f1, int i, auto role) -> int {
+    typedef decltype(role) R;
+    if (!args) return 0;
+    dst_args = *args;
+    if (int e = make_tile_grid(g, R::tiles_x(*args), R::tiles_y(*args), B)) return e;
+    r.begin = (int)((double)g.ntiles * f0 + 0.5);
+    r.end = f1 >= 1.0f ? g.ntiles : (int)((double)g.ntiles * f1 + 0.5);
+    tiles[i] = r.end - r.begin;
+    work[i] = (double)tiles[i] * cost;
+    return 0;
+  };
+  if ((rc = prep(u0.args, s.a0, s.g0, s.r0, u0.cost, u0.f0, u0.f1, 0, R0()))) return rc;
+  if ((rc = prep(u1.args, s.a1, s.g1, s.r1, u1.cost, u1.f0, u1.f1, 1, R1()))) return rc;
+  if ((rc = prep(u2.args, s.a2, s.g2, s.r2, u2.cost, u2.f0, u2.f1, 2, R2()))) return rc;
+  const long all = tiles[0] + tiles[1] + tiles[2];
+  if (all == 0) return 0;
+  int grid;
+  if (POLICY == 0) {
+    int n[3];
+    split_grid((int)(all < capacity ? all : capacity), tiles, work, n);
+    s.n0 = n[0];
+    s.n1 = n[1];
+    grid = n[0] + n[1] + n[2];
+  } else {                                    // absent roles have an empty tile range
+    long most = tiles[0] > tiles[1] ? tiles[0] : tiles[1];
+    most = most > tiles[2] ? most : tiles[2];
+    grid = (int)(most < capacity ? most : capacity);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
+  return 0;
+}
+
+template <class R0, class R1, class R2>
+static int launch_slot(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleUse<R2>& u2, int B, hipStream_t st, const char* name) {
+  if (slot_policy() == 0) return launch_slot_p<R0, R1, R2, 0>(u0, u1, u2, B, st, name);
+  return launch_slot_p<R0, R1, R2, 1>(u0, u1, u2, B, st, name);
+}
+
+// ---- the roles of one step ------------------------------------------------------------------------------------
+typedef ConvSmallRole<8, 8, 1, 1, EPI_GATES> Gates1;
+typedef Cand1TwoRowRole Cand1;
+typedef ConvSmallRole<8, 0, 1, 2, EPI_RELU> Conv2;
+typedef ConvSmallRole<16, 16, 2, 1, EPI_GATES> Gates2;
+typedef ConvSmallRole<16, 16, 1, 1, EPI_CAND> Cand2;
+typedef Gru1FusedBx3Role Gru1Bx;
+typedef ConvSmallBx3Role<8, 0, 1, 2, BXE_RELU> Conv2Bx;
+typedef ConvSmallBx3Role<16, 16, 2, 1, BXE_GATES> Gates2Bx;
+typedef ConvSmallBx3Role<16, 16, 1, 1, BXE_CAND> Cand2Bx;
+
+// Relative cost per tile (microseconds of a whole-chip launch per tile, measured at cfg2's stage-1 shape; only the
+// ratios inside a slot matter).  ADAMVS_RECUR_COSTS="g1,c1,v2,g2,c2,dec,k1bx,v2bx,g2bx,c2bx" overrides (tuning).
+// fa, fb: the fused bf16x3 level-1 kernel runs tiles [0,fa) in slot A, [fa,fb) in B, [fb,1) in C; fd: the decoder of the
+// bf16x3 schedule runs [0,fd) in slot B and the rest in C.
+struct RoleCosts { float g1, c1, v2, g2, c2, dec, k1bx, v2bx, g2bx, c2bx, fa, fb, fd; };
+static const RoleCosts& role_costs() {
+  static RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 4.46f, 13.8f, 3.2f, 6.3f, 5.0f, 0.6f, 0.8f, 0.42f};
+  static bool init = false;
+  if (!init) {
+    init = true;
+    if (const char* e = getenv("ADAMVS_RECUR_COSTS")) {
+      float v[13];
+      if (sscanf(e, "%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9, v + 10,
+                 v + 11, v + 12) == 13)
+        c = RoleCosts{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]};
+    }
+  }
+  return c;
+}
+
+// ADAMVS_RECUR_MODE: 0 = six launches per step, states updated in place; 1 / 2 = software-pipelined slots, schedule 1 / 2
+// (recurrence_lags); unset = by size.  Measured on MI355X (profiles/r02_recurrence_schedules.txt): sharing launches does
+// not make the roles faster -- a slot takes the sum of its roles' standalone times, the decoder more -- so what the
+// pipeline buys is three launch latencies per hypothesis, which pays while a step is latency-bound (few tiles per CU:
+// cfg4's 4 tiles per GPU 24.3 -> 22.0 ms) and costs 2-3 % once every role fills the chip several times over.
+int recurrence_mode(int precision, long pixels) {
+  const char* e = getenv("ADAMVS_RECUR_MODE");
+  if (e) return atoi(e);
+  const long limit = precision == PRECISION_FP32 ? (1L << 20) : (1L << 17);      // B * h * w of the stage
+  return pixels <= limit ? 1 : 0;
+}
+
+template <class R> static RoleUse<R> use(const typename R::Args* a, float cost, float f0 = 0.f, float f1 = 1.f) {
+  return RoleUse<R>{a, cost, f0, f1};
+}
+template <class R> static RoleUse<R> none() { return RoleUse<R>{nullptr, 0.f, 0.f, 1.f}; }
+
+// How far level-2's candidate and the decoder run behind level 1 (in hypotheses) under a schedule.
+//   schedule 1 (the default)         A: gates1(t) | conv2(t-1)    B: cand1(t) | gates2(t-1)              C: cand2(t-1) | decoder(t-2)
+//   schedule 2 (fp32 only)           A: gates1(t) | conv2(t-1)    B: cand1(t) | cand2(t-2) | decoder(t-3)   C: gates2(t-1)
+// Schedule 2 keeps the one role that needs 234 registers (gates2: two 16-row output tiles of 32 input channels, 144
+// registers of weights) in a launch of its own, so that the roles sharing a launch all run at three to five waves per
+// SIMD; in schedule 1 cand1 runs at gates2's two.
+RecurLags recurrence_lags(int schedule, int precision) {
+  if (schedule == 2 && precision == PRECISION_FP32) return RecurLags{2, 3};
+  return RecurLags{1, 2};
+}
+
+// Pipeline step t of a stage, 0 <= t < D + lag_dec: level 1 of hypothesis t, conv2 / gates2 of t-1, cand2 of t-lag_c2,
+// decoder of t-lag_dec (each only while its hypothesis exists).  c1_t = conv1 output of hypothesis t; vol_dec = base of
+// the cost-volume chunk that receives the decoded hypothesis as its plane d_dec of D_vol.
+int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, int B, int h, int w, int D, int t, const float* c1_t,
+                               float* vol_dec, int D_vol, int d_dec, int in_up, int precision, int schedule, hipStream_t st) {
+  const int h2 = h / 2, w2 = w / 2;
+  const RecurLags lag = recurrence_lags(schedule, precision);
+  const int s2 = t - 1, sc = t - lag.c2, sd = t - lag.dec;            // hypotheses of conv2/gates2, cand2, decoder
+  const bool l1 = t < D, l2 = s2 >= 0 && s2 < D, lc = sc >= 0 && sc < D, dec = sd >= 0 && sd < D;
+  auto H1 = [&](int s) { return rb.h1[(s + 4) % 4]; };
+  auto H2 = [&](int s) { return rb.h2[(s + 2) % 2]; };
+  auto C2 = [&](int s) { return rb.c2[(s + 2) % 2]; };
+  const RoleCosts& k = role_costs();
+  int rc;
+  DecoderArgs da{H2(sd), H1(sd), fw.upconv1, fw.upconv1_b, fw.final_w, vol_dec, h, w, D_vol, d_dec};
+
+  if (precision == PRECISION_BF16X3) {
+    Gru1Args g1{c1_t, H1(t - 1), H1(t), (const bf16x8*)fw.gates1, fw.gates1_b, (const bf16x8*)fw.cand1, fw.cand1_b, h, w};
+    SmallConvArgsBx v2{H1(s2), nullptr, (const bf16x8*)fw.conv2, nullptr, C2(s2), nullptr, nullptr, h, w, h2, w2, 16, nullptr};
+    SmallConvArgsBx g2{C2(s2), H2(s2 - 1), (const bf16x8*)fw.gates2, fw.gates2_b, rb.rh2, rb.u2, H2(s2 - 1), h2, w2, h2, w2, 32, nullptr};
+    SmallConvArgsBx c2{C2(sc), rb.rh2, (const bf16x8*)fw.cand2, fw.cand2_b, H2(sc), rb.u2, nullptr, h2, w2, h2, w2, 16, H2(sc - 1)};
+    // the level-1 kernel and the decoder have no dependant inside the step: their tiles fill up slots B and C
+    const float fa = l2 ? k.fa : 1.0f, fb = l2 ? k.fb : 1.0f;         // gru1: [0,fa) in A, [fa,fb) in B, [fb,1) in C
+    const float fd = l2 ? k.fd : 0.0f;                                 // decoder: [0,fd) in B, [fd,1) in C
+    if (l1 || l2)
+      if ((rc = launch_slot<Gru1Bx, Conv2Bx, NopRole>(l1 ? use<Gru1Bx>(&g1, k.k1bx, 0.f, fa) : none<Gru1Bx>(),
+                                                      l2 ? use<Conv2Bx>(&v2, k.v2bx) : none<Conv2Bx>(), none<NopRole>(), B, st,
+                                                      "recurrence slot A (bf16x3)")))
+        return rc;
+    if (!(l2 || lc || dec)) return 0;
+    if (in_up) {
+      if ((rc = launch_slot<Gru1Bx, Gates2Bx, DecoderRole<true>>(
+               (l1 && fa < 1.f) ? use<Gru1Bx>(&g1, k.k1bx, fa, fb) : none<Gru1Bx>(), l2 ? use<Gates2Bx>(&g2, k.g2bx) : none<Gates2Bx>(),
+               (dec && fd > 0.f) ? use<DecoderRole<true>>(&da, k.dec, 0.f, fd) : none<DecoderRole<true>>(), B, st, "recurrence slot B (bf16x3)")))
+        return rc;
+      return launch_slot<Gru1Bx, Cand2Bx, DecoderRole<true>>(
+          (l1 && fb < 1.f) ? use<Gru1Bx>(&g1, k.k1bx, fb, 1.f) : none<Gru1Bx>(), lc ? use<Cand2Bx>(&c2, k.c2bx) : none<Cand2Bx>(),
+          dec ? use<DecoderRole<true>>(&da, k.dec, fd, 1.f) : none<DecoderRole<true>>(), B, st, "recurrence slot C (bf16x3)");
+    }
+    if ((rc = launch_slot<Gru1Bx, Gates2Bx, DecoderRole<false>>(
+             (l1 && fa < 1.f) ? use<Gru1Bx>(&g1, k.k1bx, fa, fb) : none<Gru1Bx>(), l2 ? use<Gates2Bx>(&g2, k.g2bx) : none<Gates2Bx>(),
+             (dec && fd > 0.f) ? use<DecoderRole<false>>(&da, k.dec, 0.f, fd) : none<DecoderRole<false>>(), B, st, "recurrence slot B (bf16x3)")))
+      return rc;
+    return launch_slot<Gru1Bx, Cand2Bx, DecoderRole<false>>(
+        (l1 && fb < 1.f) ? use<Gru1Bx>(&g1, k.k1bx, fb, 1.f) : none<Gru1Bx>(), lc ? use<Cand2Bx>(&c2, k.c2bx) : none<Cand2Bx>(),
+        dec ? use<DecoderRole<false>>(&da, k.dec, fd, 1.f) : none<DecoderRole<false>>(), B, st, "recurrence slot C (bf16x3)");
+  }
+
+  SmallConvArgs g1{c1_t, H1(t - 1), fw.gates1, fw.gates1_b, rb.rh1, rb.u1, h, w, h, w, 16, nullptr};
+  SmallConvArgs c1{c1_t, rb.rh1, fw.cand1, fw.cand1_b, H1(t), rb.u1, h, w, h, w, 8, H1(t - 1)};
+  SmallConvArgs v2{H1(s2), nullptr, fw.conv2, nullptr, C2(s2), nullptr, h, w, h2, w2, 16, nullptr};
+  SmallConvArgs g2{C2(s2), H2(s2 - 1), fw.gates2, fw.gates2_b, rb.rh2, rb.u2, h2, w2, h2, w2, 32, nullptr};
+  SmallConvArgs c2{C2(sc), rb.rh2, fw.cand2, fw.cand2_b, H2(sc), rb.u2, h2, w2, h2, w2, 16, H2(sc - 1)};
+  if (l1 || l2)
+    if ((rc = launch_slot<Gates1, Conv2, NopRole>(l1 ? use<Gates1>(&g1, k.g1) : none<Gates1>(), l2 ? use<Conv2>(&v2, k.v2) : none<Conv2>(),
+                                                  none<NopRole>(), B, st, "recurrence slot A")))
+      return rc;
+  if (lag.c2 == 2) {                          // schedule 2
+    if (l1 || lc || dec) {
+      if (in_up)
+        rc = launch_slot<Cand1, Cand2, DecoderRole<true>>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
+                                                          dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(), B, st,
+                                                          "recurrence slot B");
+      else
+        rc = launch_slot<Cand1, Cand2, DecoderRole<false>>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
+                                                           dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st,
+                                                           "recurrence slot B");
+      if (rc) return rc;
+    }
+    if (l2) return launch_slot<Gates2, NopRole, NopRole>(use<Gates2>(&g2, k.g2), none<NopRole>(), none<NopRole>(), B, st, "recurrence slot C");
+    return 0;
+  }
+  if (l1 || l2)
+    if ((rc = launch_slot<Cand1, Gates2, NopRole>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), l2 ? use<Gates2>(&g2, k.g2) : none<Gates2>(),
+                                                  none<NopRole>(), B, st, "recurrence slot B")))
+      return rc;
+  if (lc || dec) {
+    if (in_up)
+      rc = launch_slot<Cand2, DecoderRole<true>, NopRole>(lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
+                                                          dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(),
+                                                          none<NopRole>(), B, st, "recurrence slot C");
+    else
+      rc = launch_slot<Cand2, DecoderRole<false>, NopRole>(lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
+                                                           dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(),
+                                                           none<NopRole>(), B, st, "recurrence slot C");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Soft-argmin over the regularised cost slices of one chunk of hypotheses (reference models/adamvs.py:516-531):
+// p = exp(cost) (no max subtraction), E += p, M = max(M, p) (initial 0, strict <), A += depth_d p in hypothesis order;
+// after the last chunk depth = A / (E + 1e-10), confidence = M / (E + 1e-10).  The running E, M, A of a pixel cross
+// chunks through `acc` [3][B*Ho*Wo]; the sums are formed in the order of the single-pass kernel, so chunking does
+// not change a bit.  When IN_UP the hypothesis plane is the 2x bilinear upsample (align_corners=False) of
+// planes[b][d] (adamvs.py:521-522).  vol [B][vol_D][Ho*Wo] holds hypotheses d0 .. d0+nd-1 as its planes 0 .. nd-1.
+template <bool IN_UP>
+__global__ void k_soft_argmin_chunk(const float* __restrict__ vol, int vol_D, const float* __restrict__ planes, int D, int d0, int nd,
+                                    float* __restrict__ acc, int first, int last, float* __restrict__ depth,
+                                    float* __restrict__ conf, int h, int w, size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Ho = IN_UP ? 2 * h : h, Wo = IN_UP ? 2 * w : w;
+  int X = (int)(i % Wo), Y = (int)((i / Wo) % Ho);
+  size_t b = i / ((size_t)Wo * Ho);
+  size_t hw = (size_t)h * w, HW = (size_t)Ho * Wo;
+  int y0 = Y, y1 = Y, x0 = X, x1 = X; float ly = 0.f, lx = 0.f;
+  if (IN_UP) {
+    float sy = fmaxf(((float)Y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf(((float)X + 0.5f) * 0.5f - 0.5f, 0.f);
+    y0 = (int)sy; x0 = (int)sx;
+    y1 = y0 + (y0 < h - 1 ? 1 : 0); x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    ly = sy - (float)y0; lx = sx - (float)x0;
+  }
+  const float* v = vol + b * vol_D * HW + (size_t)Y * Wo + X;
+  const float* pl = planes + (b * D + d0) * hw;
+  float E = 0.f, M = 0.f, A = 0.f;
+  if (!first) { E = acc[i]; M = acc[total + i]; A = acc[2 * total + i]; }
+  for (int d = 0; d < nd; ++d) {
+    float pr = __expf(v[(size_t)d * HW]);
+    const float* q = pl + (size_t)d * hw;
+    float dep;
+    if (IN_UP) {
+      float top = q[y0 * w + x0] * (1.f - lx) + q[y0 * w + x1] * lx;
+      float bot = q[y1 * w + x0] * (1.f - lx) + q[y1 * w + x1] * lx;
+      dep = top * (1.f - ly) + bot * ly;
+    } else {
+      dep = q[y0 * w + x0];
+    }
+    M = (M < pr) ? pr : M;
+    A = dep * pr + A;
+    E = E + pr;
+  }
+  if (last) {
+    float den = E + 1e-10f;
+    depth[i] = A / den;
+    conf[i] = M / den;
+  } else {
+    acc[i] = E; acc[total + i] = M; acc[2 * total + i] = A;
+  }
+}
+
+int launch_soft_argmin_chunk(const float* vol, int vol_D, const float* planes, int D, int d0, int nd, float* acc, int first, int last,
+                             float* depth, float* conf, int B, int h, int w, int in_up, hipStream_t st) {
+  size_t total = (size_t)B * (in_up ? 4 : 1) * h * w;
+  unsigned nb = (unsigned)((total + 255) / 256);
+  if (in_up)
+    hipLaunchKernelGGL((k_soft_argmin_chunk<true>), dim3(nb), dim3(256), 0, st, vol, vol_D, planes, D, d0, nd, acc, first, last, depth,
+                       conf, h, w, total);
+  else
+    hipLaunchKernelGGL((k_soft_argmin_chunk<false>), dim3(nb), dim3(256), 0, st, vol, vol_D, planes, D, d0, nd, acc, first, last, depth,
+                       conf, h, w, total);
+  ADAMVS_CHECK_LAUNCH("soft_argmin (chunk)");
+  return 0;
+}
+
+}  // namespace adamvs

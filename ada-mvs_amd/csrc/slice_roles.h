@@ -1,0 +1,617 @@
+// Device-side "roles" of the recurrent cost regularisation: the persistent tile loops of the small fp32 MFMA
+// convolutions (gates / candidate / conv2 of the two ConvGRU levels) and of the decoder, as device functions that
+// walk a range of tiles with a given workgroup index and workgroup count.  A role is what used to be one kernel;
+// slice_red.hip wraps each into a kernel of its own (the one-step op), recurrence.hip runs several roles of
+// different hypothesis steps side by side in one launch (the software-pipelined recurrence).
+//
+//   SliceCostRegNetRED.forward   reference models/adamvs.py:415-424
+//   ConvGRUCell.forward          reference models/module.py:24-52
+#pragma once
+#include "common.h"
+#include "conv_frag.h"
+#include "kernels.h"
+#include "persistent.h"
+
+namespace adamvs {
+
+enum { EPI_RELU = 0, EPI_GATES = 1, EPI_CAND = 2, EPI_LINEAR = 3 };   // LINEAR: out = conv + bias (MS-REDNet cells)
+
+struct SmallConvArgs {
+  const float* srcA;   // [B][hi*wi][CA]
+  const float* srcB;   // [B][hi*wi][CB] (null when CB == 0)
+  const float* wpk;    // A fragments [NT][9][(CA+CB)/4][64]
+  const float* bias;   // [16*NT], zero padded (GATES, CAND)
+  float* dst0;         // RELU: out [B][ho*wo][cout];  GATES: r*h [B][..][HC];  CAND: h, updated in place
+  float* dst1;         // GATES: u out [B][..][HC];    CAND: u in
+  int hi, wi, ho, wo, cout;
+  const float* hin;    // CAND: the state that is blended (h of the previous step); null = dst0 (update in place)
+};
+
+// Range of tiles a role instance walks: tiles [begin, end) of its TileGrid.
+struct TileRange { int begin, end; };
+
+
+// Persistent workgroups.  These launches are short (thousands of tiles of about a microsecond) and sit on the
+// sequential critical path of the recurrence, so what costs time is not the matrix work but its packaging.
+//  * The grid is exactly the resident capacity (occupancy query); workgroup i walks tiles i, i + grid, ...
+//    (A shared atomic tile counter was tried and is slower: one word serves ~88 dequeues/us.)
+//  * A tile is TR rows x 16*RW columns = four 16-pixel runs, one per wave.
+//  * fp32 MFMA and the vector ALU are the same lanes (the fp32 matrix rate of the chip IS its packed-fp32 vector
+//    rate): every VALU instruction is a slot an MFMA does not get, whatever the occupancy.  Measured here: with
+//    loads, epilogue and barriers stripped the kernels run at the MFMA bound; each phase put back added its
+//    VALU instruction count, nothing else.  So everything per-lane that does not depend on the tile (LDS
+//    addresses, offsets inside the tile window, output offsets) is computed once before the loop, the tile
+//    enters only through workgroup-uniform base pointers (scalar unit; global accesses are base + 32-bit lane
+//    offset), interior tiles take a path with no bounds checks, and the gate non-linearities use v_rcp/v_exp
+//    directly.
+//  * One wait point per tile.  vmcnt retires in order, so any wait on a late load also waits for everything
+//    issued before it.  Per tile: request the epilogue operands of this tile and the input of the NEXT tile; run
+//    the MFMA chain out of LDS; only then wait, barrier, refill the LDS tile, epilogue, stores, barrier.
+//    Nothing is waited for before it has had a whole MFMA phase to arrive; the stores drain under the next chain.
+template <int CA, int CB, int NT, int STRIDE, int EPI, int TR = 4, int RW = 1>
+struct ConvSmallRole {
+  typedef SmallConvArgs Args;
+  static_assert(TR * RW == 4, "one run per wave");
+  static constexpr int CIN = CA + CB, KC = CIN / 4, G = CIN / 4, GA = CA / 4, GB = CB / 4, TC = 16 * RW;
+  static constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
+  static constexpr int LC = (STRIDE == 1) ? TC + 2 : 2 * TC + 1;
+  static constexpr int NPIX = LR * LC;
+  static constexpr int PLANE = (STRIDE == 1) ? plane_pitch16(NPIX) : (NPIX | 1);
+  static constexpr int GP = group_pitch(PLANE, G);
+  static constexpr int HC = CB;          // hidden width for the GRU epilogues
+  // one load instruction covers 256 (pixel, channel group) items of ONE source, so that its base is uniform
+  static constexpr int NA = (NPIX * GA + 255) / 256, NB = (NPIX * GB + 255) / 256, NL = NA + NB;
+  static constexpr size_t LDS_BYTES = (size_t)G * GP * sizeof(float);         // tile [G][GP]
+  static constexpr int TILE_W = TC, TILE_H = TR;                               // output pixels per tile
+  static int tiles_x(const Args& a) { return cdiv(a.wo, TC); }
+  static int tiles_y(const Args& a) { return cdiv(a.ho, TR); }
+
+  // workgroup `wg` of `nwg` walks tiles tr.begin + wg, + nwg, ... < tr.end
+  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+  const int p = lane & 15, q = lane >> 4;
+  const int row = wave / RW, col = (wave % RW) * 16;      // the wave's run inside a tile
+
+  float wf[NT][9][KC];
+  load_wfrag<NT, KC>(wf, a.wpk, lane);
+  f32x4 bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    bias[nt] = (EPI == EPI_RELU) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(a.bias + nt * 16 + 4 * q);
+
+  // ---- per-lane constants of the tile window
+  unsigned goff[NL];      // byte offset of the item from the window's first pixel in its source
+  unsigned lbyte[NL];     // LDS byte offset of the item's first channel plane
+  int rc[NL];             // window row | column << 16 (edge tiles only)
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    const int gs = isA ? GA : GB, cs = isA ? CA : CB;
+    int j = tid + (isA ? k : k - NA) * 256;
+    j = min(j, NPIX * gs - 1);           // surplus lanes repeat the last item (same value to the same place)
+    const int g = j % gs, pp = j / gs, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * a.wi + c) * cs + 4 * g) * 4);
+    lbyte[k] = (unsigned)((((isA ? 0 : GA) + g) * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xbyte[KC];     // B-fragment origin of the run, per k-chunk
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    xbyte[kc] = (unsigned)((kc * GP + q * PLANE + (row * STRIDE) * LC + (col + p) * STRIDE) * 4);
+    pin(xbyte[kc]);
+  }
+  unsigned hbyte[NT];     // GATES: hidden-state channels co4..co4+3 of the lane's own pixel
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    hbyte[nt] = (unsigned)((((CA + min(nt * 16 + 4 * q, HC - 4)) >> 2) * GP + (row + 1) * LC + col + p + 1) * 4);
+    pin(hbyte[nt]);
+  }
+  // output offsets (bytes) of the lane's pixel inside the tile, per 16-channel slice
+  const int CO = (EPI == EPI_RELU || EPI == EPI_LINEAR) ? a.cout : HC;
+  // ooff: destination 0 (RELU out, GATES r*h, CAND h); ooff1: destination 1 (GATES u).  Rows that do not
+  // belong to a destination carry BUF_OOB, so every store is issued by all lanes with one uniform descriptor.
+  unsigned ooff[NT], ooff1[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co4 = nt * 16 + 4 * q;
+    const unsigned at = (unsigned)(((row * a.wo + col + p) * CO + (EPI == EPI_GATES && co4 >= HC ? co4 - HC : co4)) * 4);
+    const bool to0 = (EPI == EPI_RELU || EPI == EPI_LINEAR) ? co4 < a.cout : co4 < HC;
+    const bool to1 = EPI == EPI_GATES && co4 >= HC && co4 < 2 * HC;
+    ooff[nt] = to0 ? at : BUF_OOB;
+    ooff1[nt] = to1 ? at : BUF_OOB;
+    pin(ooff[nt]); pin(ooff1[nt]);
+  }
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int b, int tx, int ty) {
+    const int ix0 = tx * TC * STRIDE - 1, iy0 = ty * TR * STRIDE - 1;
+    const long pix0 = ((long)b * a.hi + iy0) * a.wi + ix0;                 // may point one row/column outside
+    const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
+    const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + LR <= a.hi && ix0 + LC <= a.wi;
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        stage[k] = buf_load4(k < NA ? ra : rb, ok ? goff[k] : BUF_OOB);              // zero padding
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  };
+
+  int t = tr.begin + wg;
+  if (t >= tr.end) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, b, tx, ty);
+  wait_vmem_all();                     // fragments, biases and the first tile: nothing is pending inside the loop
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)b * a.ho + oy0) * a.wo + ox0;
+    const bool full = oy0 + TR <= a.ho && ox0 + TC <= a.wo;            // uniform: no output of the tile is outside
+    const buf_rsrc r0 = make_rsrc((char*)a.dst0 + opix0 * (CO * 4));
+    const buf_rsrc r1 = make_rsrc((char*)a.dst1 + opix0 * (HC * 4));
+    const buf_rsrc rin = make_rsrc((const char*)(a.hin ? a.hin : a.dst0) + opix0 * (CO * 4));     // CAND: state in
+    unsigned oo[NT], oo1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { oo[nt] = ooff[nt]; oo1[nt] = ooff1[nt]; }
+    if (!full) {
+      const bool valid = oy0 + row < a.ho && ox0 + col + p < a.wo;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { oo[nt] = valid ? ooff[nt] : BUF_OOB; oo1[nt] = valid ? ooff1[nt] : BUF_OOB; }
+    }
+
+    // requests: epilogue operands first, then the next tile
+    f32x4 pre_u[NT], pre_h[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (EPI == EPI_CAND && nt * 16 < HC) {
+        pre_u[nt] = buf_load4(r1, oo[nt]);
+        pre_h[nt] = buf_load4(rin, oo[nt]);
+      }
+    }
+    const int tn = t + nwg;
+    const bool more = tn < tr.end;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_tile(stage, bn, txn, tyn);
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv3x3_run_at<NT, KC, STRIDE, LC>(acc, wf, lds, xbyte);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) drain(acc[nt]);
+
+    f32x4 hc[NT];      // GATES: the hidden state of the lane's pixel, from the tile (module.py:35-41)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (EPI == EPI_GATES && nt * 16 < HC) {
+        const float* hl = (const float*)((const char*)lds + hbyte[nt]);
+        hc[nt] = f32x4{hl[0], hl[PLANE], hl[2 * PLANE], hl[3 * PLANE]};
+      }
+    }
+
+    wait_vmem_all();                   // the wait point (explicit, so that no other wait is scheduled elsewhere)
+    __syncthreads();                   // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 v = acc[nt] + bias[nt];
+      if (EPI == EPI_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        buf_store4(r0, oo[nt], v);
+      } else if (EPI == EPI_LINEAR) {
+        buf_store4(r0, oo[nt], v);
+      } else if (EPI == EPI_GATES) {
+        f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+        if (nt * 16 < HC) buf_store4(r0, oo[nt], sg * hc[nt]);              // reset-gate rows -> r * h
+        if (nt * 16 + 16 > HC) buf_store4(r1, oo1[nt], sg);                 // update-gate rows -> u
+      } else if (nt * 16 < HC) {                        // EPI_CAND   (module.py:44-50)
+        f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+        f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
+        buf_store4(r0, oo[nt], u4 * h4 + (1.0f - u4) * cnd);
+      }
+    }
+    if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; b = bn; tx = txn; ty = tyn;
+  }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Decoder: s = ReLU(upconv1(h2) + b + h1)   (ConvTranspose2d 16->8, k3 s2 p1 op1)
+//          reg = upconv2d(s) + b            (ConvTranspose2d 8->1 k3 s2 p1 op1 when IN_UP,
+//                                            Conv2d 8->1 k3 p1 otherwise)
+// One block = inner tile 14 x 30 of s (full resolution h x w), s region 16 x 32.
+// grid: (ceil(w/30), ceil(h/14), B); block 256.  reg -> vol[b][d][Ho*Wo].
+struct DecoderArgs {
+  const float* h2;     // [B][(h/2)*(w/2)][16]
+  const float* h1;     // [B][h*w][8]
+  const float* wup1;   // A fragments [1][9][4][64]: A[cout][cin] of tap (ky,kx)
+  const float* bup1;   // [16] zero padded
+  const float* wfin;   // [72] index (ky*3 + kx)*8 + c, then bias at [72]
+  float* vol;          // [B][D][Ho*Wo]
+  int h, w, D, d;
+};
+
+// ConvTranspose2d(k3, s2, p1, op1) restricted to one output parity class (PY,PX):
+// out[2i+PY][2j+PX] = sum over taps with ky = 2(i-iy)+PY+1, i.e. PY=0 -> (ky=1, iy=i);
+// PY=1 -> (ky=2, iy=i), (ky=0, iy=i+1); same along x.  `xbyte` = LDS byte offset of the lane's
+// B-fragment origin (k-row q, h2 pixel (li, lj)) in the planar h2 tile.
+template <int PY, int PX, int HGP, int HCOLS>
+__device__ __forceinline__ f32x4 upconv1_class(const float (&wf)[1][9][4], const float* lds, unsigned xbyte) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ty = 0; ty < (PY ? 2 : 1); ++ty) {
+    const int ky = PY ? (ty ? 0 : 2) : 1;
+#pragma unroll
+    for (int tx = 0; tx < (PX ? 2 : 1); ++tx) {
+      const int kx = PX ? (tx ? 0 : 2) : 1;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+        acc = mfma16(wf[0][ky * 3 + kx][kc], *(const float*)((const char*)lds + xbyte + (kc * HGP + ty * HCOLS + tx) * 4), acc);
+    }
+  }
+  return acc;
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Persistent, software-pipelined like k_conv_small (same reasoning: uniform descriptors + pinned lane offsets,
+// no bounds checks on interior tiles, one wait per tile).  A tile is 6 x 30 pixels of s (full resolution h x w);
+// its s region is 8 x 32 (one pixel of halo each side), fed by a 5 x 17 region of h2.
+//   phase 1  upconv1 on the matrix cores: 16 runs = 4 parity classes x 4 rows; wave k takes row k of every
+//            class (equal MFMA counts).  + bias + h1 (requested during the previous tile) -> ReLU -> s in LDS.
+//   phase 2  last layer on the vector units.  Transposed (IN_UP): one thread per s pixel produces its 2 x 2
+//            output quad from s[i..i+1][j..j+1] (72 FMAs, weights as scalar operands), two 8-byte stores.
+//            Flat: one thread per pixel, 3 x 3 x 8 FMAs.
+template <bool IN_UP>
+struct DecoderRole {
+  typedef DecoderArgs Args;
+  static constexpr int TRI = 6, TCI = 30;                                   // inner tile of s
+  static constexpr int SR = 8, SC = 32, SPX = 12; // s region, channel-last, 8 channels + 4 floats of padding per
+                                                  // pixel: 16-byte lane accesses at a 48-byte stride are conflict-free
+  static constexpr int HR = 5, HCOLS = 17, HPLANE = plane_pitch16(HR * HCOLS);     // h2 region, 16 planes in 4 groups
+  static constexpr int HGP = group_pitch(HPLANE, 4);
+  static constexpr int NH = (HR * HCOLS * 4 + 255) / 256;                   // h2 load instructions per tile
+  static constexpr size_t LDS_BYTES = (size_t)(4 * HGP + SR * SC * SPX) * sizeof(float);
+  static constexpr int TILE_W = TCI, TILE_H = TRI;
+  static int tiles_x(const Args& a) { return cdiv(a.w, TCI); }
+  static int tiles_y(const Args& a) { return cdiv(a.h, TRI); }
+
+  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds) {
+  float* lh2 = lds;
+  float* ls = lds + 4 * HGP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+  const int p = lane & 15, q = lane >> 4;
+  const int h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1;
+  float wf[1][9][4];
+  load_wfrag<1, 4>(wf, a.wup1, lane);
+  const f32x4 bup = *(const f32x4*)(a.bup1 + 4 * q);
+
+  // ---- per-lane constants
+  unsigned h2off[NH], h2lds[NH];
+  int h2rc[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int j = min(tid + k * 256, HR * HCOLS * 4 - 1);
+    const int g = j & 3, pp = j >> 2, r = pp / HCOLS, c = pp % HCOLS;
+    h2off[k] = (unsigned)(((r * w2 + c) * 16 + 4 * g) * 4);
+    h2lds[k] = (unsigned)((g * HGP + r * HCOLS + c) * 4);
+    h2rc[k] = r | (c << 16);
+    pin(h2off[k]); pin(h2lds[k]); pin(h2rc[k]);
+  }
+  // run j of this wave = parity class j (py = j >> 1, px = j & 1), row k = wave of that class
+  unsigned xbyte[4], h1off[4], sbyte[4];
+  int src[4];          // s-region row | column << 16 of the lane's pixel
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int py = j >> 1, px = j & 1, k = wave;
+    const int r = py ? 2 * k : 2 * k + 1, c = px ? 2 * p : 2 * p + 1;
+    const int li = py ? k : k + 1, lj = px ? p : p + 1;
+    xbyte[j] = (unsigned)((q * HPLANE + li * HCOLS + lj) * 4);
+    h1off[j] = q < 2 ? (unsigned)(((r * w + c) * 8 + 4 * q) * 4) : BUF_OOB;       // rows 8-15 of the tile are padding
+    sbyte[j] = (unsigned)(((r * SC + c) * SPX + 4 * (q & 1)) * 4);
+    src[j] = r | (c << 16);
+    pin(xbyte[j]); pin(h1off[j]); pin(sbyte[j]); pin(src[j]);
+  }
+  // phase 2: thread -> inner pixel (i, j)
+  const bool worker = tid < TRI * TCI;
+  const int pi = min(tid, TRI * TCI - 1) / TCI, pj = min(tid, TRI * TCI - 1) % TCI;
+  unsigned qbyte = (unsigned)(((IN_UP ? (pi + 1) * SC + pj + 1 : pi * SC + pj)) * SPX * 4);   // first s pixel the thread reads
+  const int Ho = IN_UP ? 2 * h : h, Wo = IN_UP ? 2 * w : w;
+  unsigned ooff = worker ? (unsigned)((IN_UP ? (2 * pi * Wo + 2 * pj) : (pi * Wo + pj)) * 4) : BUF_OOB;
+  pin(qbyte); pin(ooff);
+  cfloat* wfin0 = as_const(a.wfin);
+
+  auto load_h2 = [&](f32x4 (&stage)[NH], int b, int tx, int ty) {
+    const int i0 = ty * (TRI / 2) - 1, j0 = tx * (TCI / 2) - 1;
+    const buf_rsrc rh = make_rsrc((const char*)a.h2 + (((long)b * h2 + i0) * w2 + j0) * 64);
+    if (i0 >= 0 && j0 >= 0 && i0 + HR <= h2 && j0 + HCOLS <= w2) {
+#pragma unroll
+      for (int k = 0; k < NH; ++k) stage[k] = buf_load4(rh, h2off[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int iy = i0 + (h2rc[k] & 0xffff), ix = j0 + (h2rc[k] >> 16);
+        stage[k] = buf_load4(rh, ((unsigned)iy < (unsigned)h2 && (unsigned)ix < (unsigned)w2) ? h2off[k] : BUF_OOB);
+      }
+    }
+  };
+  // skip operand h1 of the lane's four pixels; returns which of them lie inside the image (bit j; 15 for every
+  // lane of an interior tile, which the caller tests with a uniform branch)
+  auto load_h1 = [&](f32x4 (&hreg)[4], int b, int tx, int ty) -> unsigned {
+    const int ys0 = ty * TRI - 1, xs0 = tx * TCI - 1;
+    const buf_rsrc r1 = make_rsrc((const char*)a.h1 + (((long)b * h + ys0) * w + xs0) * 32);
+    if (ys0 >= 0 && xs0 >= 0 && ys0 + SR <= h && xs0 + SC <= w) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hreg[j] = buf_load4(r1, h1off[j]);
+      return 15u;
+    }
+    unsigned in = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ys = ys0 + (src[j] & 0xffff), xs = xs0 + (src[j] >> 16);
+      const bool ok = (unsigned)ys < (unsigned)h && (unsigned)xs < (unsigned)w;
+      hreg[j] = buf_load4(r1, ok ? h1off[j] : BUF_OOB);
+      in |= ok ? (1u << j) : 0u;
+    }
+    return in;
+  };
+  auto store_h2 = [&](const f32x4 (&stage)[NH]) {
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      float* dl = (float*)((char*)lh2 + h2lds[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[HPLANE] = v.y; dl[2 * HPLANE] = v.z; dl[3 * HPLANE] = v.w;
+    }
+  };
+
+  int t = tr.begin + wg;
+  if (t >= tr.end) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 stage[NH], hreg[4];
+  load_h2(stage, b, tx, ty);
+  unsigned inside = load_h1(hreg, b, tx, ty);
+  wait_vmem_all();
+  store_h2(stage);
+  __syncthreads();
+  for (;;) {
+    const int tn = t + nwg;
+    const bool more = tn < tr.end;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_h2(stage, bn, txn, tyn);                 // in flight during phases 1 and 2
+    }
+
+    // ---- phase 1
+    f32x4 sv[4];
+    sv[0] = upconv1_class<0, 0, HGP, HCOLS>(wf, lh2, xbyte[0]);
+    sv[1] = upconv1_class<0, 1, HGP, HCOLS>(wf, lh2, xbyte[1]);
+    sv[2] = upconv1_class<1, 0, HGP, HCOLS>(wf, lh2, xbyte[2]);
+    sv[3] = upconv1_class<1, 1, HGP, HCOLS>(wf, lh2, xbyte[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) drain(sv[j]);
+    const bool all_in = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(inside != 15u) == 0) != 0;
+    if (q < 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = sv[j] + bup + hreg[j];                                  // adamvs.py:420-421
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        sv[j] = v;
+      }
+      if (!all_in) {                                                      // s is zero outside the image
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!((inside >> j) & 1u)) sv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)((char*)ls + sbyte[j]) = sv[j];
+    }
+    unsigned inside_n = 15u;
+    if (more) inside_n = load_h1(hreg, bn, txn, tyn);                     // hreg is free again
+    __syncthreads();                                                      // s complete
+
+    // ---- phase 2
+    const int y0 = ty * TRI, x0 = tx * TCI;
+    const bool full = y0 + TRI <= h && x0 + TCI <= w;
+    unsigned oo = ooff;
+    if (!full) oo = (y0 + pi < h && x0 + pj < w) ? ooff : BUF_OOB;
+    const char* sp = (const char*)ls + qbyte;
+    // 73 scalar weights do not fit next to everything else that is uniform here; hidden from loop-invariant
+    // motion, they are fetched per tile through the scalar cache (SMEM) instead of being spilled to VGPR
+    // lanes and read back with one v_readlane each.
+    cfloat* wfin = wfin0;
+    asm volatile("" : "+s"(wfin));
+    // s pixel (dy, dx) from the thread's first pixel: 8 channels as four packed pairs
+    auto spix = [&](int dy, int dx, f32x2 (&v)[4]) {
+      const f32x4 lo = *(const f32x4*)(sp + (dy * SC + dx) * SPX * 4), hi = *(const f32x4*)(sp + (dy * SC + dx) * SPX * 4 + 16);
+      v[0] = f32x2{lo.x, lo.y}; v[1] = f32x2{lo.z, lo.w}; v[2] = f32x2{hi.x, hi.y}; v[3] = f32x2{hi.z, hi.w};
+    };
+    // acc += w[tap][0..7] . v  (packed FMAs, the weight pair is a scalar operand)
+    auto tap = [&](f32x2& acc, int t9, const f32x2 (&v)[4]) {
+#pragma unroll
+      for (int c2 = 0; c2 < 4; ++c2) acc += *(const f32x2 __attribute__((address_space(4)))*)(wfin + t9 * 8 + 2 * c2) * v[c2];
+    };
+    const float bf = wfin[72];
+    if (IN_UP) {
+      const buf_rsrc ro = make_rsrc((char*)a.vol + ((((long)b * a.D + a.d) * Ho + 2 * y0) * (long)Wo + 2 * x0) * 4);
+      // quad of s pixel (i, j): out[2i][2j] = w11 s00;  out[2i][2j+1] = w12 s00 + w10 s01;
+      // out[2i+1][2j] = w21 s00 + w01 s10;  out[2i+1][2j+1] = w22 s00 + w20 s01 + w02 s10 + w00 s11
+      f32x2 s00[4], s01[4], s10[4], s11[4];
+      spix(0, 0, s00); spix(0, 1, s01); spix(1, 0, s10); spix(1, 1, s11);
+      f32x2 o00 = {bf, 0.f}, o01 = {bf, 0.f}, o10 = {bf, 0.f}, o11 = {bf, 0.f};
+      tap(o00, 4, s00);
+      tap(o01, 5, s00); tap(o01, 3, s01);
+      tap(o10, 7, s00); tap(o10, 1, s10);
+      tap(o11, 8, s00); tap(o11, 6, s01); tap(o11, 2, s10); tap(o11, 0, s11);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o00.x + o00.y), __float_as_uint(o01.x + o01.y)}, ro, oo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o10.x + o10.y), __float_as_uint(o11.x + o11.y)}, ro,
+                                            oo == BUF_OOB ? BUF_OOB : oo + (unsigned)Wo * 4u, 0, 0);
+    } else {
+      const buf_rsrc ro = make_rsrc((char*)a.vol + ((((long)b * a.D + a.d) * Ho + y0) * (long)Wo + x0) * 4);
+      f32x2 o = {bf, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          f32x2 v[4];
+          spix(ky, kx, v);
+          tap(o, ky * 3 + kx, v);
+        }
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.x + o.y), ro, oo, 0, 0);
+    }
+    if (!more) break;
+    wait_vmem_all();                                                      // next tile's h2 and h1 have arrived
+    __syncthreads();                                                      // every wave is done with s and h2
+    store_h2(stage);
+    __syncthreads();
+    t = tn; b = bn; tx = txn; ty = tyn; inside = inside_n;
+  }
+  }
+};
+// Candidate convolution of the level-1 ConvGRU (reference models/module.py:44-50: tanh(conv(cat(x, r*h))), blend with
+// u) in the same two-row form: its 8 output channels fill half an MFMA tile in the one-row form of k_conv_small (36
+// MFMAs per 16-pixel run, half of the rows zero); with rows 8-15 = the same channels of the next output row it is
+// 24 per run.  Two sources like k_conv_small (x = c1, r*h: 2 + 2 channel groups), its fused epilogue (u and h of the
+// lane's own pixel requested before the chain; h updated in place), the tile and pipeline of k_conv1_two_row.
+struct Cand1TwoRowRole {
+  typedef SmallConvArgs Args;
+  static constexpr int CA = 8, CB = 8, C = 16, KC = C / 4, G = C / 4, GA = CA / 4, TR = 8, TC = 16, LR = TR + 2, LC = TC + 2;
+  static constexpr int NPIX = LR * LC, PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
+  static constexpr int NA = (NPIX * GA + 255) / 256, NL = 2 * NA;     // loads per source: a load's base must be uniform
+  static constexpr size_t LDS_BYTES = (size_t)G * GP * sizeof(float);         // tile [G][GP]
+  static constexpr int TILE_W = TC, TILE_H = TR;
+  static int tiles_x(const Args& a) { return cdiv(a.wo, TC); }
+  static int tiles_y(const Args& a) { return cdiv(a.ho, TR); }
+
+  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int h = a.hi, w = a.wi;
+  float wf[12][KC];
+#pragma unroll
+  for (int t = 0; t < 12; ++t)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) wf[t][kc] = a.wpk[(t * KC + kc) * 64 + lane];
+  const f32x4 bias = *(const f32x4*)(a.bias + 4 * (q & 1));
+
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    const int j = min(tid + (isA ? k : k - NA) * 256, NPIX * GA - 1);          // surplus lanes repeat the last item
+    const int g = j % GA, pp = j / GA, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * w + c) * CA + 4 * g) * 4);
+    lbyte[k] = (unsigned)((((isA ? 0 : GA) + g) * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xbyte[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    xbyte[kc] = (unsigned)((kc * GP + q * PLANE + (2 * wave) * LC + p) * 4);
+    pin(xbyte[kc]);
+  }
+  const int orow = 2 * wave + (q >> 1);                       // lane's output pixel (orow, p), channels 4*(q&1)..
+  unsigned ooff = (unsigned)(((orow * w + p) * 8 + 4 * (q & 1)) * 4);
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int n, int tx, int ty) {
+    const int ix0 = tx * TC - 1, iy0 = ty * TR - 1;
+    const long pix0 = ((long)n * h + iy0) * w + ix0;
+    const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
+    const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= h && ix0 + LC <= w) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        stage[k] = buf_load4(k < NA ? ra : rb, ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? goff[k] : BUF_OOB);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  };
+
+  int t = tr.begin + wg;
+  if (t >= tr.end) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int y0 = ty * TR, x0 = tx * TC;
+    const long opix0 = ((long)n * h + y0) * w + x0;
+    const buf_rsrc rh = make_rsrc((char*)a.dst0 + opix0 * 32);          // new h (the same buffer as the old one when hin is null)
+    const buf_rsrc rin = make_rsrc((const char*)(a.hin ? a.hin : a.dst0) + opix0 * 32);     // h of the previous step
+    const buf_rsrc ru = make_rsrc((const char*)a.dst1 + opix0 * 32);    // u
+    unsigned oo = ooff;
+    if (!(y0 + TR <= h && x0 + TC <= w)) oo = (y0 + orow < h && x0 + p < w) ? ooff : BUF_OOB;
+    const f32x4 pre_u = buf_load4(ru, oo), pre_h = buf_load4(rin, oo);  // epilogue operands first, then the next tile
+    const int tn = t + nwg;
+    const bool more = tn < tr.end;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+          acc = mfma16(wf[rr * 3 + kx][kc], *(const float*)((const char*)lds + xbyte[kc] + (rr * LC + kx) * 4), acc);
+    drain(acc);
+
+    wait_vmem_all();
+    __syncthreads();                                // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+    const f32x4 v = acc + bias;
+    const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+    buf_store4(rh, oo, pre_u * pre_h + (1.0f - pre_u) * cnd);
+    if (!more) break;
+    __syncthreads();                                // next tile visible
+    t = tn; n = nn; tx = txn; ty = tyn;
+  }
+  }
+};
+
+}  // namespace adamvs

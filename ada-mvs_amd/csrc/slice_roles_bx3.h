@@ -1,0 +1,455 @@
+// Device-side roles of the split-bf16 ("bf16x3") recurrent convolutions: see slice_roles.h for the role idea and
+// slice_red_bf16x3.hip for the arithmetic.  reference models/adamvs.py:400-424, models/module.py:5-52.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include "persistent.h"
+#include "slice_roles.h"
+
+namespace adamvs {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_bx(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split_store(__bf16* hi, __bf16* lo, f32x4 v) {
+  bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  bf16x4 l = {(__bf16)(v.x - (float)h.x), (__bf16)(v.y - (float)h.y), (__bf16)(v.z - (float)h.z), (__bf16)(v.w - (float)h.w)};
+  *(bf16x4*)hi = h;
+  *(bf16x4*)lo = l;
+}
+
+enum { BXE_RELU = 0, BXE_GATES = 1, BXE_CAND = 2, BXE_TWO_ROW = 3 };
+
+// bf16 per pixel of the LDS tile.  ds_read_b128 is serviced in four NON-contiguous 16-lane groups (lanes {0-3, 12-15,
+// 20-27}, {4-11, 16-19, 28-31}, ...: MI355X_MICROARCH.md, LDS), each mixing two k-groups over complementary pixel
+// columns: with all k-groups of a lane's fragment inside one pixel (CIN = 32, 16) the group is conflict-free when the
+// pitch in 16-byte slots is 2 (mod 4) -- 96 B for 32 channels, 32 B for 16; CIN + 8 (80 / 48 B) is 2-way.
+__host__ __device__ constexpr int bx_pixel_pitch(int cin) { return cin == 32 ? 48 : (cin == 16 ? 16 : cin + 8); }
+
+struct SmallConvArgsBx {
+  const float* srcA;      // [B][hi*wi][CA]
+  const float* srcB;      // [B][hi*wi][CB] (null when CB == 0)
+  const bf16x8* wpk;      // A fragments [NT][hi|lo][NKB][64] x 8 bf16
+  const float* bias;      // [16*NT] (GATES, CAND)
+  float* dst0;            // RELU/TWO_ROW: out [B][ho*wo][cout]; GATES: r*h; CAND: h (in place)
+  float* dst1;            // GATES: u out; CAND: u in
+  const float* hsrc;      // GATES: h [B][ho*wo][HC] (the centre-pixel state, read in fp32)
+  int hi, wi, ho, wo, cout;
+  const float* hin;       // CAND: the state that is blended; null = dst0 (update in place)
+};
+
+// Persistent and pipelined exactly like k_conv_small in slice_red.hip (uniform buffer descriptors + pinned lane
+// offsets, interior tiles without bounds checks, one wait per tile, requests before the MFMA chain, stores after
+// it); what differs is the tile in LDS (pixel-major bf16, hi and lo images, written through split_store), the
+// chain (flattened k, three MFMAs per k-block) and the GRU state of the lane's own pixel, which the reset gate
+// multiplies in full fp32 and therefore comes from global memory with the other epilogue operands.
+// Tile = 4 rows x 16 columns, one run per wave; the two-row conv1 takes 8 x 16 (a run = 2 output rows).
+// NPOS = 9 taps, or 12 (rr,kx) positions for the two-row conv1.
+template <int CA, int CB, int NT, int STRIDE, int EPI>
+struct ConvSmallBx3Role {
+  typedef SmallConvArgsBx Args;
+  static constexpr bool TWO = (EPI == BXE_TWO_ROW);
+  static constexpr int CIN = CA + CB, GA = CA / 4, GB = CB / 4, HC = CB;
+  static constexpr int NPOS = TWO ? 12 : 9;
+  static constexpr int NKB = (NPOS * CIN + 31) / 32;
+  static constexpr int TR = TWO ? 8 : 4, TC = 16;
+  static constexpr int LR = (STRIDE == 1) ? TR + 2 : 2 * TR + 1;
+  static constexpr int LC = (STRIDE == 1) ? TC + 2 : 2 * TC + 1;
+  static constexpr int NPIX = LR * LC;
+  static constexpr int PP = bx_pixel_pitch(CIN);      // bf16 per pixel
+  static constexpr int LO = NPIX * PP * 2;            // byte offset of the lo image
+  static constexpr int NA = (NPIX * GA + 255) / 256, NB = (NPIX * GB + 255) / 256, NL = NA + NB;
+  static constexpr size_t LDS_BYTES = (size_t)2 * NPIX * PP * sizeof(__bf16);         // [hi|lo][NPIX][PP]
+  static constexpr int TILE_W = TC, TILE_H = TR;
+  static int tiles_x(const Args& a) { return cdiv(a.wo, TC); }
+  static int tiles_y(const Args& a) { return cdiv(a.ho, TR); }
+
+  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds_) {
+  __bf16* ldsb = (__bf16*)lds_;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int row = TWO ? 2 * wave : wave;              // first output row of the wave's run
+
+  // A fragments (hi, lo)
+  bf16x8 wh[NT][NKB], wl[NT][NKB];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      wh[nt][kb] = a.wpk[((nt * 2 + 0) * NKB + kb) * 64 + lane];
+      wl[nt][kb] = a.wpk[((nt * 2 + 1) * NKB + kb) * 64 + lane];
+    }
+  f32x4 bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    bias[nt] = (EPI == BXE_GATES || EPI == BXE_CAND) ? *(const f32x4*)(a.bias + nt * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-lane constants
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    const int gs = isA ? GA : GB, cs = isA ? CA : CB;
+    int j = tid + (isA ? k : k - NA) * 256;
+    j = min(j, NPIX * gs - 1);                        // surplus lanes repeat the last item
+    const int g = j % gs, pp = j / gs, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * a.wi + c) * cs + 4 * g) * 4);
+    lbyte[k] = (unsigned)((pp * PP + (isA ? 0 : CA) + 4 * g) * 2);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xoff[NKB];                                 // B fragment of k-block kb: 8 channels of one position
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    int kk = 32 * kb + 8 * q;
+    int pos = kk / CIN, c0 = kk % CIN;
+    if (pos >= NPOS) { pos = 0; c0 = 0; }             // zero-weight padding: any valid address
+    const int dy = pos / 3, dx = pos % 3;
+    xoff[kb] = (unsigned)(((((row * STRIDE) + dy) * LC + p * STRIDE + dx) * PP + c0) * 2);
+    pin(xoff[kb]);
+  }
+  // outputs: lane's pixel (orow, p); two-row: lanes q < 2 own row `row`, q >= 2 row + 1 (channels 4(q&1)..)
+  const int orow = TWO ? row + (q >> 1) : row;
+  const int CO = (EPI == BXE_RELU) ? a.cout : (TWO ? 8 : HC);
+  unsigned ooff[NT], ooff1[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co4 = TWO ? 4 * (q & 1) : nt * 16 + 4 * q;
+    const unsigned at = (unsigned)(((orow * a.wo + p) * CO + (EPI == BXE_GATES && co4 >= HC ? co4 - HC : co4)) * 4);
+    const bool to0 = TWO ? true : (EPI == BXE_RELU ? co4 < a.cout : co4 < HC);
+    const bool to1 = EPI == BXE_GATES && co4 >= HC && co4 < 2 * HC;
+    ooff[nt] = to0 ? at : BUF_OOB;
+    ooff1[nt] = to1 ? at : BUF_OOB;
+    pin(ooff[nt]); pin(ooff1[nt]);
+  }
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int b, int tx, int ty) {
+    const int ix0 = tx * TC * STRIDE - 1, iy0 = ty * TR * STRIDE - 1;
+    const long pix0 = ((long)b * a.hi + iy0) * a.wi + ix0;
+    const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
+    const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= a.hi && ix0 + LC <= a.wi) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        stage[k] = buf_load4(k < NA ? ra : rb, ok ? goff[k] : BUF_OOB);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      __bf16* hi = (__bf16*)((char*)ldsb + lbyte[k]);
+      split_store(hi, (__bf16*)((char*)hi + LO), stage[k]);
+    }
+  };
+
+  int t = tr.begin + wg;
+  if (t >= tr.end) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, b, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)b * a.ho + oy0) * a.wo + ox0;
+    const bool full = oy0 + TR <= a.ho && ox0 + TC <= a.wo;
+    const buf_rsrc r0 = make_rsrc((char*)a.dst0 + opix0 * (CO * 4));
+    const buf_rsrc r1 = make_rsrc((char*)a.dst1 + opix0 * (HC * 4));
+    const buf_rsrc rh = make_rsrc((const char*)a.hsrc + opix0 * (HC * 4));
+    const buf_rsrc rin = make_rsrc((const char*)(a.hin ? a.hin : a.dst0) + opix0 * (CO * 4));     // CAND: state in
+    unsigned oo[NT], oo1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { oo[nt] = ooff[nt]; oo1[nt] = ooff1[nt]; }
+    if (!full) {
+      const bool valid = oy0 + orow < a.ho && ox0 + p < a.wo;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { oo[nt] = valid ? ooff[nt] : BUF_OOB; oo1[nt] = valid ? ooff1[nt] : BUF_OOB; }
+    }
+
+    // requests: epilogue operands first, then the next tile
+    f32x4 pre_u[NT], pre_h[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (EPI == BXE_CAND && nt * 16 < HC) {
+        pre_u[nt] = buf_load4(r1, oo[nt]);
+        pre_h[nt] = buf_load4(rin, oo[nt]);
+      }
+      if (EPI == BXE_GATES && nt * 16 < HC) pre_h[nt] = buf_load4(rh, oo[nt]);      // h of the lane's pixel, fp32
+    }
+    const int tn = t + nwg;
+    const bool more = tn < tr.end;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_tile(stage, bn, txn, tyn);
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bf16x8 bh = *(const bf16x8*)((const char*)ldsb + xoff[kb]);
+      const bf16x8 bl = *(const bf16x8*)((const char*)ldsb + xoff[kb] + LO);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[nt] = mfma_bx(wh[nt][kb], bh, acc[nt]);
+        acc[nt] = mfma_bx(wh[nt][kb], bl, acc[nt]);
+        acc[nt] = mfma_bx(wl[nt][kb], bh, acc[nt]);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) drain(acc[nt]);
+
+    wait_vmem_all();                   // the one wait point of the tile
+    __syncthreads();                   // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 v = acc[nt] + bias[nt];
+      if (EPI == BXE_RELU || EPI == BXE_TWO_ROW) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        buf_store4(r0, oo[nt], v);
+      } else if (EPI == BXE_GATES) {
+        f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+        if (nt * 16 < HC) buf_store4(r0, oo[nt], sg * pre_h[nt]);              // reset-gate rows -> r * h
+        if (nt * 16 + 16 > HC) buf_store4(r1, oo1[nt], sg);                     // update-gate rows -> u
+      } else if (nt * 16 < HC) {                                                // BXE_CAND
+        f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+        f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
+        buf_store4(r0, oo[nt], u4 * h4 + (1.0f - u4) * cnd);
+      }
+    }
+    if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; b = bn; tx = txn; ty = tyn;
+  }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Level-1 ConvGRU in one kernel (reference models/module.py:28-52 at full stage resolution): the gate convolution
+// on cat(x, h), r*h, the candidate convolution on cat(x, r*h) and the state blend, per 8 x 30 tile.  The level-1
+// maps are the widest of the recurrence (8 channels at stage resolution) and the split-bf16 chain is short, so
+// the separate gate / candidate kernels were bound by their memory traffic: x twice, h, r*h out and in, u out and
+// in, h out.  Fused, a tile reads x and h once (12 x 34 window, halo 2) and writes h once; r*h replaces h inside
+// the LDS tile (the candidate convolution only needs it split into bf16 halves anyway) and u stays in LDS.
+// The new state goes to a second buffer (neighbouring tiles still read the old one); the caller alternates them.
+//
+// LDS: window [hi|lo][12*34 pixels][x 8 | h 8] bf16, and u [10*32 region pixels][8] fp32.
+//   gates at region pixel (rr, rc) = window (rr+1, rc+1), region = tile grown by 1: 10 rows x 2 runs of 16
+//   candidate at inner pixel (ir, ic) = window (ir+2, ic+2): 8 rows x 2 runs (columns 30, 31 of a row are surplus)
+// Wave k owns runs k, k+4, ... of both convolutions (its B-fragment offsets differ by compile-time constants).
+struct Gru1Args {
+  const float* x;        // c1 [B][h*w][8]
+  const float* hin;      // state in  [B][h*w][8]
+  float* hout;           // state out [B][h*w][8] (a different buffer)
+  const bf16x8* wg; const float* bg;    // gates1 A fragments [1][hi|lo][5][64], bias [16]
+  const bf16x8* wc; const float* bc;    // cand1  A fragments [1][hi|lo][5][64], bias [16]
+  int h, w;
+};
+
+struct Gru1FusedBx3Role {
+  typedef Gru1Args Args;
+  static constexpr int TR = 8, TC = 30, WR = TR + 4, WC = TC + 4, NPIXW = WR * WC;
+  static constexpr int PB = 32;                        // bytes per window pixel: x 8 | h 8 bf16, no pad -- with ds_read_b128's
+                                                       // non-contiguous 16-lane groups a 32-byte pitch is conflict-free here, 48 is 2-way
+  static constexpr int LO = NPIXW * PB;                // lo image
+  static constexpr int U0 = 2 * LO;                    // u tile
+  static constexpr int NKB = 5, NG = 5, NC = 4;        // k-blocks (9 taps x 16 channels), gate / candidate runs per wave
+  static constexpr int NITEM = NPIXW * 2, NS = (NITEM + 255) / 256;      // 4-channel groups per source, loads per thread
+  static constexpr size_t LDS_BYTES = (size_t)2 * 12 * 34 * 32 + 10 * 32 * 32;
+  static constexpr int TILE_W = TC, TILE_H = TR;
+  static int tiles_x(const Args& a) { return cdiv(a.w, TC); }
+  static int tiles_y(const Args& a) { return cdiv(a.h, TR); }
+
+  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds_) {
+  char* lds = (char*)lds_;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int rr0 = wave >> 1, c0w = (wave & 1) * 16;    // first run of the wave: region row / first column
+
+  bf16x8 gh[NKB], gl[NKB], ch[NKB], cl[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    gh[kb] = a.wg[(0 * NKB + kb) * 64 + lane]; gl[kb] = a.wg[(1 * NKB + kb) * 64 + lane];
+    ch[kb] = a.wc[(0 * NKB + kb) * 64 + lane]; cl[kb] = a.wc[(1 * NKB + kb) * 64 + lane];
+  }
+  const f32x4 bias_g = *(const f32x4*)(a.bg + 4 * q);
+  const f32x4 bias_c = *(const f32x4*)(a.bc + 4 * q);
+
+  unsigned goff[NS], lbyte[NS];
+  int rc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    int j = min(tid + k * 256, NITEM - 1);
+    const int g = j & 1, pp = j >> 1, r = pp / WC, c = pp % WC;
+    goff[k] = (unsigned)(((r * a.w + c) * 8 + 4 * g) * 4);
+    lbyte[k] = (unsigned)(pp * PB + 8 * g);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xoff[NKB];                                  // gate run 0 of the wave; candidate runs add (WC + 1) * PB
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    int kk = 32 * kb + 8 * q;
+    int pos = kk / 16, ch0 = kk % 16;
+    if (pos >= 9) { pos = 0; ch0 = 0; }
+    xoff[kb] = (unsigned)((((rr0 + pos / 3) * WC + c0w + p + pos % 3) * PB) + ch0 * 2);
+    pin(xoff[kb]);
+  }
+  // gate epilogue: lanes q < 2 turn h into r*h in the window tile, lanes q >= 2 keep u
+  const unsigned hbyte = (unsigned)(((rr0 + 1) * WC + c0w + p + 1) * PB + (8 + 4 * (q & 1)) * 2);
+  const unsigned ubyte_w = (unsigned)(U0 + ((rr0 * 32 + c0w + p) * 8 + 4 * (q & 1)) * 4);
+  // candidate epilogue: lanes q < 2, inner pixel (rr0 + 2j, c0w + p): u of region (ir+1, ic+1)
+  const unsigned ubyte_r = (unsigned)(U0 + (((rr0 + 1) * 32 + c0w + p + 1) * 8 + 4 * (q & 1)) * 4);
+  const bool lane_out = q < 2 && c0w + p < TC;
+  unsigned ooff = lane_out ? (unsigned)(((rr0 * a.w + c0w + p) * 8 + 4 * q) * 4) : BUF_OOB;
+  const unsigned orow2 = (unsigned)(a.w * 64);         // two rows of the state maps, bytes
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&sx)[NS], f32x4 (&sh)[NS], int b, int tx, int ty) {
+    const int ix0 = tx * TC - 2, iy0 = ty * TR - 2;
+    const long pix0 = ((long)b * a.h + iy0) * a.w + ix0;
+    const buf_rsrc rx = make_rsrc((const char*)a.x + pix0 * 32);
+    const buf_rsrc rh = make_rsrc((const char*)a.hin + pix0 * 32);
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + WR <= a.h && ix0 + WC <= a.w) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) { sx[k] = buf_load4(rx, goff[k]); sh[k] = buf_load4(rh, goff[k]); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+        const unsigned o = ok ? goff[k] : BUF_OOB;
+        sx[k] = buf_load4(rx, o); sh[k] = buf_load4(rh, o);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&sx)[NS], const f32x4 (&sh)[NS]) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      __bf16* hi = (__bf16*)(lds + lbyte[k]);
+      split_store(hi, (__bf16*)((char*)hi + LO), sx[k]);
+      split_store(hi + 8, (__bf16*)((char*)hi + LO) + 8, sh[k]);
+    }
+  };
+
+  int t = tr.begin + wg;
+  if (t >= tr.end) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 sx[NS], sh[NS];
+  load_tile(sx, sh, b, tx, ty);
+  wait_vmem_all();
+  store_tile(sx, sh);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)b * a.h + oy0) * a.w + ox0;
+    const buf_rsrc rin = make_rsrc((const char*)a.hin + opix0 * 32);
+    const buf_rsrc rout = make_rsrc((char*)a.hout + opix0 * 32);
+    const bool full = oy0 + TR <= a.h && ox0 + TC <= a.w;
+    unsigned oo[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      oo[j] = ooff + j * orow2;
+      if (!full && !(oy0 + rr0 + 2 * j < a.h && ox0 + c0w + p < a.w)) oo[j] = BUF_OOB;
+    }
+    f32x4 pre_h[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) pre_h[j] = buf_load4(rin, oo[j]);       // exact fp32 state for the blend
+    const int tn = t + nwg;
+    const bool more = tn < tr.end;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_tile(sx, sh, bn, txn, tyn);
+    }
+
+    // ---- gates on cat(x, h)
+    f32x4 ag[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      ag[j] = bias_g;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const char* at = lds + xoff[kb] + j * (2 * WC * PB);
+        const bf16x8 bh = *(const bf16x8*)at;
+        const bf16x8 bl = *(const bf16x8*)(at + LO);
+        ag[j] = mfma_bx(gh[kb], bh, ag[j]);
+        ag[j] = mfma_bx(gh[kb], bl, ag[j]);
+        ag[j] = mfma_bx(gl[kb], bh, ag[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) drain(ag[j]);
+    __syncthreads();                   // nobody reads the old h halves any more
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const f32x4 v = ag[j];
+      const f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+      if (q < 2) {
+        __bf16* hi = (__bf16*)(lds + hbyte + j * (2 * WC * PB));
+        __bf16* lo = (__bf16*)((char*)hi + LO);
+        const bf16x4 h4 = *(const bf16x4*)hi, l4 = *(const bf16x4*)lo;
+        const f32x4 hv = {(float)h4.x + (float)l4.x, (float)h4.y + (float)l4.y, (float)h4.z + (float)l4.z, (float)h4.w + (float)l4.w};
+        split_store(hi, lo, sg * hv);
+      } else {
+        *(f32x4*)(lds + ubyte_w + j * (2 * 32 * 32)) = sg;
+      }
+    }
+    __syncthreads();                   // r*h and u visible
+
+    // ---- candidate on cat(x, r*h)
+    f32x4 ac[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      ac[j] = bias_c;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const char* at = lds + xoff[kb] + (WC + 1) * PB + j * (2 * WC * PB);
+        const bf16x8 bh = *(const bf16x8*)at;
+        const bf16x8 bl = *(const bf16x8*)(at + LO);
+        ac[j] = mfma_bx(ch[kb], bh, ac[j]);
+        ac[j] = mfma_bx(ch[kb], bl, ac[j]);
+        ac[j] = mfma_bx(cl[kb], bh, ac[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) drain(ac[j]);
+    f32x4 u4[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) u4[j] = *(const f32x4*)(lds + ubyte_r + j * (2 * 32 * 32));
+
+    wait_vmem_all();                   // the one wait point of the tile
+    __syncthreads();                   // every wave is done with the tile
+    if (more) store_tile(sx, sh);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const f32x4 v = ac[j];
+      const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+      buf_store4(rout, oo[j], u4[j] * pre_h[j] + (1.0f - u4[j]) * cnd);
+    }
+    if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; b = bn; tx = txn; ty = tyn;
+  }
+  }
+};
+
+}  // namespace adamvs

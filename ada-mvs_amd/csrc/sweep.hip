@@ -185,21 +185,31 @@ size_t sweep_workspace_floats(int B, int C, int D, int h, int w) {
   return (size_t)sweep_chunk_planes(D) * B * h * w * C;
 }
 
+// hypotheses [d0, d1) (at most sweep_chunk_planes(D)): weighted aggregation into sim_ws, conv1 of it into
+// c1_chunk [d1-d0][B][hw][8]
+int launch_sweep_conv1_chunk(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+                             float* c1_chunk, float* sim_ws, int B, int S, int C, int D, int d0, int d1, int h, int w, int precision,
+                             int eps_num, hipStream_t st) {
+  if (S > 8 || S < 1) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
+  int rc;
+  if (C == 32) rc = launch_sweep_c<32>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
+  else if (C == 16) rc = launch_sweep_c<16>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
+  else if (C == 8) rc = launch_sweep_c<8>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
+  else return set_error(-1, "aggregate_conv1: C=%d unsupported (8, 16 or 32)", C);
+  if (rc) return rc;
+  // conv1 over the (d1-d0)*B similarity maps of the chunk; image n = dlocal*B + b lands in c1_chunk[dlocal][b]
+  return launch_conv1(sim_ws, w1pk, c1_chunk, (d1 - d0) * B, C, h, w, precision, st);
+}
+
 int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
                        float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, int eps_num,
                        hipStream_t st) {
-  if (S > 8 || S < 1) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
   const int dc = sweep_chunk_planes(D);
   for (int d0 = 0; d0 < D; d0 += dc) {
     const int d1 = (d0 + dc < D) ? d0 + dc : D;
-    int rc;
-    if (C == 32) rc = launch_sweep_c<32>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
-    else if (C == 16) rc = launch_sweep_c<16>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
-    else if (C == 8) rc = launch_sweep_c<8>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
-    else return set_error(-1, "aggregate_conv1: C=%d unsupported (8, 16 or 32)", C);
-    if (rc) return rc;
-    // conv1 over the (d1-d0)*B similarity maps of the chunk; image n = dlocal*B + b lands in c1[d0 + dlocal][b]
-    if ((rc = launch_conv1(sim_ws, w1pk, c1 + (size_t)d0 * B * h * w * 8, (d1 - d0) * B, C, h, w, precision, st))) return rc;
+    if (int rc = launch_sweep_conv1_chunk(feat, rt, planes, vw, w1pk, c1 + (size_t)d0 * B * h * w * 8, sim_ws, B, S, C, D, d0, d1, h, w,
+                                          precision, eps_num, st))
+      return rc;
   }
   return 0;
 }

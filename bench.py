@@ -122,9 +122,12 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 del sim, score
             else:
                 mark("s%d.view_weight_resample" % (s + 1), lambda: phase(_lib.PHASE_VIEW_WEIGHTS))
+            # the three phases below are interleaved chunk by chunk in a real run; called one by one each runs alone over
+            # all chunks (its own duration, no maps), so the maps that feed the next stage come from one untimed full call
             mark("s%d.aggregate_conv1" % (s + 1), lambda: phase(_lib.PHASE_AGGREGATE))
             mark("s%d.recurrence" % (s + 1), lambda: phase(_lib.PHASE_RECURRENCE))
             mark("s%d.soft_argmin" % (s + 1), lambda: phase(_lib.PHASE_SOFT_ARGMIN))
+            phase(_lib.PHASE_AGGREGATE | _lib.PHASE_RECURRENCE | _lib.PHASE_SOFT_ARGMIN)
             depth, conf = outs[2], outs[0]
     torch.cuda.synchronize()
     for name, a, b in evs:
@@ -165,12 +168,32 @@ def cpu_baseline(cfg, sd):
     with torch.no_grad(), O.use_grid_sample():
         feats = [O.feature_net(imgs[:, v], sd_cpu) for v in range(c["views"])]
         t0 = time.time()
-        O.infer_adamvs_forward(imgs, proj, dv, sd_cpu, c["num_depth"], c["ndepths"],
-                               synth.DEPTH_INTERVALS_RATIO[:len(c["ndepths"])], features=feats)
+        ref = O.infer_adamvs_forward(imgs, proj, dv, sd_cpu, c["num_depth"], c["ndepths"],
+                                     synth.DEPTH_INTERVALS_RATIO[:len(c["ndepths"])], features=feats)
         dt = time.time() - t0
     return {"value": 1.0 / dt, "unit": "depth maps/s", "cores": threads, "kind": "port",
             "sample": "1 tile of %s, hot path only (features precomputed), %.1f s, oracle/adamvs_oracle.py "
-                      "(grid_sample form of the warp, as the reference issues it)" % (cfg, dt)}
+                      "(grid_sample form of the warp, as the reference issues it)" % (cfg, dt)}, ref
+
+
+def rel_l1(x, ref):
+    """mean|x - ref| / mean|ref|."""
+    x, ref = x.detach().double().cpu(), ref.detach().double().cpu()
+    return float((x - ref).abs().mean() / ref.abs().mean().clamp_min(1e-30))
+
+
+def source_stamp():
+    """sha256 over the kernel sources and the C ABI header: profiles/*_traffic.json carry the stamp of the build they were
+    measured on, and a stale file is refused instead of being quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ada-mvs_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "adamvs_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 # ---- the sibling model (SURVEY.md section 8f row f3): not the headline, selected with --model msrednet ---------------
@@ -375,6 +398,7 @@ def main():
         result = None
         if rank == 0:
             assert gathered[0].shape[0] == n_tiles and bool(torch.isfinite(gathered[0]).all())
+            tile0 = (gathered[0][0].clone(), gathered[1][0].clone())      # the graph's output buffers are reused below
             result = {
                 "metric": "depth maps/sec at 768x384x5-view x192-hyp (hot path, features resident in HBM)",
                 "value": n_tiles * args.steps / elapsed, "unit": "depth maps/s", "n_gpus": world,
@@ -408,33 +432,43 @@ def main():
             st = work[int(dom[1]) - 1]
             kind = dom.split(".", 1)[1]
             c0 = synth.CONFIGS[cfg]
+            split = args.precision == "bf16x3"
             if kind == "cost_reg_net_2d":
-                # dominant kernel = the stride-1 instantiation of k_conv_dd (conv0, conv2, conv4, conv6, prob)
+                # dominant kernel = the stride-1 instantiation of k_conv_dd (conv0, conv2, conv4, conv6, prob).  The split-bf16
+                # mode EXECUTES three bf16 products per fp32 product on the bf16 matrix pipe: priced against that pipe's peak.
                 lay = {k: v for k, v in avg.items() if ".costreg." in k and k.endswith("mode0")}
                 hw0, Dd, N = st["h"] * st["w"], st["D"], (c0["views"] - 1) * Bg
                 res = {"conv0": 1, "conv2": 4, "conv4": 16, "conv6": 64, "prob": 1}
-                flops = sum(2.0 * N * (hw0 // res[k.split(".")[2]]) * Dd * Dd * 9 for k in lay)
+                flops = sum(2.0 * N * (hw0 // res[k.split(".")[2]]) * Dd * Dd * 9 for k in lay) * (3 if split else 1)
                 ms = sum(lay.values())
                 ach = flops / (ms * 1e-3) / 1e12
-                roof = {"kernel": "k_conv_dd<MT,WM,CONV_S1> (CostRegNet2D 3x3 stride-1 layers, %d launches per step)" % len(lay),
-                        "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "launch_ms": ms / len(lay),
+                peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+                roof = {"kernel": "%s (CostRegNet2D 3x3 stride-1 layers, %d launches per step)" % (
+                            "k_conv_dd_bx3<MT,WM,CONV_S1>, executed bf16 flops = 3 x fp32 products" if split else "k_conv_dd<MT,WM,CONV_S1>", len(lay)),
+                        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                        "frac": ach / peak, "launch_ms": ms / len(lay),
                         "flops_per_launch": flops / len(lay), "traffic": None}
-                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")          # tools/profile_round.sh
-                if os.path.exists(tpath):          # HBM bytes per launch from the committed PMC passes, same workload and batch
-                    tj = json.load(open(tpath))
-                    if tj["config"] == {"workload": cfg, "tiles_per_launch": Bg}:
-                        k0 = [v for k, v in tj["kernels"].items() if "k_conv_dd<3, 4, 0" in k]        # stride-1 instantiation
-                        if k0:
-                            roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
-                            roof["traffic_note"] = "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), profiles/r01_traffic.json"
+                stamp = source_stamp()
+                for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+                    tj = json.load(open(tpath))       # HBM bytes per launch from committed PMC passes (tools/profile_round.sh)
+                    if tj.get("config") != {"workload": cfg, "tiles_per_launch": Bg} or tj.get("precision", "fp32") != args.precision:
+                        continue
+                    if tj.get("source_stamp") != stamp:
+                        roof["traffic_note"] = "%s was measured on another build (stamp %s, this build %s): not quoted" % (
+                            os.path.basename(tpath), tj.get("source_stamp"), stamp)
+                        continue
+                    k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_dd<3, 4, 0") in k]
+                    if k0:
+                        roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
+                        roof["traffic_note"] = ("bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), %s, "
+                                                "same source stamp %s" % (os.path.basename(tpath), stamp))
+                        break
             elif kind == "recurrence":
                 # executed flops: the split-bf16 mode issues three bf16 products per fp32 product
-                split = args.precision == "bf16x3"
                 ach = st["recurrence_flops"] * (3 if split else 1) / (avg[dom] * 1e-3) / 1e12
                 peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-                nl = 5 if split else 6
-                roof = {"kernel": "recurrent step kernels (%d steps x %d launches)" % (st["D"], nl), "bound": "mfma",
+                nl = 3
+                roof = {"kernel": "recurrent slot kernels k_slot<...> (%d steps x %d launches)" % (st["D"], nl), "bound": "mfma",
                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                         "launch_ms": avg[dom] / (nl * st["D"]), "traffic": None}
                 if split:
@@ -447,12 +481,31 @@ def main():
                 ach = st[key] / (avg[dom] * 1e-3) / 1e9
                 roof = {"kernel": "k_" + kind, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "launch_ms": avg[dom], "traffic": None}
+            # the whole step against both rooflines: algorithmic conv flops and algorithmic bytes of ALL
+            # phases / the measured ms_per_step; fp32 is bound by the fp32 matrix pipe, the split-bf16 mode by HBM
+            step_s = 1e-3 * result["ms_per_step"] * (Bg / float(B))
+            tot_flops = sum(w_.get("costreg_flops", 0) + w_["recurrence_flops"] + w_["conv1_flops"] for w_ in work)
+            tot_bytes = sum(sum(v for k_, v in w_.items() if k_.endswith("_bytes")) for w_ in work)
+            roof["step_frac_mfma"] = tot_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            roof["step_frac_hbm"] = tot_bytes / step_s / 1e9 / HBM_PEAK_GBS
+            roof["step_frac"] = roof["step_frac_hbm"] if split else roof["step_frac_mfma"]
+            roof["step_bound"] = "hbm" if split else "mfma (fp32)"
+            roof["step_algorithmic"] = {"conv_gflop_per_tile": tot_flops / Bg / 1e9, "gbytes_per_tile": tot_bytes / Bg / 1e9}
             roof["dominant_phase"] = dom
             result["roofline"] = roof
+        parity_ok = True
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, sd)
+            # the oracle runs tile 0 of this very workload: its maps are the parity check of the timed run
+            result["cpu_baseline"], ref = cpu_baseline(cfg, sd)
+            result["parity_rel_l1"] = {"depth": rel_l1(tile0[0], ref["depth"][0]),
+                                       "photometric_confidence": rel_l1(tile0[1], ref["photometric_confidence"][0]),
+                                       "tolerance": 1e-3, "tile": 0, "against": "oracle/adamvs_oracle.py (cpu_baseline run)"}
+            parity_ok = max(result["parity_rel_l1"]["depth"], result["parity_rel_l1"]["photometric_confidence"]) <= 1e-3
         if rank == 0:
             print(json.dumps(result))
+        if not parity_ok:
+            print("bench.py: parity_rel_l1 above 1e-3 -- the measured path is wrong", file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         torch.distributed.destroy_process_group()
 

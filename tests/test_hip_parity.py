@@ -478,3 +478,48 @@ def test_train_test_twin_golden(hip):
     m.train()
     with pytest.raises(Exception):
         m(dev(g["imgs"]), proj, dev(dv3))
+
+
+# --------------------------------------------------------------------------- software-pipelined recurrence
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("cfg,batch", [("tiny", 3), ("cfg1", 2)])
+def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, monkeypatch, cfg, batch, precision):
+    """The stage driver skews the steps (level 1 of hypothesis t, level 2 of t-1 / t-2 and the decoder of t-2 / t-3 share
+    launches, state rings of 4 / 2 buffers, hypotheses in chunks of 32 across which the pipeline keeps running): the
+    arithmetic per tile is that of the one-role kernels, so the maps of both schedules must equal, bit for bit, those
+    of ADAMVS_RECUR_MODE=0 (six dependent launches per hypothesis, states updated in place).  cfg1 has 48 hypotheses
+    at stage 1: two chunks."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    c = synth.CONFIGS[cfg]
+    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8], precision=precision)
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=batch, seed=21)
+    args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+    outs = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
+        with torch.no_grad():
+            outs[mode] = m(*args)
+        torch.cuda.synchronize()
+    for mode in ("1", "2"):
+        for s in ("stage1", "stage2", "stage3"):
+            for key in ("depth", "photometric_confidence"):
+                assert torch.equal(outs["0"][s][key], outs[mode][s][key]), (mode, s, key)
+
+
+def test_soft_argmin_op(hip):
+    """adamvs_soft_argmin (reference adamvs.py:516-531) by itself: exp without max subtraction, strict
+    '<' running maximum from 0, +1e-10 on the sum.  (The 2x-upsampled-plane form and the chunked accumulation of the
+    stage driver are held by the stage / end-to-end fixtures.)"""
+    B, D, h, w = 2, 7, 6, 10
+    g = torch.Generator().manual_seed(3)
+    planes = 400 + 200 * torch.rand(B, D, h, w, generator=g)
+    vol = torch.randn(B, D, h, w, generator=g) * 2
+    vol[0, :, 0, 0] = -200.0                               # exp underflows to 0 everywhere: depth = 0 / 1e-10, confidence 0
+    p = vol.exp()
+    den = p.sum(1) + 1e-10
+    ref_d, ref_c = (planes * p).sum(1) / den, p.max(1)[0] / den
+    d, cf = hip.soft_argmin(dev(vol), dev(planes), B, D, h, w)
+    assert rel_l1(d, ref_d) < 1e-6 and rel_l1(cf, ref_c) < 1e-5
+    assert float(d[0, 0, 0]) == 0.0 and float(cf[0, 0, 0]) == 0.0

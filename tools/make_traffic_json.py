@@ -6,8 +6,12 @@
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_stamp  # noqa: E402  (bench.py refuses a traffic file measured on another build)
 
 workload, tiles, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -32,7 +36,8 @@ for k, cs in sorted(acc.items(), key=lambda kv: -dur[kv[0]][0]):
         kernels[k[:96]] = {"fetch_size_kib": round(cs["FETCH_SIZE"][0] / cs["FETCH_SIZE"][1], 1),
                            "write_size_kib": round(cs["WRITE_SIZE"][0] / cs["WRITE_SIZE"][1], 1),
                            "avg_us": round(dur[k][0] / dur[k][1], 1), "launches": dur[k][1]}
-json.dump({"config": {"workload": workload, "tiles_per_launch": tiles},
+json.dump({"config": {"workload": workload, "tiles_per_launch": tiles}, "precision": os.environ.get("PRECISION", "fp32"),
+           "source_stamp": source_stamp(),
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --batch %d --no-graph --steps 1 "
                    "--warmup 1); per-launch averages, KiB. gfx950: FETCH_SIZE counts half of a 16-byte-per-lane coalesced read "
                    "(MI355X_MICROARCH.md, HBM) -> hbm_bytes = 2*FETCH + WRITE for the float4 kernels." % tiles,
