@@ -50,9 +50,9 @@ def scale_image(image, scale=1, interpolation="linear"):
         return image[ys][:, xs]
     if interpolation != "linear":
         return None
-    if scale == 0.5 and h % 2 == 0 and w % 2 == 0 and np.issubdtype(image.dtype, np.integer) and image.dtype.itemsize <= 2:
+    if scale == 0.5 and h % 2 == 0 and w % 2 == 0 and image.dtype.kind == "u" and image.dtype.itemsize <= 2:
         # the default predict setting: every sample centre falls between four pixels with weights 1/4 -- the 2 x 2 box,
-        # in integer arithmetic (same rounding as the general path below: half up)
+        # in unsigned integer arithmetic (same rounding as the general path below: half up); signed images take that path
         acc = image[0::2, 0::2].astype(np.uint32)
         acc += image[0::2, 1::2]
         acc += image[1::2, 0::2]

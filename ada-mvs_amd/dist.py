@@ -8,8 +8,12 @@ the CPU tests).  No collective sits on the data path.
 """
 import os
 
-import torch
-import torch.distributed as dist
+# the host driver of this pool only supports dmabuf IPC; must be in the environment before the HIP runtime starts,
+# i.e. before anything in the process touches the GPU (importing this module first is enough)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def init_from_env(backend=None):
@@ -19,7 +23,6 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = os.environ.get("ADAMVS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
@@ -67,6 +70,70 @@ def gather_maps(depth, conf, n_tiles, dst=0):
         out_d[r::world] = bufs[r][0, :n_r]
         out_c[r::world] = bufs[r][1, :n_r]
     return out_d, out_c
+
+
+class MapGatherer:
+    """The per-step gather of a sharded run with everything allocated once and the collective off the critical path.
+
+        g = MapGatherer(n_tiles, tiles_here, H, W, device)        # once
+        for step in ...:
+            replay the hot path -> depth, conf [tiles_here, H, W]
+            g.start(depth, conf)       # copies the maps out of the (reused) output buffers, issues the gather, returns
+        depth_all, conf_all = g.finish()                          # rank dst: [n_tiles, H, W] of the LAST started step
+
+    start() of step k+1 first completes the gather of step k (its result is overwritten: a throughput loop only needs
+    the last one).  With the RCCL backend the collective runs on RCCL's own stream, after the copy and concurrently
+    with the next replay; two staging buffers alternate so that a gather in flight is never overwritten.  With gloo
+    (CPU tests, single-GPU dry runs) the staging buffers live in host memory and the gather is synchronous."""
+
+    def __init__(self, n_tiles, tiles_here, H, W, device, dst=0, dtype=torch.float32):
+        self.n_tiles, self.own, self.dst = n_tiles, tiles_here, dst
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.work, self.slot, self.last = None, 0, None
+        if self.world == 1:
+            return
+        self.per_rank = (n_tiles + self.world - 1) // self.world
+        self.host = dist.get_backend() == "gloo"
+        dev = torch.device("cpu") if self.host else device
+        self.pack = [torch.zeros(2, self.per_rank, H, W, device=dev, dtype=dtype) for _ in range(2)]
+        if self.host and device.type != "cpu":
+            self.pack = [p.pin_memory() for p in self.pack]
+        self.bufs = [torch.empty(2, self.per_rank, H, W, device=dev, dtype=dtype) for _ in range(self.world)] if self.rank == dst else None
+        self.out = torch.empty(2, n_tiles, H, W, device=dev, dtype=dtype) if self.rank == dst else None
+
+    def start(self, depth, conf):
+        if self.world == 1:
+            self.last = (depth, conf)
+            return
+        self._complete()
+        pack = self.pack[self.slot]
+        self.slot ^= 1
+        pack[0, :self.own].copy_(depth, non_blocking=True)
+        pack[1, :self.own].copy_(conf, non_blocking=True)
+        if self.host:
+            if depth.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            dist.gather(pack, self.bufs, dst=self.dst)
+        else:
+            self.work = dist.gather(pack, self.bufs, dst=self.dst, async_op=True)
+
+    def _complete(self):
+        if self.work is not None:
+            self.work.wait()               # orders the current stream after the collective; does not block the host
+            self.work = None
+
+    def finish(self):
+        """-> (depth, conf) [n_tiles, H, W] in global tile order on `dst`, (None, None) elsewhere."""
+        if self.world == 1:
+            return self.last
+        self._complete()
+        if self.rank != self.dst:
+            return None, None
+        for r in range(self.world):              # round-robin ownership = a strided slice (one copy per rank)
+            n_r = len(range(r, self.n_tiles, self.world))
+            self.out[:, r::self.world] = self.bufs[r][:, :n_r]
+        return self.out[0], self.out[1]
 
 
 def run_sharded(infer_tiles, n_tiles, dst=0):

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from ada_mvs_amd import hip_ops, packing
 from ada_mvs_amd._lib import AdaMVSHipError, PRECISIONS as _PRECISIONS
-from .module import Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse
+from .module import Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, PackedCache, module_state
 
 STAGE_SCALE = {"stage1": 4, "stage2": 2, "stage3": 1}
 
@@ -27,7 +27,7 @@ def _pooled_context(in_ch, out_ch, pool):
                          Conv2d(in_ch, out_ch, 1, stride=1, padding=0, dilation=1))
 
 
-class FeatureNet0(nn.Module):
+class FeatureNet0(PackedCache, nn.Module):
     """2D U-Net with pooled-context branches, three output scales (C = 32/16/8 at 1/4, 1/2, 1/1);
     reference models/adamvs.py:49-152.  forward() = adamvs_feature_net0 (csrc/featnet.hip) on GPU tensors whose
     height and width are multiples of 32 and base_channels = 8; other shapes run the same layers through PyTorch."""
@@ -53,22 +53,14 @@ class FeatureNet0(nn.Module):
         self.out2 = nn.Conv2d(4 * c, 2 * c, 1, bias=False)
         self.out3 = nn.Conv2d(2 * c, c, 1, bias=False)
         self.out_channels = [4 * c, 2 * c, c]
-        self._packed = None
+        self._cache_init()
         self.workspace_limit_bytes = 32 << 30      # forward_cl runs larger batches in chunks
 
-    def _apply(self, fn, *a, **k):             # .cuda()/.to(): repack on next use
-        self._packed = None
-        return super()._apply(fn, *a, **k)
-
-    def _load_from_state_dict(self, *a, **k):
-        self._packed = None
-        return super()._load_from_state_dict(*a, **k)
-
     def packed(self, device):
-        if self._packed is None or self._packed.buf.device != device:
-            flat, offsets = packing.pack_feature_net(self.state_dict(), "")
-            self._packed = hip_ops.PackedFeature(flat, offsets, device)
-        return self._packed
+        def build():
+            flat, offsets = packing.pack_feature_net(module_state(self), "")
+            return hip_ops.PackedFeature(flat, offsets, device)
+        return self.cached(device, build)
 
     def hip_supported(self, x):
         return x.is_cuda and self.base_channels == 8 and x.shape[-2] % 32 == 0 and x.shape[-1] % 32 == 0
@@ -113,7 +105,7 @@ class FeatureNet0(nn.Module):
         return out
 
 
-class CostRegNet2D(nn.Module):
+class CostRegNet2D(PackedCache, nn.Module):
     """Depth-as-channel 2D hourglass (reference models/adamvs.py:198-238); forward = adamvs_cost_reg_net_2d."""
 
     def __init__(self, in_channels, base_channels=8):
@@ -127,16 +119,14 @@ class CostRegNet2D(nn.Module):
                 nn.BatchNorm2d(d), nn.ReLU(inplace=True)))
         self.prob = nn.Conv2d(d, d, 3, stride=1, padding=1)
         self.precision = "fp32"            # or "bf16x3": split-bf16 MFMA, fp32-equivalent to ~1e-5 (needs d % 32 == 0)
-        self._packed = None
+        self._cache_init()
 
     def effective_precision(self):
         return self.precision if self.prob.weight.shape[0] % 32 == 0 else "fp32"
 
     def packed(self, device):
         prec = self.effective_precision()
-        if self._packed is None or self._packed[0] != prec or self._packed[1].device != device:
-            self._packed = (prec, packing.pack_cost_reg_net_2d(self.state_dict(), "", prec).to(device))
-        return self._packed[1]
+        return self.cached((device, prec), lambda: packing.pack_cost_reg_net_2d(module_state(self), "", prec).to(device))
 
     def forward(self, x):
         N, D, h, w = x.shape
@@ -145,7 +135,7 @@ class CostRegNet2D(nn.Module):
         return hip_ops.unpack_features(score, h, w)
 
 
-class SliceCostRegNetRED(nn.Module):
+class SliceCostRegNetRED(PackedCache, nn.Module):
     """One recurrent regularisation step (reference models/adamvs.py:400-424); forward = adamvs_slice_reg_step."""
 
     def __init__(self, in_channels, up=True, base_channels=8):
@@ -162,15 +152,17 @@ class SliceCostRegNetRED(nn.Module):
         else:
             self.upconv2d = nn.Conv2d(c, 1, kernel_size=3, stride=1, padding=1)
         self.precision = "fp32"            # or "bf16x3" (split-bf16 MFMA for conv1 and the ConvGRU convolutions)
-        self._packed = None
+        self._cache_init()
 
     def packed(self, device):
         if self.base_channels != 8:
             raise AdaMVSHipError("SliceCostRegNetRED: the reference hard-codes 8/16 GRU widths (adamvs.py:448-449)")
-        if self._packed is None or self._packed[0] != self.precision or self._packed[1].buf.device != device:
-            flat, offsets = packing.pack_slice_reg_net(self.state_dict(), "", self.precision)
-            self._packed = (self.precision, hip_ops.PackedFuse(flat, offsets, device))
-        return self._packed[1]
+        prec = self.precision
+
+        def build():
+            flat, offsets = packing.pack_slice_reg_net(module_state(self), "", prec)
+            return hip_ops.PackedFuse(flat, offsets, device)
+        return self.cached((device, prec), build)
 
     def forward(self, cost, state1, state2):
         B, C, h, w = cost.shape
@@ -179,12 +171,6 @@ class SliceCostRegNetRED(nn.Module):
         reg = hip_ops.slice_reg_step(hip_ops.pack_features(cost), s1, s2, self.packed(cost.device), B, C, h, w, self.up,
                                      _PRECISIONS[self.precision])
         return reg, hip_ops.unpack_features(s1, h, w), hip_ops.unpack_features(s2, h // 2, w // 2)
-
-
-def _drop_packed(module):
-    for m in module.modules():
-        if hasattr(m, "_packed"):
-            m._packed = None
 
 
 class InferDepthNet0(nn.Module):
@@ -196,16 +182,11 @@ class InferDepthNet0(nn.Module):
         self.reg = CostRegNet2D(in_depths, base_channels)
         self.reg_fuse = SliceCostRegNetRED(in_channels, in_up, base_channels)
         self.mirror_list_lengths = True        # pair_confidence carries the reference's S*D duplicate entries (quirk Q1)
-        self._workspace = {}                   # one workspace per concurrent tile group
+        self._workspace = {}                   # one workspace per (device, concurrent tile group); shared by DataParallel replicas
 
-    def _apply(self, fn, *a, **k):             # .cuda()/.to(): repack on next use
-        _drop_packed(self)
-        self._workspace = {}
+    def _apply(self, fn, *a, **k):             # .cuda()/.to(): the workspaces belong to the old placement
+        self._workspace.clear()
         return super()._apply(fn, *a, **k)
-
-    def _load_from_state_dict(self, *a, **k):
-        _drop_packed(self)
-        return super()._load_from_state_dict(*a, **k)
 
     def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0, twin=False):
         """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w];
@@ -218,9 +199,10 @@ class InferDepthNet0(nn.Module):
         desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()],
                                   _PRECISIONS[self.reg_fuse.precision], eps_in_numerator=int(twin))
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4
-        ws = self._workspace.get(group)
-        if ws is None or ws.numel() < need or ws.device != feat_cl.device:
-            ws = self._workspace[group] = torch.empty(need, device=feat_cl.device, dtype=torch.float32)
+        key = (feat_cl.device, group)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._workspace[key] = torch.empty(need, device=feat_cl.device, dtype=torch.float32)
         dev = feat_cl.device
         w_reg = self.reg.packed(dev) if first else None
         return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev), ws)
@@ -281,7 +263,6 @@ class Infer_AdaMVSNet(nn.Module):
         self.precision = precision
         for net in self.DepthNet:
             net.reg.precision = net.reg_fuse.precision = precision
-            net.reg._packed = net.reg_fuse._packed = None
 
     # ---- the hot path on pre-extracted features ---------------------------------------------
     def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval, group=0, twin=False):
@@ -336,6 +317,10 @@ class Infer_AdaMVSNet(nn.Module):
         if not imgs.is_cuda:
             raise AdaMVSHipError("Infer_AdaMVSNet runs on MI355X only: move the model and its inputs to the GPU "
                                  "(no CPU fallback for the depth-inference path)")
+        if self.training:
+            # the kernels fold BatchNorm's running statistics (eval semantics); the reference's predict script always
+            # calls .eval() (predict_whu.py:89), in train mode its BatchNorm would normalise with batch statistics
+            raise AdaMVSHipError("Infer_AdaMVSNet implements the eval-mode forward only: call .eval() (predict_whu.py:89)")
         return self._forward_infer(imgs, proj_matrices, depth_values)
 
     def _forward_infer(self, imgs, proj_matrices, depth_values):

@@ -17,6 +17,54 @@ import torch.nn.functional as F
 from ada_mvs_amd import hip_ops
 
 
+def module_state(module):
+    """state_dict() of `module` that also works on an nn.DataParallel replica.  torch.nn.parallel.replicate() empties a
+    replica's `_parameters` and re-attaches the per-device copies as plain attributes (kept in `_former_parameters`), so
+    `replica.state_dict()` holds buffers only (reference predict_whu.py:82 wraps the model in nn.DataParallel, which
+    replicates on every forward as soon as two GPUs are visible)."""
+    out = {}
+    for name, m in module.named_modules():
+        pre = name + "." if name else ""
+        for k, v in m._parameters.items():
+            if v is not None:
+                out[pre + k] = v
+        for k, v in getattr(m, "_former_parameters", {}).items():
+            out.setdefault(pre + k, v)
+        for k, v in m._buffers.items():
+            if v is not None and k not in m._non_persistent_buffers_set:
+                out[pre + k] = v
+    return out
+
+
+class PackedCache:
+    """Mixin for the networks whose forward runs on packed weights (BatchNorm folded, MFMA fragment order).
+
+    The cache is ONE dict per source module, keyed by device (and precision): a replica's __dict__ is a shallow copy,
+    so every nn.DataParallel replica of every forward finds the weights its device packed before, and the per-device
+    threads never evict each other.  Moving the module (.cuda() / .to()) or loading a state dict drops the cache;
+    weights edited in place afterwards need an explicit drop_cache()."""
+
+    def _cache_init(self):
+        self._cache = {}
+
+    def cached(self, key, build):
+        c = self._cache
+        if key not in c:
+            c[key] = build()
+        return c[key]
+
+    def drop_cache(self):
+        self._cache.clear()
+
+    def _apply(self, fn, *a, **k):
+        self.drop_cache()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.drop_cache()
+        return super()._load_from_state_dict(*a, **k)
+
+
 # ---- functions (reference models/module.py:527-663) -------------------------
 def homo_warping_float(src_fea, src_proj, ref_proj, depth_values):
     """src_fea [B,C,H,W], src_proj/ref_proj [B,4,4], depth_values [B,Nd,H,W] -> [B,C,Nd,H,W]

@@ -14,7 +14,7 @@ import torch.nn as nn
 from ada_mvs_amd import hip_ops, packing
 from ada_mvs_amd._lib import AdaMVSHipError
 from .adamvs import STAGE_SCALE, FeatureNet0
-from .module import Conv2d, ConvReLU, DeConv2dFuse, _FusedLayer
+from .module import Conv2d, ConvReLU, DeConv2dFuse, PackedCache, _FusedLayer, module_state
 
 
 class FeatureNet(FeatureNet0):
@@ -37,14 +37,14 @@ class FeatureNet(FeatureNet0):
         self.out2 = nn.Conv2d(2 * c, 2 * c, 1, bias=False)
         self.out3 = nn.Conv2d(c, c, 1, bias=False)
         self.out_channels = [4 * c, 2 * c, c]
-        self._packed = None
+        self._cache_init()
         self.workspace_limit_bytes = 32 << 30
 
     def packed(self, device):
-        if self._packed is None or self._packed.buf.device != device:
-            flat, offsets = packing.pack_feature_net(self.state_dict(), "", context=False)
-            self._packed = hip_ops.PackedFeature(flat, offsets, device)
-        return self._packed
+        def build():
+            flat, offsets = packing.pack_feature_net(module_state(self), "", context=False)
+            return hip_ops.PackedFeature(flat, offsets, device)
+        return self.cached(device, build)
 
     def forward_torch(self, x):
         c0 = self.conv0(x)
@@ -81,7 +81,7 @@ class ConvGRUCell2(_FusedLayer):
         self.output_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
 
 
-class slice_RED_Regularization(nn.Module):
+class slice_RED_Regularization(PackedCache, nn.Module):
     """reference models/msrednet.py:330-366, restructured around what is and is not recurrent.
 
     In the reference step, conv1-3 (the encoder) depend only on the cost of the plane, every ConvGRUCell2 only on its
@@ -118,22 +118,16 @@ class slice_RED_Regularization(nn.Module):
         self.upconv2 = ConvTransReLU(4 * c, 2 * c, 3, 2, 1, 1)
         self.upconv1 = ConvTransReLU(2 * c, c, 3, 2, 1, 1)
         self.upconv2d = nn.ConvTranspose2d(c, 1, kernel_size=3, stride=1, padding=1, output_padding=0)
-        self._packed = None
+        self._cache_init()
+        self._packed = None                    # the packed weights of the device the current forward runs on
         self._streams = None
         self.concurrent_levels = True
 
-    def _apply(self, fn, *a, **k):
-        self._packed = None
-        return super()._apply(fn, *a, **k)
-
-    def _load_from_state_dict(self, *a, **k):
-        self._packed = None
-        return super()._load_from_state_dict(*a, **k)
-
     def packed(self, device):
-        if self._packed is None or self._packed[0].device != device:
-            flat, offsets = packing.pack_red_regularization(self.state_dict(), "", self.in_channels)
-            self._packed = (flat.to(device), offsets)
+        def build():
+            flat, offsets = packing.pack_red_regularization(module_state(self), "", self.in_channels)
+            return (flat.to(device), offsets)
+        self._packed = self.cached(device, build)
         return self._packed
 
     def _w(self, name):

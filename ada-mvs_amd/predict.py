@@ -107,8 +107,8 @@ def save_outputs(args, output_folder, depth_est, prob, ref_image, ref_cam, ref_p
     save_pfm(folder + ("/%s_init.pfm" % name), depth_est)
     save_pfm(folder + ("/%s_prob.pfm" % name), prob)
     from PIL import Image
-    with open(folder + ("/%s.jpg" % name), "wb") as f:      # PNG bytes under a .jpg name, as the reference writes it
-        Image.fromarray(np.ascontiguousarray(ref_image)).save(f, format="png")
+    with open(folder + ("/%s.jpg" % name), "wb") as f:      # PNG bytes under a .jpg name, RGBA, as the reference's plt.imsave writes it
+        Image.fromarray(np.ascontiguousarray(ref_image)).convert("RGBA").save(f, format="png")
     write_red_cam(folder + ("/%s.txt" % name), ref_cam, ref_path)
 
 
@@ -121,7 +121,10 @@ def predict_depth(args):
     dataset = find_dataset_def(args.dataset)(args.data_folder, args.view_num, args)
     if world > 1:                                    # independent samples: deal them out, no data-path collective
         dataset = Subset(dataset, list(range(rank, len(dataset), world)))
-    loader = DataLoader(dataset, args.batch_size, shuffle=False, num_workers=args.num_workers, drop_last=False)
+    # loader processes come from a fork server started before this process touches the GPU: a child forked from a process
+    # with an initialised HIP runtime must never call into it
+    loader = DataLoader(dataset, args.batch_size, shuffle=False, num_workers=args.num_workers, drop_last=False,
+                        multiprocessing_context="forkserver" if args.num_workers > 0 else None)
     model = build_model(args, device)
     os.makedirs(args.output_folder, exist_ok=True)
     step, t_first = 0, time.time()

@@ -107,7 +107,7 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                     torch.empty(B, Ho, Wo, device=dev), torch.empty(B, Ho, Wo, device=dev))
             w_reg = net.reg.packed(dev) if first else None
             fuse = net.reg_fuse.packed(dev)
-            ws = net._workspace[0]
+            ws = net._workspace[(dev, 0)]
 
             def phase(mask):
                 return hip_ops.depth_stage_forward(desc, feats_cl[s], rt, planes, conf, w_reg, fuse, ws, phases=mask, outputs=outs)
@@ -370,22 +370,28 @@ def main():
             graph.replay()
             torch.cuda.synchronize()
 
+        # one gather of the finished maps per step, staged through preallocated buffers and issued asynchronously:
+        # the collective of step k overlaps the replay of step k+1 (ada_mvs_amd/dist.py)
+        gatherer = adist.MapGatherer(n_tiles, B, depth.shape[-2], depth.shape[-1], dev)
+
         def step():
             if graph is not None:
                 graph.replay()
                 d, p = depth, conf
             else:
                 d, p = hot_path()
-            return adist.gather_maps(d, p, n_tiles, dst=0)
+            gatherer.start(d, p)
 
         for _ in range(args.warmup):
             step()
+        gatherer.finish()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            gathered = step()
+            step()
+        gathered = gatherer.finish()             # the last gather is inside the timed region
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()

@@ -37,11 +37,31 @@ def _worker(rank, world, port, n_tiles, q):
     dist.destroy_process_group()
 
 
-def _run(n_tiles):
+def _worker_steps(rank, world, port, n_tiles, q):
+    """bench.py's loop: one MapGatherer, several steps, the result of the last started step survives."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    adist.init_from_env(backend="gloo")
+    tiles = adist.tiles_of_rank(n_tiles, rank, world)
+    g = adist.MapGatherer(n_tiles, len(tiles), 4, 6, torch.device("cpu"))
+    out = torch.zeros(max(len(tiles), 1), 4, 6)[:len(tiles)]          # reused "graph output" buffers
+    for step in range(3):
+        for i, t in enumerate(tiles):
+            out[i] = 100.0 * step + t
+        g.start(out, out + 0.25)
+    depth, conf = g.finish()
+    if rank == 0:
+        q.put((depth.clone(), conf.clone()))
+    else:
+        assert depth is None and conf is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n_tiles, worker=None):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_tiles, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker or _worker, args=(r, 2, port, n_tiles, q)) for r in range(2)]
     for p in procs:
         p.start()
     depth, conf = q.get()
@@ -69,4 +89,22 @@ def test_gather_orders_tiles_globally_even_and_uneven():
 def test_single_process_is_identity():
     d, c = torch.ones(2, 3, 3), torch.zeros(2, 3, 3)
     gd, gc = adist.gather_maps(d, c, 2)
+    assert gd is d and gc is c
+
+
+def test_map_gatherer_steps_even_and_uneven():
+    """Preallocated, double-buffered gather of bench.py's step loop: after three steps rank 0 holds step 2's maps."""
+    for n_tiles in (4, 5):
+        depth, conf = _run(n_tiles, _worker_steps)
+        assert depth.shape == (n_tiles, 4, 6)
+        for t in range(n_tiles):
+            assert float(depth[t].min()) == float(depth[t].max()) == 200.0 + t
+            assert float(conf[t, 0, 0]) == 200.25 + t
+
+
+def test_map_gatherer_single_process_is_identity():
+    g = adist.MapGatherer(2, 2, 3, 3, torch.device("cpu"))
+    d, c = torch.ones(2, 3, 3), torch.zeros(2, 3, 3)
+    g.start(d, c)
+    gd, gc = g.finish()
     assert gd is d and gc is c

@@ -202,3 +202,66 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from ada_mvs_amd import hip_ops
     with pytest.raises(_lib.AdaMVSHipError):                    # every op goes through load(): same failure
         hip_ops.feature_net0_workspace_bytes(1, 64, 96)
+
+
+def _emulated_replica(model):
+    """What torch.nn.parallel.replicate() hands nn.DataParallel for one device (torch/nn/parallel/replicate.py): every
+    module shallow-copied, `_parameters` emptied, the per-device parameter copies re-attached as plain attributes and
+    listed in `_former_parameters`.  On CPU the 'device copy' is a clone."""
+    from collections import OrderedDict
+    modules = list(model.modules())
+    copies = {m: m._replicate_for_data_parallel() for m in modules}
+    for m, r in copies.items():
+        r._former_parameters = OrderedDict()
+    for m, r in copies.items():
+        for key, child in m._modules.items():
+            if child is not None:
+                setattr(r, key, copies[child])
+        for key, p in m._parameters.items():
+            if p is not None:
+                c = p.detach().clone()
+                setattr(r, key, c)
+                r._former_parameters[key] = c
+        for key, b in m._buffers.items():
+            if b is not None:
+                setattr(r, key, b.clone())
+    return copies[model]
+
+
+def test_packing_works_on_data_parallel_replicas():
+    """reference predict_whu.py:82 wraps the model in nn.DataParallel; with two or more visible GPUs every forward
+    runs on replicas whose state_dict() holds buffers only.  Packing must read the replica's weights all the same,
+    give the very same packed stream as the source module, and land in the cache shared with the source module."""
+    from ada_mvs_amd.models.module import module_state
+    m = Infer_AdaMVSNet(16, [16, 8, 4], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    rep = _emulated_replica(m)
+    assert len(rep.state_dict()) < len(sd)                                   # what broke round 1's packed(): buffers only
+    got = module_state(rep)
+    assert set(got) == set(sd)
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    ref_reg = packing.pack_cost_reg_net_2d(sd, "DepthNet.0.reg.", "fp32")
+    assert torch.equal(packing.pack_cost_reg_net_2d(module_state(rep.DepthNet[0].reg), "", "fp32"), ref_reg)
+    flat_ref, _ = packing.pack_slice_reg_net(sd, "DepthNet.1.reg_fuse.", "fp32")
+    flat_rep, _ = packing.pack_slice_reg_net(module_state(rep.DepthNet[1].reg_fuse), "", "fp32")
+    assert torch.equal(flat_rep, flat_ref)
+    f_ref, _ = packing.pack_feature_net(sd, "feature.")
+    f_rep, _ = packing.pack_feature_net(module_state(rep.feature), "")
+    assert torch.equal(f_rep, f_ref)
+    # one cache and one workspace table per source module, shared by its replicas and keyed by device
+    assert rep.DepthNet[0].reg._cache is m.DepthNet[0].reg._cache
+    assert rep.DepthNet[0]._workspace is m.DepthNet[0]._workspace
+    key = (torch.device("cpu"), "fp32")
+    rep.DepthNet[0].reg.cached(key, lambda: "packed on the replica")
+    assert m.DepthNet[0].reg._cache[key] == "packed on the replica"
+    m.load_state_dict(sd)                                                    # loading drops every cache
+    assert not m.DepthNet[0].reg._cache and not m.feature._cache
+
+
+def test_inference_model_refuses_train_mode():
+    m = Infer_AdaMVSNet(16, [16, 8, 4], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    assert m.training
+    imgs, proj, dv = synth.tile_inputs("tiny", batch=1, seed=0)
+    with pytest.raises(_lib.AdaMVSHipError):
+        m(imgs, proj, dv)
