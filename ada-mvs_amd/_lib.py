@@ -45,7 +45,8 @@ class FeatureWeights(ctypes.Structure):
 
 class StageDesc(ctypes.Structure):
     """adamvs_stage_desc"""
-    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision", "precision_fuse", "eps_in_numerator")]
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision", "precision_fuse",
+                                            "eps_in_numerator", "plane_mode")] + [("half_span", ctypes.c_float)]
 
 
 # name -> (restype, argtypes); every symbol include/adamvs_hip.h declares
@@ -91,8 +92,9 @@ SIGNATURES = {
     "adamvs_soft_argmin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
+PLANES_EXPLICIT, PLANES_UNIFORM, PLANES_WINDOW = 0, 1, 2
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15
 _lib = None
 

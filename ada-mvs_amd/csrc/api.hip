@@ -69,6 +69,7 @@ static int check_desc(const adamvs_stage_desc* d) {
   ADAMVS_CHECK_ARG((size_t)d->B * d->D <= 65535, "stage: B*D=%d exceeds the grid z limit", d->B * d->D);
   ADAMVS_CHECK_ARG(d->precision == PRECISION_FP32 || d->precision == PRECISION_BF16X3, "stage: precision=%d (0 fp32, 1 bf16x3)", d->precision);
   ADAMVS_CHECK_ARG(d->eps_in_numerator == 0 || d->eps_in_numerator == 1, "stage: eps_in_numerator=%d (0 or 1)", d->eps_in_numerator);
+  ADAMVS_CHECK_ARG(d->plane_mode >= PLANES_EXPLICIT && d->plane_mode <= PLANES_WINDOW, "stage: plane_mode=%d (0 explicit, 1 uniform, 2 window)", d->plane_mode);
   ADAMVS_CHECK_ARG(d->precision_fuse == PRECISION_FP32 || d->precision_fuse == PRECISION_BF16X3,
                    "stage: precision_fuse=%d (0 fp32, 1 bf16x3)", d->precision_fuse);
   if (d->first_stage) {
@@ -143,13 +144,14 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   float* ws = (float*)workspace;
   FuseWeights fw;
   memcpy(&fw, w_fuse, sizeof(fw));
+  const PlaneSrc ps{planes, s.plane_mode, s.half_span};
 
   // -- view weights: scored by CostRegNet2D (stage 1) or resampled from the previous stage
   if (!(phases & ADAMVS_PHASE_VIEW_WEIGHTS)) {
   } else if (s.first_stage) {
-    if ((rc = adamvs_pair_similarity(feat, rt, planes, ws + c.sim, s.B, s.S, s.C, s.D, s.h, s.w, stream))) return rc;
+    if ((rc = launch_pair_similarity(feat, rt, ps, ws + c.sim, s.B, s.S, s.C, s.D, s.h, s.w, st))) return rc;
     if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, s.precision, st))) return rc;
-    if ((rc = launch_softmax_regress(ws + c.score, planes, view_weight, pair_depth, s.S, s.B, s.D, s.h, s.w, st))) return rc;
+    if ((rc = launch_softmax_regress(ws + c.score, ps, view_weight, pair_depth, s.S, s.B, s.D, s.h, s.w, st))) return rc;
   } else {
     if ((rc = adamvs_resize_bilinear(prev_conf, view_weight, s.S * s.B, s.prev_h, s.prev_w, s.h, s.w, stream))) return rc;
   }
@@ -176,13 +178,13 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   auto vol_of = [&](int d) { return ws + c.vol[(d / dc) & 1]; };
   auto argmin_chunk = [&](int k) {
     const int d0 = k * dc, nd = (d0 + dc < s.D ? d0 + dc : s.D) - d0;
-    return launch_soft_argmin_chunk(ws + c.vol[k & 1], dc, planes, s.D, d0, nd, ws + c.acc, k == 0, k == nchunks - 1, depth, confidence,
+    return launch_soft_argmin_chunk(ws + c.vol[k & 1], dc, ps, s.D, d0, nd, ws + c.acc, k == 0, k == nchunks - 1, depth, confidence,
                                     s.B, s.h, s.w, s.in_up, st);
   };
   StepBuffers sb{rb.h1[0], rb.rh1, rb.u1, rb.c2[0], rb.h2[0], rb.rh2, rb.u2};     // sequential mode: states updated in place
   for (int k = 0; k < nchunks; ++k) {
     const int d0 = k * dc, d1 = d0 + dc < s.D ? d0 + dc : s.D;
-    if (do_agg && (rc = launch_sweep_conv1_chunk(feat, rt, planes, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, d0,
+    if (do_agg && (rc = launch_sweep_conv1_chunk(feat, rt, ps, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, d0,
                                                  d1, s.h, s.w, s.precision_fuse, s.eps_in_numerator, st)))
       return rc;
     if (do_rec) {

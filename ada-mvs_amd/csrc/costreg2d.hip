@@ -488,7 +488,7 @@ static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) 
 // NQ = D/64 rounded up: the lane's scores stay in registers between the max pass and the exp pass, so the
 // score volume is read once (NQ = 0: any D, two passes over global memory).
 template <int NQ>
-__global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict__ score, const float* __restrict__ planes,
+__global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict__ score, PlaneSrc planes,
                                                          float* __restrict__ vw, float* __restrict__ pd, int B, int D, int hw,
                                                          size_t npix) {
   size_t gp = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -498,16 +498,17 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
   size_t n = pix / hw, pp = pix % hw;
   size_t b = n % B;
   const float* sc = score + pix * D;
-  const float* pl = planes + b * D * hw + pp;
+  const PlaneLine pl = plane_line(planes, b, pp, D, hw);
   // The 16 pixels of a block are consecutive; read per lane, a plane value costs a whole 64-byte sector for 16 bytes
   // (lanes of a wave hold 16 different planes of 4 pixels: 4x the plane volume through L2).  When the block lies inside
   // one map the [D][16] patch is staged through LDS with full sectors instead (row pitch 17: 2-way at worst).
   constexpr int DMAX = NQ > 0 ? 64 * NQ : 1;
   __shared__ float lp[NQ > 0 ? DMAX * 17 : 1];
   const size_t gp0 = (size_t)blockIdx.x * 16;
-  const bool staged = NQ > 0 && gp0 + 16 <= npix && (gp0 % hw) + 16 <= (size_t)hw;     // uniform
+  // (generated planes need no staging: a plane value is one multiply and one add)
+  const bool staged = NQ > 0 && planes.mode == PLANES_EXPLICIT && gp0 + 16 <= npix && (gp0 % hw) + 16 <= (size_t)hw;     // uniform
   if (staged) {
-    const float* src = planes + ((gp0 / hw) % B) * D * hw + gp0 % hw;
+    const float* src = planes.p + ((gp0 / hw) % B) * D * hw + gp0 % hw;
     for (int i = threadIdx.x; i < D * 16; i += 256) lp[(i >> 4) * 17 + (i & 15)] = src[(size_t)(i >> 4) * hw + (i & 15)];
     __syncthreads();
   }
@@ -534,7 +535,8 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
     float e0 = __expf(v.x - m), e1 = __expf(v.y - m), e2 = __expf(v.z - m), e3 = __expf(v.w - m);
     se += (e0 + e1) + (e2 + e3);
     if (staged) sd += e0 * lpp[d * 17] + e1 * lpp[(d + 1) * 17] + e2 * lpp[(d + 2) * 17] + e3 * lpp[(d + 3) * 17];
-    else sd += e0 * pl[(size_t)d * hw] + e1 * pl[(size_t)(d + 1) * hw] + e2 * pl[(size_t)(d + 2) * hw] + e3 * pl[(size_t)(d + 3) * hw];
+    else sd += e0 * plane_at(planes, pl, d, hw) + e1 * plane_at(planes, pl, d + 1, hw) + e2 * plane_at(planes, pl, d + 2, hw) +
+               e3 * plane_at(planes, pl, d + 3, hw);
   };
   if (NQ > 0) {
 #pragma unroll
@@ -601,7 +603,7 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
   return 0;
 }
 
-int launch_softmax_regress(const float* score, const float* planes, float* vw, float* pd, int S, int B, int D, int h, int w,
+int launch_softmax_regress(const float* score, PlaneSrc planes, float* vw, float* pd, int S, int B, int D, int h, int w,
                            hipStream_t st) {
   size_t npix = (size_t)S * B * h * w;
   const dim3 grid((unsigned)((npix + 15) / 16));
@@ -664,5 +666,5 @@ extern "C" int adamvs_softmax_max_regress(const float* score, const float* plane
                                           int S, int B, int D, int h, int w, void* stream) {
   ADAMVS_CHECK_ARG(score && planes && view_weight && pair_depth && S > 0 && B > 0 && D > 0 && (D % 4) == 0 && h > 0 && w > 0,
                    "softmax_max_regress: bad arguments (D=%d must be a multiple of 4)", D);
-  return launch_softmax_regress(score, planes, view_weight, pair_depth, S, B, D, h, w, (hipStream_t)stream);
+  return launch_softmax_regress(score, explicit_planes(planes), view_weight, pair_depth, S, B, D, h, w, (hipStream_t)stream);
 }

@@ -7,6 +7,7 @@
 //   depth_regression      reference models/module.py:617-625
 //   NCHW -> channel-last feature packing (layout the plane-sweep kernels gather from)
 #include "common.h"
+#include "planes.h"
 #include "warp_math.h"
 
 namespace adamvs {
@@ -79,8 +80,8 @@ __global__ void k_depth_samples_uniform(const float* __restrict__ dv, float* __r
   size_t bd = i / hw;
   int b = (int)(bd / D), d = (int)(bd % D);
   float dmin = dv[2 * b], dmax = dv[2 * b + 1];
-  float step = (dmax - dmin) / (float)(D - 1);
-  out[i] = dmin + (float)d * step;
+  float step = __fdiv_rn(__fsub_rn(dmax, dmin), (float)(D - 1));
+  out[i] = plane_value(dmin, step, d);                    // module.py:651-656: a rounded product, then a rounded sum
 }
 
 __global__ void k_depth_samples_window(const float* __restrict__ cur, float* __restrict__ out, float half_span,
@@ -91,9 +92,9 @@ __global__ void k_depth_samples_window(const float* __restrict__ cur, float* __r
   size_t bd = i / hw;
   int b = (int)(bd / D), d = (int)(bd % D);
   float c = cur[(size_t)b * hw + p];
-  float lo = c - half_span, hi = c + half_span;
-  float step = (hi - lo) / (float)(D - 1);
-  out[i] = lo + (float)d * step;
+  float lo = __fsub_rn(c, half_span), hi = __fadd_rn(c, half_span);
+  float step = __fdiv_rn(__fsub_rn(hi, lo), (float)(D - 1));
+  out[i] = plane_value(lo, step, d);                      // module.py:632-641
 }
 
 // ---------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // Launchers shared between the kernel translation units and the C-ABI glue.
 #pragma once
 #include "common.h"
+#include "planes.h"
 
 namespace adamvs {
 
@@ -33,10 +34,10 @@ int recurrence_mode(int precision, long pixels);
 RecurLags recurrence_lags(int schedule, int precision);
 int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, int B, int h, int w, int D, int t, const float* c1_t,
                                float* vol_dec, int D_vol, int d_dec, int in_up, int precision, int schedule, hipStream_t st);
-int launch_soft_argmin_chunk(const float* vol, int vol_D, const float* planes, int D, int d0, int nd, float* acc, int first, int last,
+int launch_soft_argmin_chunk(const float* vol, int vol_D, PlaneSrc planes, int D, int d0, int nd, float* acc, int first, int last,
                              float* depth, float* conf, int B, int h, int w, int in_up, hipStream_t st);
 int sweep_chunk_planes(int D);
-int launch_sweep_conv1_chunk(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+int launch_sweep_conv1_chunk(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,
                              float* c1_chunk, float* sim_ws, int B, int S, int C, int D, int d0, int d1, int h, int w, int precision,
                              int eps_in_numerator, hipStream_t st);
 
@@ -52,7 +53,7 @@ int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const
                      int cout, int B, int h, int w, hipStream_t st);
 int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,
                        int in_up, hipStream_t st);
-int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+int launch_sweep_conv1(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,
                        float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, int eps_in_numerator,
                        hipStream_t st);
 int launch_sweep_variance(const float* feat, const float* rt, const float* planes, float* out_a, int Da, float* out_b, int Db,
@@ -64,7 +65,9 @@ int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, 
                           int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st);
 bool costreg_bf16x3_depth_supported(int D);
 
-int launch_softmax_regress(const float* score, const float* planes, float* vw, float* pd, int S, int B, int D, int h, int w,
+int launch_pair_similarity(const float* feat, const float* rt, PlaneSrc planes, float* sim, int B, int S, int C, int D, int h,
+                           int w, hipStream_t st);
+int launch_softmax_regress(const float* score, PlaneSrc planes, float* vw, float* pd, int S, int B, int D, int h, int w,
                            hipStream_t st);
 bool costreg_depth_supported(int D);
 

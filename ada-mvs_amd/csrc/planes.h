@@ -1,0 +1,58 @@
+// Where the hypothesis planes of a stage come from (reference models/module.py:628-663).
+//
+// The reference materialises depth_values [B,D,h,w] for every stage; on the fused stage path (adamvs_depth_stage_forward)
+// the planes are instead generated where they are used:
+//   mode 0  explicit tensor [B][D][hw] (the op-level entry points, InferDepthNet0.forward with caller-made planes)
+//   mode 1  uniform, get_depth_range_samples with a 2-D cur_depth (module.py:650-658): p = [B][2] = (min, max),
+//           plane d = min + d * ((max - min) / (D - 1))
+//   mode 2  window, get_cur_depth_range_samples (module.py:628-643): p = cur_depth [B][hw],
+//           lo = cur - half_span, hi = cur + half_span, plane d = lo + d * ((hi - lo) / (D - 1))
+// with the reference's fp32 operation order (a rounded product, then a rounded sum: no fused multiply-add), so a
+// generated plane equals the materialised one bit for bit.
+#pragma once
+#include "common.h"
+
+namespace adamvs {
+
+enum { PLANES_EXPLICIT = 0, PLANES_UNIFORM = 1, PLANES_WINDOW = 2 };
+
+struct PlaneSrc {
+  const float* p;
+  int mode;
+  float half_span;
+};
+static inline PlaneSrc explicit_planes(const float* planes) { return PlaneSrc{planes, PLANES_EXPLICIT, 0.f}; }
+
+// the planes of one (tile b, pixel): a strided line of the tensor, or (lo, step)
+struct PlaneLine {
+  const float* q;
+  float lo, step;
+};
+
+__device__ __forceinline__ float plane_value(float lo, float step, int d) { return __fadd_rn(lo, __fmul_rn((float)d, step)); }
+
+__device__ __forceinline__ PlaneLine plane_line(const PlaneSrc& s, size_t b, size_t pix, int D, size_t hw) {
+  PlaneLine l{nullptr, 0.f, 0.f};
+  if (s.mode == PLANES_EXPLICIT) {
+    l.q = s.p + b * D * hw + pix;
+  } else {
+    float lo, hi;
+    if (s.mode == PLANES_UNIFORM) {
+      lo = s.p[2 * b];
+      hi = s.p[2 * b + 1];
+    } else {
+      const float c = s.p[b * hw + pix];
+      lo = __fsub_rn(c, s.half_span);
+      hi = __fadd_rn(c, s.half_span);
+    }
+    l.lo = lo;
+    l.step = __fdiv_rn(__fsub_rn(hi, lo), (float)(D - 1));
+  }
+  return l;
+}
+
+__device__ __forceinline__ float plane_at(const PlaneSrc& s, const PlaneLine& l, int d, size_t hw) {
+  return s.mode == PLANES_EXPLICIT ? l.q[(size_t)d * hw] : plane_value(l.lo, l.step, d);
+}
+
+}  // namespace adamvs

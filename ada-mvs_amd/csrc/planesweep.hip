@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "conv_frag.h"
+#include "planes.h"
 #include "warp_math.h"
 
 namespace adamvs {
@@ -30,7 +31,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // grid: (pixel groups, S, B); block 256.  sim [S][B][hw][D] (channel-last in d).
 template <int C>
 __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict__ feat, const float* __restrict__ rt,
-                                                         const float* __restrict__ planes, float* __restrict__ sim,
+                                                         PlaneSrc planes, float* __restrict__ sim,
                                                          int B, int S, int D, int h, int w) {
   constexpr int G = C / 4;          // lanes per pixel
   constexpr int PPB = 256 / G;      // pixels per block
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   // rot_xyz = R.[x,y,1] once per pixel (module.py:549); per plane: * depth + t, divide (550-553)
   const float ax = r[0] * fx + r[1] * fy + r[2], ay = r[3] * fx + r[4] * fy + r[5], az = r[6] * fx + r[7] * fy + r[8];
   const float tx = r[9], ty = r[10], tz = r[11];
-  const float* pl = planes + (size_t)b * D * hw + pc;
+  const PlaneLine pl = plane_line(planes, b, pc, D, hw);
   float* out = sim + (((size_t)s * B + b) * hw + pc) * D;
   // sim = mean_c ref[c] * sum_t w_t tap_t[c] = (1/C) sum_t w_t * dot(ref, tap_t): while consecutive planes fall into
   // the same source cell (192 planes span ~1.5 px at stage 1) the four tap . ref dot products do not change, so they
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   const int gbase = (threadIdx.x & 63) & ~(G - 1);
   for (int d0 = 0; d0 < D; d0 += G) {
     float keep = 0.f;
-    const PlaneTaps mine = plane_taps(ax, ay, az, tx, ty, tz, pl[(size_t)min(d0 + g, D - 1) * hw], h, w);
+    const PlaneTaps mine = plane_taps(ax, ay, az, tx, ty, tz, plane_at(planes, pl, min(d0 + g, D - 1), hw), h, w);
     if (__all(mine.cell == ccell || mine.cell == -1)) {            // whole wave still inside its cached cells
       keep = (mine.w00 * d00 + mine.w01 * d01 + mine.w10 * d10 + mine.w11 * d11) * (1.0f / (float)C);
     } else
@@ -89,13 +90,12 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
 
 using namespace adamvs;
 
-extern "C" int adamvs_pair_similarity(const float* feat, const float* rt, const float* planes, float* sim, int B, int S,
-                                      int C, int D, int h, int w, void* stream) {
-  ADAMVS_CHECK_ARG(feat && rt && planes && sim && B > 0 && S > 0 && D > 0 && h > 1 && w > 1,
+int adamvs::launch_pair_similarity(const float* feat, const float* rt, PlaneSrc planes, float* sim, int B, int S, int C, int D, int h,
+                                   int w, hipStream_t st) {
+  ADAMVS_CHECK_ARG(feat && rt && planes.p && sim && B > 0 && S > 0 && D > 0 && h > 1 && w > 1,
                    "pair_similarity: bad arguments (B=%d S=%d D=%d h=%d w=%d)", B, S, D, h, w);
   ADAMVS_CHECK_ARG(C == 8 || C == 16 || C == 32, "pair_similarity: C=%d unsupported (8, 16 or 32)", C);
   int hw = h * w;
-  hipStream_t st = (hipStream_t)stream;
   if (C == 32)
     hipLaunchKernelGGL((k_pair_similarity<32>), dim3(cdiv(hw, 32), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w);
   else if (C == 16)
@@ -104,6 +104,11 @@ extern "C" int adamvs_pair_similarity(const float* feat, const float* rt, const 
     hipLaunchKernelGGL((k_pair_similarity<8>), dim3(cdiv(hw, 128), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w);
   ADAMVS_CHECK_LAUNCH("pair_similarity");
   return 0;
+}
+
+extern "C" int adamvs_pair_similarity(const float* feat, const float* rt, const float* planes, float* sim, int B, int S,
+                                      int C, int D, int h, int w, void* stream) {
+  return launch_pair_similarity(feat, rt, explicit_planes(planes), sim, B, S, C, D, h, w, (hipStream_t)stream);
 }
 
 extern "C" size_t adamvs_aggregate_conv1_workspace_bytes(int B, int C, int D, int h, int w) {
@@ -120,6 +125,6 @@ extern "C" int adamvs_aggregate_conv1(const float* feat, const float* rt, const 
   ADAMVS_CHECK_ARG(workspace && workspace_bytes >= sweep_workspace_floats(B, C, D, h, w) * sizeof(float),
                    "aggregate_conv1: workspace too small (%zu < %zu bytes)", workspace_bytes,
                    sweep_workspace_floats(B, C, D, h, w) * sizeof(float));
-  return launch_sweep_conv1(feat, rt, planes, view_weight, w1pk, c1, (float*)workspace, B, S, C, D, h, w, precision, 0,
+  return launch_sweep_conv1(feat, rt, explicit_planes(planes), view_weight, w1pk, c1, (float*)workspace, B, S, C, D, h, w, precision, 0,
                             (hipStream_t)stream);
 }

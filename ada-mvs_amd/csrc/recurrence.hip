@@ -322,7 +322,7 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
 // not change a bit.  When IN_UP the hypothesis plane is the 2x bilinear upsample (align_corners=False) of
 // planes[b][d] (adamvs.py:521-522).  vol [B][vol_D][Ho*Wo] holds hypotheses d0 .. d0+nd-1 as its planes 0 .. nd-1.
 template <bool IN_UP>
-__global__ void k_soft_argmin_chunk(const float* __restrict__ vol, int vol_D, const float* __restrict__ planes, int D, int d0, int nd,
+__global__ void k_soft_argmin_chunk(const float* __restrict__ vol, int vol_D, PlaneSrc planes, int D, int d0, int nd,
                                     float* __restrict__ acc, int first, int last, float* __restrict__ depth,
                                     float* __restrict__ conf, int h, int w, size_t total) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,19 +339,20 @@ __global__ void k_soft_argmin_chunk(const float* __restrict__ vol, int vol_D, co
     ly = sy - (float)y0; lx = sx - (float)x0;
   }
   const float* v = vol + b * vol_D * HW + (size_t)Y * Wo + X;
-  const float* pl = planes + (b * D + d0) * hw;
+  // the (up to) four plane lines the pixel blends; generated planes cost a multiply and an add per hypothesis
+  const PlaneLine p00 = plane_line(planes, b, (size_t)y0 * w + x0, D, hw), p01 = plane_line(planes, b, (size_t)y0 * w + x1, D, hw);
+  const PlaneLine p10 = plane_line(planes, b, (size_t)y1 * w + x0, D, hw), p11 = plane_line(planes, b, (size_t)y1 * w + x1, D, hw);
   float E = 0.f, M = 0.f, A = 0.f;
   if (!first) { E = acc[i]; M = acc[total + i]; A = acc[2 * total + i]; }
   for (int d = 0; d < nd; ++d) {
     float pr = __expf(v[(size_t)d * HW]);
-    const float* q = pl + (size_t)d * hw;
     float dep;
     if (IN_UP) {
-      float top = q[y0 * w + x0] * (1.f - lx) + q[y0 * w + x1] * lx;
-      float bot = q[y1 * w + x0] * (1.f - lx) + q[y1 * w + x1] * lx;
+      float top = plane_at(planes, p00, d0 + d, hw) * (1.f - lx) + plane_at(planes, p01, d0 + d, hw) * lx;
+      float bot = plane_at(planes, p10, d0 + d, hw) * (1.f - lx) + plane_at(planes, p11, d0 + d, hw) * lx;
       dep = top * (1.f - ly) + bot * ly;
     } else {
-      dep = q[y0 * w + x0];
+      dep = plane_at(planes, p00, d0 + d, hw);
     }
     M = (M < pr) ? pr : M;
     A = dep * pr + A;
@@ -366,7 +367,7 @@ __global__ void k_soft_argmin_chunk(const float* __restrict__ vol, int vol_D, co
   }
 }
 
-int launch_soft_argmin_chunk(const float* vol, int vol_D, const float* planes, int D, int d0, int nd, float* acc, int first, int last,
+int launch_soft_argmin_chunk(const float* vol, int vol_D, PlaneSrc planes, int D, int d0, int nd, float* acc, int first, int last,
                              float* depth, float* conf, int B, int h, int w, int in_up, hipStream_t st) {
   size_t total = (size_t)B * (in_up ? 4 : 1) * h * w;
   unsigned nb = (unsigned)((total + 255) / 256);

@@ -29,7 +29,7 @@ namespace adamvs {
 // (vw and eps_num unused).
 template <int C, int SV, int MODE = 0>
 __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict__ feat, const float* __restrict__ rt,
-                                                         const float* __restrict__ planes, const float* __restrict__ vw,
+                                                         PlaneSrc planes, const float* __restrict__ vw,
                                                          float* __restrict__ sim, int B, int S, int D, int d0, int d1,
                                                          int h, int w, int eps_num, float* __restrict__ sim_b = nullptr,
                                                          int Da = C, int Db = C) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
     for (int s = 0; s < SV; ++s) refw[s] = ref4 * (wv[s] * inv);
   }
   const int gbase = (threadIdx.x & 63) & ~(G - 1);   // first lane of this pixel's group
-  const float* pl = planes + (size_t)b * D * hw + pc;
+  const PlaneLine pl = plane_line(planes, b, pc, D, hw);
   const int OA = (MODE == 1) ? Da : C;
   float* out = sim + ((size_t)b * hw + pc) * OA + 4 * g;
   const size_t ostride = (size_t)B * hw * OA;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
   // front of them.  The plane loop stays rolled (unrolled, the scheduler hoists every plane's projection: spills).
   __shared__ f32x4 park[G][256];
   for (int dg = d0; dg < d1; dg += G) {
-  const float mydepth = pl[(size_t)min(dg + g, d1 - 1) * hw];
+  const float mydepth = plane_at(planes, pl, min(dg + g, d1 - 1), hw);
 #pragma unroll 1
   for (int j = 0; j < G; ++j) {
     const int d = dg + j;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
 }
 
 template <int C>
-static int launch_sweep_variance_c(const float* feat, const float* rt, const float* planes, float* out_a, int Da, float* out_b,
+static int launch_sweep_variance_c(const float* feat, const float* rt, PlaneSrc planes, float* out_a, int Da, float* out_b,
                                    int Db, int B, int S, int D, int h, int w, hipStream_t st) {
   dim3 grid(cdiv(h * w, 256 / (C / 4)), 1, B);
   if (S <= 4)
@@ -160,14 +160,15 @@ static int launch_sweep_variance_c(const float* feat, const float* rt, const flo
 // -variance of (reference, S warped views) for all D planes with register-resident taps; S <= 8, C in {8, 16, 32}
 int launch_sweep_variance(const float* feat, const float* rt, const float* planes, float* out_a, int Da, float* out_b, int Db,
                           int B, int S, int C, int D, int h, int w, hipStream_t st) {
-  if (C == 32) return launch_sweep_variance_c<32>(feat, rt, planes, out_a, Da, out_b, Db, B, S, D, h, w, st);
-  if (C == 16) return launch_sweep_variance_c<16>(feat, rt, planes, out_a, Da, out_b, Db, B, S, D, h, w, st);
-  if (C == 8) return launch_sweep_variance_c<8>(feat, rt, planes, out_a, Da, out_b, Db, B, S, D, h, w, st);
+  const PlaneSrc ps = explicit_planes(planes);
+  if (C == 32) return launch_sweep_variance_c<32>(feat, rt, ps, out_a, Da, out_b, Db, B, S, D, h, w, st);
+  if (C == 16) return launch_sweep_variance_c<16>(feat, rt, ps, out_a, Da, out_b, Db, B, S, D, h, w, st);
+  if (C == 8) return launch_sweep_variance_c<8>(feat, rt, ps, out_a, Da, out_b, Db, B, S, D, h, w, st);
   return set_error(-1, "sweep_variance: C=%d unsupported (8, 16 or 32)", C);
 }
 
 template <int C>
-static int launch_sweep_c(const float* feat, const float* rt, const float* planes, const float* vw, float* sim, int B, int S,
+static int launch_sweep_c(const float* feat, const float* rt, PlaneSrc planes, const float* vw, float* sim, int B, int S,
                           int D, int d0, int d1, int h, int w, int eps_num, hipStream_t st) {
   dim3 grid(cdiv(h * w, 256 / (C / 4)), 1, B);
   if (S <= 4)
@@ -187,7 +188,7 @@ size_t sweep_workspace_floats(int B, int C, int D, int h, int w) {
 
 // hypotheses [d0, d1) (at most sweep_chunk_planes(D)): weighted aggregation into sim_ws, conv1 of it into
 // c1_chunk [d1-d0][B][hw][8]
-int launch_sweep_conv1_chunk(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+int launch_sweep_conv1_chunk(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,
                              float* c1_chunk, float* sim_ws, int B, int S, int C, int D, int d0, int d1, int h, int w, int precision,
                              int eps_num, hipStream_t st) {
   if (S > 8 || S < 1) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
@@ -201,7 +202,7 @@ int launch_sweep_conv1_chunk(const float* feat, const float* rt, const float* pl
   return launch_conv1(sim_ws, w1pk, c1_chunk, (d1 - d0) * B, C, h, w, precision, st);
 }
 
-int launch_sweep_conv1(const float* feat, const float* rt, const float* planes, const float* vw, const float* w1pk,
+int launch_sweep_conv1(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,
                        float* c1, float* sim_ws, int B, int S, int C, int D, int h, int w, int precision, int eps_num,
                        hipStream_t st) {
   const int dc = sweep_chunk_planes(D);

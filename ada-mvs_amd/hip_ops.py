@@ -221,9 +221,26 @@ def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up, precision=0
     return reg
 
 
-def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0), precision=0, precision_fuse=0, eps_in_numerator=0):
+def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0), precision=0, precision_fuse=0, eps_in_numerator=0,
+               plane_mode=_lib.PLANES_EXPLICIT, half_span=0.0):
     return StageDesc(B, S, C, h, w, D, int(in_up), int(first_stage), int(prev_hw[0]), int(prev_hw[1]), int(precision),
-                     int(precision_fuse), int(eps_in_numerator))
+                     int(precision_fuse), int(eps_in_numerator), int(plane_mode), float(half_span))
+
+
+def plane_source(cur_depth, ndepth, depth_interval_pixel, shape):
+    """What get_depth_range_samples (module.py:646-663) would materialise, as (plane_mode, half_span, tensor) for
+    adamvs_depth_stage_forward: a 2-D cur_depth [B, >=2] gives uniform planes over [min, max] (the interval is ignored
+    there, quirk Q3), a map [B,h,w] gives the per-pixel window cur -+ ndepth / 2 * depth_interval_pixel.  The planes are
+    generated inside the kernels, bit-identical to depth_range_samples()."""
+    cur_depth = _dev(cur_depth, "cur_depth")
+    B, h, w = shape
+    if cur_depth.dim() == 2:
+        if cur_depth.shape[1] != 2:        # the reference reads [:,0] and [:,-1] only
+            cur_depth = torch.stack((cur_depth[:, 0], cur_depth[:, -1]), 1).contiguous()
+        return _lib.PLANES_UNIFORM, 0.0, cur_depth
+    if tuple(cur_depth.shape) != (B, h, w):
+        raise _lib.AdaMVSHipError("cur_depth:%s, input shape:%s" % (tuple(cur_depth.shape), shape))
+    return _lib.PLANES_WINDOW, float(ndepth / 2.0 * float(depth_interval_pixel)), cur_depth
 
 
 def depth_stage_workspace_bytes(desc):

@@ -188,16 +188,20 @@ class InferDepthNet0(nn.Module):
         self._workspace.clear()
         return super()._apply(fn, *a, **k)
 
-    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0, twin=False):
-        """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w];
+    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0, twin=False, planes=None, num_depth=None):
+        """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w] -- or None with
+        planes = hip_ops.plane_source(...) and num_depth: the hypothesis planes are then generated inside the kernels;
         prev_conf None (stage 1) or [S,B,hp,wp].  -> (view_weight [S,B,h,w], pair_depth|None, depth, conf).
         twin: the train/test model's placement of the 1e-5 in the weighted aggregation (adamvs.py:262-300)."""
         S = feat_cl.shape[0] // B - 1
-        D = depth_values.shape[1]
         first = prev_conf is None
         prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
+        if planes is None:
+            D, mode, half_span = depth_values.shape[1], 0, 0.0
+        else:
+            (mode, half_span, depth_values), D = planes, num_depth
         desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()],
-                                  _PRECISIONS[self.reg_fuse.precision], eps_in_numerator=int(twin))
+                                  _PRECISIONS[self.reg_fuse.precision], eps_in_numerator=int(twin), plane_mode=mode, half_span=half_span)
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4
         key = (feat_cl.device, group)
         ws = self._workspace.get(key)
@@ -247,6 +251,7 @@ class Infer_AdaMVSNet(nn.Module):
         self.cr_base_chs = cr_base_chs
         self.num_stage = len(ndepths)
         self.feature_chunk = 40                  # images per FeatureNet0 call (extract_features)
+        self.materialize_planes = False          # True: hypothesis planes as a [B,D,h,w] tensor instead of generated in the kernels
         self.stage_infos = {k: {"scale": float(v)} for k, v in STAGE_SCALE.items()}
         self.feature = FeatureNet0(base_channels=8, stride=4, num_stage=self.num_stage)
         ch = self.feature.out_channels
@@ -277,10 +282,17 @@ class Infer_AdaMVSNet(nn.Module):
             name = "stage%d" % (s + 1)
             B, C, h, w = shapes[s]
             cur = depth_values if depth is None else depth
-            planes = hip_ops.depth_range_samples(cur, self.ndepths[s], self.depth_intervals_ratio[s] * depth_interval, [B, h, w])
+            # get_depth_range_samples (module.py:646-663) without its [B,D,h,w] tensor: uniform planes at stage 1, the
+            # per-pixel window around the previous stage's depth afterwards, generated where they are used
             rt = hip_ops.relative_transforms(proj_matrices[name])
             net = self.DepthNet[s]
-            vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, planes, conf, group, twin)
+            span = self.depth_intervals_ratio[s] * depth_interval
+            if self.materialize_planes:      # the reference's way (and the A/B of the generated planes): a [B,D,h,w] tensor
+                vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, hip_ops.depth_range_samples(cur, self.ndepths[s], span, [B, h, w]),
+                                               conf, group, twin)
+            else:
+                planes = hip_ops.plane_source(cur, self.ndepths[s], span, [B, h, w])
+                vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, None, conf, group, twin, planes=planes, num_depth=self.ndepths[s])
             if twin:
                 # DepthNet0 hands its input confidence list on unchanged (adamvs.py:298): every later stage resamples
                 # the stage-1 maps, and the lists carry S entries

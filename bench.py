@@ -94,13 +94,14 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
             B, C, h, w = shapes[s]
             net = model.DepthNet[s]
             cur = dv if depth is None else depth
-            planes = hip_ops.depth_range_samples(cur, model.ndepths[s], model.depth_intervals_ratio[s] * interval, [B, h, w])
+            mode, half_span, planes = hip_ops.plane_source(cur, model.ndepths[s], model.depth_intervals_ratio[s] * interval, [B, h, w])
             rt = hip_ops.relative_transforms(proj[name])
             S = feats_cl[s].shape[0] // B - 1
             D = model.ndepths[s]
             first = conf is None
             desc = hip_ops.stage_desc(B, S, C, h, w, D, net.in_up, first, (0, 0) if first else tuple(conf.shape[-2:]),
-                                      _lib.PRECISIONS[net.reg.effective_precision()], _lib.PRECISIONS[net.reg_fuse.precision])
+                                      _lib.PRECISIONS[net.reg.effective_precision()], _lib.PRECISIONS[net.reg_fuse.precision],
+                                      plane_mode=mode, half_span=half_span)
             dev = feats_cl[s].device
             Ho, Wo = (2 * h, 2 * w) if net.in_up else (h, w)
             outs = (torch.empty(S, B, h, w, device=dev), torch.empty(S, B, h, w, device=dev) if first else None,
@@ -115,11 +116,13 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
             if first:
                 # pass A split further, op by op; CostRegNet2D layer by layer so that every launch of its
                 # convolution kernel is timed by itself (the roofline object is per launch of one kernel)
-                sim = mark("s%d.pair_similarity" % (s + 1), lambda: hip_ops.pair_similarity(feats_cl[s], rt, planes, B, S, C, D, h, w))
+                # the op-level entry points of pass A take a planes tensor; inside the stage call they are generated
+                planes_t = hip_ops.depth_range_samples(cur, D, 0.0, [B, h, w])
+                sim = mark("s%d.pair_similarity" % (s + 1), lambda: hip_ops.pair_similarity(feats_cl[s], rt, planes_t, B, S, C, D, h, w))
                 score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w, _lib.PRECISIONS[net.reg.effective_precision()])
-                vw_pd = mark("s%d.softmax_max_regress" % (s + 1), lambda: hip_ops.softmax_max_regress(score, planes, S, B, D, h, w))
+                vw_pd = mark("s%d.softmax_max_regress" % (s + 1), lambda: hip_ops.softmax_max_regress(score, planes_t, S, B, D, h, w))
                 outs[0].copy_(vw_pd[0])
-                del sim, score
+                del sim, score, planes_t
             else:
                 mark("s%d.view_weight_resample" % (s + 1), lambda: phase(_lib.PHASE_VIEW_WEIGHTS))
             # the three phases below are interleaved chunk by chunk in a real run; called one by one each runs alone over

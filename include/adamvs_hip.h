@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 7
+#define ADAMVS_ABI_VERSION 8
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -184,7 +184,16 @@ typedef struct adamvs_stage_desc {
   int eps_in_numerator;   /* where the 1e-5 of the weighted aggregation sits: 0 = InferDepthNet0, sum_v w_v x_v / (1e-5 +
                              sum_v w_v) (adamvs.py:497-512); 1 = the train/test twin DepthNet0, (1e-5 + sum_v w_v x_v) /
                              sum_v w_v (adamvs.py:262-300) */
+  int plane_mode;         /* what `planes` points to: ADAMVS_PLANES_EXPLICIT [B][D][h*w] (caller-made depth_values, as
+                             InferDepthNet0.forward receives them); ADAMVS_PLANES_UNIFORM [B][2] = (min, max) -> plane d =
+                             min + d (max - min)/(D - 1) (module.py:650-658); ADAMVS_PLANES_WINDOW cur_depth [B][h*w] ->
+                             lo = cur - half_span, hi = cur + half_span, plane d = lo + d (hi - lo)/(D - 1) (module.py:628-643).
+                             Generated planes equal the materialised ones bit for bit and never cross HBM. */
+  float half_span;        /* ADAMVS_PLANES_WINDOW: ndepth / 2 * depth_interval_pixel (module.py:632) */
 } adamvs_stage_desc;
+#define ADAMVS_PLANES_EXPLICIT 0
+#define ADAMVS_PLANES_UNIFORM  1
+#define ADAMVS_PLANES_WINDOW   2
 
 size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);
 
@@ -195,7 +204,7 @@ size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);
 #define ADAMVS_PHASE_SOFT_ARGMIN  8  /* depth / confidence from the regularised slices */
 #define ADAMVS_PHASE_ALL         15
 
-/* feat [V=S+1][B][h*w][C]; rt [B][S][12]; planes [B][D][h*w];
+/* feat [V=S+1][B][h*w][C]; rt [B][S][12]; planes: see adamvs_stage_desc.plane_mode;
  * prev_conf [S][B][prev_h*prev_w] (previous stage's view weights; ignored when first_stage);
  * w_reg: packed CostRegNet2D weights (first_stage only);
  * outputs: view_weight [S][B][h*w] (what the next stage consumes as prev_conf),

@@ -523,3 +523,31 @@ def test_soft_argmin_op(hip):
     d, cf = hip.soft_argmin(dev(vol), dev(planes), B, D, h, w)
     assert rel_l1(d, ref_d) < 1e-6 and rel_l1(cf, ref_c) < 1e-5
     assert float(d[0, 0, 0]) == 0.0 and float(cf[0, 0, 0]) == 0.0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_generated_planes_equal_materialised_planes(hip, precision):
+    """The stage kernels generate the hypothesis planes (uniform over [min, max] at stage 1, the per-pixel window around the
+    previous depth afterwards; reference module.py:628-663) instead of reading a [B,D,h,w] tensor: with the reference's
+    operation order (rounded product, rounded sum) every map must equal, bit for bit, the run on materialised planes --
+    pass A, the aggregation sweep, and the soft-argmin with and without the 2x upsampling of the planes."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    c = synth.CONFIGS["cfg1"]
+    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8], precision=precision)
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs("cfg1", batch=2, seed=5)
+    dv[1] = torch.tensor([380.0, 640.0])                       # per-tile ranges (quirk Q4: the interval still comes from tile 0)
+    args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+    outs = []
+    for flag in (False, True):
+        m.materialize_planes = flag
+        with torch.no_grad():
+            outs.append(m(*args))
+    for s in ("stage1", "stage2", "stage3"):
+        for key in ("depth", "photometric_confidence"):
+            assert torch.equal(outs[0][s][key], outs[1][s][key]), (s, key)
+        for a, b in zip(outs[0][s]["pair_confidence"][:2], outs[1][s]["pair_confidence"][:2]):
+            assert torch.equal(a, b)
+    for a, b in zip(outs[0]["stage1"]["pair_result"], outs[1]["stage1"]["pair_result"]):
+        assert torch.equal(a, b)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.adamvs_version() == _lib.ABI_VERSION
     assert ctypes.sizeof(_lib.FuseWeights) == 13 * ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_lib.StageDesc) == 13 * ctypes.sizeof(ctypes.c_int)
+    assert ctypes.sizeof(_lib.StageDesc) == 14 * ctypes.sizeof(ctypes.c_int) + ctypes.sizeof(ctypes.c_float)      # 14 ints + half_span
 
 
 def test_argument_errors_surface_as_exceptions_without_a_gpu():

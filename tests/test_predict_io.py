@@ -1,6 +1,9 @@
 """Predict-time input/output: ada_mvs_amd.datasets against files and records the
-reference's own datasets/data_io.py produced (tests/golden/io/, tools/gen_golden_io.py), and the pieces that have
-no reference-run fixture here (cv2 / imageio are absent) against independent formulas."""
+reference's own code produced -- datasets/data_io.py (tests/golden/io/, tools/gen_golden_io.py) and the cv2-free
+functions of datasets/preprocess.py / predict_oblique.py (preprocess.npz, tools/gen_golden_preprocess.py: scale_camera,
+crop_input, create_cams, center_image).  The one piece without a reference run is cv2.resize (cv2 is absent from the
+build container): scale_image restates OpenCV's published 8-bit fixed-point INTER_LINEAR and is held to hand-derived
+vectors below -- parity-unpinned against a cv2 run, and said so here."""
 import argparse
 import json
 import os
@@ -103,22 +106,95 @@ def test_scale_and_crop_cameras():
     assert d.shape == (64, 96)
 
 
-def test_scale_image_bilinear_half_pixel_centres():
+PRE = np.load(os.path.join(GOLD, "preprocess.npz"))
+
+
+def test_scale_camera_and_crop_input_match_reference_run():
+    """scale_camera / crop_input against what the reference's own functions returned (tools/gen_golden_preprocess.py),
+    including sides below the limit that are no multiple of 32 (the slice ends at the image border) and limits
+    scaled by resize_scale."""
+    cam = PRE["create_cams_192"][0]
+    for k in range(4):
+        got = preprocess.scale_camera(cam, float(PRE["scale_camera_%d_scale" % k]))
+        assert got.dtype == PRE["scale_camera_%d" % k].dtype and np.array_equal(got, PRE["scale_camera_%d" % k])
+    for k, (h, w, mh, mw, rs) in enumerate(PRE["crop_cases"]):
+        h, w, mh, mw = int(h), int(w), int(mh), int(mw)
+        rs = int(rs) if rs == int(rs) else float(rs)
+        image = (np.arange(h * w * 3) % 251).astype(np.uint8).reshape(h, w, 3)
+        depth = np.arange(h * w, dtype=np.float32).reshape(h, w)
+        im2, c2, d2 = preprocess.crop_input(image, cam.copy(), depth_image=depth, max_h=mh, max_w=mw, resize_scale=rs)
+        assert tuple(im2.shape) == tuple(PRE["crop_%d_shape" % k]) and tuple(d2.shape) == tuple(PRE["crop_%d_depth_shape" % k])
+        assert np.array_equal(c2, PRE["crop_%d_cam" % k])
+        assert int(im2.astype(np.int64).sum()) == int(PRE["crop_%d_checksum" % k][0])
+        assert float(d2.astype(np.float64).sum()) == float(PRE["crop_%d_checksum" % k][1])
+
+
+def test_create_cams_and_center_image_match_reference_run():
+    """MVSDataset.create_cams (axis flip, float32 pose inverse, depth row) and center_image, bit for bit against the
+    reference's methods run on the records of tests/golden/io."""
+    ds_cls = find_dataset_def("predict_oblique")
+    cams = data_io.read_cameras_text(os.path.join(GOLD, "camera_info.txt"))
+    imgs = data_io.read_images_text(os.path.join(GOLD, "image_info.txt"))
+    for nd in (192, 384):
+        for row, image_id in enumerate(PRE["create_cams_ids"]):
+            got = ds_cls.create_cams(None, imgs[int(image_id)], cams, nd, 0.1)
+            want = PRE["create_cams_%d" % nd][row]
+            assert got.dtype == want.dtype == np.float32
+            assert np.array_equal(got[1], want[1])                                  # intrinsics and depth row: exact
+            assert np.allclose(got[0], want[0], rtol=0, atol=1e-6 * np.abs(want[0]).max())     # LAPACK inverse, same float32 input
+    img = PRE["center_input"]
+    assert np.array_equal(ds_cls.center_image(None, img, mode="mean"), PRE["center_mean"])
+    assert np.array_equal(ds_cls.center_image(None, img, mode="standard"), PRE["center_standard"])
+    assert np.array_equal(preprocess.center_image(img), PRE["center_mean"])
+
+
+def test_scale_image_fixed_point_hand_vector():
+    """cv2.resize(INTER_LINEAR) on uint8, derived by hand from OpenCV's arithmetic (11-bit weights, int32 rows,
+    (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2):
+
+    row [0, 100, 200, 50], fx = fy = 1.5 -> 2 x 6.  scale_x = 2/3; sample centres -0.167, 0.5, 1.167, 1.833, 2.5, 3.167:
+      x weights (2048, 0) on pixel 0 | (1024, 1024) on 0, 1 | (1707, 341) on 1, 2 | (341, 1707) on 1, 2 | (1024, 1024) on 2, 3 |
+      (2048, 0) on pixel 3   ->   horizontal sums S = 0, 102400, 238900, 375500, 256000, 102400
+    y: centre -0.167 -> rows (0, 0) with weights (341, 1707); centre 0.5 -> rows (0, 0) with weights (1024, 1024)
+      S = 238900: S >> 4 = 14931;  (341 * 14931) >> 16 = 77, (1707 * 14931) >> 16 = 388 -> (465 + 2) >> 2 = 116
+                                    (1024 * 14931) >> 16 = 233, twice                    -> (466 + 2) >> 2 = 117
+      (the exact bilinear value is 116.65: float arithmetic would give 117 in both rows)
+      S = 375500 -> 183, 183;  S = 256000 -> 125, 125;  S = 102400 -> 50, 50."""
+    img = np.array([[0, 100, 200, 50]], dtype=np.uint8)
+    out = preprocess.scale_image(img, 1.5)
+    assert out.dtype == np.uint8 and out.shape == (2, 6)
+    assert out.tolist() == [[0, 50, 116, 183, 125, 50], [0, 50, 117, 183, 125, 50]]
+    rgb = np.stack((img, img[:, ::-1], np.full_like(img, 9)), -1)                     # channels are filtered independently
+    out3 = preprocess.scale_image(rgb, 1.5)
+    assert out3[..., 0].tolist() == out.tolist() and out3[..., 1].tolist() == [r[::-1] for r in out.tolist()]
+    assert np.all(out3[..., 2] == 9)                                                  # a constant stays constant
+
+
+def test_scale_image_geometry_and_special_cases():
     rng = np.random.RandomState(0)
     img = rng.randint(0, 256, size=(8, 12, 3)).astype(np.uint8)
     assert preprocess.scale_image(img, 1) is img
-    half = preprocess.scale_image(img, 0.5)
-    box = img.reshape(4, 2, 6, 2, 3).astype(np.float64).mean(axis=(1, 3))          # at 0.5 the taps are the 2x2 box
-    assert half.shape == (4, 6, 3) and half.dtype == np.uint8
-    assert np.array_equal(half, np.floor(box + 0.5).astype(np.uint8))
-    up = preprocess.scale_image(img[..., 0].astype(np.float32), 2.0)
-    assert up.shape == (16, 24)
-    assert up[0, 0] == img[0, 0, 0] and up[-1, -1] == img[-1, -1, 0]                # border clamp
-    assert np.isclose(up[1, 1], (0.75 * 0.75 * img[0, 0, 0] + 0.75 * 0.25 * (float(img[0, 1, 0]) + img[1, 0, 0]) + 0.0625 * img[1, 1, 0]))
+    half = preprocess.scale_image(img, 0.5)                                         # exactly 1/2: OpenCV switches to INTER_AREA
+    box = img.reshape(4, 2, 6, 2, 3).astype(np.int64).sum(axis=(1, 3))
+    assert half.shape == (4, 6, 3) and half.dtype == np.uint8 and np.array_equal(half, ((box + 2) >> 2).astype(np.uint8))
+    odd = preprocess.scale_image(np.arange(35, dtype=np.uint8).reshape(5, 7), 0.5)   # cvRound: 2.5 -> 2, 3.5 -> 4
+    assert odd.shape == (2, 4)
+    assert odd[0, 0] == (0 + 1 + 7 + 8 + 2) >> 2 and odd[1, 2] == (18 + 19 + 25 + 26 + 2) >> 2
+    assert odd[0, 3] == 10 and odd[1, 3] == 24                                       # block cut by the border: mean of (6, 13), of (20, 27): 9.5 -> 10 (even), 23.5 -> 24
+    for scale in (0.3, 0.75, 1.25, 2.0, 3.1):                                        # constants survive the fixed point; sizes are cvRound
+        c = preprocess.scale_image(np.full((9, 14), 255, dtype=np.uint8), scale)
+        assert c.shape == (int(np.rint(9 * scale)), int(np.rint(14 * scale))) and np.all(c == 255)
+    smooth = (np.add.outer(np.arange(20), np.arange(30)) * 3).astype(np.uint8)       # a ramp: fixed point within one grey level of float bilinear
+    up = preprocess.scale_image(smooth, 2.0)
+    ref = preprocess.scale_image(smooth.astype(np.float32), 2.0)
+    assert up.shape == (40, 60) and np.abs(up.astype(np.float32) - ref).max() <= 1.0
+    f = preprocess.scale_image(img[..., 0].astype(np.float32), 2.0)                  # float images: plain bilinear, border clamp
+    assert f.shape == (16, 24) and f[0, 0] == img[0, 0, 0] and f[-1, -1] == img[-1, -1, 0]
+    assert np.isclose(f[1, 1], (0.75 * 0.75 * img[0, 0, 0] + 0.75 * 0.25 * (float(img[0, 1, 0]) + img[1, 0, 0]) + 0.0625 * img[1, 1, 0]))
+    s16 = preprocess.scale_image(img[..., 0].astype(np.int16) - 100, 0.5)            # signed 16-bit: the general path (no unsigned box)
+    assert s16.dtype == np.int16 and s16.shape == (4, 6)
     near = preprocess.scale_image(img, 0.5, interpolation="biculic")                 # nearest neighbour, as the reference maps it
     assert np.array_equal(near, img[::2, ::2])
-    odd = preprocess.scale_image(np.zeros((5, 7), dtype=np.uint8), 0.5)              # cvRound: 2.5 -> 2, 3.5 -> 4
-    assert odd.shape == (2, 4)
     im2, cam2 = preprocess.scale_input(img, np.ones((2, 4, 4), dtype=np.float32), scale=0.5)
     assert im2.shape == (4, 6, 3) and cam2[1, 0, 0] == 0.5
 
@@ -270,7 +346,8 @@ def test_predict_end_to_end_writes_reference_layout(tmp_path, model_name):
         assert np.allclose(prob, o["photometric_confidence"][0].cpu().numpy(), atol=1e-4)
         assert np.isfinite(depth).all() and 300.0 < depth.min() and depth.max() < 700.0         # later stages may leave [min, max]
         assert 0 <= prob.min() and prob.max() <= 1 + 1e-5
-        assert np.array_equal(np.array(Image.open(str(folder / ("%03d.jpg" % i)))), s["outimage"])
+        saved = np.array(Image.open(str(folder / ("%03d.jpg" % i))))                           # RGBA PNG bytes, as plt.imsave writes them
+        assert saved.shape[-1] == 4 and np.array_equal(saved[..., :3], s["outimage"]) and np.all(saved[..., 3] == 255)
         cam_txt = open(str(folder / ("%03d.txt" % i))).read().splitlines()
         assert cam_txt[0] == "extrinsic: XrightYdown, [Rcw|tcw]" and cam_txt[-1] == s["ref_image_path"]
         assert cam_txt[11].split() == [str(v) for v in s["outcam"][1, 3]]
