@@ -57,7 +57,7 @@ SIGNATURES = {
     "adamvs_pack_features": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_unpack_features": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_depth_range_samples_uniform": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
-    "adamvs_depth_range_samples_window": (c_i, [c_f, ctypes.c_float, c_f, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_depth_range_samples_window": (c_i, [c_f, ctypes.c_double, c_f, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_depth_regression": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_homo_warp": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),

@@ -531,12 +531,15 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   float se = 0.f, sd = 0.f;
+  // explicit fused multiply-adds in a fixed order: the sum must not depend on where the plane values come from (staged
+  // through LDS, read from the tensor or generated), which a contraction left to the compiler would not guarantee
   auto term = [&](f32x4 v, int d) {
     float e0 = __expf(v.x - m), e1 = __expf(v.y - m), e2 = __expf(v.z - m), e3 = __expf(v.w - m);
     se += (e0 + e1) + (e2 + e3);
-    if (staged) sd += e0 * lpp[d * 17] + e1 * lpp[(d + 1) * 17] + e2 * lpp[(d + 2) * 17] + e3 * lpp[(d + 3) * 17];
-    else sd += e0 * plane_at(planes, pl, d, hw) + e1 * plane_at(planes, pl, d + 1, hw) + e2 * plane_at(planes, pl, d + 2, hw) +
-               e3 * plane_at(planes, pl, d + 3, hw);
+    float p0, p1, p2, p3;
+    if (staged) { p0 = lpp[d * 17]; p1 = lpp[(d + 1) * 17]; p2 = lpp[(d + 2) * 17]; p3 = lpp[(d + 3) * 17]; }
+    else { p0 = plane_at(planes, pl, d, hw); p1 = plane_at(planes, pl, d + 1, hw); p2 = plane_at(planes, pl, d + 2, hw); p3 = plane_at(planes, pl, d + 3, hw); }
+    sd = __fmaf_rn(e3, p3, __fmaf_rn(e2, p2, __fmaf_rn(e1, p1, __fmaf_rn(e0, p0, sd))));
   };
   if (NQ > 0) {
 #pragma unroll

@@ -80,7 +80,7 @@ __global__ void k_depth_samples_uniform(const float* __restrict__ dv, float* __r
   size_t bd = i / hw;
   int b = (int)(bd / D), d = (int)(bd % D);
   float dmin = dv[2 * b], dmax = dv[2 * b + 1];
-  float step = __fdiv_rn(__fsub_rn(dmax, dmin), (float)(D - 1));
+  float step = (dmax - dmin) / (float)(D - 1);
   out[i] = plane_value(dmin, step, d);                    // module.py:651-656: a rounded product, then a rounded sum
 }
 
@@ -92,8 +92,8 @@ __global__ void k_depth_samples_window(const float* __restrict__ cur, float* __r
   size_t bd = i / hw;
   int b = (int)(bd / D), d = (int)(bd % D);
   float c = cur[(size_t)b * hw + p];
-  float lo = __fsub_rn(c, half_span), hi = __fadd_rn(c, half_span);
-  float step = __fdiv_rn(__fsub_rn(hi, lo), (float)(D - 1));
+  float lo = c - half_span, hi = c + half_span;
+  float step = (hi - lo) / (float)(D - 1);
   out[i] = plane_value(lo, step, d);                      // module.py:632-641
 }
 
@@ -223,12 +223,12 @@ extern "C" int adamvs_depth_range_samples_uniform(const float* depth_values, flo
   return 0;
 }
 
-extern "C" int adamvs_depth_range_samples_window(const float* cur_depth, float depth_interval_pixel, float* out, int B, int D,
+extern "C" int adamvs_depth_range_samples_window(const float* cur_depth, double depth_interval_pixel, float* out, int B, int D,
                                                  int h, int w, void* stream) {
   ADAMVS_CHECK_ARG(cur_depth && out && B > 0 && D > 1 && h > 0 && w > 0, "depth_range_samples_window: bad arguments (D=%d)", D);
   size_t total = (size_t)B * D * h * w;
   // reference: ndepth / 2 * depth_inteval_pixel, Python float arithmetic (module.py:632)
-  float half_span = (float)((double)D / 2.0 * (double)depth_interval_pixel);
+  float half_span = (float)((double)D / 2.0 * depth_interval_pixel);
   hipLaunchKernelGGL(k_depth_samples_window, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      cur_depth, out, half_span, D, h * w, total);
   ADAMVS_CHECK_LAUNCH("depth_range_samples_window");

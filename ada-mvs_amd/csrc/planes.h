@@ -29,7 +29,14 @@ struct PlaneLine {
   float lo, step;
 };
 
-__device__ __forceinline__ float plane_value(float lo, float step, int d) { return __fadd_rn(lo, __fmul_rn((float)d, step)); }
+// HIP's __fmul_rn / __fadd_rn are plain operators and hipcc contracts a * b + c into one fused multiply-add by default
+// (-ffp-contract=fast): measured, the "rounded product, rounded sum" came out as the fma.  The pragma is what keeps the
+// two roundings of the reference's tensor arithmetic.
+__device__ __forceinline__ float plane_value(float lo, float step, int d) {
+#pragma clang fp contract(off)
+  const float prod = (float)d * step;
+  return lo + prod;
+}
 
 __device__ __forceinline__ PlaneLine plane_line(const PlaneSrc& s, size_t b, size_t pix, int D, size_t hw) {
   PlaneLine l{nullptr, 0.f, 0.f};
@@ -42,11 +49,11 @@ __device__ __forceinline__ PlaneLine plane_line(const PlaneSrc& s, size_t b, siz
       hi = s.p[2 * b + 1];
     } else {
       const float c = s.p[b * hw + pix];
-      lo = __fsub_rn(c, s.half_span);
-      hi = __fadd_rn(c, s.half_span);
+      lo = c - s.half_span;
+      hi = c + s.half_span;
     }
     l.lo = lo;
-    l.step = __fdiv_rn(__fsub_rn(hi, lo), (float)(D - 1));
+    l.step = (hi - lo) / (float)(D - 1);          // single operations: nothing to contract
   }
   return l;
 }

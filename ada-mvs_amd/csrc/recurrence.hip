@@ -42,32 +42,16 @@ struct SlotArgs {
   typename R2::Args a2; TileGrid g2; TileRange r2;             // role 2: the rest of the grid
 };
 
-// POLICY 0: the grid is divided between the roles (workgroups [0, n0) run role 0, ...), in proportion to their estimated
-// work: roles with different bottlenecks are resident side by side for the whole launch, at the price of a cost model.
-// POLICY 1: every workgroup walks its share of EVERY role, one role after the other, the order rotated by the workgroup
-// index: no cost model (each workgroup gets the same number of tiles of each role), the mixture on a CU comes from
-// neighbouring workgroups being in different roles.
-template <class R0, class R1, class R2, int POLICY>
+// The grid is divided between the roles (workgroups [0, n0) run role 0, ...) in proportion to their estimated work.
+// (Tried and dropped: every workgroup walking its share of every role, one role after the other -- no cost model, but
+// 20-30 % slower: each workgroup then pays every role's prologue and holds no role's weights for long.)
+template <class R0, class R1, class R2>
 __global__ __launch_bounds__(256) void k_slot(SlotArgs<R0, R1, R2> s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wg = blockIdx.x;                  // workgroup-uniform: the role dispatch is a scalar branch
-  if (POLICY == 0) {
-    if (wg < s.n0) R0::run(s.a0, s.g0, s.r0, wg, s.n0, lds);
-    else if (wg < s.n0 + s.n1) R1::run(s.a1, s.g1, s.r1, wg - s.n0, s.n1, lds);
-    else R2::run(s.a2, s.g2, s.r2, wg - s.n0 - s.n1, (int)gridDim.x - s.n0 - s.n1, lds);
-  } else {
-    const int nwg = (int)gridDim.x;
-#pragma unroll 1
-    for (int p = 0; p < 3; ++p) {
-      int r = p + wg % 3;
-      r = r >= 3 ? r - 3 : r;
-      // a workgroup without a tile of a role (absent role: empty range, null arguments) must not even run its prologue
-      if (r == 0) { if (s.r0.begin + wg < s.r0.end) R0::run(s.a0, s.g0, s.r0, wg, nwg, lds); }
-      else if (r == 1) { if (s.r1.begin + wg < s.r1.end) R1::run(s.a1, s.g1, s.r1, wg, nwg, lds); }
-      else if (s.r2.begin + wg < s.r2.end) R2::run(s.a2, s.g2, s.r2, wg, nwg, lds);
-      __syncthreads();                        // the next role refills the LDS tile
-    }
-  }
+  if (wg < s.n0) R0::run(s.a0, s.g0, s.r0, wg, s.n0, lds);
+  else if (wg < s.n0 + s.n1) R1::run(s.a1, s.g1, s.r1, wg - s.n0, s.n1, lds);
+  else R2::run(s.a2, s.g2, s.r2, wg - s.n0 - s.n1, (int)gridDim.x - s.n0 - s.n1, lds);
 }
 
 constexpr size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -108,16 +92,11 @@ static void split_grid(int total, const long (&tiles)[3], const double (&work)[3
   }
 }
 
-int slot_policy() {                           // ADAMVS_SLOT_POLICY: 0 (default) = grid divided between the roles, 1 = every workgroup runs every role
-  const char* e = getenv("ADAMVS_SLOT_POLICY");
-  return e ? atoi(e) : 0;
-}
-
-template <class R0, class R1, class R2, int POLICY>
-static int launch_slot_p(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleUse<R2>& u2, int B, hipStream_t st, const char* name) {
+template <class R0, class R1, class R2>
+static int launch_slot(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleUse<R2>& u2, int B, hipStream_t st, const char* name) {
   constexpr size_t lds = max3(R0::LDS_BYTES, R1::LDS_BYTES, R2::LDS_BYTES);
   static_assert(lds <= 64 * 1024, "slot exceeds the default dynamic LDS limit");
-  auto kern = k_slot<R0, R1, R2, POLICY>;
+  auto kern = k_slot<R0, R1, R2>;
   static int capacity = 0;                    // per instantiation; a pure function of the kernel and the device
   if (!capacity) capacity = resident_blocks(kern, 256, lds);
   SlotArgs<R0, R1, R2> s;
@@ -141,28 +120,14 @@ static int launch_slot_p(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const Rol
   if ((rc = prep(u2.args, s.a2, s.g2, s.r2, u2.cost, u2.f0, u2.f1, 2, R2()))) return rc;
   const long all = tiles[0] + tiles[1] + tiles[2];
   if (all == 0) return 0;
-  int grid;
-  if (POLICY == 0) {
-    int n[3];
-    split_grid((int)(all < capacity ? all : capacity), tiles, work, n);
-    s.n0 = n[0];
-    s.n1 = n[1];
-    grid = n[0] + n[1] + n[2];
-  } else {                                    // absent roles have an empty tile range
-    long most = tiles[0] > tiles[1] ? tiles[0] : tiles[1];
-    most = most > tiles[2] ? most : tiles[2];
-    grid = (int)(most < capacity ? most : capacity);
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, s);
+  int n[3];
+  split_grid((int)(all < capacity ? all : capacity), tiles, work, n);
+  s.n0 = n[0];
+  s.n1 = n[1];
+  hipLaunchKernelGGL(kern, dim3(n[0] + n[1] + n[2]), dim3(256), lds, st, s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
   return 0;
-}
-
-template <class R0, class R1, class R2>
-static int launch_slot(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleUse<R2>& u2, int B, hipStream_t st, const char* name) {
-  if (slot_policy() == 0) return launch_slot_p<R0, R1, R2, 0>(u0, u1, u2, B, st, name);
-  return launch_slot_p<R0, R1, R2, 1>(u0, u1, u2, B, st, name);
 }
 
 // ---- the roles of one step ------------------------------------------------------------------------------------
@@ -196,16 +161,19 @@ static const RoleCosts& role_costs() {
   return c;
 }
 
-// ADAMVS_RECUR_MODE: 0 = six launches per step, states updated in place; 1 / 2 = software-pipelined slots, schedule 1 / 2
-// (recurrence_lags); unset = by size.  Measured on MI355X (profiles/r02_recurrence_schedules.txt): sharing launches does
+// ADAMVS_RECUR_MODE: 0 = six launches per step, states updated in place; 1 / 2 / 3 = software-pipelined slots, schedule
+// 1 / 2 / 3 (recurrence_lags); unset = by size.  Measured on MI355X (profiles/r02_recurrence_schedules.txt): sharing launches does
 // not make the roles faster -- a slot takes the sum of its roles' standalone times, the decoder more -- so what the
 // pipeline buys is three launch latencies per hypothesis, which pays while a step is latency-bound (few tiles per CU:
 // cfg4's 4 tiles per GPU 24.3 -> 22.0 ms) and costs 2-3 % once every role fills the chip several times over.
 int recurrence_mode(int precision, long pixels) {
   const char* e = getenv("ADAMVS_RECUR_MODE");
   if (e) return atoi(e);
-  const long limit = precision == PRECISION_FP32 ? (1L << 20) : (1L << 17);      // B * h * w of the stage
-  return pixels <= limit ? 1 : 0;
+  // B * h * w of the stage.  Measured (profiles/r02_recurrence_schedules.txt): fp32 -- two launches per hypothesis win up
+  // to ~200k pixels (cfg4's 4 tiles per GPU at stage 1: 7.8 -> 5.9 -> 5.1 ms), three up to ~800k, six beyond;
+  // bf16x3 (its level 1 is one kernel already) -- three up to ~130k, five beyond.
+  if (precision != PRECISION_FP32) return pixels <= (1L << 17) ? 1 : 0;
+  return pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0);
 }
 
 template <class R> static RoleUse<R> use(const typename R::Args* a, float cost, float f0 = 0.f, float f1 = 1.f) {
@@ -216,6 +184,8 @@ template <class R> static RoleUse<R> none() { return RoleUse<R>{nullptr, 0.f, 0.
 // How far level-2's candidate and the decoder run behind level 1 (in hypotheses) under a schedule.
 //   schedule 1 (the default)         A: gates1(t) | conv2(t-1)    B: cand1(t) | gates2(t-1)              C: cand2(t-1) | decoder(t-2)
 //   schedule 2 (fp32 only)           A: gates1(t) | conv2(t-1)    B: cand1(t) | cand2(t-2) | decoder(t-3)   C: gates2(t-1)
+//   schedule 3 (fp32 only)           A: gates1(t) | conv2+gates2(t-1)   B: cand1(t) | cand2(t-1) | decoder(t-2)
+//                                    two dependent launches per hypothesis (Conv2Gates2Role fuses conv2 into the gate kernel)
 // Schedule 2 keeps the one role that needs 234 registers (gates2: two 16-row output tiles of 32 input channels, 144
 // registers of weights) in a launch of its own, so that the roles sharing a launch all run at three to five waves per
 // SIMD; in schedule 1 cand1 runs at gates2's two.
@@ -277,6 +247,22 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
   SmallConvArgs v2{H1(s2), nullptr, fw.conv2, nullptr, C2(s2), nullptr, h, w, h2, w2, 16, nullptr};
   SmallConvArgs g2{C2(s2), H2(s2 - 1), fw.gates2, fw.gates2_b, rb.rh2, rb.u2, h2, w2, h2, w2, 32, nullptr};
   SmallConvArgs c2{C2(sc), rb.rh2, fw.cand2, fw.cand2_b, H2(sc), rb.u2, h2, w2, h2, w2, 16, H2(sc - 1)};
+  if (schedule == 3) {
+    Conv2Gates2Args vg{H1(s2), H2(s2 - 1), fw.conv2, fw.gates2, fw.gates2_b, C2(s2), rb.rh2, rb.u2, h, w, h2, w2};
+    if (l1 || l2)
+      if ((rc = launch_slot<Gates1, Conv2Gates2Role<0>, Conv2Gates2Role<1>>(
+               l1 ? use<Gates1>(&g1, k.g1) : none<Gates1>(), l2 ? use<Conv2Gates2Role<0>>(&vg, 0.5f * k.g2 + k.v2) : none<Conv2Gates2Role<0>>(),
+               l2 ? use<Conv2Gates2Role<1>>(&vg, 0.5f * k.g2 + k.v2) : none<Conv2Gates2Role<1>>(), B, st, "recurrence slot A (schedule 3)")))
+        return rc;
+    if (!(l1 || lc || dec)) return 0;
+    if (in_up)
+      return launch_slot<Cand1, Cand2, DecoderRole<true>>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
+                                                          dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(), B, st,
+                                                          "recurrence slot B (schedule 3)");
+    return launch_slot<Cand1, Cand2, DecoderRole<false>>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
+                                                         dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st,
+                                                         "recurrence slot B (schedule 3)");
+  }
   if (l1 || l2)
     if ((rc = launch_slot<Gates1, Conv2, NopRole>(l1 ? use<Gates1>(&g1, k.g1) : none<Gates1>(), l2 ? use<Conv2>(&v2, k.v2) : none<Conv2>(),
                                                   none<NopRole>(), B, st, "recurrence slot A")))

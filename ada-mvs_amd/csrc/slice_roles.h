@@ -238,6 +238,211 @@ struct ConvSmallRole {
 };
 
 // ---------------------------------------------------------------------------
+// conv2 (8 -> 16, stride 2, ReLU; reference adamvs.py:418) and the gate convolution of the level-2 ConvGRU
+// (module.py:28-41 on cat(c2, h2)) in one tile loop.  The two are consecutive links of the per-step chain
+// conv2 -> gates2 -> cand2; fused, the software pipeline of recurrence.hip needs two dependent launches per hypothesis
+// instead of three, which is what a latency-bound stage (few tiles per CU) pays for.  conv2 is cheap (288 MAC per
+// half-resolution pixel against 2304 for the gates), so its recomputation on the one-pixel halo of the 4 x 16 tile
+// (6 x 18 window: 1.7x) costs little; c2 of the tile proper also goes to memory for the candidate convolution.
+//   LDS: h1 window 13 x 37 full-resolution pixels (stride-2 layout of ConvSmallRole), then the 6 x 18 window of
+//   cat(c2, h2) in the stride-1 layout the gate chain reads.
+struct Conv2Gates2Args {
+  const float* st1;     // [B][h*w][8]      level-1 state of the step
+  const float* st2;     // [B][h2*w2][16]   level-2 state of the previous step
+  const float* wconv2;  // A fragments [1][9][2][64]
+  const float* wgates;  // A fragments [2][9][8][64]
+  const float* bgates;  // [32]
+  float* c2;            // [B][h2*w2][16]   ReLU(conv2(h1)), for the candidate convolution
+  float* rh;            // [B][h2*w2][16]   r * h2
+  float* u;             // [B][h2*w2][16]
+  int h, w, h2, w2;
+};
+
+// HALF 0: the reset-gate rows (-> r * h2) and c2 to memory; HALF 1: the update-gate rows (-> u).  One role with both
+// halves holds 162 registers of weights and leaves one wave per SIMD to every role of its launch; two half roles
+// (72 + 18 registers of weights each, the window loaded and conv2 evaluated twice) keep the launch at two to three.
+template <int HALF>
+struct Conv2Gates2Role {
+  typedef Conv2Gates2Args Args;
+  static constexpr int TR = 4, TC = 16, LR = TR + 2, LC = TC + 2, NW = LR * LC;             // c2 / h2 window (half resolution)
+  static constexpr int HR = 2 * LR + 1, HC = 2 * LC + 1, NH = HR * HC;                      // h1 window (full resolution)
+  static constexpr int PLANE_A = NH | 1, GP_A = group_pitch(PLANE_A, 2);
+  static constexpr int PLANE = plane_pitch16(NW), G = 8, GP = group_pitch(PLANE, G);
+  static constexpr int LDS_A = 2 * GP_A;                                                    // floats
+  static constexpr int NA = (NH * 2 + 255) / 256, NB = (NW * 4 + 255) / 256, NL = NA + NB;
+  static constexpr int NRUN = 2;                                                            // conv2 runs per wave (7 runs of 16 window pixels)
+  static constexpr size_t LDS_BYTES = (size_t)(LDS_A + G * GP) * sizeof(float);
+  static constexpr int TILE_W = TC, TILE_H = TR;
+  static int tiles_x(const Args& a) { return cdiv(a.w2, TC); }
+  static int tiles_y(const Args& a) { return cdiv(a.h2, TR); }
+
+  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds) {
+  // lds: the h1 window, then (at LDS_A floats) the cat(c2, h2) window
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+
+  float wc[1][9][2];
+  load_wfrag<1, 2>(wc, a.wconv2, lane);
+  float wf[1][9][8];
+  load_wfrag<1, 8>(wf, a.wgates + HALF * 9 * 8 * 64, lane);                 // fragment stream [nt][tap][kc][64]: nt = HALF
+  const f32x4 bias = *(const f32x4*)(a.bgates + HALF * 16 + 4 * q);
+
+  // ---- per-lane constants: the two windows
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    if (isA) {
+      const int j = min(tid + k * 256, NH * 2 - 1);
+      const int g = j % 2, pp = j / 2, r = pp / HC, c = pp % HC;
+      goff[k] = (unsigned)(((r * a.w + c) * 8 + 4 * g) * 4);
+      lbyte[k] = (unsigned)((g * GP_A + r * HC + c) * 4);
+      rc[k] = r | (c << 16);
+    } else {
+      const int j = min(tid + (k - NA) * 256, NW * 4 - 1);
+      const int g = j % 4, pp = j / 4, r = pp / LC, c = pp % LC;
+      goff[k] = (unsigned)(((r * a.w2 + c) * 16 + 4 * g) * 4);
+      lbyte[k] = (unsigned)((LDS_A + (4 + g) * GP + r * LC + c) * 4);
+      rc[k] = r | (c << 16);
+    }
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  // conv2: run j of the wave covers window pixels 16 (wave + 4 j) .. + 15 (runs past the 108 pixels repeat the last one)
+  unsigned xa[NRUN][2], cbyte[NRUN], coff[NRUN];
+  int wrc[NRUN];
+#pragma unroll
+  for (int j = 0; j < NRUN; ++j) {
+    const int i = 16 * (wave + 4 * j) + p, ic = min(i, NW - 1);
+    const int wr = ic / LC, wcol = ic % LC;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      xa[j][kc] = (unsigned)((kc * GP_A + q * PLANE_A + (2 * wr) * HC + 2 * wcol) * 4);
+      pin(xa[j][kc]);
+    }
+    cbyte[j] = (unsigned)((LDS_A + q * GP + ic) * 4);                           // c2 channels 4q..4q+3 of the window pixel: planes 0..3 of group q
+    const bool inner = i < NW && wr >= 1 && wr <= TR && wcol >= 1 && wcol <= TC;
+    coff[j] = inner ? (unsigned)((((wr - 1) * a.w2 + wcol - 1) * 16 + 4 * q) * 4) : BUF_OOB;
+    wrc[j] = wr | (wcol << 16) | (i < NW ? 0 : (1 << 30));
+    pin(cbyte[j]); pin(coff[j]); pin(wrc[j]);
+  }
+  // gates: the wave's run is row `wave` of the tile
+  unsigned xbyte[8];
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) {
+    xbyte[kc] = (unsigned)((LDS_A + kc * GP + q * PLANE + wave * LC + p) * 4);
+    pin(xbyte[kc]);
+  }
+  const unsigned hbyte = (unsigned)((LDS_A + (4 + q) * GP + (wave + 1) * LC + p + 1) * 4);     // h2 channels 4q.. of the lane's pixel (q < 4)
+  unsigned ooff = (unsigned)(((wave * a.w2 + p) * 16 + 4 * q) * 4);         // the lane's pixel, channels 4q.. of rh (HALF 0) or u (HALF 1)
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int b, int tx, int ty) {
+    const int j0 = tx * TC - 1, i0 = ty * TR - 1;                       // window origin, half resolution
+    const int ix0 = 2 * j0 - 1, iy0 = 2 * i0 - 1;                       // h1 window origin
+    const buf_rsrc ra = make_rsrc((const char*)a.st1 + (((long)b * a.h + iy0) * a.w + ix0) * 32);
+    const buf_rsrc rb = make_rsrc((const char*)a.st2 + (((long)b * a.h2 + i0) * a.w2 + j0) * 64);
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HR <= a.h && ix0 + HC <= a.w && i0 + LR <= a.h2 && j0 + LC <= a.w2;
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const bool isA = k < NA;
+        const int iy = (isA ? iy0 : i0) + (rc[k] & 0xffff), ix = (isA ? ix0 : j0) + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)(isA ? a.h : a.h2) && (unsigned)ix < (unsigned)(isA ? a.w : a.w2);
+        stage[k] = buf_load4(isA ? ra : rb, ok ? goff[k] : BUF_OOB);              // zero padding
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      const int pl = k < NA ? PLANE_A : PLANE;
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[pl] = v.y; dl[2 * pl] = v.z; dl[3 * pl] = v.w;
+    }
+  };
+
+  int t = tr.begin + wg;
+  if (t >= tr.end) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, b, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)b * a.h2 + oy0) * a.w2 + ox0;
+    const bool full = oy0 + TR <= a.h2 && ox0 + TC <= a.w2;
+    const buf_rsrc rc2 = make_rsrc((char*)a.c2 + opix0 * 64);
+    const buf_rsrc r0 = make_rsrc((char*)a.rh + opix0 * 64);
+    const buf_rsrc r1 = make_rsrc((char*)a.u + opix0 * 64);
+    const int tn = t + nwg;
+    const bool more = tn < tr.end;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_tile(stage, bn, txn, tyn);
+    }
+
+    // ---- conv2 on the 6 x 18 window -> ReLU -> LDS (groups 0..3) and, for the tile proper, memory
+    const bool win_in = oy0 >= 1 && ox0 >= 1 && oy0 + TR + 1 <= a.h2 && ox0 + TC + 1 <= a.w2;      // whole window inside the map
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc)
+            acc = mfma16(wc[0][ky * 3 + kx][kc], *(const float*)((const char*)lds + xa[j][kc] + (ky * HC + kx) * 4), acc);
+      drain(acc);
+      const int wr = wrc[j] & 0xffff, wcol = (wrc[j] >> 16) & 0x3fff;
+      bool inside = true;                                                     // c2 is zero outside the map (the gates' padding)
+      if (!win_in) inside = (unsigned)(oy0 - 1 + wr) < (unsigned)a.h2 && (unsigned)(ox0 - 1 + wcol) < (unsigned)a.w2;
+      f32x4 v = {fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+      if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      float* dl = (float*)((char*)lds + cbyte[j]);
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;   // surplus runs rewrite pixel 107 with its own value
+      unsigned co = coff[j];
+      if (!full && !(oy0 + wr - 1 < a.h2 && ox0 + wcol - 1 < a.w2)) co = BUF_OOB;
+      if (HALF == 0) buf_store4(rc2, co, v);
+    }
+    __syncthreads();                     // c2 window complete
+
+    // ---- gates on cat(c2, h2)
+    unsigned oo = ooff;
+    if (!full && !(oy0 + wave < a.h2 && ox0 + p < a.w2)) oo = BUF_OOB;
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    conv3x3_run_at<1, 8, 1, LC>(acc, wf, lds, xbyte);
+    drain(acc[0]);
+    const float* hl = (const float*)((const char*)lds + hbyte);
+    const f32x4 hc = {hl[0], hl[PLANE], hl[2 * PLANE], hl[3 * PLANE]};          // module.py:35-41
+
+    wait_vmem_all();                     // the wait point of the tile
+    __syncthreads();                     // every wave is done reading both windows
+    if (more) store_tile(stage);
+
+    {
+      const f32x4 v = acc[0] + bias;
+      const f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+      if (HALF == 0) buf_store4(r0, oo, sg * hc);                              // reset-gate rows -> r * h
+      else buf_store4(r1, oo, sg);                                             // update-gate rows -> u
+    }
+    if (!more) break;
+    __syncthreads();                     // next tile visible
+    t = tn; b = bn; tx = txn; ty = tyn;
+  }
+  }
+};
+
+// ---------------------------------------------------------------------------
 // Decoder: s = ReLU(upconv1(h2) + b + h1)   (ConvTranspose2d 16->8, k3 s2 p1 op1)
 //          reg = upconv2d(s) + b            (ConvTranspose2d 8->1 k3 s2 p1 op1 when IN_UP,
 //                                            Conv2d 8->1 k3 p1 otherwise)

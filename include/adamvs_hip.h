@@ -46,8 +46,9 @@ int adamvs_unpack_features(const float* nhwc, float* nchw, int B, int C, int h, 
  * -> out [B][D][h][w], D uniform samples (the interval argument is ignored there). */
 int adamvs_depth_range_samples_uniform(const float* depth_values, float* out, int B, int D, int h, int w, void* stream);
 /* get_cur_depth_range_samples, models/module.py:628-643: window cur -+ D/2*interval,
- * D samples, no clamping.  cur_depth [B][h][w] -> out [B][D][h][w]. */
-int adamvs_depth_range_samples_window(const float* cur_depth, float depth_interval_pixel, float* out, int B, int D,
+ * D samples, no clamping.  cur_depth [B][h][w] -> out [B][D][h][w].  The interval is a double: the reference forms
+ * ndepth / 2 * depth_inteval_pixel in Python floats and only the product is rounded to fp32 (module.py:632). */
+int adamvs_depth_range_samples_window(const float* cur_depth, double depth_interval_pixel, float* out, int B, int D,
                                       int h, int w, void* stream);
 
 /* F.interpolate(x, [ho,wo], mode='bilinear', align_corners=False) on [N][hi][wi];

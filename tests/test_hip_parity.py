@@ -68,6 +68,28 @@ def test_homo_warping_float_golden(hip):
         assert float(out.cpu().abs().sum(1)[zero_ref].max() if zero_ref.any() else 0.0) < 1e-4
 
 
+def test_depth_range_samples_bit_exact_arithmetic(hip):
+    """Hypothesis planes in the reference's fp32 operation order (module.py:632-641, 651-656): step = (hi - lo) / (D - 1),
+    plane d = lo + d * step with a rounded product and a rounded sum -- emulated in numpy float32, compared bit for bit."""
+    import numpy as np
+    rng = np.random.RandomState(0)
+    for D in (12, 48, 192, 256):
+        lo = (350 + 100 * rng.rand(3)).astype(np.float32)
+        hi = (lo + 150 + 100 * rng.rand(3)).astype(np.float32)
+        step = ((hi - lo) / np.float32(D - 1)).astype(np.float32)
+        want = (lo[:, None] + (np.arange(D, dtype=np.float32)[None] * step[:, None]).astype(np.float32)).astype(np.float32)
+        got = hip.depth_range_samples(dev(torch.from_numpy(np.stack((lo, hi), 1))), D, 0.0, [3, 2, 4]).cpu().numpy()
+        assert np.array_equal(got, np.broadcast_to(want[:, :, None, None], got.shape)), D
+        cur = (400 + 200 * rng.rand(3, 2, 4)).astype(np.float32)
+        interval = 2.0 * 200.0 / 48                                   # a Python float, as in the reference's driver
+        half = np.float32(D / 2 * interval)
+        wlo, whi = (cur - half).astype(np.float32), (cur + half).astype(np.float32)
+        wstep = ((whi - wlo) / np.float32(D - 1)).astype(np.float32)
+        wwant = wlo[:, None] + (np.arange(D, dtype=np.float32)[None, :, None, None] * wstep[:, None]).astype(np.float32)
+        wgot = hip.depth_range_samples(dev(torch.from_numpy(cur)), D, interval, [3, 2, 4]).cpu().numpy()
+        assert np.array_equal(wgot, wwant.astype(np.float32)), D
+
+
 def test_depth_range_samples_golden(hip):
     from ada_mvs_amd.models.module import get_depth_range_samples
     g = load_golden("op_depth_samples")
@@ -497,12 +519,12 @@ def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, monkeypatch, c
     imgs, proj, dv = synth.tile_inputs(cfg, batch=batch, seed=21)
     args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
     outs = {}
-    for mode in ("0", "1", "2"):
+    for mode in ("0", "1", "2", "3"):
         monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
         with torch.no_grad():
             outs[mode] = m(*args)
         torch.cuda.synchronize()
-    for mode in ("1", "2"):
+    for mode in ("1", "2", "3"):
         for s in ("stage1", "stage2", "stage3"):
             for key in ("depth", "photometric_confidence"):
                 assert torch.equal(outs["0"][s][key], outs[mode][s][key]), (mode, s, key)
