@@ -188,11 +188,14 @@ class InferDepthNet0(nn.Module):
         self._workspace.clear()
         return super()._apply(fn, *a, **k)
 
-    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0, twin=False, planes=None, num_depth=None):
+    def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0, twin=False, planes=None, num_depth=None,
+            workspaces=None):
         """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w] -- or None with
         planes = hip_ops.plane_source(...) and num_depth: the hypothesis planes are then generated inside the kernels;
         prev_conf None (stage 1) or [S,B,hp,wp].  -> (view_weight [S,B,h,w], pair_depth|None, depth, conf).
-        twin: the train/test model's placement of the 1e-5 in the weighted aggregation (adamvs.py:262-300)."""
+        twin: the train/test model's placement of the 1e-5 in the weighted aggregation (adamvs.py:262-300).
+        workspaces: a table shared with the other stages of a cascade (they run one after the other on one stream, so
+        one buffer of the largest stage's size serves all three); default: this stage's own."""
         S = feat_cl.shape[0] // B - 1
         first = prev_conf is None
         prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
@@ -203,10 +206,13 @@ class InferDepthNet0(nn.Module):
         desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()],
                                   _PRECISIONS[self.reg_fuse.precision], eps_in_numerator=int(twin), plane_mode=mode, half_span=half_span)
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4
+        table = self._workspace if workspaces is None else workspaces
         key = (feat_cl.device, group)
-        ws = self._workspace.get(key)
+        ws = table.get(key)
         if ws is None or ws.numel() < need:
-            ws = self._workspace[key] = torch.empty(need, device=feat_cl.device, dtype=torch.float32)
+            table.pop(key, None)               # release the smaller buffer before asking for the larger one
+            ws = None
+            ws = table[key] = torch.empty(need, device=feat_cl.device, dtype=torch.float32)
         dev = feat_cl.device
         w_reg = self.reg.packed(dev) if first else None
         return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev), ws)
@@ -252,6 +258,7 @@ class Infer_AdaMVSNet(nn.Module):
         self.num_stage = len(ndepths)
         self.feature_chunk = 40                  # images per FeatureNet0 call (extract_features)
         self.materialize_planes = False          # True: hypothesis planes as a [B,D,h,w] tensor instead of generated in the kernels
+        self._stage_workspace = {}               # one workspace per (device, tile group) for all stages; shared by DataParallel replicas
         self.stage_infos = {k: {"scale": float(v)} for k, v in STAGE_SCALE.items()}
         self.feature = FeatureNet0(base_channels=8, stride=4, num_stage=self.num_stage)
         ch = self.feature.out_channels
@@ -259,6 +266,10 @@ class Infer_AdaMVSNet(nn.Module):
                                        InferDepthNet0(in_depths=self.ndepths[0], in_channels=ch[1]),
                                        InferDepthNet0(in_depths=self.ndepths[0], in_up=False, in_channels=ch[2])])
         self.set_precision(precision)
+
+    def _apply(self, fn, *a, **k):             # .cuda()/.to(): the workspaces belong to the old placement
+        self._stage_workspace.clear()
+        return super()._apply(fn, *a, **k)
 
     def set_precision(self, precision):
         """"fp32": exact fp32 MFMA everywhere (default).  "bf16x3": CostRegNet2D, conv1 and the ConvGRU convolutions
@@ -289,10 +300,11 @@ class Infer_AdaMVSNet(nn.Module):
             span = self.depth_intervals_ratio[s] * depth_interval
             if self.materialize_planes:      # the reference's way (and the A/B of the generated planes): a [B,D,h,w] tensor
                 vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, hip_ops.depth_range_samples(cur, self.ndepths[s], span, [B, h, w]),
-                                               conf, group, twin)
+                                               conf, group, twin, workspaces=self._stage_workspace)
             else:
                 planes = hip_ops.plane_source(cur, self.ndepths[s], span, [B, h, w])
-                vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, None, conf, group, twin, planes=planes, num_depth=self.ndepths[s])
+                vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, None, conf, group, twin, planes=planes, num_depth=self.ndepths[s],
+                                               workspaces=self._stage_workspace)
             if twin:
                 # DepthNet0 hands its input confidence list on unchanged (adamvs.py:298): every later stage resamples
                 # the stage-1 maps, and the lists carry S entries

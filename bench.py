@@ -108,7 +108,7 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                     torch.empty(B, Ho, Wo, device=dev), torch.empty(B, Ho, Wo, device=dev))
             w_reg = net.reg.packed(dev) if first else None
             fuse = net.reg_fuse.packed(dev)
-            ws = net._workspace[(dev, 0)]
+            ws = model._stage_workspace[(dev, 0)]
 
             def phase(mask):
                 return hip_ops.depth_stage_forward(desc, feats_cl[s], rt, planes, conf, w_reg, fuse, ws, phases=mask, outputs=outs)
@@ -495,7 +495,9 @@ def main():
             step_s = 1e-3 * result["ms_per_step"] * (Bg / float(B))
             tot_flops = sum(w_.get("costreg_flops", 0) + w_["recurrence_flops"] + w_["conv1_flops"] for w_ in work)
             tot_bytes = sum(sum(v for k_, v in w_.items() if k_.endswith("_bytes")) for w_ in work)
-            roof["step_frac_mfma"] = tot_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            # (the split-bf16 mode executes three bf16 products per fp32 product, on the bf16 pipe)
+            roof["step_frac_mfma"] = (tot_flops * 3 / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS if split
+                                      else tot_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS)
             roof["step_frac_hbm"] = tot_bytes / step_s / 1e9 / HBM_PEAK_GBS
             roof["step_frac"] = roof["step_frac_hbm"] if split else roof["step_frac_mfma"]
             roof["step_bound"] = "hbm" if split else "mfma (fp32)"

@@ -17,4 +17,4 @@ for path in sys.argv[1:]:
             print("   CostRegNet2D layers:", "  ".join("%s %.2f" % kv for kv in d["cost_reg_layers_ms"].items()))
         r = d.get("roofline")
         if r:
-            print("   roofline: %.1f %s (%.1f %% of %.1f), %.2f ms per launch" % (r["achieved"], r["unit"], 100 * r["frac"], r["peak"], r["launch_ms"]))
+            print("   roofline: %.1f %s (%.1f %% of %.1f), %.2f ms per launch" % (r["achieved"], r["unit"], 100 * r["frac"], r["peak"], r.get("launch_ms", float("nan"))))
