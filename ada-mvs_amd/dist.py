@@ -136,6 +136,62 @@ class MapGatherer:
         return self.out[0], self.out[1]
 
 
+def views_of_rank(n_views, rank, world):
+    """Source views s = rank, rank + world, ... of the S source views."""
+    return list(range(rank, n_views, world))
+
+
+def all_gather_maps(t):
+    """all_gather of equally shaped maps -> [world, *t.shape] on every rank (RCCL on device tensors; gloo through the host)."""
+    world = dist.get_world_size()
+    if dist.get_backend() == "gloo":
+        host = t.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        return torch.stack(parts, 0).to(t.device)
+    out = torch.empty((world,) + tuple(t.shape), device=t.device, dtype=t.dtype)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+def stage_with_sharded_views(net, feat_cl, B, C, h, w, rt, planes, num_depth, group, twin, workspaces, rank, world):
+    """Stage 1 of one tile (or batch) computed by `world` ranks together -- the latency mode of SURVEY.md section 8e for
+    BASELINE cfg5 (1 reference + 8 source views on 8 GPUs).  Pass A (pair similarity, CostRegNet2D, softmax / max /
+    regression: reference models/adamvs.py:462-490) is independent per source view and carries 62 % of cfg5's flops:
+    rank r scores source views r, r + world, ...; ONE all_gather of the view weights and pair depths ([S][B][h*w] each,
+    295 KB per view at cfg5) follows; every rank then runs pass B (aggregation, recurrence, soft-argmin) on all
+    views.  The result equals the single-process stage bit for bit (a view's weights do not depend on the other
+    views).  feat_cl [V*B, h*w, C] view-major, rt [B,S,12]: every rank holds all views (the images are replicated).
+    -> (view_weight [S,B,h,w], pair_depth [S,B,h,w], depth, confidence)"""
+    from . import _lib
+    S = feat_cl.shape[0] // B - 1
+    dev = feat_cl.device
+    mine = views_of_rank(S, rank, world)
+    per_rank = (S + world - 1) // world
+    part = torch.zeros(2, per_rank, B, h, w, device=dev, dtype=torch.float32)          # [vw | pd][local view]
+    if mine:
+        idx = torch.tensor([0] + [1 + v for v in mine], device=dev)
+        feat_sub = feat_cl.reshape(S + 1, B, h * w, C).index_select(0, idx).reshape(-1, h * w, C)
+        rt_sub = rt.index_select(1, torch.tensor(mine, device=dev)).contiguous()
+        n = len(mine)
+        unused = torch.empty(1, device=dev, dtype=torch.float32)           # depth / confidence are not written by pass A
+        net.run(feat_sub, B, C, h, w, rt_sub, None, None, group, twin, planes=planes, num_depth=num_depth, workspaces=workspaces,
+                phases=_lib.PHASE_VIEW_WEIGHTS, outputs=(part[0, :n], part[1, :n], unused, unused))     # leading slices: contiguous [n,B,h,w]
+    gathered = all_gather_maps(part) if world > 1 else part[None]                       # [world, 2, per_rank, B, h, w]
+    vw = torch.empty(S, B, h, w, device=dev, dtype=torch.float32)
+    pd = torch.empty(S, B, h, w, device=dev, dtype=torch.float32)
+    for r in range(world):
+        for i, v in enumerate(views_of_rank(S, r, world)):
+            vw[v] = gathered[r, 0, i]
+            pd[v] = gathered[r, 1, i]
+    Ho, Wo = (2 * h, 2 * w) if net.in_up else (h, w)
+    depth = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
+    conf = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
+    net.run(feat_cl, B, C, h, w, rt, None, None, group, twin, planes=planes, num_depth=num_depth, workspaces=workspaces,
+            phases=_lib.PHASE_AGGREGATE | _lib.PHASE_RECURRENCE | _lib.PHASE_SOFT_ARGMIN, outputs=(vw, pd, depth, conf))
+    return vw, pd, depth, conf
+
+
 def run_sharded(infer_tiles, n_tiles, dst=0):
     """infer_tiles(list_of_tile_indices) -> (depth [T,H,W], conf [T,H,W]) for this rank's tiles;
     returns the gathered maps on `dst`."""

@@ -189,13 +189,15 @@ class InferDepthNet0(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0, twin=False, planes=None, num_depth=None,
-            workspaces=None):
+            workspaces=None, phases=None, outputs=None):
         """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w] -- or None with
         planes = hip_ops.plane_source(...) and num_depth: the hypothesis planes are then generated inside the kernels;
         prev_conf None (stage 1) or [S,B,hp,wp].  -> (view_weight [S,B,h,w], pair_depth|None, depth, conf).
         twin: the train/test model's placement of the 1e-5 in the weighted aggregation (adamvs.py:262-300).
         workspaces: a table shared with the other stages of a cascade (they run one after the other on one stream, so
-        one buffer of the largest stage's size serves all three); default: this stage's own."""
+        one buffer of the largest stage's size serves all three); default: this stage's own.
+        phases / outputs: run a subset of the stage's phases on given output tensors (ada_mvs_amd.dist: pass A of
+        stage 1 for a subset of the source views, then pass B on the gathered view weights)."""
         S = feat_cl.shape[0] // B - 1
         first = prev_conf is None
         prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
@@ -215,7 +217,10 @@ class InferDepthNet0(nn.Module):
             ws = table[key] = torch.empty(need, device=feat_cl.device, dtype=torch.float32)
         dev = feat_cl.device
         w_reg = self.reg.packed(dev) if first else None
-        return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev), ws)
+        if phases is None:
+            return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev), ws)
+        return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev), ws,
+                                           phases=phases, outputs=outputs)
 
     def forward(self, features, proj_matrices, depth_values, num_depth, confidence_map=None):
         assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
@@ -259,6 +264,8 @@ class Infer_AdaMVSNet(nn.Module):
         self.feature_chunk = 40                  # images per FeatureNet0 call (extract_features)
         self.materialize_planes = False          # True: hypothesis planes as a [B,D,h,w] tensor instead of generated in the kernels
         self._stage_workspace = {}               # one workspace per (device, tile group) for all stages; shared by DataParallel replicas
+        self.view_shard = None                   # (rank, world): latency mode -- pass A of stage 1 over this rank's share of the
+                                                 # source views, one all_gather of the view weights (ada_mvs_amd.dist.sharded_view_weights)
         self.stage_infos = {k: {"scale": float(v)} for k, v in STAGE_SCALE.items()}
         self.feature = FeatureNet0(base_channels=8, stride=4, num_stage=self.num_stage)
         ch = self.feature.out_channels
@@ -301,6 +308,11 @@ class Infer_AdaMVSNet(nn.Module):
             if self.materialize_planes:      # the reference's way (and the A/B of the generated planes): a [B,D,h,w] tensor
                 vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, hip_ops.depth_range_samples(cur, self.ndepths[s], span, [B, h, w]),
                                                conf, group, twin, workspaces=self._stage_workspace)
+            elif s == 0 and self.view_shard is not None:
+                from ada_mvs_amd import dist as adist          # the one exchange step of the path
+                planes = hip_ops.plane_source(cur, self.ndepths[s], span, [B, h, w])
+                vw, pd, depth, pconf = adist.stage_with_sharded_views(net, feats_cl[s], B, C, h, w, rt, planes, self.ndepths[s], group, twin,
+                                                                      self._stage_workspace, *self.view_shard)
             else:
                 planes = hip_ops.plane_source(cur, self.ndepths[s], span, [B, h, w])
                 vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, None, conf, group, twin, planes=planes, num_depth=self.ndepths[s],

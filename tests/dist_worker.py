@@ -17,9 +17,33 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+def latency_mode(cfg, out, rank, world, dev):
+    """Every rank holds the same tile; source views are dealt to the ranks for pass A of stage 1 (one all_gather)."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    c = synth.CONFIGS[cfg] if cfg in synth.CONFIGS else dict(views=9, H=64, W=96, ndepths=[16, 8, 4], num_depth=16)
+    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.to(dev).eval()
+    m.view_shard = (rank, world)
+    imgs, proj, dv = synth.tile_inputs(c, batch=2, seed=3)
+    with torch.no_grad():
+        o = m(imgs.to(dev), {k: v.to(dev) for k, v in proj.items()}, dv.to(dev))
+    torch.cuda.synchronize()
+    np.savez(out + ".rank%d.npz" % rank, depth=o["depth"].cpu().numpy(), conf=o["photometric_confidence"].cpu().numpy(),
+             vw=torch.stack([t[:, 0] for t in o["stage1"]["pair_confidence"][:c["views"] - 1]]).cpu().numpy(),
+             pd=torch.stack(o["stage1"]["pair_result"]).cpu().numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def main():
     cfg, n_tiles, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     rank, world, local = adist.init_from_env()
+    if n_tiles == 0:                             # latency mode
+        if os.environ.get("ADAMVS_BENCH_ONE_DEVICE"):
+            local = 0
+        torch.cuda.set_device(local)
+        return latency_mode(cfg, out, rank, world, torch.device("cuda", local))
     if os.environ.get("ADAMVS_BENCH_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)

@@ -57,6 +57,25 @@ def _worker_steps(rank, world, port, n_tiles, q):
     dist.destroy_process_group()
 
 
+def _worker_views(rank, world, port, n_views, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    adist.init_from_env(backend="gloo")
+    mine = adist.views_of_rank(n_views, rank, world)
+    per_rank = (n_views + world - 1) // world
+    part = torch.zeros(per_rank, 2, 3)
+    for i, v in enumerate(mine):
+        part[i] = 10.0 * v                          # the "view weight" of source view v
+    g = adist.all_gather_maps(part)                 # [world, per_rank, 2, 3] on every rank
+    full = torch.empty(n_views, 2, 3)
+    for r in range(world):
+        for i, v in enumerate(adist.views_of_rank(n_views, r, world)):
+            full[v] = g[r, i]
+    if rank == 0:
+        q.put((full.clone(), full.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _run(n_tiles, worker=None):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -108,3 +127,12 @@ def test_map_gatherer_single_process_is_identity():
     g.start(d, c)
     gd, gc = g.finish()
     assert gd is d and gc is c
+
+
+def test_source_views_are_dealt_and_gathered_back():
+    """The exchange step of the latency mode (cfg5: source views over ranks): every rank reassembles all views."""
+    for n_views in (8, 5, 1):
+        owned = sum((adist.views_of_rank(n_views, r, 2) for r in range(2)), [])
+        assert sorted(owned) == list(range(n_views))
+        full, _ = _run(n_views, _worker_views)
+        assert [float(full[v, 0, 0]) for v in range(n_views)] == [10.0 * v for v in range(n_views)]

@@ -43,18 +43,18 @@ def _single_process_maps():
     return o["depth"].cpu().numpy(), o["photometric_confidence"].cpu().numpy()
 
 
-def _run_ranks(tmp_path, extra_env):
+def _run_ranks(tmp_path, extra_env, cfg=CFG, n_tiles=N_TILES, world=2):
     port = _free_port()
     out = str(tmp_path / "gathered.npz")
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), CFG, str(N_TILES), out], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), cfg, str(n_tiles), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
-    return np.load(out)
+    return np.load(out) if n_tiles else [np.load(out + ".rank%d.npz" % r) for r in range(world)]
 
 
 def _check(z, backend):
@@ -71,3 +71,23 @@ def test_two_ranks_on_one_device_over_gloo_match_single_process(tmp_path):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs (RCCL over xGMI)")
 def test_two_ranks_over_rccl_match_single_process(tmp_path):
     _check(_run_ranks(tmp_path, {}), "nccl")
+
+
+def test_latency_mode_source_views_sharded_over_three_ranks(tmp_path):
+    """SURVEY.md section 8e, cfg5's latency mode: 8 source views dealt to 3 ranks (3 + 3 + 2: uneven) for pass A of stage
+    1, one all_gather of the view weights and pair depths, pass B on every rank.  Every rank must end with the maps of a
+    single process, bit for bit (a view's weight does not depend on the other views)."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    cfg = dict(views=9, H=64, W=96, ndepths=[16, 8, 4], num_depth=16)
+    m = Infer_AdaMVSNet(cfg["num_depth"], cfg["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=2, seed=3)
+    with torch.no_grad():
+        o = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+    ranks = _run_ranks(tmp_path, {"ADAMVS_BENCH_ONE_DEVICE": "1", "ADAMVS_DIST_BACKEND": "gloo"}, cfg="nine_views", n_tiles=0, world=3)
+    vw = torch.stack([t[:, 0] for t in o["stage1"]["pair_confidence"][:8]]).cpu().numpy()
+    for z in ranks:
+        assert np.array_equal(z["vw"], vw) and np.array_equal(z["pd"], torch.stack(o["stage1"]["pair_result"]).cpu().numpy())
+        assert np.array_equal(z["depth"], o["depth"].cpu().numpy())
+        assert np.array_equal(z["conf"], o["photometric_confidence"].cpu().numpy())
