@@ -8,8 +8,10 @@ it calls in models/module.py) running in libadamvs_hip.so.
     model = nn.DataParallel(model).cuda(); model.load_state_dict(ckpt["model"]); model.eval()
     out = model(imgs, proj_matrices, depth_values)     # out["depth"], out["photometric_confidence"], ...
 
-FeatureNet0 (upstream of the hot path) stays on PyTorch/MIOpen.  There is no
-CPU fallback: CPU tensors, or a missing library, raise.
+FeatureNet0 (upstream of the hot path) runs on hand-written kernels as well
+(adamvs_feature_net0; image sizes that are no multiple of 32 go through the
+same layers in PyTorch on the GPU).  There is no CPU fallback: CPU tensors, a
+missing library, or train mode raise.
 """
 import torch
 import torch.nn as nn
