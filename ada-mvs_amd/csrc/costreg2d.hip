@@ -32,10 +32,11 @@ struct ConvDDArgs {
 
 enum { CONV_S1 = 0, CONV_S2 = 1, CONV_T2 = 2 };
 
-template <int MODE> struct TileGeom;
-template <> struct TileGeom<CONV_S1> { static constexpr int LR = 10, LC = 18, PLANE = plane_pitch16(10 * 18); };
-template <> struct TileGeom<CONV_S2> { static constexpr int LR = 17, LC = 33, PLANE = (17 * 33) | 1; };
-template <> struct TileGeom<CONV_T2> { static constexpr int LR = 9, LC = 17, PLANE = plane_pitch16(9 * 17); };
+// window of a block of BR output rows x 16 output columns (CONV_T2: input positions)
+template <int MODE, int BR = 8> struct TileGeom;
+template <int BR> struct TileGeom<CONV_S1, BR> { static constexpr int LR = BR + 2, LC = 18, PLANE = plane_pitch16((BR + 2) * 18); };
+template <int BR> struct TileGeom<CONV_S2, BR> { static constexpr int LR = 2 * BR + 1, LC = 33, PLANE = ((2 * BR + 1) * 33) | 1; };
+template <int BR> struct TileGeom<CONV_T2, BR> { static constexpr int LR = BR + 1, LC = 17, PLANE = plane_pitch16((BR + 1) * 17); };
 
 // KB = input channels per LDS chunk (template parameter: 8 = two MFMA k-steps, 4 = one)
 
@@ -52,11 +53,12 @@ template <> struct TileGeom<CONV_T2> { static constexpr int LR = 9, LC = 17, PLA
 //  * two named register sets for the A fragments and two chunks per loop trip: the fragments and the activation
 //    tile of chunk k+1 are requested before the MFMAs of chunk k and waited for once, after them (vmcnt retires
 //    in order; a single explicit wait keeps the compiler from scheduling its own in the middle of the chain).
-template <int MT, int WM, int MODE, int KB, int PY, int PX>
+template <int MT, int WM, int MODE, int KB, int PY, int PX, int BR = 8>
 __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
-  using TG = TileGeom<MODE>;
+  using TG = TileGeom<MODE, BR>;
   constexpr int LR = TG::LR, LC = TG::LC, PLANE = TG::PLANE, GP = group_pitch(PLANE, KB / 4);
-  constexpr int WN = 4 / WM, NTR = 8 / WN;
+  constexpr int WN = 4 / WM, NTR = BR / WN;
+  static_assert(NTR >= 1, "rows per wave");
   constexpr int STR = (MODE == CONV_S2) ? 2 : 1;
   constexpr int NTY = (MODE == CONV_T2) ? 1 + PY : 3;
   constexpr int NTX = (MODE == CONV_T2) ? 1 + PX : 3;
@@ -64,7 +66,7 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
   const int wm = wave % WM, wn = wave / WM;
   const int p = lane & 15, q = lane >> 4;
   const int D = a.D, KCT = D / 4, NTILES = D / 16;
-  const int r0 = by * 8, c0 = bx * 16;                       // block origin (output rows/cols, or input i/j for T2)
+  const int r0 = by * BR, c0 = bx * 16;                      // block origin (output rows/cols, or input i/j for T2)
   const int iy0 = (MODE == CONV_T2) ? r0 : r0 * STR - 1;
   const int ix0 = (MODE == CONV_T2) ? c0 : c0 * STR - 1;
   constexpr int NTAP = NTY * NTX;
@@ -331,6 +333,155 @@ __device__ __forceinline__ void conv_dd_t2_all(const ConvDDArgs& a, float* lds, 
   run_class(I0{}, I0{}, I0{}, I0{}, std::false_type{});
 }
 
+// ConvTranspose2d(k3, s2, p1, op1) with the four output parity classes of a block of input positions advanced TOGETHER,
+// chunk by chunk of input channels.  conv_dd_t2_all above runs the classes one after the other: each loads the whole
+// input window again and spends a barrier pair per channel chunk on 1, 2, 2 or 4 taps (24 ... 96 MFMAs per wave), which is
+// why the transposed layers sat at 40-71 % of the matrix rate.  Here a chunk is loaded once and feeds all nine
+// (input offset, class) pairs -- exactly the nine taps of the 3 x 3 kernel, each used once:
+//     offset (0,0): class 00 tap (1,1) | 01 (1,2) | 10 (2,1) | 11 (2,2);  offset (0,1): 01 (1,0) | 11 (2,0);
+//     offset (1,0): 10 (0,1) | 11 (0,2);  offset (1,1): 11 (0,0)          (class = output parity (py, px))
+// The price is four accumulator sets: at two waves per SIMD they leave room for BR = 2 rows x 16 columns of input
+// positions per block (4 x 32 outputs; 4 rows need one wave per SIMD and were 40 % slower, 8 rows spill), i.e. 54 MFMAs
+// per wave and barrier pair -- the average of the class-by-class kernel, but uniformly, with the window loaded once and
+// four times the workgroups: it wins on SMALL grids (the deep levels of the hourglass, few tiles per launch) and is
+// chosen there (launch_conv_dd_cfg).
+template <int MT, int WM, int KB, int BR>
+__device__ __forceinline__ void conv_dd_t2_fused(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
+  constexpr int LR = BR + 1, LC = 17, PLANE = plane_pitch16(LR * LC), GP = group_pitch(PLANE, KB / 4);
+  constexpr int WN = 4 / WM, NTR = BR / WN;
+  static_assert(NTR >= 1, "rows per wave");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+  const int wm = wave % WM, wn = wave / WM;
+  const int p = lane & 15, q = lane >> 4;
+  const int D = a.D, KCT = D / 4, NTILES = D / 16;
+  const int r0 = by * BR, c0 = bx * 16;                      // block origin: input positions (i, j)
+  constexpr int NITEMS = LR * LC * (KB / 4), NITA = (NITEMS + 255) / 256;
+
+  const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.hi + r0) * a.wi + c0) * (long)D * 4);
+  unsigned xoff[NITA], xlds[NITA];
+#pragma unroll
+  for (int it = 0; it < NITA; ++it) {
+    const int i = min(tid + it * 256, NITEMS - 1);           // surplus lanes repeat the last item
+    const int g = i % (KB / 4), pp = i / (KB / 4), r = pp / LC, c = pp % LC;
+    const bool ok = r0 + r < a.hi && c0 + c < a.wi;
+    xoff[it] = ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB;
+    xlds[it] = (unsigned)((g * GP + r * LC + c) * 4);
+    pin(xoff[it]); pin(xlds[it]);
+  }
+  const buf_rsrc rw = make_rsrc(a.wpk);
+  unsigned woff = (unsigned)(lane * 4);
+  pin(woff);
+  unsigned xb[KB / 4];
+#pragma unroll
+  for (int kc = 0; kc < KB / 4; ++kc) {
+    xb[kc] = (unsigned)((kc * GP + q * PLANE + (wn * NTR) * LC + p) * 4);
+    pin(xb[kc]);
+  }
+
+  f32x4 acc[4][MT][NTR];                                     // [class = 2 py + px]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NTR; ++r) acc[c][mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_w = [&](float (&wf)[9][KB / 4][MT], int ch) {    // all nine taps of the chunk, tap = ky * 3 + kx
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kc = 0; kc < KB / 4; ++kc)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned frag = (unsigned)((t * KCT + ch / 4 + kc) * NTILES + wm * MT + mt) * 256u;   // uniform
+          wf[t][kc][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, frag, 0));
+        }
+  };
+  auto load_x = [&](f32x4 (&st)[NITA], int ch) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it)
+      st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+  };
+  auto store_x = [&](const f32x4 (&st)[NITA]) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+      float* dl = (float*)((char*)lds + xlds[it]);
+      dl[0] = st[it].x; dl[PLANE] = st[it].y; dl[2 * PLANE] = st[it].z; dl[3 * PLANE] = st[it].w;
+    }
+  };
+  auto mfma_chunk = [&](const float (&wf)[9][KB / 4][MT]) {
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+        for (int kc = 0; kc < KB / 4; ++kc) {
+          float bv[NTR];
+#pragma unroll
+          for (int r = 0; r < NTR; ++r) bv[r] = *(const float*)((const char*)lds + xb[kc] + ((r + ty) * LC + tx) * 4);
+#pragma unroll
+          for (int py = ty; py < 2; ++py)                    // classes that reach input offset (ty, tx)
+#pragma unroll
+            for (int px = tx; px < 2; ++px) {
+              const int ky = py ? (ty ? 0 : 2) : 1, kx = px ? (tx ? 0 : 2) : 1;
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < NTR; ++r)
+                  acc[2 * py + px][mt][r] = mfma16(wf[ky * 3 + kx][kc][mt], bv[r], acc[2 * py + px][mt][r]);
+            }
+        }
+  };
+
+  float wfA[9][KB / 4][MT], wfB[9][KB / 4][MT];
+  f32x4 xs[NITA];
+  load_w(wfA, 0);
+  load_x(xs, 0);
+  for (int ch = 0; ch < D; ch += 2 * KB) {       // D / KB is even for every supported D
+    wait_vmem_all();
+    __syncthreads();                    // previous chunk's readers are done
+    store_x(xs);
+    __syncthreads();
+    load_w(wfB, ch + KB);
+    load_x(xs, ch + KB);
+    mfma_chunk(wfA);
+
+    wait_vmem_all();
+    __syncthreads();
+    store_x(xs);
+    __syncthreads();
+    if (ch + 2 * KB < D) {
+      load_w(wfA, ch + 2 * KB);
+      load_x(xs, ch + 2 * KB);
+    }
+    mfma_chunk(wfB);
+  }
+
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < NTR; ++r) {
+      const int row = r0 + wn * NTR + r, col = c0 + p;
+      if (!(row < a.hi && col < a.wi)) continue;
+      const size_t opix = ((size_t)n * a.ho + 2 * row + (c >> 1)) * a.wo + 2 * col + (c & 1);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co4 = (wm * MT + mt) * 16 + 4 * q;
+        f32x4 v = acc[c][mt][r] + *(const f32x4*)(a.bias + co4);
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.skip) v += *(const f32x4*)(a.skip + opix * D + co4);
+        *(f32x4*)(a.out + opix * D + co4) = v;
+      }
+    }
+}
+
+// grid: (ceil(cols/16), ceil(rows/BR), N); block 256; OCC = waves per SIMD the register budget is held to
+template <int MT, int WM, int KB, int BR, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_conv_dd_t2_fused(ConvDDArgs a) {
+  __shared__ float lds[(KB / 4) * group_pitch(plane_pitch16((BR + 1) * 17), KB / 4)];
+  conv_dd_t2_fused<MT, WM, KB, BR>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+}
+
 // grid: (ceil(cols/16), ceil(rows/8), N); block 256
 template <int MT, int WM, int MODE, int KB>
 __global__ __launch_bounds__(256, (MT == 4 && WM == 4) ? 1 : 2) void k_conv_dd(ConvDDArgs a) {
@@ -342,16 +493,50 @@ __global__ __launch_bounds__(256, (MT == 4 && WM == 4) ? 1 : 2) void k_conv_dd(C
   }
 }
 
+// Stride-1 / stride-2 layers on a SMALL grid (the deep levels of the hourglass when few maps are in flight: 12 x 24 maps
+// of 16 tiles are 64 blocks of 8 x 16 on 256 CUs, a third of each block padding): blocks of 2 output rows, four times the
+// workgroups, no padded rows.  54 MFMAs per wave and barrier pair instead of 216 -- it pays only while the chip is not full.
+template <int MT, int WM, int MODE, int KB>
+__global__ __launch_bounds__(256, 2) void k_conv_dd_rows2(ConvDDArgs a) {
+  __shared__ float lds[(KB / 4) * group_pitch(TileGeom<MODE, 2>::PLANE, KB / 4)];
+  conv_dd_body<MT, WM, MODE, KB, 0, 0, 2>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+}
+
+// Measured (cfg3, 4 / 32 tiles per step): 64 blocks of 8 rows 0.185 -> 0.073 ms, 144: 0.193 -> 0.139, 576: 0.49 -> 0.38, 512: 0.33 -> 0.25,
+// 1152: 0.80 -> 0.72; at 4608 blocks it is a wash and beyond it loses (10.9 -> 11.2 ms).  ADAMVS_CONV_ROWS2=0 / 1 forces.
+static bool small_grid_rows2(long blocks8) {
+  const char* e = getenv("ADAMVS_CONV_ROWS2");
+  if (e && *e) return atoi(e) != 0;
+  return blocks8 <= 2048;
+}
+
 // Two waves per SIMD (a single wave feeding the matrix pipe from LDS reaches ~83 % of it, two reach ~92 %:
 // tools/microbench/mfma_issue.hip), i.e. at most 256 registers: the widest tilings take one k-step per chunk
 // (D = 256 does not fit even so and keeps one wave).
+// Which transposed kernel: measured (tools/r02_t2_ab.sh), the fused form wins while the class-by-class grid is small --
+// 64 ... 2048 blocks: 0.246 -> 0.080 ms, 0.267 -> 0.169, 0.646 -> 0.509, 1.57 -> 1.31 -- and loses on the large layers
+// (4608 blocks: 3.61 -> 3.92 ms; 18432: 14.1 -> 15.4), where the 4-tap class alone already gives the class-by-class
+// kernel 96 MFMAs per barrier pair.  ADAMVS_T2_FUSED=0 / 1 forces one of them (A/B timing).
+static bool t2_fused(long blocks_class_by_class) {
+  const char* e = getenv("ADAMVS_T2_FUSED");
+  if (e && *e) return atoi(e) != 0;
+  return blocks_class_by_class <= 2048;
+}
+
 template <int MT, int WM>
 static int launch_conv_dd_cfg(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
   constexpr int KB = (WM == 4 || (MT == 4 && WM == 2)) ? 4 : 8;
-  if (mode == CONV_S1)
+  const bool rows2 = WM >= 2 && mode != CONV_T2 && small_grid_rows2((long)cdiv(a.wo, 16) * cdiv(a.ho, 8) * N);
+  if (mode == CONV_S1 && rows2)
+    hipLaunchKernelGGL((k_conv_dd_rows2<MT, (WM >= 2 ? WM : 2), CONV_S1, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 2), N), dim3(256), 0, st, a);
+  else if (mode == CONV_S2 && rows2)
+    hipLaunchKernelGGL((k_conv_dd_rows2<MT, (WM >= 2 ? WM : 2), CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 2), N), dim3(256), 0, st, a);
+  else if (mode == CONV_S1)
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S1, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
   else if (mode == CONV_S2)
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
+  else if (WM >= 2 && t2_fused((long)cdiv(a.wi, 16) * cdiv(a.hi, 8) * N))      // small grids: 2-row blocks, all classes per chunk
+    hipLaunchKernelGGL((k_conv_dd_t2_fused<MT, (WM >= 2 ? WM : 2), 4, 2, 2>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 2), N), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_T2, KB>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N), dim3(256), 0, st, a);
   ADAMVS_CHECK_LAUNCH("conv_dd");

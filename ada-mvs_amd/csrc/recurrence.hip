@@ -168,7 +168,7 @@ static const RoleCosts& role_costs() {
 // cfg4's 4 tiles per GPU 24.3 -> 22.0 ms) and costs 2-3 % once every role fills the chip several times over.
 int recurrence_mode(int precision, long pixels) {
   const char* e = getenv("ADAMVS_RECUR_MODE");
-  if (e) return atoi(e);
+  if (e && *e) return atoi(e);
   // B * h * w of the stage.  Measured (profiles/r02_recurrence_schedules.txt): fp32 -- two launches per hypothesis win up
   // to ~200k pixels (cfg4's 4 tiles per GPU at stage 1: 7.8 -> 5.9 -> 5.1 ms), three up to ~800k, six beyond;
   // bf16x3 (its level 1 is one kernel already) -- three up to ~130k, five beyond.
