@@ -12,7 +12,9 @@
 //
 //   fp32     slot A(t): gates1(t) | conv2(t-1)      slot B(t): cand1(t) | gates2(t-1)     slot C(t): cand2(t-1) | decoder(t-2)
 //   bf16x3   slot A(t): gru1(t)   | conv2(t-1)      slot B(t): gru1(t)' | gates2(t-1) | decoder(t-2)'    slot C(t): gru1(t)'' | cand2(t-1) | decoder(t-2)''
-//            (the fused level-1 kernel has no dependant inside its step: its tiles are spread over the three slots)
+//            (the fused level-1 kernel has no dependant inside its step: its tiles are spread over the slots)
+//   two launches (schedule 3, small stages):  A(t): level-1 gates (bf16x3: gru1) | conv2+gates2(t-1) in two halves
+//                                             B(t): cand1 (bf16x3: gru1') | cand2(t-1) | decoder(t-2)
 //
 // State rings: h1 of step t lives in h1[t % 4] (the decoder still reads h1[t-2] or h1[t-3] while cand1 writes h1[t]),
 // h2 and conv2's output of step t in h2[t % 2], c2[t % 2].  The arithmetic of every tile is that of the one-role kernels (slice_roles.h): the pipelined stage
@@ -171,8 +173,9 @@ int recurrence_mode(int precision, long pixels) {
   if (e && *e) return atoi(e);
   // B * h * w of the stage.  Measured (profiles/r02_recurrence_schedules.txt): fp32 -- two launches per hypothesis win up
   // to ~200k pixels (cfg4's 4 tiles per GPU at stage 1: 7.8 -> 5.9 -> 5.1 ms), three up to ~800k, six beyond;
-  // bf16x3 (its level 1 is one kernel already) -- three up to ~130k, five beyond.
-  if (precision != PRECISION_FP32) return pixels <= (1L << 17) ? 1 : 0;
+  // bf16x3 (its level 1 is one kernel already) -- two up to ~300k (cfg4's share at stage 1: 5.85 / 4.79 / 4.35 ms with five /
+  // three / two launches; at 295k pixels 10.5 / 11.4 / 10.0), five beyond.
+  if (precision != PRECISION_FP32) return pixels <= 300000 ? 3 : 0;
   return pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0);
 }
 
@@ -184,8 +187,9 @@ template <class R> static RoleUse<R> none() { return RoleUse<R>{nullptr, 0.f, 0.
 // How far level-2's candidate and the decoder run behind level 1 (in hypotheses) under a schedule.
 //   schedule 1 (the default)         A: gates1(t) | conv2(t-1)    B: cand1(t) | gates2(t-1)              C: cand2(t-1) | decoder(t-2)
 //   schedule 2 (fp32 only)           A: gates1(t) | conv2(t-1)    B: cand1(t) | cand2(t-2) | decoder(t-3)   C: gates2(t-1)
-//   schedule 3 (fp32 only)           A: gates1(t) | conv2+gates2(t-1)   B: cand1(t) | cand2(t-1) | decoder(t-2)
-//                                    two dependent launches per hypothesis (Conv2Gates2Role fuses conv2 into the gate kernel)
+//   schedule 3                       A: gates1(t) | conv2+gates2(t-1)   B: cand1(t) | cand2(t-1) | decoder(t-2)
+//                                    two dependent launches per hypothesis (Conv2Gates2Role fuses conv2 into the gate kernel);
+//                                    bf16x3: the fused level-1 kernel takes the place of gates1 and cand1, its tiles dealt to both
 // Schedule 2 keeps the one role that needs 234 registers (gates2: two 16-row output tiles of 32 input channels, 144
 // registers of weights) in a launch of its own, so that the roles sharing a launch all run at three to five waves per
 // SIMD; in schedule 1 cand1 runs at gates2's two.
@@ -218,6 +222,29 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
     // the level-1 kernel and the decoder have no dependant inside the step: their tiles fill up slots B and C
     const float fa = l2 ? k.fa : 1.0f, fb = l2 ? k.fb : 1.0f;         // gru1: [0,fa) in A, [fa,fb) in B, [fb,1) in C
     const float fd = l2 ? k.fd : 0.0f;                                 // decoder: [0,fd) in B, [fd,1) in C
+    if (schedule == 3) {
+      // two launches: A: gru1(t) [0,f) | conv2+gates2(t-1), r half | u half     B: gru1(t) [f,1) | cand2(t-1) | decoder(t-2)
+      Conv2Gates2BxArgs vg{H1(s2), H2(s2 - 1), (const bf16x8*)fw.conv2, (const bf16x8*)fw.gates2, fw.gates2_b, C2(s2), rb.rh2, rb.u2, h, w, h2, w2};
+      const float vgc = 0.5f * k.g2bx + 1.7f * k.v2bx;                 // one half per level-2 tile: conv2 on the 6 x 18 window + 16 gate rows
+      float f = 0.5f + ((0.25f * k.c2bx + k.dec) - 0.5f * vgc) / (2.f * k.k1bx);      // equal work in the two launches (4 level-1 tiles per level-2 tile)
+      f = !l2 ? 1.0f : (f < 0.1f ? 0.1f : (f > 1.f ? 1.f : f));
+      if (l1 || l2)
+        if ((rc = launch_slot<Gru1Bx, Conv2Gates2Bx3Role<0>, Conv2Gates2Bx3Role<1>>(
+                 l1 ? use<Gru1Bx>(&g1, k.k1bx, 0.f, f) : none<Gru1Bx>(), l2 ? use<Conv2Gates2Bx3Role<0>>(&vg, vgc) : none<Conv2Gates2Bx3Role<0>>(),
+                 l2 ? use<Conv2Gates2Bx3Role<1>>(&vg, vgc) : none<Conv2Gates2Bx3Role<1>>(), B, st, "recurrence slot A (bf16x3, schedule 3)")))
+          return rc;
+      const bool rest = l1 && f < 1.f;
+      if (!(rest || lc || dec)) return 0;
+      if (in_up)
+        return launch_slot<Gru1Bx, Cand2Bx, DecoderRole<true>>(rest ? use<Gru1Bx>(&g1, k.k1bx, f, 1.f) : none<Gru1Bx>(),
+                                                               lc ? use<Cand2Bx>(&c2, k.c2bx) : none<Cand2Bx>(),
+                                                               dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(), B, st,
+                                                               "recurrence slot B (bf16x3, schedule 3)");
+      return launch_slot<Gru1Bx, Cand2Bx, DecoderRole<false>>(rest ? use<Gru1Bx>(&g1, k.k1bx, f, 1.f) : none<Gru1Bx>(),
+                                                              lc ? use<Cand2Bx>(&c2, k.c2bx) : none<Cand2Bx>(),
+                                                              dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st,
+                                                              "recurrence slot B (bf16x3, schedule 3)");
+    }
     if (l1 || l2)
       if ((rc = launch_slot<Gru1Bx, Conv2Bx, NopRole>(l1 ? use<Gru1Bx>(&g1, k.k1bx, 0.f, fa) : none<Gru1Bx>(),
                                                       l2 ? use<Conv2Bx>(&v2, k.v2bx) : none<Conv2Bx>(), none<NopRole>(), B, st,
