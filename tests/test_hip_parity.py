@@ -530,6 +530,44 @@ def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, monkeypatch, c
                 assert torch.equal(outs["0"][s][key], outs[mode][s][key]), (mode, s, key)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("stage,h,w", [(1, 22, 38), (2, 26, 50), (1, 4, 6)])
+def test_pipelined_recurrence_on_ragged_stage_sizes(hip, O, monkeypatch, precision, stage, h, w):
+    """One cascade stage (InferDepthNet0.forward, reference adamvs.py:433-533) on maps no tile size of any role divides
+    (level-2 maps 11 x 19, 13 x 25, 2 x 3; the end-to-end model only meets multiples of 8) and 40 hypotheses = one
+    full chunk of 32 plus a ragged one.  Every schedule of the recurrence -- the two-launch one runs conv2 inside the
+    level-2 gate tiles -- must equal the sequential launches bit for bit, and those the CPU oracle."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    B, V, D = 2, 3, 40
+    m = Infer_AdaMVSNet(48, [48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8], precision=precision)
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    net = m.DepthNet[stage]
+    C = (32, 16, 8)[stage]
+    feats = [synth.smooth_features(B, C, h, w, seed=40 + v) for v in range(V)]
+    proj = synth.rig_projections(V, 4 * h, 4 * w, batch=B)["stage1"]
+    g = torch.Generator().manual_seed(7)
+    near = 420.0 + 20.0 * torch.rand(B, 1, h, w, generator=g)
+    planes = (near + 4.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).contiguous()
+    prev = [torch.rand(B, 1, h // 2, w // 2, generator=g) for _ in range(V - 1)]
+    outs = {}
+    for mode in ("0", "1", "2", "3"):
+        monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
+        with torch.no_grad():
+            outs[mode] = net([dev(f) for f in feats], dev(proj), dev(planes), D, [dev(c) for c in prev])
+        torch.cuda.synchronize()
+    for mode in ("1", "2", "3"):
+        for key in ("depth", "photometric_confidence"):
+            assert torch.equal(outs["0"][key], outs[mode][key]), (mode, key)
+    with torch.no_grad():
+        ref = O.infer_depth_stage(feats, proj, planes, sd, "DepthNet.%d." % stage, net.in_up, prev)
+    tol = E2E_TOL if precision == "fp32" else 5e-4
+    for key in ("depth", "photometric_confidence"):
+        assert outs["0"][key].shape == ref[key].shape
+        assert rel_l1(outs["0"][key], ref[key]) < tol, key
+
+
 def test_soft_argmin_op(hip):
     """adamvs_soft_argmin (reference adamvs.py:516-531) by itself: exp without max subtraction, strict
     '<' running maximum from 0, +1e-10 on the sum.  (The 2x-upsampled-plane form and the chunked accumulation of the
