@@ -43,6 +43,13 @@ class FeatureWeights(ctypes.Structure):
                [(n, ContextWeights) for n in ("br1_1", "br1_2", "br2_1", "br2_2", "br3_1", "br3_2")]
 
 
+class FeatureFpnWeights(ctypes.Structure):
+    """adamvs_feature_fpn_weights"""
+    _fields_ = [(n, FConvWeights) for n in (
+        "conv0_0", "conv0_1", "conv1_0", "conv1_1", "conv1_2", "conv2_0", "conv2_1", "conv2_2",
+        "out1", "inner1", "out2", "inner2", "out3")]
+
+
 class StageDesc(ctypes.Structure):
     """adamvs_stage_desc"""
     _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision", "precision_fuse",
@@ -76,6 +83,8 @@ SIGNATURES = {
                                          c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_feature_net0_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "adamvs_feature_net0": (c_i, [c_f, ctypes.POINTER(FeatureWeights), c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_feature_net_fpn_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "adamvs_feature_net_fpn": (c_i, [c_f, ctypes.POINTER(FeatureFpnWeights), c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_red_variance_cost": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_channel_copy": (c_i, [c_f, c_f, c_i, c_i, c_i, ctypes.c_long, c_i, c_i, ctypes.c_long, c_i, c_i, c_st]),
     "adamvs_group_stats_workspace_bytes": (c_sz, [c_i, c_i]),
@@ -92,7 +101,7 @@ SIGNATURES = {
     "adamvs_soft_argmin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 PLANES_EXPLICIT, PLANES_UNIFORM, PLANES_WINDOW = 0, 1, 2
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15

@@ -24,7 +24,7 @@
 namespace adamvs {
 
 enum { FM_K3 = 0, FM_K5S2 = 1, FM_K1 = 2, FM_TALL = 3 };      // FM_TALL: ConvTranspose2d(k3, s2, p1, op1), all four parity classes
-enum { FE_RELU = 1, FE_CONTEXT = 2 };
+enum { FE_RELU = 1, FE_CONTEXT = 2, FE_ADD_UP = 4 };       // FE_ADD_UP: + nearest-neighbour 2x upsampling of ctxA [N][(ho/2)(wo/2)][ctot] (FPN top-down path)
 
 struct FConvArgs {
   const float* srcA;     // [N][hi*wi][CA]
@@ -184,6 +184,10 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
         ctx[nt] = up_sample4(a.ctxA, n, a.hA, a.wA, a.ctot, c, y, x, a.syA, a.sxA) +
                   up_sample4(a.ctxB, n, a.hB, a.wB, a.ctot, c, y, x, a.syB, a.sxB);
       }
+      if ((EPI & FE_ADD_UP) && valid && nt * 16 + 4 * q < a.cout) {      // F.interpolate(scale_factor=2, mode="nearest"): source (y/2, x/2)
+        const int c = a.co0 + nt * 16 + 4 * q, y = (oy0 + row) >> 1, x = (ox0 + p) >> 1;
+        ctx[nt] = *(const f32x4*)(a.ctxA + (((size_t)n * a.hA + y) * a.wA + x) * a.ctot + c);
+      }
     }
     const int tn = t + gridDim.x;
     const bool more = tn < tg.ntiles;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
       for (int nt = 0; nt < NT; ++nt) {
         f32x4 v = acc[nt] + bias[nt];
         if (EPI & FE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (EPI & FE_CONTEXT) v += ctx[nt];
+        if (EPI & (FE_CONTEXT | FE_ADD_UP)) v += ctx[nt];
         buf_store4(ro, valid ? ooff[nt] : BUF_OOB, v);
       }
     }
@@ -374,6 +378,89 @@ extern "C" size_t adamvs_feature_net0_workspace_bytes(int N, int H, int W) {
   return f * sizeof(float);
 }
 
+// conv0 / conv1 / conv2 of both feature nets (reference models/adamvs.py:57-76 = models/msrednet.py:38-54): imgs -> c0 [N][HW][8],
+// c1 [N][HW/4][16], c2 [N][HW/16][32]; rgb4, c0a, c1a, c1b, c2a, c2b are scratch.
+struct EncoderWeights { adamvs_fconv_weights conv0_0, conv0_1, conv1_0, conv1_1, conv1_2, conv2_0, conv2_1, conv2_2; };
+static FConvArgs fconv_args(const float* sa, const float* sb, const adamvs_fconv_weights& w, float* out, int hi, int wi, int ho, int wo,
+                            int cout, int ctot, int co0) {
+  return FConvArgs{sa, sb, w.w, w.b, out, nullptr, nullptr, hi, wi, ho, wo, cout, ctot, co0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
+}
+static int run_encoder(const float* imgs, const EncoderWeights& fw, float* rgb4, float* c0a, float* c0, float* c1a, float* c1b, float* c1,
+                       float* c2a, float* c2b, float* c2, int N, int H, int W, hipStream_t st) {
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+  int rc;
+  {
+    const size_t hw = (size_t)H * W, total = (size_t)N * hw;
+    hipLaunchKernelGGL(k_pack_rgb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, imgs, rgb4, hw, total);
+    ADAMVS_CHECK_LAUNCH("feature net pack_rgb");
+  }
+  auto A = fconv_args;
+  // conv0: 3(+1) -> 8 -> 8 at full resolution
+  if ((rc = launch_fconv<4, 0, 1, FM_K3, FE_RELU>(A(rgb4, nullptr, fw.conv0_0, c0a, H, W, H, W, 8, 8, 0), N, st, "conv0.0"))) return rc;
+  if ((rc = launch_fconv<8, 0, 1, FM_K3, FE_RELU>(A(c0a, nullptr, fw.conv0_1, c0, H, W, H, W, 8, 8, 0), N, st, "conv0.1"))) return rc;
+  // conv1: 5x5 stride 2 (8 -> 16), two 3x3
+  if ((rc = launch_fconv<8, 0, 1, FM_K5S2, FE_RELU>(A(c0, nullptr, fw.conv1_0, c1a, H, W, H2, W2, 16, 16, 0), N, st, "conv1.0"))) return rc;
+  if ((rc = launch_fconv<16, 0, 1, FM_K3, FE_RELU>(A(c1a, nullptr, fw.conv1_1, c1b, H2, W2, H2, W2, 16, 16, 0), N, st, "conv1.1"))) return rc;
+  if ((rc = launch_fconv<16, 0, 1, FM_K3, FE_RELU>(A(c1b, nullptr, fw.conv1_2, c1, H2, W2, H2, W2, 16, 16, 0), N, st, "conv1.2"))) return rc;
+  // conv2: 5x5 stride 2 (16 -> 32: two launches of 16 output channels, 100 fragment registers each), two 3x3
+  for (int half = 0; half < 2; ++half) {
+    adamvs_fconv_weights wh{fw.conv2_0.w + (size_t)half * 25 * 4 * 64, fw.conv2_0.b + half * 16};
+    if ((rc = launch_fconv<16, 0, 1, FM_K5S2, FE_RELU>(A(c1, nullptr, wh, c2a, H2, W2, H4, W4, 16, 32, 16 * half), N, st, "conv2.0"))) return rc;
+  }
+  if ((rc = launch_fconv<32, 0, 2, FM_K3, FE_RELU>(A(c2a, nullptr, fw.conv2_1, c2b, H4, W4, H4, W4, 32, 32, 0), N, st, "conv2.1"))) return rc;
+  if ((rc = launch_fconv<32, 0, 2, FM_K3, FE_RELU>(A(c2b, nullptr, fw.conv2_2, c2, H4, W4, H4, W4, 32, 32, 0), N, st, "conv2.2"))) return rc;
+  return 0;
+}
+
+// ---- the FPN variant of MS-REDNet's FeatureNet (reference models/msrednet.py:74-91, 115-125; arch_mode "fpn", three stages).
+// Workspace (floats): the encoder's maps, then t1 [N][HW/4][32] and t2 [N][HW][32] (the top-down maps).
+extern "C" size_t adamvs_feature_net_fpn_workspace_bytes(int N, int H, int W) {
+  const size_t hw = (size_t)H * W, n = (size_t)N;
+  const size_t f = al64(n * hw * 4) + 2 * al64(n * hw * 8) + 3 * al64(n * hw / 4 * 16) + 3 * al64(n * hw / 16 * 32) +
+                   al64(n * hw / 4 * 32) + al64(n * hw * 32);
+  return f * sizeof(float);
+}
+
+extern "C" int adamvs_feature_net_fpn(const float* imgs, const adamvs_feature_fpn_weights* wts, float* stage1, float* stage2,
+                                      float* stage3, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(imgs && wts && stage1 && stage2 && stage3 && workspace, "feature_net_fpn: null pointer");
+  ADAMVS_CHECK_ARG(N > 0 && H >= 32 && W >= 32 && (H % 32) == 0 && (W % 32) == 0,
+                   "feature_net_fpn: N=%d H=%d W=%d (H, W multiples of 32)", N, H, W);
+  ADAMVS_CHECK_ARG(workspace_bytes >= adamvs_feature_net_fpn_workspace_bytes(N, H, W), "feature_net_fpn: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const adamvs_feature_fpn_weights& fw = *wts;
+  const size_t hw = (size_t)H * W, n = (size_t)N;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+  float* p = (float*)workspace;
+  auto take = [&](size_t floats) { float* r = p; p += al64(floats); return r; };
+  float* rgb4 = take(n * hw * 4);
+  float* c0a = take(n * hw * 8); float* c0 = take(n * hw * 8);
+  float* c1a = take(n * hw / 4 * 16); float* c1b = take(n * hw / 4 * 16); float* c1 = take(n * hw / 4 * 16);
+  float* c2a = take(n * hw / 16 * 32); float* c2b = take(n * hw / 16 * 32); float* c2 = take(n * hw / 16 * 32);
+  float* t1 = take(n * hw / 4 * 32); float* t2 = take(n * hw * 32);
+  int rc;
+  const EncoderWeights enc{fw.conv0_0, fw.conv0_1, fw.conv1_0, fw.conv1_1, fw.conv1_2, fw.conv2_0, fw.conv2_1, fw.conv2_2};
+  if ((rc = run_encoder(imgs, enc, rgb4, c0a, c0, c1a, c1b, c1, c2a, c2b, c2, N, H, W, st))) return rc;
+  auto A = fconv_args;
+  // stage 1: out1 (1x1, 32 -> 32) on conv2
+  if ((rc = launch_fconv<32, 0, 2, FM_K1, 0>(A(c2, nullptr, fw.out1, stage1, H4, W4, H4, W4, 32, 32, 0), N, st, "fpn out1"))) return rc;
+  // t1 = nearest2x(conv2) + inner1(conv1) (1x1, 16 -> 32, bias); stage 2: out2 (3x3, 32 -> 16) on t1
+  {
+    FConvArgs a = A(c1, nullptr, fw.inner1, t1, H2, W2, H2, W2, 32, 32, 0);
+    a.ctxA = c2; a.hA = H4; a.wA = W4;
+    if ((rc = launch_fconv<16, 0, 2, FM_K1, FE_ADD_UP>(a, N, st, "fpn inner1"))) return rc;
+  }
+  if ((rc = launch_fconv<32, 0, 1, FM_K3, 0>(A(t1, nullptr, fw.out2, stage2, H2, W2, H2, W2, 16, 16, 0), N, st, "fpn out2"))) return rc;
+  // t2 = nearest2x(t1) + inner2(conv0) (1x1, 8 -> 32, bias); stage 3: out3 (3x3, 32 -> 8) on t2
+  {
+    FConvArgs a = A(c0, nullptr, fw.inner2, t2, H, W, H, W, 32, 32, 0);
+    a.ctxA = t1; a.hA = H2; a.wA = W2;
+    if ((rc = launch_fconv<8, 0, 2, FM_K1, FE_ADD_UP>(a, N, st, "fpn inner2"))) return rc;
+  }
+  if ((rc = launch_fconv<32, 0, 1, FM_K3, 0>(A(t2, nullptr, fw.out3, stage3, H, W, H, W, 8, 8, 0), N, st, "fpn out3"))) return rc;
+  return 0;
+}
+
 extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weights* wts, float* stage1, float* stage2,
                                    float* stage3, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
   ADAMVS_CHECK_ARG(imgs && wts && stage1 && stage2 && stage3 && workspace, "feature_net0: null pointer");
@@ -396,30 +483,9 @@ extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weigh
   float* x2a = take(n * (hw / 4 / 16) * 16); float* x2b = take(n * (hw / 4 / 16) * 16);
   float* x3a = take(n * (hw / 16) * 8); float* x3b = take(n * (hw / 16) * 8);
   int rc;
-  {
-    const size_t total = n * hw;
-    hipLaunchKernelGGL(k_pack_rgb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, imgs, rgb4, hw, total);
-    ADAMVS_CHECK_LAUNCH("feature_net0 pack_rgb");
-  }
-  auto A = [&](const float* sa, const float* sb, const adamvs_fconv_weights& w, float* out, int hi, int wi, int ho, int wo,
-               int cout, int ctot, int co0) {
-    FConvArgs a{sa, sb, w.w, w.b, out, nullptr, nullptr, hi, wi, ho, wo, cout, ctot, co0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
-    return a;
-  };
-  // conv0: 3(+1) -> 8 -> 8 at full resolution
-  if ((rc = launch_fconv<4, 0, 1, FM_K3, FE_RELU>(A(rgb4, nullptr, fw.conv0_0, c0a, H, W, H, W, 8, 8, 0), N, st, "conv0.0"))) return rc;
-  if ((rc = launch_fconv<8, 0, 1, FM_K3, FE_RELU>(A(c0a, nullptr, fw.conv0_1, c0, H, W, H, W, 8, 8, 0), N, st, "conv0.1"))) return rc;
-  // conv1: 5x5 stride 2 (8 -> 16), two 3x3
-  if ((rc = launch_fconv<8, 0, 1, FM_K5S2, FE_RELU>(A(c0, nullptr, fw.conv1_0, c1a, H, W, H2, W2, 16, 16, 0), N, st, "conv1.0"))) return rc;
-  if ((rc = launch_fconv<16, 0, 1, FM_K3, FE_RELU>(A(c1a, nullptr, fw.conv1_1, c1b, H2, W2, H2, W2, 16, 16, 0), N, st, "conv1.1"))) return rc;
-  if ((rc = launch_fconv<16, 0, 1, FM_K3, FE_RELU>(A(c1b, nullptr, fw.conv1_2, c1, H2, W2, H2, W2, 16, 16, 0), N, st, "conv1.2"))) return rc;
-  // conv2: 5x5 stride 2 (16 -> 32: two launches of 16 output channels, 100 fragment registers each), two 3x3
-  for (int half = 0; half < 2; ++half) {
-    adamvs_fconv_weights wh{fw.conv2_0.w + (size_t)half * 25 * 4 * 64, fw.conv2_0.b + half * 16};
-    if ((rc = launch_fconv<16, 0, 1, FM_K5S2, FE_RELU>(A(c1, nullptr, wh, c2a, H2, W2, H4, W4, 16, 32, 16 * half), N, st, "conv2.0"))) return rc;
-  }
-  if ((rc = launch_fconv<32, 0, 2, FM_K3, FE_RELU>(A(c2a, nullptr, fw.conv2_1, c2b, H4, W4, H4, W4, 32, 32, 0), N, st, "conv2.1"))) return rc;
-  if ((rc = launch_fconv<32, 0, 2, FM_K3, FE_RELU>(A(c2b, nullptr, fw.conv2_2, c2, H4, W4, H4, W4, 32, 32, 0), N, st, "conv2.2"))) return rc;
+  const EncoderWeights enc{fw.conv0_0, fw.conv0_1, fw.conv1_0, fw.conv1_1, fw.conv1_2, fw.conv2_0, fw.conv2_1, fw.conv2_2};
+  if ((rc = run_encoder(imgs, enc, rgb4, c0a, c0, c1a, c1b, c1, c2a, c2b, c2, N, H, W, st))) return rc;
+  auto A = fconv_args;
   // stage 1 output: out1 . cat(up(branch1_1), up(branch1_2), c2)
   if ((rc = launch_context<32>(c2, fw.br1_1, fw.br1_2, x1a, x1b, N, H4, W4, st))) return rc;
   {

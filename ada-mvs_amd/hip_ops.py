@@ -209,6 +209,44 @@ def feature_net0(imgs, packed, workspace=None):
     return s1, s2, s3
 
 
+class PackedFeatureFpn:
+    """Device copy of a packed FPN FeatureNet + its adamvs_feature_fpn_weights struct."""
+
+    def __init__(self, flat, offsets, device):
+        from ._lib import FeatureFpnWeights, FConvWeights
+        from . import packing
+        self.buf = flat.to(device)
+        base = self.buf.data_ptr()
+        at = lambda f: base + 4 * offsets[f]
+        self.struct = FeatureFpnWeights(**{n: FConvWeights(at(n + ".w"), at(n + ".b")) for n in packing.FEATURE_FPN_CONVS})
+
+    def ptr(self):
+        return ctypes.byref(self.struct)
+
+
+def feature_net_fpn_workspace_bytes(N, H, W):
+    return int(_lib.load().adamvs_feature_net_fpn_workspace_bytes(int(N), int(H), int(W)))
+
+
+def feature_net_fpn(imgs, packed, workspace=None):
+    """FeatureNet(arch_mode="fpn").forward (reference models/msrednet.py:115-125) on [N,3,H,W] images -> channel-last maps."""
+    lib = _lib.load()
+    imgs = _dev(imgs, "imgs")
+    N, c, H, W = imgs.shape
+    if c != 3:
+        check(-1, "feature_net_fpn")
+    dev = imgs.device
+    s1 = torch.empty(N, (H // 4) * (W // 4), 32, device=dev, dtype=torch.float32)
+    s2 = torch.empty(N, (H // 2) * (W // 2), 16, device=dev, dtype=torch.float32)
+    s3 = torch.empty(N, H * W, 8, device=dev, dtype=torch.float32)
+    nbytes = lib.adamvs_feature_net_fpn_workspace_bytes(N, H, W)
+    if workspace is None or workspace.numel() * 4 < nbytes:
+        workspace = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+    check(lib.adamvs_feature_net_fpn(_p(imgs), packed.ptr(), _p(s1), _p(s2), _p(s3), N, H, W, _p(workspace), nbytes, _stream()),
+          "feature_net_fpn")
+    return s1, s2, s3
+
+
 def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up, precision=0):
     """SliceCostRegNetRED.forward on channel-last maps; states updated in place. -> reg [B,1,Ho,Wo]"""
     lib = _lib.load()

@@ -6,10 +6,11 @@ four-level GroupNorm ConvGRU encoder-decoder (slice_RED_Regularization, msrednet
 exp-sum / max / weighted-depth update (msrednet.py:415-436).  Every convolution runs on the fp32-MFMA k_conv_dd
 kernel (adamvs_conv3x3_dd) over channel-last maps whose channel count is zero-padded to a supported width; the
 GroupNorm statistics, gate / candidate epilogues and the variance cost are the kernels of csrc/msred.hip; FeatureNet
-is adamvs_feature_net0 with zero context-branch weights.  No CPU fallback.
+is adamvs_feature_net0 with zero context-branch weights ('unet') or adamvs_feature_net_fpn ('fpn').  No CPU fallback.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ada_mvs_amd import hip_ops, packing
 from ada_mvs_amd._lib import AdaMVSHipError
@@ -18,12 +19,14 @@ from .module import Conv2d, ConvReLU, DeConv2dFuse, PackedCache, _FusedLayer, mo
 
 
 class FeatureNet(FeatureNet0):
-    """The plain U-Net of reference models/msrednet.py:29-127 (arch_mode 'unet', three stages): FeatureNet0 without
-    the pooled-context branches."""
+    """Reference models/msrednet.py:29-127, three stages.  arch_mode 'unet': the plain U-Net = FeatureNet0 without the
+    pooled-context branches (adamvs_feature_net0 with zero branch weights); arch_mode 'fpn': lateral 1x1 convolutions
+    added to the nearest-upsampled coarser map, 3x3 output convolutions (adamvs_feature_net_fpn)."""
 
     def __init__(self, base_channels, num_stage=3, stride=4, arch_mode="unet"):
         nn.Module.__init__(self)
-        assert arch_mode == "unet" and num_stage == 3, "this build implements arch_mode 'unet' with three stages"
+        assert arch_mode in ["unet", "fpn"], "mode must be in 'unet' or 'fpn', but get:{}".format(arch_mode)
+        assert num_stage == 3, "this build implements three stages"
         c = base_channels
         self.arch_mode, self.stride, self.base_channels, self.num_stage = arch_mode, stride, c, num_stage
         self.conv0 = nn.Sequential(Conv2d(3, c, 3, 1, padding=1), Conv2d(c, c, 3, 1, padding=1))
@@ -32,29 +35,68 @@ class FeatureNet(FeatureNet0):
         self.conv2 = nn.Sequential(Conv2d(2 * c, 4 * c, 5, stride=2, padding=2), Conv2d(4 * c, 4 * c, 3, 1, padding=1),
                                    Conv2d(4 * c, 4 * c, 3, 1, padding=1))
         self.out1 = nn.Conv2d(4 * c, 4 * c, 1, bias=False)
-        self.deconv1 = DeConv2dFuse(4 * c, 2 * c, 3)
-        self.deconv2 = DeConv2dFuse(2 * c, c, 3)
-        self.out2 = nn.Conv2d(2 * c, 2 * c, 1, bias=False)
-        self.out3 = nn.Conv2d(c, c, 1, bias=False)
+        if arch_mode == "unet":
+            self.deconv1 = DeConv2dFuse(4 * c, 2 * c, 3)
+            self.deconv2 = DeConv2dFuse(2 * c, c, 3)
+            self.out2 = nn.Conv2d(2 * c, 2 * c, 1, bias=False)
+            self.out3 = nn.Conv2d(c, c, 1, bias=False)
+        else:
+            self.inner1 = nn.Conv2d(2 * c, 4 * c, 1, bias=True)
+            self.inner2 = nn.Conv2d(c, 4 * c, 1, bias=True)
+            self.out2 = nn.Conv2d(4 * c, 2 * c, 3, padding=1, bias=False)
+            self.out3 = nn.Conv2d(4 * c, c, 3, padding=1, bias=False)
         self.out_channels = [4 * c, 2 * c, c]
         self._cache_init()
         self.workspace_limit_bytes = 32 << 30
 
     def packed(self, device):
         def build():
+            if self.arch_mode == "fpn":
+                flat, offsets = packing.pack_feature_net_fpn(module_state(self), "")
+                return hip_ops.PackedFeatureFpn(flat, offsets, device)
             flat, offsets = packing.pack_feature_net(module_state(self), "", context=False)
             return hip_ops.PackedFeature(flat, offsets, device)
         return self.cached(device, build)
+
+    def _run_hip(self, x):
+        if self.arch_mode == "fpn":
+            return hip_ops.feature_net_fpn(x, self.packed(x.device))
+        return hip_ops.feature_net0(x, self.packed(x.device))
+
+    def forward_cl(self, x):
+        if self.arch_mode == "unet":
+            return FeatureNet0.forward_cl(self, x)
+        if self.hip_supported(x):
+            per_image = hip_ops.feature_net_fpn_workspace_bytes(1, x.shape[-2], x.shape[-1])
+            chunk = max(1, int(self.workspace_limit_bytes // per_image))
+            parts = [self._run_hip(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)]
+            return parts[0] if len(parts) == 1 else tuple(torch.cat([p[k] for p in parts], 0) for k in range(3))
+        f = self.forward_torch(x)
+        return tuple(hip_ops.pack_features(f["stage%d" % (k + 1)]) for k in range(3))
+
+    def forward(self, x):
+        if self.arch_mode == "unet" or not self.hip_supported(x):
+            return FeatureNet0.forward(self, x)
+        H, W = x.shape[-2:]
+        s1, s2, s3 = self._run_hip(x)
+        return {"stage1": hip_ops.unpack_features(s1, H // 4, W // 4), "stage2": hip_ops.unpack_features(s2, H // 2, W // 2),
+                "stage3": hip_ops.unpack_features(s3, H, W)}
 
     def forward_torch(self, x):
         c0 = self.conv0(x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
         out = {"stage1": self.out1(c2)}
-        f = self.deconv1(c1, c2)
-        out["stage2"] = self.out2(f)
-        f = self.deconv2(c0, f)
-        out["stage3"] = self.out3(f)
+        if self.arch_mode == "unet":
+            f = self.deconv1(c1, c2)
+            out["stage2"] = self.out2(f)
+            f = self.deconv2(c0, f)
+            out["stage3"] = self.out3(f)
+        else:
+            f = F.interpolate(c2, scale_factor=2, mode="nearest") + self.inner1(c1)
+            out["stage2"] = self.out2(f)
+            f = F.interpolate(f, scale_factor=2, mode="nearest") + self.inner2(c0)
+            out["stage3"] = self.out3(f)
         return out
 
 

@@ -284,6 +284,42 @@ def pack_feature_net(sd, pre="feature.", context=True):
     return torch.cat(chunks), offsets
 
 
+FEATURE_FPN_CONVS = ("conv0_0", "conv0_1", "conv1_0", "conv1_1", "conv1_2", "conv2_0", "conv2_1", "conv2_2",
+                     "out1", "inner1", "out2", "inner2", "out3")
+
+
+def pack_feature_net_fpn(sd, pre="feature."):
+    """The FPN variant of MS-REDNet's FeatureNet (reference models/msrednet.py:74-91) -> (flat fp32 tensor, {field: offset})
+    for adamvs_feature_fpn_weights: the encoder as in pack_feature_net; out1 / inner1 / inner2 1x1 (the inner ones with
+    their bias), out2 / out3 3x3 without bias or BatchNorm."""
+    parts = {}
+
+    def conv_bn(name, key, taps):
+        w = sd[pre + key + "conv.weight"].detach().float().cpu()
+        scale, shift = _bn_scale_shift(sd, pre + key + "bn.")
+        w = (w * scale.reshape(-1, 1, 1, 1)).reshape(w.shape[0], w.shape[1], taps)
+        parts[name + ".w"] = pack_taps(w)
+        parts[name + ".b"] = pad_bias(shift, (w.shape[0] + 15) // 16 * 16)
+
+    for name, key, taps in (("conv0_0", "conv0.0.", 9), ("conv0_1", "conv0.1.", 9), ("conv1_0", "conv1.0.", 25), ("conv1_1", "conv1.1.", 9),
+                            ("conv1_2", "conv1.2.", 9), ("conv2_0", "conv2.0.", 25), ("conv2_1", "conv2.1.", 9), ("conv2_2", "conv2.2.", 9)):
+        conv_bn(name, key, taps)
+    for name in ("out1", "inner1", "out2", "inner2", "out3"):
+        w = sd[pre + name + ".weight"].detach().float().cpu()
+        cout = w.shape[0]
+        parts[name + ".w"] = pack_taps(w.reshape(cout, w.shape[1], w.shape[2] * w.shape[3]))
+        b = sd.get(pre + name + ".bias")
+        b = torch.zeros(cout) if b is None else b.detach().float().cpu()
+        parts[name + ".b"] = pad_bias(b, (cout + 15) // 16 * 16)
+    offsets, chunks, o = {}, [], 0
+    for f, t in parts.items():
+        pad = (-t.numel()) % 64
+        offsets[f] = o
+        chunks.append(torch.cat([t.reshape(-1), torch.zeros(pad)]))
+        o += t.numel() + pad
+    return torch.cat(chunks), offsets
+
+
 # ---- MS-REDNet regulariser (reference models/msrednet.py:330-366) on adamvs_conv3x3_dd -------------------------------
 def pad16(n):
     return (n + 15) // 16 * 16

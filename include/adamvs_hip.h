@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 8
+#define ADAMVS_ABI_VERSION 9
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -154,6 +154,19 @@ typedef struct adamvs_feature_weights {
 size_t adamvs_feature_net0_workspace_bytes(int N, int H, int W);
 int adamvs_feature_net0(const float* imgs, const adamvs_feature_weights* weights, float* stage1, float* stage2, float* stage3,
                         int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The FPN variant of MS-REDNet's FeatureNet, reference models/msrednet.py:74-91 (constructor), 115-125 (forward), arch_mode
+ * "fpn" with three stages: stage1 = out1(conv2); t1 = nearest2x(conv2) + inner1(conv1); stage2 = out2(t1);
+ * t2 = nearest2x(t1) + inner2(conv0); stage3 = out3(t2).  Same images, outputs and size rule as adamvs_feature_net0.
+ * conv* as in adamvs_feature_weights; out1 [32][32] 1x1 (no bias: b = zeros); inner1 [32][16], inner2 [32][8] 1x1 with
+ * b = their bias; out2 [16][32], out3 [8][32] 3x3, b = zeros (fragment layout of adamvs_fconv_weights). */
+typedef struct adamvs_feature_fpn_weights {
+  adamvs_fconv_weights conv0_0, conv0_1, conv1_0, conv1_1, conv1_2, conv2_0, conv2_1, conv2_2;
+  adamvs_fconv_weights out1, inner1, out2, inner2, out3;
+} adamvs_feature_fpn_weights;
+size_t adamvs_feature_net_fpn_workspace_bytes(int N, int H, int W);
+int adamvs_feature_net_fpn(const float* imgs, const adamvs_feature_fpn_weights* weights, float* stage1, float* stage2,
+                           float* stage3, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 
 /* models/adamvs.py:495-512 fused with conv1 of SliceCostRegNetRED (adamvs.py:416), for all
  * D hypotheses at once: c1[d][b][pix][8] = ReLU(conv1(sum_v w_v warp_v ref / (1e-5 + sum_v w_v))).

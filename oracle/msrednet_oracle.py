@@ -30,6 +30,24 @@ def feature_net_unet(x, sd, pre="feature."):
 
 
 # ----------------------------------------------------------------------------
+# FeatureNet (arch_mode 'fpn'), models/msrednet.py:74-91 (layers), 115-125 (forward): lateral 1x1 convolutions with bias
+# added to the nearest-neighbour 2x upsampling of the coarser map, 3x3 output convolutions without bias
+# ----------------------------------------------------------------------------
+def feature_net_fpn(x, sd, pre="feature."):
+    c0 = ao._f_conv(ao._f_conv(x, sd, pre + "conv0.0."), sd, pre + "conv0.1.")
+    c1 = ao._f_conv(c0, sd, pre + "conv1.0.", 2, 2)
+    c1 = ao._f_conv(ao._f_conv(c1, sd, pre + "conv1.1."), sd, pre + "conv1.2.")
+    c2 = ao._f_conv(c1, sd, pre + "conv2.0.", 2, 2)
+    c2 = ao._f_conv(ao._f_conv(c2, sd, pre + "conv2.1."), sd, pre + "conv2.2.")
+    out = {"stage1": F.conv2d(c2, sd[pre + "out1.weight"])}
+    f = c2.repeat_interleave(2, 2).repeat_interleave(2, 3) + F.conv2d(c1, sd[pre + "inner1.weight"], sd[pre + "inner1.bias"])
+    out["stage2"] = F.conv2d(f, sd[pre + "out2.weight"], padding=1)
+    f = f.repeat_interleave(2, 2).repeat_interleave(2, 3) + F.conv2d(c0, sd[pre + "inner2.weight"], sd[pre + "inner2.bias"])
+    out["stage3"] = F.conv2d(f, sd[pre + "out3.weight"], padding=1)
+    return out
+
+
+# ----------------------------------------------------------------------------
 # ConvGRUCell2, models/module.py:54-106: GroupNorm(1 group) on both gates and on the candidate
 # ----------------------------------------------------------------------------
 def conv_gru_cell2(x, h, sd, pre):

@@ -80,6 +80,18 @@ def test_oracle_end_to_end_matches_reference():
     assert rel_l1(out["photometric_confidence"], g["photometric_confidence"]) < 1e-4
 
 
+def test_oracle_feature_net_fpn_matches_reference():
+    """FeatureNet(arch_mode="fpn") (reference msrednet.py:74-91, 115-125; no model class selects it, the constructor and
+    forward exist): the oracle against a run of the reference's class on seeded weights."""
+    g = gold("msred_featnet_fpn")
+    from ada_mvs_amd.models.msrednet import FeatureNet
+    sd = synth.seeded_state_dict(FeatureNet(8, 3, 4, "fpn"), seed=4)
+    out = mo.feature_net_fpn(g["x"], sd, "")
+    for k in ("stage1", "stage2", "stage3"):
+        assert out[k].shape == g[k].shape
+        assert rel_l1(out[k], g[k]) < 1e-6, k
+
+
 def test_state_dict_keys_match_reference_layout():
     m, sd = tiny_model_state()
     keys = set(m.state_dict())
@@ -218,6 +230,31 @@ def test_feature_net_unet_against_oracle():
         got = m.feature(x.cuda())
     for k in ("stage1", "stage2", "stage3"):
         assert rel_l1(got[k].cpu(), want[k]) < 5e-5, k
+
+
+@pytest.mark.gpu
+def test_feature_net_fpn_against_reference_golden():
+    """adamvs_feature_net_fpn through the module mirror: the reference fixture (2 images, 32 x 64) and, at a size with
+    several tiles per map, the oracle; state-dict keys as the reference's class."""
+    from ada_mvs_amd.models.msrednet import FeatureNet
+    g = gold("msred_featnet_fpn")
+    net = FeatureNet(8, 3, 4, "fpn")
+    sd = synth.seeded_state_dict(net, seed=4)
+    net.load_state_dict(sd)
+    assert {"inner1.weight", "inner1.bias", "inner2.bias", "out2.weight", "out3.weight"} <= set(sd) and "deconv1.conv.conv.weight" not in sd
+    net = net.cuda().eval()
+    with torch.no_grad():
+        got = net(g["x"].cuda())
+    for k in ("stage1", "stage2", "stage3"):
+        assert rel_l1(got[k].cpu(), g[k]) < OP_TOL, k
+    x = torch.randn(3, 3, 96, 160, generator=torch.Generator().manual_seed(2))
+    want = mo.feature_net_fpn(x, sd, "")
+    with torch.no_grad():
+        got = net(x.cuda())
+        cl = net.forward_cl(x.cuda())
+    for i, k in enumerate(("stage1", "stage2", "stage3")):
+        assert rel_l1(got[k].cpu(), want[k]) < OP_TOL, k
+        assert torch.equal(cl[i].reshape(3, want[k].shape[2], want[k].shape[3], -1).permute(0, 3, 1, 2), got[k])
 
 
 @pytest.mark.gpu

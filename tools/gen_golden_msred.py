@@ -6,8 +6,9 @@ tools/gen_golden.py) on the seeded recipes of ada-mvs_amd/synth.py:
   msred_gru_cell.npz    ConvGRUCell2 (x 16 ch, h 16 ch)
   msred_slice_step.npz  two consecutive slice_RED_Regularization steps, C = 32
   msred_e2e_tiny.npz    Infer_CascadeREDNet end to end, 3 views, 64x96, ndepths 16/8/4
+  msred_featnet_fpn.npz FeatureNet(arch_mode="fpn") on 2 images of 32x64 (the variant no model class of the reference selects)
 
-Run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_msred.py
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_msred.py [--only-fpn]
 """
 import os
 import sys
@@ -40,7 +41,20 @@ def save(name, **arrays):
 
 
 @torch.no_grad()
+def fpn():
+    net = ref_red.FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode="fpn")
+    net.load_state_dict(synth.seeded_state_dict(net, seed=4))
+    net.eval()
+    x = torch.randn(2, 3, 32, 64, generator=torch.Generator().manual_seed(12))
+    out = net(x)
+    save("msred_featnet_fpn", x=x, stage1=out["stage1"], stage2=out["stage2"], stage3=out["stage3"])
+
+
+@torch.no_grad()
 def main():
+    fpn()
+    if "--only-fpn" in sys.argv:
+        return
     g = torch.Generator().manual_seed(11)
     cell = ref_module.ConvGRUCell2(16, 16, 3)
     cell.load_state_dict(synth.seeded_state_dict(cell, seed=2))
