@@ -99,14 +99,22 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
   // plane.  The results of G planes are therefore parked in LDS (each thread reads back only what it wrote: no
   // barrier) and flushed as one burst of G stores, so the reloads of G - 1 of every G planes find no store in
   // front of them.  The plane loop stays rolled (unrolled, the scheduler hoists every plane's projection: spills).
-  __shared__ f32x4 park[G][256];
-  for (int dg = d0; dg < d1; dg += G) {
-  const float mydepth = plane_at(planes, pl, min(dg + g, d1 - 1), hw);
+  // The burst is 8 planes for every C (with C = 16 / 8 a pixel has 4 / 2 lanes: bursts of G planes would put a store in
+  // front of the reloads of every fourth / second plane); lane g then fetches planes dg+g, dg+G+g, ...
+  constexpr int PK = 8, NM = PK / G;
+  __shared__ f32x4 park[PK][256];
+  for (int dg = d0; dg < d1; dg += PK) {
+  float mydepth[NM];
+#pragma unroll
+  for (int k = 0; k < NM; ++k) mydepth[k] = plane_at(planes, pl, min(dg + k * G + g, d1 - 1), hw);
 #pragma unroll 1
-  for (int j = 0; j < G; ++j) {
+  for (int j = 0; j < PK; ++j) {
     const int d = dg + j;
     if (d >= d1) break;
-    const float depth = __shfl(mydepth, gbase + j, 64);
+    float mine_d = mydepth[0];
+#pragma unroll
+    for (int k = 1; k < NM; ++k) mine_d = (j / G == k) ? mydepth[k] : mine_d;      // uniform select
+    const float depth = __shfl(mine_d, gbase + (j % G), 64);
     PlaneTaps mine[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) mine[k] = plane_taps(ax[k], ay[k], az[k], tx[k], ty[k], tz[k], depth, h, w);
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
     park[j][tid] = acc;
   }
   if (live) {
-    const int nd = min(G, d1 - dg);
+    const int nd = min(PK, d1 - dg);
 #pragma unroll 1
     for (int j = 0; j < nd; ++j) {
       *(f32x4*)(out + (size_t)(dg + j - d0) * ostride) = park[j][tid];
