@@ -200,15 +200,27 @@ struct ConvSmallBx3Role {
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B fragments two k-blocks ahead of the MFMAs that consume them (LDS latency ~ two k-blocks of a 16-row tile)
+    constexpr int AHEAD = 2;
+    bf16x8 bh[NKB], bl[NKB];
+#pragma unroll
+    for (int kb = 0; kb < (AHEAD < NKB ? AHEAD : NKB); ++kb) {
+      bh[kb] = *(const bf16x8*)((const char*)ldsb + xoff[kb]);
+      bl[kb] = *(const bf16x8*)((const char*)ldsb + xoff[kb] + LO);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      const bf16x8 bh = *(const bf16x8*)((const char*)ldsb + xoff[kb]);
-      const bf16x8 bl = *(const bf16x8*)((const char*)ldsb + xoff[kb] + LO);
+      if (kb + AHEAD < NKB) {
+        bh[kb + AHEAD] = *(const bf16x8*)((const char*)ldsb + xoff[kb + AHEAD]);
+        bl[kb + AHEAD] = *(const bf16x8*)((const char*)ldsb + xoff[kb + AHEAD] + LO);
+      }
+      __builtin_amdgcn_sched_barrier(0);          // the scheduler would sink the reads back to their uses
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        acc[nt] = mfma_bx(wh[nt][kb], bh, acc[nt]);
-        acc[nt] = mfma_bx(wh[nt][kb], bl, acc[nt]);
-        acc[nt] = mfma_bx(wl[nt][kb], bh, acc[nt]);
+        acc[nt] = mfma_bx(wh[nt][kb], bh[kb], acc[nt]);
+        acc[nt] = mfma_bx(wh[nt][kb], bl[kb], acc[nt]);
+        acc[nt] = mfma_bx(wl[nt][kb], bh[kb], acc[nt]);
       }
     }
 #pragma unroll
