@@ -443,17 +443,30 @@ def main():
             c0 = synth.CONFIGS[cfg]
             split = args.precision == "bf16x3"
             if kind == "cost_reg_net_2d":
-                # dominant kernel = the stride-1 instantiation of k_conv_dd (conv0, conv2, conv4, conv6, prob).  The split-bf16
+                # dominant kernel = the stride-1 instantiation of k_conv_dd (conv0, conv2, conv4, prob; conv6 too unless its grid is small).  The split-bf16
                 # mode EXECUTES three bf16 products per fp32 product on the bf16 matrix pipe: priced against that pipe's peak.
-                lay = {k: v for k, v in avg.items() if ".costreg." in k and k.endswith("mode0")}
                 hw0, Dd, N = st["h"] * st["w"], st["D"], (c0["views"] - 1) * Bg
-                res = {"conv0": 1, "conv2": 4, "conv4": 16, "conv6": 64, "prob": 1}
-                flops = sum(2.0 * N * (hw0 // res[k.split(".")[2]]) * Dd * Dd * 9 for k in lay) * (3 if split else 1)
+                res = {"conv0": 1, "conv2": 2, "conv4": 4, "conv6": 8, "prob": 1}       # linear down-scale of the layer's maps
+
+                def on_dominant_kernel(layer):
+                    # the fp32 path sends stride-1 layers of at most 2048 blocks of 8 x 16 pixels to the 2-row kernel
+                    # k_conv_dd_rows2 (csrc/costreg2d.hip: small_grid_rows2); those launches are not the dominant kernel's
+                    if split:
+                        return True
+                    e = os.environ.get("ADAMVS_CONV_ROWS2", "")
+                    if e:
+                        return int(e) == 0
+                    r = res[layer]
+                    return -(-(st["w"] // r) // 16) * -(-(st["h"] // r) // 8) * N > 2048
+
+                lay = {k: v for k, v in avg.items() if ".costreg." in k and k.endswith("mode0") and on_dominant_kernel(k.split(".")[2])}
+                flops = sum(2.0 * N * (hw0 // res[k.split(".")[2]] ** 2) * Dd * Dd * 9 for k in lay) * (3 if split else 1)
                 ms = sum(lay.values())
                 ach = flops / (ms * 1e-3) / 1e12
                 peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-                roof = {"kernel": "%s (CostRegNet2D 3x3 stride-1 layers, %d launches per step)" % (
-                            "k_conv_dd_bx3<MT,WM,CONV_S1>, executed bf16 flops = 3 x fp32 products" if split else "k_conv_dd<MT,WM,CONV_S1>", len(lay)),
+                roof = {"kernel": "%s (CostRegNet2D 3x3 stride-1 layers %s, %d launches per step)" % (
+                            "k_conv_dd_bx3<MT,WM,CONV_S1>, executed bf16 flops = 3 x fp32 products" if split else "k_conv_dd<MT,WM,CONV_S1>",
+                            "+".join(k.split(".")[2] for k in lay), len(lay)),
                         "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "launch_ms": ms / len(lay),
                         "flops_per_launch": flops / len(lay), "traffic": None}
