@@ -376,6 +376,16 @@ def test_error_behaviour_of_the_new_entry_points():
     from ada_mvs_amd.models.msrednet import Infer_CascadeREDNet
     with pytest.raises(AdaMVSHipError, match="share_cr"):
         Infer_CascadeREDNet(16, [16, 8, 4], [4, 2, 1], share_cr=True)
+    from ada_mvs_amd.models.msrednet import FeatureNet
+    fpn = FeatureNet(8, 3, 4, "fpn")
+    fpn.load_state_dict(synth.seeded_state_dict(fpn, seed=4))
+    fpn = fpn.cuda().eval()
+    with pytest.raises(AdaMVSHipError, match="multiples of 32"):           # the C entry point itself; the module falls back to torch ops
+        hip_ops.feature_net_fpn(torch.zeros(1, 3, 40, 64, device=dev), fpn.packed(dev))
+    with pytest.raises(AdaMVSHipError, match="feature_net_fpn"):           # 4 channels
+        hip_ops.feature_net_fpn(torch.zeros(1, 4, 32, 64, device=dev), fpn.packed(dev))
+    with pytest.raises(AssertionError):
+        FeatureNet(8, 3, 4, "resnet")
 
 
 def test_regulariser_packing_layout():
