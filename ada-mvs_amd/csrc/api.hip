@@ -113,9 +113,14 @@ extern "C" int adamvs_slice_reg_step(const float* cost, float* state1, float* st
   int rc = launch_conv1(cost, fw.conv1, c1, B, C, h, w, precision, st);
   if (rc) return rc;
   float* h1_now = state1;
-  if ((rc = launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, precision, st, &h1_now))) return rc;
-  if (h1_now != state1) {              // the split-bf16 level-1 kernel writes the new state to the other buffer
+  float* h2_now = state2;
+  if ((rc = launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, precision, st, &h1_now, &h2_now))) return rc;
+  if (h1_now != state1) {              // the split-bf16 GRU kernels write the new state to the other buffer
     hipError_t e = hipMemcpyAsync(state1, h1_now, (size_t)B * h * w * 8 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return set_error((int)e, "slice_reg_step: hipMemcpyAsync: %s", hipGetErrorString(e));
+  }
+  if (h2_now != state2) {
+    hipError_t e = hipMemcpyAsync(state2, h2_now, (size_t)B * (h / 2) * (w / 2) * 16 * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return set_error((int)e, "slice_reg_step: hipMemcpyAsync: %s", hipGetErrorString(e));
   }
   return 0;

@@ -44,11 +44,11 @@ int launch_sweep_conv1_chunk(const float* feat, const float* rt, PlaneSrc planes
 int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, int precision, hipStream_t st);
 int launch_conv1_bf16x3(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st);
 int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBuffers& sb, int B, int h, int w, int d,
-                            float** h1_now, hipStream_t st);
-// step d of a stage; *h1_now (optional) receives the buffer holding the level-1 state afterwards (sb.h1, or sb.rh1
-// after an even step of the split-bf16 path, whose fused level-1 kernel alternates the two)
+                            float** h1_now, float** h2_now, hipStream_t st);
+// step d of a stage; *h1_now / *h2_now (optional) receive the buffers holding the states afterwards (sb.h1 / sb.h2, or
+// sb.rh1 / sb.rh2 after an even step of the split-bf16 path, whose fused GRU kernels alternate the two)
 int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers& sb, float* vol, int B, int h, int w, int D,
-                      int d, int in_up, int precision, hipStream_t st, float** h1_now = nullptr);
+                      int d, int in_up, int precision, hipStream_t st, float** h1_now = nullptr, float** h2_now = nullptr);
 int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias, float* out,
                      int cout, int B, int h, int w, hipStream_t st);
 int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,

@@ -11,10 +11,10 @@
 // matrix-bound and memory-bound tile loops resident side by side on every CU:
 //
 //   fp32     slot A(t): gates1(t) | conv2(t-1)      slot B(t): cand1(t) | gates2(t-1)     slot C(t): cand2(t-1) | decoder(t-2)
-//   bf16x3   slot A(t): gru1(t)   | conv2(t-1)      slot B(t): gru1(t)' | gates2(t-1) | decoder(t-2)'    slot C(t): gru1(t)'' | cand2(t-1) | decoder(t-2)''
-//            (the fused level-1 kernel has no dependant inside its step: its tiles are spread over the slots)
-//   two launches (schedule 3, small stages):  A(t): level-1 gates (bf16x3: gru1) | conv2+gates2(t-1) in two halves
-//                                             B(t): cand1 (bf16x3: gru1') | cand2(t-1) | decoder(t-2)
+//   two launches (schedule 3, small stages):  A(t): gates1(t) | conv2+gates2(t-1) in two halves    B(t): cand1(t) | cand2(t-1) | decoder(t-2)
+//   bf16x3   both GRU levels are one kernel each (gru1, gru2):
+//            slot A(t): gru1(t) | conv2(t-1)        slot B(t): gru1(t)' | gru2(t-1) | decoder(t-2)
+//            (the level-1 kernel has no dependant inside its step: its tiles are dealt to both launches)
 //
 // State rings: h1 of step t lives in h1[t % 4] (the decoder still reads h1[t-2] or h1[t-3] while cand1 writes h1[t]),
 // h2 and conv2's output of step t in h2[t % 2], c2[t % 2].  The arithmetic of every tile is that of the one-role kernels (slice_roles.h): the pipelined stage
@@ -47,8 +47,15 @@ struct SlotArgs {
 // The grid is divided between the roles (workgroups [0, n0) run role 0, ...) in proportion to their estimated work.
 // (Tried and dropped: every workgroup walking its share of every role, one role after the other -- no cost model, but
 // 20-30 % slower: each workgroup then pays every role's prologue and holds no role's weights for long.)
+// Workgroups per CU the register budget of a launch is held to: the fused split-bf16 GRU roles are written for two
+// (256 registers); without the bound the compiler lets a launch that contains them grow past that.
+template <class R> struct min_blocks { static constexpr int value = 1; };
+template <> struct min_blocks<Gru1FusedBx3Role> { static constexpr int value = 2; };
+template <> struct min_blocks<Gru2FusedBx3Role> { static constexpr int value = 2; };
+constexpr int imax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
 template <class R0, class R1, class R2>
-__global__ __launch_bounds__(256) void k_slot(SlotArgs<R0, R1, R2> s) {
+__global__ __launch_bounds__(256, imax3(min_blocks<R0>::value, min_blocks<R1>::value, min_blocks<R2>::value)) void k_slot(SlotArgs<R0, R1, R2> s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wg = blockIdx.x;                  // workgroup-uniform: the role dispatch is a scalar branch
   if (wg < s.n0) R0::run(s.a0, s.g0, s.r0, wg, s.n0, lds);
@@ -140,8 +147,7 @@ typedef ConvSmallRole<16, 16, 2, 1, EPI_GATES> Gates2;
 typedef ConvSmallRole<16, 16, 1, 1, EPI_CAND> Cand2;
 typedef Gru1FusedBx3Role Gru1Bx;
 typedef ConvSmallBx3Role<8, 0, 1, 2, BXE_RELU> Conv2Bx;
-typedef ConvSmallBx3Role<16, 16, 2, 1, BXE_GATES> Gates2Bx;
-typedef ConvSmallBx3Role<16, 16, 1, 1, BXE_CAND> Cand2Bx;
+typedef Gru2FusedBx3Role Gru2Bx;
 
 // Relative cost per tile (microseconds of a whole-chip launch per tile, measured at cfg2's stage-1 shape; only the
 // ratios inside a slot matter).  ADAMVS_RECUR_COSTS="g1,c1,v2,g2,c2,dec,k1bx,v2bx,g2bx,c2bx" overrides (tuning).
@@ -149,7 +155,7 @@ typedef ConvSmallBx3Role<16, 16, 1, 1, BXE_CAND> Cand2Bx;
 // bf16x3 schedule runs [0,fd) in slot B and the rest in C.
 struct RoleCosts { float g1, c1, v2, g2, c2, dec, k1bx, v2bx, g2bx, c2bx, fa, fb, fd; };
 static const RoleCosts& role_costs() {
-  static RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 4.46f, 13.8f, 3.2f, 6.3f, 5.0f, 0.6f, 0.8f, 0.42f};
+  static RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 4.46f, 13.8f, 3.2f, 12.0f, 5.0f, 0.6f, 0.8f, 0.42f};
   static bool init = false;
   if (!init) {
     init = true;
@@ -173,9 +179,9 @@ int recurrence_mode(int precision, long pixels) {
   if (e && *e) return atoi(e);
   // B * h * w of the stage.  Measured (profiles/r02_recurrence_schedules.txt): fp32 -- two launches per hypothesis win up
   // to ~200k pixels (cfg4's 4 tiles per GPU at stage 1: 7.8 -> 5.9 -> 5.1 ms), three up to ~800k, six beyond;
-  // bf16x3 (its level 1 is one kernel already) -- two up to ~300k (cfg4's share at stage 1: 5.85 / 4.79 / 4.35 ms with five /
-  // three / two launches; at 295k pixels 10.5 / 11.4 / 10.0), five beyond.
-  if (precision != PRECISION_FP32) return pixels <= 300000 ? 3 : 0;
+  // bf16x3 (both GRU levels are one kernel each: four launches per hypothesis, or two) -- two up to ~1M pixels (cfg4's share:
+  // stage 1 5.29 -> 3.77 ms, stage 2 3.29 -> 2.77; at 590k pixels 15.8 -> 15.1; at 1.18M a tie; at 2.36M 51.3 -> 55.2).
+  if (precision != PRECISION_FP32) return pixels <= 1000000 ? 3 : 0;
   return pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0);
 }
 
@@ -215,58 +221,31 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
   DecoderArgs da{H2(sd), H1(sd), fw.upconv1, fw.upconv1_b, fw.final_w, vol_dec, h, w, D_vol, d_dec};
 
   if (precision == PRECISION_BF16X3) {
+    // both GRU levels are one kernel each: two launches per hypothesis whatever the schedule number
+    //   A: gru1(t) [0,f) | conv2(t-1)        B: gru1(t) [f,1) | gru2(t-1) | decoder(t-2)
+    // (the level-1 kernel has no dependant inside its step: its tiles are dealt to both launches so that they carry equal work)
     Gru1Args g1{c1_t, H1(t - 1), H1(t), (const bf16x8*)fw.gates1, fw.gates1_b, (const bf16x8*)fw.cand1, fw.cand1_b, h, w};
     SmallConvArgsBx v2{H1(s2), nullptr, (const bf16x8*)fw.conv2, nullptr, C2(s2), nullptr, nullptr, h, w, h2, w2, 16, nullptr};
-    SmallConvArgsBx g2{C2(s2), H2(s2 - 1), (const bf16x8*)fw.gates2, fw.gates2_b, rb.rh2, rb.u2, H2(s2 - 1), h2, w2, h2, w2, 32, nullptr};
-    SmallConvArgsBx c2{C2(sc), rb.rh2, (const bf16x8*)fw.cand2, fw.cand2_b, H2(sc), rb.u2, nullptr, h2, w2, h2, w2, 16, H2(sc - 1)};
-    // the level-1 kernel and the decoder have no dependant inside the step: their tiles fill up slots B and C
-    const float fa = l2 ? k.fa : 1.0f, fb = l2 ? k.fb : 1.0f;         // gru1: [0,fa) in A, [fa,fb) in B, [fb,1) in C
-    const float fd = l2 ? k.fd : 0.0f;                                 // decoder: [0,fd) in B, [fd,1) in C
-    if (schedule == 3) {
-      // two launches: A: gru1(t) [0,f) | conv2+gates2(t-1), r half | u half     B: gru1(t) [f,1) | cand2(t-1) | decoder(t-2)
-      Conv2Gates2BxArgs vg{H1(s2), H2(s2 - 1), (const bf16x8*)fw.conv2, (const bf16x8*)fw.gates2, fw.gates2_b, C2(s2), rb.rh2, rb.u2, h, w, h2, w2};
-      const float vgc = 0.5f * k.g2bx + 1.7f * k.v2bx;                 // one half per level-2 tile: conv2 on the 6 x 18 window + 16 gate rows
-      float f = 0.5f + ((0.25f * k.c2bx + k.dec) - 0.5f * vgc) / (2.f * k.k1bx);      // equal work in the two launches (4 level-1 tiles per level-2 tile)
-      f = !l2 ? 1.0f : (f < 0.1f ? 0.1f : (f > 1.f ? 1.f : f));
-      if (l1 || l2)
-        if ((rc = launch_slot<Gru1Bx, Conv2Gates2Bx3Role<0>, Conv2Gates2Bx3Role<1>>(
-                 l1 ? use<Gru1Bx>(&g1, k.k1bx, 0.f, f) : none<Gru1Bx>(), l2 ? use<Conv2Gates2Bx3Role<0>>(&vg, vgc) : none<Conv2Gates2Bx3Role<0>>(),
-                 l2 ? use<Conv2Gates2Bx3Role<1>>(&vg, vgc) : none<Conv2Gates2Bx3Role<1>>(), B, st, "recurrence slot A (bf16x3, schedule 3)")))
-          return rc;
-      const bool rest = l1 && f < 1.f;
-      if (!(rest || lc || dec)) return 0;
-      if (in_up)
-        return launch_slot<Gru1Bx, Cand2Bx, DecoderRole<true>>(rest ? use<Gru1Bx>(&g1, k.k1bx, f, 1.f) : none<Gru1Bx>(),
-                                                               lc ? use<Cand2Bx>(&c2, k.c2bx) : none<Cand2Bx>(),
-                                                               dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(), B, st,
-                                                               "recurrence slot B (bf16x3, schedule 3)");
-      return launch_slot<Gru1Bx, Cand2Bx, DecoderRole<false>>(rest ? use<Gru1Bx>(&g1, k.k1bx, f, 1.f) : none<Gru1Bx>(),
-                                                              lc ? use<Cand2Bx>(&c2, k.c2bx) : none<Cand2Bx>(),
-                                                              dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st,
-                                                              "recurrence slot B (bf16x3, schedule 3)");
-    }
+    Gru2Args g2{C2(s2), H2(s2 - 1), H2(s2), (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2};
+    // per level-1 tile (8 x 30 pixels): 0.94 conv2 tiles (4 x 16 at half resolution), 0.54 gru2 tiles (8 x 14), 1.33 decoder tiles (6 x 30)
+    float f = 0.5f + ((0.54f * k.g2bx + 1.33f * k.dec) - 0.94f * k.v2bx) / (2.f * k.k1bx);
+    f = !l2 ? 1.0f : (f < 0.1f ? 0.1f : (f > 1.f ? 1.f : f));
     if (l1 || l2)
-      if ((rc = launch_slot<Gru1Bx, Conv2Bx, NopRole>(l1 ? use<Gru1Bx>(&g1, k.k1bx, 0.f, fa) : none<Gru1Bx>(),
+      if ((rc = launch_slot<Gru1Bx, Conv2Bx, NopRole>(l1 ? use<Gru1Bx>(&g1, k.k1bx, 0.f, f) : none<Gru1Bx>(),
                                                       l2 ? use<Conv2Bx>(&v2, k.v2bx) : none<Conv2Bx>(), none<NopRole>(), B, st,
                                                       "recurrence slot A (bf16x3)")))
         return rc;
-    if (!(l2 || lc || dec)) return 0;
-    if (in_up) {
-      if ((rc = launch_slot<Gru1Bx, Gates2Bx, DecoderRole<true>>(
-               (l1 && fa < 1.f) ? use<Gru1Bx>(&g1, k.k1bx, fa, fb) : none<Gru1Bx>(), l2 ? use<Gates2Bx>(&g2, k.g2bx) : none<Gates2Bx>(),
-               (dec && fd > 0.f) ? use<DecoderRole<true>>(&da, k.dec, 0.f, fd) : none<DecoderRole<true>>(), B, st, "recurrence slot B (bf16x3)")))
-        return rc;
-      return launch_slot<Gru1Bx, Cand2Bx, DecoderRole<true>>(
-          (l1 && fb < 1.f) ? use<Gru1Bx>(&g1, k.k1bx, fb, 1.f) : none<Gru1Bx>(), lc ? use<Cand2Bx>(&c2, k.c2bx) : none<Cand2Bx>(),
-          dec ? use<DecoderRole<true>>(&da, k.dec, fd, 1.f) : none<DecoderRole<true>>(), B, st, "recurrence slot C (bf16x3)");
-    }
-    if ((rc = launch_slot<Gru1Bx, Gates2Bx, DecoderRole<false>>(
-             (l1 && fa < 1.f) ? use<Gru1Bx>(&g1, k.k1bx, fa, fb) : none<Gru1Bx>(), l2 ? use<Gates2Bx>(&g2, k.g2bx) : none<Gates2Bx>(),
-             (dec && fd > 0.f) ? use<DecoderRole<false>>(&da, k.dec, 0.f, fd) : none<DecoderRole<false>>(), B, st, "recurrence slot B (bf16x3)")))
-      return rc;
-    return launch_slot<Gru1Bx, Cand2Bx, DecoderRole<false>>(
-        (l1 && fb < 1.f) ? use<Gru1Bx>(&g1, k.k1bx, fb, 1.f) : none<Gru1Bx>(), lc ? use<Cand2Bx>(&c2, k.c2bx) : none<Cand2Bx>(),
-        dec ? use<DecoderRole<false>>(&da, k.dec, fd, 1.f) : none<DecoderRole<false>>(), B, st, "recurrence slot C (bf16x3)");
+    const bool rest = l1 && f < 1.f;
+    if (!(rest || l2 || dec)) return 0;
+    if (in_up)
+      return launch_slot<Gru1Bx, Gru2Bx, DecoderRole<true>>(rest ? use<Gru1Bx>(&g1, k.k1bx, f, 1.f) : none<Gru1Bx>(),
+                                                            l2 ? use<Gru2Bx>(&g2, k.g2bx) : none<Gru2Bx>(),
+                                                            dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(), B, st,
+                                                            "recurrence slot B (bf16x3)");
+    return launch_slot<Gru1Bx, Gru2Bx, DecoderRole<false>>(rest ? use<Gru1Bx>(&g1, k.k1bx, f, 1.f) : none<Gru1Bx>(),
+                                                           l2 ? use<Gru2Bx>(&g2, k.g2bx) : none<Gru2Bx>(),
+                                                           dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st,
+                                                           "recurrence slot B (bf16x3)");
   }
 
   SmallConvArgs g1{c1_t, H1(t - 1), fw.gates1, fw.gates1_b, rb.rh1, rb.u1, h, w, h, w, 16, nullptr};

@@ -421,11 +421,12 @@ int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int
 
 // One recurrent step after conv1: c1 -> GRU1 -> conv2 -> GRU2 -> decoder -> vol[:, d].
 int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers& sb, float* vol, int B, int h, int w, int D,
-                      int d, int in_up, int precision, hipStream_t st, float** h1_now) {
+                      int d, int in_up, int precision, hipStream_t st, float** h1_now, float** h2_now) {
   int h2 = h / 2, w2 = w / 2, rc;
   float* h1 = sb.h1;
+  float* h2s = sb.h2;
   if (precision == PRECISION_BF16X3) {
-    if ((rc = launch_gru_convs_bf16x3(c1, fw, sb, B, h, w, d, &h1, st))) return rc;
+    if ((rc = launch_gru_convs_bf16x3(c1, fw, sb, B, h, w, d, &h1, &h2s, st))) return rc;
   } else {
   {  // GRU level 1: gates on cat(c1, h1), candidate on cat(c1, r*h1)
     SmallConvArgs g{c1, sb.h1, fw.gates1, fw.gates1_b, sb.rh1, sb.u1, h, w, h, w, 16};
@@ -445,7 +446,8 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   }
   }
   if (h1_now) *h1_now = h1;
-  DecoderArgs da{sb.h2, h1, fw.upconv1, fw.upconv1_b, fw.final_w, vol, h, w, D, d};
+  if (h2_now) *h2_now = h2s;
+  DecoderArgs da{h2s, h1, fw.upconv1, fw.upconv1_b, fw.final_w, vol, h, w, D, d};
   TileGrid tg;
   if ((rc = make_tile_grid(tg, cdiv(w, 30), cdiv(h, 6), B))) return rc;
   static int cap_up = 0, cap_flat = 0;          // resident capacity per instantiation (pure function of kernel + device)

@@ -53,6 +53,24 @@ int launch_conv1_bf16x3(const float* cost, const float* w, float* c1, int N, int
   return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
 }
 
+__global__ __launch_bounds__(256, 2) void k_gru2_fused_bx3(Gru2Args a, TileGrid tg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  Gru2FusedBx3Role::run(a, tg, TileRange{0, tg.ntiles}, blockIdx.x, gridDim.x, lds);
+}
+
+static int launch_gru2_fused(const Gru2Args& a, int B, hipStream_t st) {
+  constexpr size_t lds = Gru2FusedBx3Role::LDS_BYTES;
+  static int capacity = 0;
+  if (!capacity) capacity = resident_blocks(k_gru2_fused_bx3, 256, lds);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, Gru2FusedBx3Role::tiles_x(a), Gru2FusedBx3Role::tiles_y(a), B)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(k_gru2_fused_bx3, dim3(grid), dim3(256), lds, st, a, tg);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "gru2 fused (bf16x3): %s", hipGetErrorString(e));
+  return 0;
+}
+
 static int launch_gru1_fused(const Gru1Args& a, int B, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * 12 * 34 * 32 + 10 * 32 * 32;
   static int capacity = 0;
@@ -66,10 +84,10 @@ static int launch_gru1_fused(const Gru1Args& a, int B, hipStream_t st) {
   return 0;
 }
 
-// GRU level 1 (fused) / conv2 / gates2 / cand2 of one recurrent step (the decoder stays on the fp32 path).
-// *h1_now receives the buffer that holds the level-1 state after the step.
+// GRU level 1 (fused) / conv2 / GRU level 2 (fused) of one recurrent step (the decoder stays on the fp32 path).
+// *h1_now, *h2_now receive the buffers that hold the states after the step.
 int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBuffers& sb, int B, int h, int w, int d,
-                            float** h1_now, hipStream_t st) {
+                            float** h1_now, float** h2_now, hipStream_t st) {
   const int h2 = h / 2, w2 = w / 2;
   int rc;
   // level 1 fused; its state alternates between the h1 and rh1 buffers (step d reads the one step d-1 wrote)
@@ -84,11 +102,12 @@ int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBu
     SmallConvArgsBx a{hout, nullptr, (const bf16x8*)fw.conv2, nullptr, sb.c2, nullptr, nullptr, h, w, h2, w2, 16};
     if ((rc = launch_bx<8, 0, 1, 2, BXE_RELU>(a, B, st, "conv2 (bf16x3)"))) return rc;
   }
-  {
-    SmallConvArgsBx g{sb.c2, sb.h2, (const bf16x8*)fw.gates2, fw.gates2_b, sb.rh2, sb.u2, sb.h2, h2, w2, h2, w2, 32};
-    if ((rc = launch_bx<16, 16, 2, 1, BXE_GATES>(g, B, st, "gates2 (bf16x3)"))) return rc;
-    SmallConvArgsBx c{sb.c2, sb.rh2, (const bf16x8*)fw.cand2, fw.cand2_b, sb.h2, sb.u2, nullptr, h2, w2, h2, w2, 16};
-    if ((rc = launch_bx<16, 16, 1, 1, BXE_CAND>(c, B, st, "cand2 (bf16x3)"))) return rc;
+  {  // level 2 fused; its state alternates between the h2 and rh2 buffers like level 1's
+    float* gin = (d & 1) ? sb.rh2 : sb.h2;
+    float* gout = (d & 1) ? sb.h2 : sb.rh2;
+    Gru2Args g{sb.c2, gin, gout, (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2};
+    if ((rc = launch_gru2_fused(g, B, st))) return rc;
+    *h2_now = gout;
   }
   return 0;
 }

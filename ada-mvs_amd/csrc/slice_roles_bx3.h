@@ -254,214 +254,6 @@ struct ConvSmallBx3Role {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// conv2 (8 -> 16, stride 2, ReLU) and one half of the level-2 gate convolution in one tile loop, split-bf16: the twin of
-// Conv2Gates2Role<HALF> (slice_roles.h) for the two-launch schedule of the pipelined recurrence.  LDS: the 13 x 37 h1 window
-// [hi|lo][481][16 bf16] (8 channels + padding, as ConvSmallBx3Role<8,...>), then the 6 x 18 window of cat(c2, h2)
-// [hi|lo][108][48 bf16]; conv2's fp32 result is split when it is written there, exactly as a loaded c2 would be.
-struct Conv2Gates2BxArgs {
-  const float* st1;        // [B][h*w][8]      level-1 state of the step
-  const float* st2;        // [B][h2*w2][16]   level-2 state of the previous step
-  const bf16x8* wconv2;    // A fragments [1][hi|lo][3][64]
-  const bf16x8* wgates;    // A fragments [2][hi|lo][9][64]
-  const float* bgates;     // [32]
-  float* c2;               // [B][h2*w2][16]
-  float* rh;               // [B][h2*w2][16]   r * h2
-  float* u;                // [B][h2*w2][16]
-  int h, w, h2, w2;
-};
-
-template <int HALF>
-struct Conv2Gates2Bx3Role {
-  typedef Conv2Gates2BxArgs Args;
-  static constexpr int TR = 4, TC = 16, LR = TR + 2, LC = TC + 2, NW = LR * LC;
-  static constexpr int HR = 2 * LR + 1, HC = 2 * LC + 1, NH = HR * HC;
-  static constexpr int PPA = bx_pixel_pitch(8), PPB = bx_pixel_pitch(32);       // bf16 per pixel
-  static constexpr int LOA = NH * PPA * 2, LOB = NW * PPB * 2;                 // byte offsets of the lo images
-  static constexpr int BASE_B = 2 * LOA;
-  static constexpr int NA = (NH * 2 + 255) / 256, NB = (NW * 4 + 255) / 256, NL = NA + NB;
-  static constexpr int NKA = 3, NKG = 9, NRUN = 2;
-  static constexpr size_t LDS_BYTES = (size_t)2 * LOA + 2 * LOB;
-  static constexpr int TILE_W = TC, TILE_H = TR;
-  static_assert(BASE_B % 16 == 0, "16-byte fragment reads");
-  static int tiles_x(const Args& a) { return cdiv(a.w2, TC); }
-  static int tiles_y(const Args& a) { return cdiv(a.h2, TR); }
-
-  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds_) {
-  char* lds = (char*)lds_;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p = lane & 15, q = lane >> 4;
-
-  bf16x8 ch[NKA], cl[NKA], gh[NKG], gl[NKG];
-#pragma unroll
-  for (int kb = 0; kb < NKA; ++kb) { ch[kb] = a.wconv2[(0 * NKA + kb) * 64 + lane]; cl[kb] = a.wconv2[(1 * NKA + kb) * 64 + lane]; }
-#pragma unroll
-  for (int kb = 0; kb < NKG; ++kb) {
-    gh[kb] = a.wgates[((HALF * 2 + 0) * NKG + kb) * 64 + lane];
-    gl[kb] = a.wgates[((HALF * 2 + 1) * NKG + kb) * 64 + lane];
-  }
-  const f32x4 bias = *(const f32x4*)(a.bgates + HALF * 16 + 4 * q);
-
-  unsigned goff[NL], lbyte[NL];
-  int rc[NL];
-#pragma unroll
-  for (int k = 0; k < NL; ++k) {
-    if (k < NA) {
-      const int j = min(tid + k * 256, NH * 2 - 1);
-      const int g = j % 2, pp = j / 2, r = pp / HC, c = pp % HC;
-      goff[k] = (unsigned)(((r * a.w + c) * 8 + 4 * g) * 4);
-      lbyte[k] = (unsigned)((pp * PPA + 4 * g) * 2);
-      rc[k] = r | (c << 16);
-    } else {
-      const int j = min(tid + (k - NA) * 256, NW * 4 - 1);
-      const int g = j % 4, pp = j / 4, r = pp / LC, c = pp % LC;
-      goff[k] = (unsigned)(((r * a.w2 + c) * 16 + 4 * g) * 4);
-      lbyte[k] = (unsigned)(BASE_B + (pp * PPB + 16 + 4 * g) * 2);
-      rc[k] = r | (c << 16);
-    }
-    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
-  }
-  // conv2: run j of the wave = window pixels 16 (wave + 4 j) .. + 15; k-block kb, lane q: tap 4 kb + q, channels 0..7
-  unsigned xa[NRUN][NKA], cbyte[NRUN], coff[NRUN];
-  int wrc[NRUN];
-#pragma unroll
-  for (int j = 0; j < NRUN; ++j) {
-    const int i = 16 * (wave + 4 * j) + p, ic = min(i, NW - 1);
-    const int wr = ic / LC, wcol = ic % LC;
-#pragma unroll
-    for (int kb = 0; kb < NKA; ++kb) {
-      int pos = 4 * kb + q;
-      if (pos >= 9) pos = 0;                          // zero-weight padding: any valid address
-      xa[j][kb] = (unsigned)((((2 * wr + pos / 3) * HC + 2 * wcol + pos % 3) * PPA) * 2);
-      pin(xa[j][kb]);
-    }
-    cbyte[j] = (unsigned)(BASE_B + (ic * PPB + 4 * q) * 2);
-    const bool inner = i < NW && wr >= 1 && wr <= TR && wcol >= 1 && wcol <= TC;
-    coff[j] = inner ? (unsigned)((((wr - 1) * a.w2 + wcol - 1) * 16 + 4 * q) * 4) : BUF_OOB;
-    wrc[j] = wr | (wcol << 16);
-    pin(cbyte[j]); pin(coff[j]); pin(wrc[j]);
-  }
-  unsigned xg[NKG];                                   // gates: k-block kb = tap kb, lane q: channels 8q..8q+7 of cat(c2, h2)
-#pragma unroll
-  for (int kb = 0; kb < NKG; ++kb) {
-    xg[kb] = (unsigned)(BASE_B + (((wave + kb / 3) * LC + p + kb % 3) * PPB + 8 * q) * 2);
-    pin(xg[kb]);
-  }
-  unsigned ooff = (unsigned)(((wave * a.w2 + p) * 16 + 4 * q) * 4);
-  pin(ooff);
-
-  auto load_tile = [&](f32x4 (&stage)[NL], int b, int tx, int ty) {
-    const int j0 = tx * TC - 1, i0 = ty * TR - 1;
-    const int ix0 = 2 * j0 - 1, iy0 = 2 * i0 - 1;
-    const buf_rsrc ra = make_rsrc((const char*)a.st1 + (((long)b * a.h + iy0) * a.w + ix0) * 32);
-    const buf_rsrc rb = make_rsrc((const char*)a.st2 + (((long)b * a.h2 + i0) * a.w2 + j0) * 64);
-    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HR <= a.h && ix0 + HC <= a.w && i0 + LR <= a.h2 && j0 + LC <= a.w2;
-    if (interior) {
-#pragma unroll
-      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < NL; ++k) {
-        const bool isA = k < NA;
-        const int iy = (isA ? iy0 : i0) + (rc[k] & 0xffff), ix = (isA ? ix0 : j0) + (rc[k] >> 16);
-        const bool ok = (unsigned)iy < (unsigned)(isA ? a.h : a.h2) && (unsigned)ix < (unsigned)(isA ? a.w : a.w2);
-        stage[k] = buf_load4(isA ? ra : rb, ok ? goff[k] : BUF_OOB);
-      }
-    }
-  };
-  auto store_tile = [&](const f32x4 (&stage)[NL]) {
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      __bf16* hi = (__bf16*)(lds + lbyte[k]);
-      split_store(hi, (__bf16*)((char*)hi + (k < NA ? LOA : LOB)), stage[k]);
-    }
-  };
-
-  int t = tr.begin + wg;
-  if (t >= tr.end) return;
-  int b, tx, ty;
-  tile_coords(tg, t, b, tx, ty);
-  f32x4 stage[NL];
-  load_tile(stage, b, tx, ty);
-  wait_vmem_all();
-  store_tile(stage);
-  __syncthreads();
-  for (;;) {
-    const int oy0 = ty * TR, ox0 = tx * TC;
-    const long opix0 = ((long)b * a.h2 + oy0) * a.w2 + ox0;
-    const bool full = oy0 + TR <= a.h2 && ox0 + TC <= a.w2;
-    const buf_rsrc rc2 = make_rsrc((char*)a.c2 + opix0 * 64);
-    const buf_rsrc r0 = make_rsrc((char*)a.rh + opix0 * 64);
-    const buf_rsrc r1 = make_rsrc((char*)a.u + opix0 * 64);
-    const buf_rsrc rhs = make_rsrc((const char*)a.st2 + opix0 * 64);
-    unsigned oo = ooff;
-    if (!full && !(oy0 + wave < a.h2 && ox0 + p < a.w2)) oo = BUF_OOB;
-    f32x4 pre_h = {0.f, 0.f, 0.f, 0.f};
-    if (HALF == 0) pre_h = buf_load4(rhs, oo);                    // the exact fp32 state of the lane's pixel (r * h)
-    const int tn = t + nwg;
-    const bool more = tn < tr.end;
-    int bn = 0, txn = 0, tyn = 0;
-    if (more) {
-      tile_coords(tg, tn, bn, txn, tyn);
-      load_tile(stage, bn, txn, tyn);
-    }
-
-    // ---- conv2 on the 6 x 18 window -> ReLU -> split into the cat(c2, h2) tile and, for the tile proper, memory
-    const bool win_in = oy0 >= 1 && ox0 >= 1 && oy0 + TR + 1 <= a.h2 && ox0 + TC + 1 <= a.w2;
-#pragma unroll
-    for (int j = 0; j < NRUN; ++j) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < NKA; ++kb) {
-        const bf16x8 bh = *(const bf16x8*)(lds + xa[j][kb]);
-        const bf16x8 bl = *(const bf16x8*)(lds + xa[j][kb] + LOA);
-        acc = mfma_bx(ch[kb], bh, acc);
-        acc = mfma_bx(ch[kb], bl, acc);
-        acc = mfma_bx(cl[kb], bh, acc);
-      }
-      drain(acc);
-      const int wr = wrc[j] & 0xffff, wcol = wrc[j] >> 16;
-      bool inside = true;
-      if (!win_in) inside = (unsigned)(oy0 - 1 + wr) < (unsigned)a.h2 && (unsigned)(ox0 - 1 + wcol) < (unsigned)a.w2;
-      f32x4 v = {fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
-      if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      __bf16* hi = (__bf16*)(lds + cbyte[j]);
-      split_store(hi, (__bf16*)((char*)hi + LOB), v);
-      unsigned co = coff[j];
-      if (!full && !(oy0 + wr - 1 < a.h2 && ox0 + wcol - 1 < a.w2)) co = BUF_OOB;
-      if (HALF == 0) buf_store4(rc2, co, v);
-    }
-    __syncthreads();                   // c2 window complete
-
-    // ---- one half of the gates on cat(c2, h2)
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < NKG; ++kb) {
-      const bf16x8 bh = *(const bf16x8*)(lds + xg[kb]);
-      const bf16x8 bl = *(const bf16x8*)(lds + xg[kb] + LOB);
-      acc = mfma_bx(gh[kb], bh, acc);
-      acc = mfma_bx(gh[kb], bl, acc);
-      acc = mfma_bx(gl[kb], bh, acc);
-    }
-    drain(acc);
-
-    wait_vmem_all();                   // the one wait point of the tile
-    __syncthreads();                   // every wave is done reading both windows
-    if (more) store_tile(stage);
-
-    {
-      const f32x4 v = acc + bias;
-      const f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
-      if (HALF == 0) buf_store4(r0, oo, sg * pre_h);
-      else buf_store4(r1, oo, sg);
-    }
-    if (!more) break;
-    __syncthreads();                   // next tile visible
-    t = tn; b = bn; tx = txn; ty = tyn;
-  }
-  }
-};
-
-// ---------------------------------------------------------------------------------------------------------------
 // Level-1 ConvGRU in one kernel (reference models/module.py:28-52 at full stage resolution): the gate convolution
 // on cat(x, h), r*h, the candidate convolution on cat(x, r*h) and the state blend, per 8 x 30 tile.  The level-1
 // maps are the widest of the recurrence (8 channels at stage resolution) and the split-bf16 chain is short, so
@@ -666,6 +458,215 @@ struct Gru1FusedBx3Role {
       buf_store4(rout, oo[j], u4[j] * pre_h[j] + (1.0f - u4[j]) * cnd);
     }
     if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; b = bn; tx = txn; ty = tyn;
+  }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Level-2 ConvGRU in one kernel (reference models/module.py:28-52 on cat(conv2 output, state2), 16 hidden channels at half
+// the stage resolution): the twin of Gru1FusedBx3Role.  The separate gate / candidate kernels exchanged r*h and u through
+// memory and each read c2 and the state with their halo (816 B per pixel); fused, a tile reads c2 and the state once
+// (12 x 18 window, halo 2, for 8 x 14 pixels: 247 B per pixel) and writes the new state.
+// The gate convolution has 32 output rows = two MFMA row tiles, 144 registers of split weights -- too many next to the
+// candidate's 72 -- so the waves specialise: waves 0, 1 own the reset-gate rows, waves 2, 3 the update-gate rows, each
+// over half of the ten region rows (the 8 x 14 tile grown by one pixel, one 16-pixel run per row); all four then share the
+// candidate (two of the eight rows each).  r*h goes, split, to a buffer of its own (the window keeps the state: no
+// barrier between a gate run and its epilogue, one accumulator live), where the lanes that carry the state channels of
+// the candidate's B fragments read it; u waits in LDS as fp32.
+//   LDS: window [hi|lo][12*18 pixels][c2 16 | h 16 | pad 16] bf16; u [10*16 region pixels][16] fp32;
+//        r*h [hi|lo][10 rows x 18 (16 + 2 never-written columns that only the two surplus lanes of a run read)][16] bf16.
+struct Gru2Args {
+  const float* x;        // conv2 output [B][h*w][16]     (h, w: the level-2 size)
+  const float* hin;      // state in  [B][h*w][16]
+  float* hout;           // state out [B][h*w][16] (a different buffer)
+  const bf16x8* wg; const float* bg;    // gates2 A fragments [2][hi|lo][9][64], bias [32]
+  const bf16x8* wc; const float* bc;    // cand2  A fragments [1][hi|lo][9][64], bias [16]
+  int h, w;
+};
+
+struct Gru2FusedBx3Role {
+  typedef Gru2Args Args;
+  static constexpr int TR = 8, TC = 14, WR = TR + 4, WC = TC + 4, NPIXW = WR * WC;
+  static constexpr int PB = 2 * bx_pixel_pitch(32);    // bytes per window pixel
+  static constexpr int LO = NPIXW * PB;                // lo image of the window
+  static constexpr int U0 = 2 * LO;                    // u tile
+  static constexpr int RH0 = U0 + 10 * 16 * 64;        // r*h buffer
+  static constexpr int RC = 18, RPB = 2 * bx_pixel_pitch(16), RLO = 10 * RC * RPB;      // its row length, pixel pitch, lo image
+  static constexpr int NKB = 9, NG = 5, NC = 2;        // k-blocks (9 taps x 32 channels), gate / candidate runs per wave
+  static constexpr int NITEM = NPIXW * 4, NS = (NITEM + 255) / 256;      // 4-channel groups per source, loads per thread
+  static constexpr int BIAS0 = RH0 + 2 * RLO;          // gate bias [32], candidate bias [16] (fp32): read where they are used
+  static constexpr size_t LDS_BYTES = (size_t)BIAS0 + 48 * 4;
+  static_assert(LDS_BYTES <= 64 * 1024, "default dynamic LDS limit");
+  static constexpr int TILE_W = TC, TILE_H = TR;
+  static int tiles_x(const Args& a) { return cdiv(a.w, TC); }
+  static int tiles_y(const Args& a) { return cdiv(a.h, TR); }
+
+  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds_) {
+  char* lds = (char*)lds_;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int half = wave >> 1, rr0 = wave & 1;          // gate rows (0 reset, 1 update); first region row of the wave
+
+  bf16x8 gh[NKB], gl[NKB], ch[NKB], cl[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    gh[kb] = a.wg[((half * 2 + 0) * NKB + kb) * 64 + lane]; gl[kb] = a.wg[((half * 2 + 1) * NKB + kb) * 64 + lane];
+    ch[kb] = a.wc[(0 * NKB + kb) * 64 + lane]; cl[kb] = a.wc[(1 * NKB + kb) * 64 + lane];
+  }
+  if (tid < 48) ((float*)(lds + BIAS0))[tid] = tid < 32 ? a.bg[tid] : a.bc[tid - 32];      // visible after the first barrier
+  const unsigned bgbyte = (unsigned)(BIAS0 + (half * 16 + 4 * q) * 4), bcbyte = (unsigned)(BIAS0 + (32 + 4 * q) * 4);
+
+  unsigned goff[NS], lbyte[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    int j = min(tid + k * 256, NITEM - 1);
+    const int g = j & 3, pp = j >> 2, r = pp / WC, c = pp % WC;
+    goff[k] = (unsigned)(((r * a.w + c) * 16 + 4 * g) * 4);
+    lbyte[k] = (unsigned)(pp * PB + 8 * g);
+    pin(goff[k]); pin(lbyte[k]);
+  }
+  // B fragments: k-block = tap, lane q: channels 8q .. 8q+7 of cat(c2, state).  Gate run 0 of the wave reads the window;
+  // candidate run 0 (inner row `wave`) reads c2 (q < 2) from the window and r*h (q >= 2) from its buffer.
+  // All lanes of a k-block share its tap (32 channels = one k-block per tap), so a fragment address is a lane base plus a
+  // compile-time offset; the candidate's lanes differ in geometry (window or r*h buffer), chosen per lane at the read.
+  unsigned xg = (unsigned)((rr0 * WC + p) * PB + 16 * q);
+  const bool from_window = q < 2;
+  unsigned xc = from_window ? (unsigned)(((wave + 1) * WC + p + 1) * PB + 16 * q) : (unsigned)(RH0 + (wave * RC + p) * RPB + 16 * (q - 2));
+  pin(xg); pin(xc);
+  const unsigned hbyte = (unsigned)(((rr0 + 1) * WC + p + 1) * PB + (16 + 4 * q) * 2);            // the state of the lane's region pixel
+  const unsigned rbyte = (unsigned)(RH0 + (rr0 * RC + p) * RPB + 8 * q);                          // its r*h
+  const unsigned ubyte_w = (unsigned)(U0 + ((rr0 * 16 + p) * 16 + 4 * q) * 4);
+  const unsigned ubyte_r = (unsigned)(U0 + (((wave + 1) * 16 + p + 1) * 16 + 4 * q) * 4);        // inner (ir, p) = region (ir+1, p+1)
+  unsigned ooff = p < TC ? (unsigned)(((wave * a.w + p) * 16 + 4 * q) * 4) : BUF_OOB;
+  const unsigned orow4 = (unsigned)(a.w * 4 * 64);     // four rows of the state maps, bytes
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&sx)[NS], f32x4 (&sh)[NS], int b, int tx, int ty) {
+    const int ix0 = tx * TC - 2, iy0 = ty * TR - 2;
+    const long pix0 = ((long)b * a.h + iy0) * a.w + ix0;
+    const buf_rsrc rx = make_rsrc((const char*)a.x + pix0 * 64);
+    const buf_rsrc rh = make_rsrc((const char*)a.hin + pix0 * 64);
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + WR <= a.h && ix0 + WC <= a.w) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) { sx[k] = buf_load4(rx, goff[k]); sh[k] = buf_load4(rh, goff[k]); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int pp = min(tid + k * 256, NITEM - 1) >> 2;          // (edge tiles only: not worth a register per item)
+        const int iy = iy0 + pp / WC, ix = ix0 + pp % WC;
+        const bool ok = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+        const unsigned o = ok ? goff[k] : BUF_OOB;
+        sx[k] = buf_load4(rx, o); sh[k] = buf_load4(rh, o);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&sx)[NS], const f32x4 (&sh)[NS]) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      __bf16* hi = (__bf16*)(lds + lbyte[k]);
+      split_store(hi, (__bf16*)((char*)hi + LO), sx[k]);
+      split_store(hi + 16, (__bf16*)((char*)hi + LO) + 16, sh[k]);
+    }
+  };
+
+  int t = tr.begin + wg;
+  if (t >= tr.end) return;
+  int b, tx, ty;
+  tile_coords(tg, t, b, tx, ty);
+  f32x4 sx[NS], sh[NS];
+  load_tile(sx, sh, b, tx, ty);
+  wait_vmem_all();
+  store_tile(sx, sh);
+  __syncthreads();
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)b * a.h + oy0) * a.w + ox0;
+    const buf_rsrc rin = make_rsrc((const char*)a.hin + opix0 * 64);
+    const buf_rsrc rout = make_rsrc((char*)a.hout + opix0 * 64);
+    const bool full = oy0 + TR <= a.h && ox0 + TC <= a.w;
+    unsigned oo[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      oo[j] = ooff == BUF_OOB ? BUF_OOB : ooff + j * orow4;
+      if (!full && !(oy0 + wave + 4 * j < a.h && ox0 + p < a.w)) oo[j] = BUF_OOB;
+    }
+
+    // ---- the wave's gate rows on cat(c2, h): region rows rr0, rr0 + 2, ...; r*h (from the split state of the window:
+    //      what the candidate convolution multiplies is a split value anyway) and u go to their own buffers
+#pragma unroll 1                       // (unrolled, the scheduler interleaves the five chains: spills)
+    for (int j = 0; j < NG; ++j) {
+      f32x4 ag = *(const f32x4*)(lds + bgbyte);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const char* at = lds + xg + ((kb / 3) * WC + kb % 3) * PB + j * (2 * WC * PB);
+        const bf16x8 bh = *(const bf16x8*)at;
+        const bf16x8 bl = *(const bf16x8*)(at + LO);
+        ag = mfma_bx(gh[kb], bh, ag);
+        ag = mfma_bx(gh[kb], bl, ag);
+        ag = mfma_bx(gl[kb], bh, ag);
+      }
+      drain(ag);
+      const f32x4 sg = {sigmoidf_(ag.x), sigmoidf_(ag.y), sigmoidf_(ag.z), sigmoidf_(ag.w)};
+      if (half == 0) {
+        const __bf16* hi = (const __bf16*)(lds + hbyte + j * (2 * WC * PB));
+        const bf16x4 h4 = *(const bf16x4*)hi, l4 = *(const bf16x4*)((const char*)hi + LO);
+        const f32x4 hv = {(float)h4.x + (float)l4.x, (float)h4.y + (float)l4.y, (float)h4.z + (float)l4.z, (float)h4.w + (float)l4.w};
+        __bf16* rh = (__bf16*)(lds + rbyte + j * (2 * RC * RPB));
+        split_store(rh, (__bf16*)((char*)rh + RLO), sg * hv);
+      } else {
+        *(f32x4*)(lds + ubyte_w + j * (2 * 16 * 64)) = sg;
+      }
+    }
+    __syncthreads();                   // r*h and u visible
+
+    // ---- request: the exact fp32 state of the lane's pixels for the blend
+    f32x4 pre_h[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) pre_h[j] = buf_load4(rin, oo[j]);
+
+    // ---- candidate on cat(c2, r*h): inner rows wave, wave + 4
+    f32x4 ac[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      ac[j] = *(const f32x4*)(lds + bcbyte);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const unsigned off = from_window ? (unsigned)(((kb / 3 + 4 * j) * WC + kb % 3) * PB) : (unsigned)(((kb / 3 + 4 * j) * RC + kb % 3) * RPB);
+        const char* at = lds + xc + off;
+        const bf16x8 bh = *(const bf16x8*)at;
+        const bf16x8 bl = *(const bf16x8*)(at + (from_window ? LO : RLO));
+        ac[j] = mfma_bx(ch[kb], bh, ac[j]);
+        ac[j] = mfma_bx(ch[kb], bl, ac[j]);
+        ac[j] = mfma_bx(cl[kb], bh, ac[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) drain(ac[j]);
+    f32x4 u4[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) u4[j] = *(const f32x4*)(lds + ubyte_r + j * (4 * 16 * 64));
+
+    // the next window is requested only now: its 32 staging registers do not fit next to the chains (144 registers of
+    // weights); the blend and the other workgroup of the CU cover part of its latency
+    const int tn = t + nwg;
+    const bool more = tn < tr.end;
+    int bn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, bn, txn, tyn);
+      load_tile(sx, sh, bn, txn, tyn);
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const f32x4 v = ac[j];
+      const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+      buf_store4(rout, oo[j], u4[j] * pre_h[j] + (1.0f - u4[j]) * cnd);
+    }
+    if (!more) break;
+    __syncthreads();                   // every wave is done with the tile
+    wait_vmem_all();
+    store_tile(sx, sh);
     __syncthreads();                   // next tile visible
     t = tn; b = bn; tx = txn; ty = tyn;
   }
