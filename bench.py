@@ -489,10 +489,11 @@ def main():
                 # executed flops: the split-bf16 mode issues three bf16 products per fp32 product
                 ach = st["recurrence_flops"] * (3 if split else 1) / (avg[dom] * 1e-3) / 1e12
                 peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-                nl = 3
-                roof = {"kernel": "recurrent slot kernels k_slot<...> (%d steps x %d launches)" % (st["D"], nl), "bound": "mfma",
+                # launches per hypothesis depend on the stage size (csrc/recurrence.hip: 6 / 3 / 2 in fp32, 4 / 2 in bf16x3):
+                # the figure priced here is one hypothesis = one recurrent step of all tiles
+                roof = {"kernel": "the ConvGRU / decoder tile loops of one hypothesis (%d hypotheses per step)" % st["D"], "bound": "mfma",
                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                        "launch_ms": avg[dom] / (nl * st["D"]), "traffic": None}
+                        "launch_ms": avg[dom] / st["D"], "traffic": None}
                 if split:
                     roof["note"] = ("short K (72-288) convolutions on 8-16 channel maps: bound by launch latency, LDS and the "
                                     "VALU work of the hi/lo split, not by the bf16 matrix pipe")
