@@ -190,17 +190,24 @@ def feature_net0_workspace_bytes(N, H, W):
     return int(_lib.load().adamvs_feature_net0_workspace_bytes(int(N), int(H), int(W)))
 
 
-def feature_net0(imgs, packed, workspace=None):
-    """FeatureNet0.forward on [N,3,H,W] images -> channel-last (stage1 [N,hw/16,32], stage2 [N,hw/4,16], stage3 [N,hw,8])."""
+def feature_net0(imgs, packed, workspace=None, out=None):
+    """FeatureNet0.forward on [N,3,H,W] images -> channel-last (stage1 [N,hw/16,32], stage2 [N,hw/4,16], stage3 [N,hw,8]).
+    out: the three (contiguous) result tensors, e.g. slices of the maps of a larger batch run in chunks."""
     lib = _lib.load()
     imgs = _dev(imgs, "imgs")
     N, c, H, W = imgs.shape
     if c != 3:
         check(-1, "feature_net0")
     dev = imgs.device
-    s1 = torch.empty(N, (H // 4) * (W // 4), 32, device=dev, dtype=torch.float32)
-    s2 = torch.empty(N, (H // 2) * (W // 2), 16, device=dev, dtype=torch.float32)
-    s3 = torch.empty(N, H * W, 8, device=dev, dtype=torch.float32)
+    if out is None:
+        s1 = torch.empty(N, (H // 4) * (W // 4), 32, device=dev, dtype=torch.float32)
+        s2 = torch.empty(N, (H // 2) * (W // 2), 16, device=dev, dtype=torch.float32)
+        s3 = torch.empty(N, H * W, 8, device=dev, dtype=torch.float32)
+    else:
+        s1, s2, s3 = out
+        want = ((N, (H // 4) * (W // 4), 32), (N, (H // 2) * (W // 2), 16), (N, H * W, 8))
+        if any(tuple(t.shape) != w or not t.is_contiguous() or t.dtype != torch.float32 or t.device != dev for t, w in zip(out, want)):
+            raise _lib.AdaMVSHipError("feature_net0: out tensors must be contiguous float32 %s on %s" % (want, dev))
     nbytes = lib.adamvs_feature_net0_workspace_bytes(N, H, W)
     if workspace is None or workspace.numel() * 4 < nbytes:
         workspace = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)

@@ -75,8 +75,11 @@ class FeatureNet0(PackedCache, nn.Module):
             chunk = max(1, int(self.workspace_limit_bytes // per_image))
             if x.shape[0] <= chunk:
                 return hip_ops.feature_net0(x, self.packed(x.device))
-            parts = [hip_ops.feature_net0(x[i:i + chunk], self.packed(x.device)) for i in range(0, x.shape[0], chunk)]
-            return tuple(torch.cat([p[k] for p in parts], 0) for k in range(3))
+            N, H, W = x.shape[0], x.shape[-2], x.shape[-1]      # chunks write into their slices of the whole maps (no concatenation copy)
+            maps = tuple(torch.empty(N, (H // s) * (W // s), c, device=x.device, dtype=torch.float32) for s, c in ((4, 32), (2, 16), (1, 8)))
+            for i in range(0, N, chunk):
+                hip_ops.feature_net0(x[i:i + chunk], self.packed(x.device), out=tuple(m[i:i + chunk] for m in maps))
+            return maps
         f = self.forward_torch(x)
         return tuple(hip_ops.pack_features(f["stage%d" % (k + 1)]) for k in range(3))
 

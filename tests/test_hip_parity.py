@@ -140,6 +140,25 @@ def test_feature_net0_against_oracle(hip, O, N, H, W):
     assert all(torch.equal(a, b) for a, b in zip(chunked, maps))
 
 
+def test_feature_net0_in_chunks_equals_one_call(hip):
+    """forward_cl bounds its workspace by running large batches in chunks that write into slices of the whole maps."""
+    m, _ = _model("tiny")
+    x = torch.randn(5, 3, 64, 96, generator=torch.Generator().manual_seed(8)).cuda()
+    with torch.no_grad():
+        whole = m.feature.forward_cl(x)
+        per_image = hip.feature_net0_workspace_bytes(1, 64, 96)
+        limit = m.feature.workspace_limit_bytes
+        m.feature.workspace_limit_bytes = 2 * per_image          # chunks of 2, 2, 1 images
+        try:
+            parts = m.feature.forward_cl(x)
+        finally:
+            m.feature.workspace_limit_bytes = limit
+    for a, b in zip(whole, parts):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception, match="out tensors"):
+        hip.feature_net0(x[:1], m.feature.packed(x.device), out=tuple(t[:1, :, :4] for t in whole))
+
+
 def test_feature_net0_golden(hip):
     """Against the reference's own FeatureNet0 outputs (end-to-end fixture, 64x96, 3 views)."""
     g = load_golden("e2e_tiny")
