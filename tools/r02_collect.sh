@@ -19,3 +19,4 @@ for n in cfg2_bf16x3 cfg3_fp32_b128 cfg3_bf16x3_b128 cfg4_share_fp32_b4 cfg4_sha
   cp ${g}_bench_$n.json profiles/r02_bench_$n.json
 done
 cp ${g}_gpu_tests.txt profiles/r02_gpu_tests.txt
+cp gpurun_out/parity_full_size.jsonl profiles/r02_parity_full_size.jsonl
