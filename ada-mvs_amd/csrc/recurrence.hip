@@ -15,6 +15,7 @@
 //   bf16x3   both GRU levels are one kernel each (gru1, gru2):
 //            slot A(t): gru1(t) | conv2(t-1)        slot B(t): gru1(t)' | gru2(t-1) | decoder(t-2)
 //            (the level-1 kernel has no dependant inside its step: its tiles are dealt to both launches)
+//            or ONE launch per hypothesis (schedule 5, the smallest stages):  gru1(t) | conv2(t-1) | gru2(t-2) | decoder(t-3)
 //
 // State rings: h1 of step t lives in h1[t % 4] (the decoder still reads h1[t-2] or h1[t-3] while cand1 writes h1[t]),
 // h2 and conv2's output of step t in h2[t % 2], c2[t % 2].  The arithmetic of every tile is that of the one-role kernels (slice_roles.h): the pipelined stage
@@ -75,11 +76,12 @@ struct RoleUse {
 };
 
 // Divide `total` workgroups over the roles in proportion to their work, at least one and at most one per tile.
-static void split_grid(int total, const long (&tiles)[3], const double (&work)[3], int (&n)[3]) {
+template <int NR>
+static void split_grid(int total, const long (&tiles)[NR], const double (&work)[NR], int (&n)[NR]) {
   double W = 0;
-  for (int i = 0; i < 3; ++i) W += tiles[i] ? work[i] : 0;
+  for (int i = 0; i < NR; ++i) W += tiles[i] ? work[i] : 0;
   int sum = 0;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NR; ++i) {
     n[i] = 0;
     if (!tiles[i]) continue;
     long v = (long)(total * (work[i] / W) + 0.5);
@@ -88,13 +90,13 @@ static void split_grid(int total, const long (&tiles)[3], const double (&work)[3
   }
   while (sum > total) {                       // rounding: take from the role with the most workgroups
     int k = -1;
-    for (int i = 0; i < 3; ++i) if (n[i] > 1 && (k < 0 || n[i] > n[k])) k = i;
+    for (int i = 0; i < NR; ++i) if (n[i] > 1 && (k < 0 || n[i] > n[k])) k = i;
     if (k < 0) break;
     --n[k]; --sum;
   }
   while (sum < total) {                       // give to the role with the most work per workgroup that can still grow
     int k = -1;
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NR; ++i)
       if (tiles[i] && n[i] < tiles[i] && (k < 0 || work[i] / n[i] > work[k] / n[k])) k = i;
     if (k < 0) break;
     ++n[k]; ++sum;
@@ -130,10 +132,73 @@ static int launch_slot(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleU
   const long all = tiles[0] + tiles[1] + tiles[2];
   if (all == 0) return 0;
   int n[3];
-  split_grid((int)(all < capacity ? all : capacity), tiles, work, n);
+  split_grid<3>((int)(all < capacity ? all : capacity), tiles, work, n);
   s.n0 = n[0];
   s.n1 = n[1];
   hipLaunchKernelGGL(kern, dim3(n[0] + n[1] + n[2]), dim3(256), lds, st, s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
+  return 0;
+}
+
+// ---- a launch of four roles: when both ConvGRU levels are one kernel each, nothing inside a step depends on anything else
+// once the levels are skewed by one hypothesis each -- gru1(t) | conv2(t-1) | gru2(t-2) | decoder(t-3) -- and a
+// hypothesis costs ONE dependent launch.
+template <class R0, class R1, class R2, class R3>
+struct SlotArgs4 {
+  typename R0::Args a0; TileGrid g0; TileRange r0; int n0;
+  typename R1::Args a1; TileGrid g1; TileRange r1; int n1;
+  typename R2::Args a2; TileGrid g2; TileRange r2; int n2;
+  typename R3::Args a3; TileGrid g3; TileRange r3;
+};
+constexpr int imax4(int a, int b, int c, int d) { return imax3(imax3(a, b, c), d, d); }
+constexpr size_t max4(size_t a, size_t b, size_t c, size_t d) { return max3(max3(a, b, c), d, d); }
+
+template <class R0, class R1, class R2, class R3>
+__global__ __launch_bounds__(256, imax4(min_blocks<R0>::value, min_blocks<R1>::value, min_blocks<R2>::value, min_blocks<R3>::value))
+void k_slot4(SlotArgs4<R0, R1, R2, R3> s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wg = blockIdx.x;
+  if (wg < s.n0) R0::run(s.a0, s.g0, s.r0, wg, s.n0, lds);
+  else if (wg < s.n0 + s.n1) R1::run(s.a1, s.g1, s.r1, wg - s.n0, s.n1, lds);
+  else if (wg < s.n0 + s.n1 + s.n2) R2::run(s.a2, s.g2, s.r2, wg - s.n0 - s.n1, s.n2, lds);
+  else R3::run(s.a3, s.g3, s.r3, wg - s.n0 - s.n1 - s.n2, (int)gridDim.x - s.n0 - s.n1 - s.n2, lds);
+}
+
+template <class R0, class R1, class R2, class R3>
+static int launch_slot4(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleUse<R2>& u2, const RoleUse<R3>& u3, int B, hipStream_t st,
+                        const char* name) {
+  constexpr size_t lds = max4(R0::LDS_BYTES, R1::LDS_BYTES, R2::LDS_BYTES, R3::LDS_BYTES);
+  static_assert(lds <= 64 * 1024, "slot exceeds the default dynamic LDS limit");
+  auto kern = k_slot4<R0, R1, R2, R3>;
+  static int capacity = 0;
+  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  SlotArgs4<R0, R1, R2, R3> s;
+  memset(&s, 0, sizeof(s));
+  long tiles[4] = {0, 0, 0, 0};
+  double work[4] = {0, 0, 0, 0};
+  int rc;
+  auto prep = [&](auto* args, auto& dst_args, TileGrid& g, TileRange& r, float cost, float f0, float f1, int i, auto role) -> int {
+    typedef decltype(role) R;
+    if (!args) return 0;
+    dst_args = *args;
+    if (int e = make_tile_grid(g, R::tiles_x(*args), R::tiles_y(*args), B)) return e;
+    r.begin = (int)((double)g.ntiles * f0 + 0.5);
+    r.end = f1 >= 1.0f ? g.ntiles : (int)((double)g.ntiles * f1 + 0.5);
+    tiles[i] = r.end - r.begin;
+    work[i] = (double)tiles[i] * cost;
+    return 0;
+  };
+  if ((rc = prep(u0.args, s.a0, s.g0, s.r0, u0.cost, u0.f0, u0.f1, 0, R0()))) return rc;
+  if ((rc = prep(u1.args, s.a1, s.g1, s.r1, u1.cost, u1.f0, u1.f1, 1, R1()))) return rc;
+  if ((rc = prep(u2.args, s.a2, s.g2, s.r2, u2.cost, u2.f0, u2.f1, 2, R2()))) return rc;
+  if ((rc = prep(u3.args, s.a3, s.g3, s.r3, u3.cost, u3.f0, u3.f1, 3, R3()))) return rc;
+  const long all = tiles[0] + tiles[1] + tiles[2] + tiles[3];
+  if (all == 0) return 0;
+  int n[4];
+  split_grid<4>((int)(all < capacity ? all : capacity), tiles, work, n);
+  s.n0 = n[0]; s.n1 = n[1]; s.n2 = n[2];
+  hipLaunchKernelGGL(kern, dim3(n[0] + n[1] + n[2] + n[3]), dim3(256), lds, st, s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
   return 0;
@@ -169,8 +234,8 @@ static const RoleCosts& role_costs() {
   return c;
 }
 
-// ADAMVS_RECUR_MODE: 0 = six launches per step, states updated in place; 1 / 2 / 3 = software-pipelined slots, schedule
-// 1 / 2 / 3 (recurrence_lags); unset = by size.  Measured on MI355X (profiles/r02_recurrence_schedules.txt): sharing launches does
+// ADAMVS_RECUR_MODE: 0 = six launches per step, states updated in place; 1 / 2 / 3 / 5 = software-pipelined slots, schedule
+// 1 / 2 / 3 / 5 (recurrence_lags; 5: bf16x3 only); unset = by size.  Measured on MI355X (profiles/r02_recurrence_schedules.txt): sharing launches does
 // not make the roles faster -- a slot takes the sum of its roles' standalone times, the decoder more -- so what the
 // pipeline buys is three launch latencies per hypothesis, which pays while a step is latency-bound (few tiles per CU:
 // cfg4's 4 tiles per GPU 24.3 -> 22.0 ms) and costs 2-3 % once every role fills the chip several times over.
@@ -179,9 +244,10 @@ int recurrence_mode(int precision, long pixels) {
   if (e && *e) return atoi(e);
   // B * h * w of the stage.  Measured (profiles/r02_recurrence_schedules.txt): fp32 -- two launches per hypothesis win up
   // to ~200k pixels (cfg4's 4 tiles per GPU at stage 1: 7.8 -> 5.9 -> 5.1 ms), three up to ~800k, six beyond;
-  // bf16x3 (both GRU levels are one kernel each: four launches per hypothesis, or two) -- two up to ~1M pixels (cfg4's share:
-  // stage 1 5.29 -> 3.77 ms, stage 2 3.29 -> 2.77; at 590k pixels 15.8 -> 15.1; at 1.18M a tie; at 2.36M 51.3 -> 55.2).
-  if (precision != PRECISION_FP32) return pixels <= 1000000 ? 3 : 0;
+  // bf16x3 (both GRU levels are one kernel each: four launches per hypothesis, two, or one) -- one up to ~300k pixels
+  // (cfg4's share at stage 1: 5.27 / 3.75 / 3.49 ms with four / two / one; at 295k 9.95 / 9.40 / 8.99), two up to ~1M (at
+  // 590k 15.6 / 15.1 / 15.5; at 1.18M a tie), four beyond (at 2.36M 51.3 against 55.2).
+  if (precision != PRECISION_FP32) return pixels <= 300000 ? 5 : (pixels <= 1000000 ? 3 : 0);
   return pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0);
 }
 
@@ -201,6 +267,7 @@ template <class R> static RoleUse<R> none() { return RoleUse<R>{nullptr, 0.f, 0.
 // SIMD; in schedule 1 cand1 runs at gates2's two.
 RecurLags recurrence_lags(int schedule, int precision) {
   if (schedule == 2 && precision == PRECISION_FP32) return RecurLags{2, 3};
+  if (schedule == 5 && precision == PRECISION_BF16X3) return RecurLags{2, 3};       // one launch: gru2 two, the decoder three behind
   return RecurLags{1, 2};
 }
 
@@ -226,6 +293,17 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
     // (the level-1 kernel has no dependant inside its step: its tiles are dealt to both launches so that they carry equal work)
     Gru1Args g1{c1_t, H1(t - 1), H1(t), (const bf16x8*)fw.gates1, fw.gates1_b, (const bf16x8*)fw.cand1, fw.cand1_b, h, w};
     SmallConvArgsBx v2{H1(s2), nullptr, (const bf16x8*)fw.conv2, nullptr, C2(s2), nullptr, nullptr, h, w, h2, w2, 16, nullptr};
+    if (schedule == 5) {
+      // ONE launch per hypothesis: gru1(t) | conv2(t-1) | gru2(t-2) | decoder(t-3) -- every role reads only what earlier launches wrote
+      Gru2Args g2s{C2(sc), H2(sc - 1), H2(sc), (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2};
+      if (in_up)
+        return launch_slot4<Gru1Bx, Conv2Bx, Gru2Bx, DecoderRole<true>>(
+            l1 ? use<Gru1Bx>(&g1, k.k1bx) : none<Gru1Bx>(), l2 ? use<Conv2Bx>(&v2, k.v2bx) : none<Conv2Bx>(), lc ? use<Gru2Bx>(&g2s, k.g2bx) : none<Gru2Bx>(),
+            dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(), B, st, "recurrence, one launch (bf16x3)");
+      return launch_slot4<Gru1Bx, Conv2Bx, Gru2Bx, DecoderRole<false>>(
+          l1 ? use<Gru1Bx>(&g1, k.k1bx) : none<Gru1Bx>(), l2 ? use<Conv2Bx>(&v2, k.v2bx) : none<Conv2Bx>(), lc ? use<Gru2Bx>(&g2s, k.g2bx) : none<Gru2Bx>(),
+          dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st, "recurrence, one launch (bf16x3)");
+    }
     Gru2Args g2{C2(s2), H2(s2 - 1), H2(s2), (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2};
     // per level-1 tile (8 x 30 pixels): 0.94 conv2 tiles (4 x 16 at half resolution), 0.54 gru2 tiles (8 x 14), 1.33 decoder tiles (6 x 30)
     float f = 0.5f + ((0.54f * k.g2bx + 1.33f * k.dec) - 0.94f * k.v2bx) / (2.f * k.k1bx);

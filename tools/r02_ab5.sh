@@ -2,9 +2,9 @@
 # tools/r02_ab5.sh <tag>: bf16x3 with both GRU levels fused -- four launches per hypothesis (mode 0) against two (mode 1)
 tag=$1
 cd "$(dirname "$0")/.."
-for cfgargs in "cfg3 4" "cfg3 8" "cfg3 16" "cfg3 32" "cfg3 128" "cfg2 16" "cfg2 128"; do
+for cfgargs in "cfg3 4" "cfg3 8" "cfg3 16" "cfg3 32" "cfg2 16" "cfg1 32"; do
   set -- $cfgargs
-  for mode in 0 1; do
+  for mode in 0 1 5; do
     out=gpurun_out/${tag}_$1_b$2_m${mode}.json
     ADAMVS_RECUR_MODE=$mode timeout 600 python3 bench.py --no-cpu-baseline --precision bf16x3 --steps 4 --warmup 2 --workload $1 --batch $2 > $out 2> ${out%.json}.err
     python3 -c "
