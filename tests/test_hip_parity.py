@@ -5,6 +5,7 @@ Bar (BASELINE.json north_star): depth / probability maps within 1e-3 relative L1
 of the reference CPU path.  The asserts below use tighter, per-op tolerances
 (fp32 kernels agree to ~1e-5) so that a real bug cannot hide under the bar.
 """
+import numpy as np
 import pytest
 import torch
 
@@ -585,6 +586,47 @@ def test_pipelined_recurrence_on_ragged_stage_sizes(hip, O, monkeypatch, precisi
     for key in ("depth", "photometric_confidence"):
         assert outs["0"][key].shape == ref[key].shape
         assert rel_l1(outs["0"][key], ref[key]) < tol, key
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_stage_on_random_shapes_against_oracle(hip, O, seed):
+    """InferDepthNet0.forward (reference adamvs.py:433-533) on shapes drawn at random -- stage (first stage with
+    CostRegNet2D, or a later one with resampled view weights), batch, number of source views, map size (even, down to
+    4 x 4), number of hypotheses, precision -- against the CPU oracle.  Seeds are fixed: the cases are reproducible."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    rng = np.random.default_rng(1000 + seed)
+    stage = int(rng.integers(0, 3))
+    precision = "bf16x3" if seed % 2 else "fp32"
+    B, V = int(rng.integers(1, 4)), int(rng.choice([2, 3, 5, 9]))
+    if stage == 0:
+        D = int(rng.choice([32, 48, 64]))
+        h, w = 8 * int(rng.integers(1, 4)), 8 * int(rng.integers(1, 5))          # CostRegNet2D: three stride-2 levels
+    else:
+        D = int(rng.integers(2, 41))          # one hypothesis is refused (the reference's plane spacing divides by D - 1)
+        h, w = 2 * int(rng.integers(2, 20)), 2 * int(rng.integers(2, 24))
+    m = Infer_AdaMVSNet(D if stage == 0 else 48, [D if stage == 0 else 48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8],
+                        precision=precision)
+    sd = synth.seeded_state_dict(m, seed=seed)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    net = m.DepthNet[stage]
+    C = (32, 16, 8)[stage]
+    feats = [synth.smooth_features(B, C, h, w, seed=100 * seed + v) for v in range(V)]
+    proj = synth.rig_projections(V, 4 * h, 4 * w, batch=B)["stage1"]
+    g = torch.Generator().manual_seed(seed)
+    near = 420.0 + 20.0 * torch.rand(B, 1, h, w, generator=g)
+    planes = (near + (160.0 / max(D, 2)) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).contiguous()
+    prev = None if stage == 0 else [torch.rand(B, 1, max(h // 2, 1), max(w // 2, 1), generator=g) for _ in range(V - 1)]
+    with torch.no_grad():
+        got = net([dev(f) for f in feats], dev(proj), dev(planes), D, None if prev is None else [dev(c) for c in prev])
+        ref = O.infer_depth_stage(feats, proj, planes, sd, "DepthNet.%d." % stage, net.in_up, prev)
+    tol = E2E_TOL if precision == "fp32" else 5e-4
+    case = (stage, precision, B, V, h, w, D)
+    for key in ("depth", "photometric_confidence"):
+        assert got[key].shape == ref[key].shape, case
+        assert rel_l1(got[key], ref[key]) < tol, (key,) + case
+    for a, b in zip(got["pair_confidence"][:V - 1], ref["pair_confidence"]):
+        assert rel_l1(a, b) < tol, ("pair_confidence",) + case
 
 
 def test_soft_argmin_op(hip):
