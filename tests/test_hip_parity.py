@@ -460,6 +460,18 @@ def test_batch_of_tiles_matches_single_tiles(hip, O):
             assert rel_l1(out["photometric_confidence"][b:b + 1], ref["photometric_confidence"]) < NORTH_STAR_TOL
 
 
+def test_batch_items_with_different_depth_ranges(hip):
+    """Quirk Q4: interval from batch item 0, stage-1 planes per item -- against the reference-run fixture."""
+    g = load_golden("e2e_tiny_two_ranges")
+    m, _ = _model("tiny")
+    imgs, proj, _ = synth.tile_inputs("tiny", batch=2, seed=3)
+    with torch.no_grad():
+        out = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(g["depth_values"]))
+    for key in ("depth", "photometric_confidence"):
+        assert rel_l1(out[key], g[key]) < E2E_TOL, key
+    assert rel_l1(out["stage1"]["depth"], g["s1_depth"]) < E2E_TOL and rel_l1(out["stage2"]["depth"], g["s2_depth"]) < E2E_TOL
+
+
 # --------------------------------------------------------------------------- full-size properties (cfg2 shapes)
 def test_full_size_properties_cfg2(hip):
     """BASELINE cfg2 (5 views, 384x768, single stage, 192 hypotheses): too big for the oracle in seconds,

@@ -116,3 +116,18 @@ def test_end_to_end_cfg1():
     out = O.infer_adamvs_forward(imgs, proj, dv, sd, c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO)
     _check_e2e("cfg1", g, out, 5e-5)
     assert g["s1_n_pairconf"] == 2 + 2 * 48 and g["s2_n_pairconf"] == 2 * 32     # quirk Q1 list lengths
+
+
+def test_batch_items_with_different_depth_ranges():
+    """Quirk Q4 (adamvs.py:569-571): the hypothesis interval of the later stages comes from batch item 0, the stage-1 planes
+    from every item's own [min, max] -- the oracle against a run of the reference on two tiles with different ranges."""
+    g = load_golden("e2e_tiny_two_ranges")
+    c = synth.CONFIGS["tiny"]
+    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=0)
+    imgs, proj, _ = synth.tile_inputs("tiny", batch=2, seed=3)
+    out = O.infer_adamvs_forward(imgs, proj, g["depth_values"], sd, c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    for key in ("depth", "photometric_confidence"):
+        assert rel_l1(out[key], g[key]) < 5e-5, key
+    assert rel_l1(out["stage1"]["depth"], g["s1_depth"]) < 5e-5 and rel_l1(out["stage2"]["depth"], g["s2_depth"]) < 5e-5
+    assert not torch.equal(g["depth_values"][0], g["depth_values"][1])

@@ -139,9 +139,25 @@ def end_to_end(cfg, with_inputs):
         save("e2e_" + cfg + "_twin", depth=o2["depth"], photometric_confidence=o2["photometric_confidence"])
 
 
+@torch.no_grad()
+def two_ranges():
+    """Quirk Q4: a batch whose items have different depth ranges -- the interval comes from item 0 (adamvs.py:569-571), the
+    stage-1 planes from each item's own [min, max].  Inputs: synth.tile_inputs("tiny", batch=2, seed=3) with these ranges."""
+    m = build_ref_model("tiny")
+    imgs, proj, _ = synth.tile_inputs("tiny", batch=2, seed=3)
+    dv = torch.tensor([[400.0, 600.0], [450.0, 640.0]])
+    r = m(imgs, proj, dv)
+    save("e2e_tiny_two_ranges", depth_values=dv, depth=r["depth"], photometric_confidence=r["photometric_confidence"],
+         s1_depth=r["stage1"]["depth"], s2_depth=r["stage2"]["depth"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--only-two-ranges" in sys.argv:
+        two_ranges()
+        sys.exit(0)
     op_level()
     net_level()
     end_to_end("tiny", with_inputs=True)
     end_to_end("cfg1", with_inputs=False)
+    two_ranges()
