@@ -265,3 +265,14 @@ def test_inference_model_refuses_train_mode():
     imgs, proj, dv = synth.tile_inputs("tiny", batch=1, seed=0)
     with pytest.raises(_lib.AdaMVSHipError):
         m(imgs, proj, dv)
+
+
+def test_share_cr_and_cr_base_chs_are_accepted_and_ignored():
+    """Quirk Q8 (reference adamvs.py:537-565): `share_cr` and `cr_base_chs` are constructor arguments of Infer_AdaMVSNet
+    that change nothing -- three DepthNets with GRU widths 8 / 16 whatever is passed; the mirror keeps the same
+    state-dict layout so that reference checkpoints load either way."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    a = Infer_AdaMVSNet(48, [48, 32, 8], [4.0, 2.0, 1.0], False, [8, 8, 8]).state_dict()
+    b = Infer_AdaMVSNet(48, [48, 32, 8], [4.0, 2.0, 1.0], True, [4, 16, 2]).state_dict()
+    assert list(a) == list(b) and len(a) == 339
+    assert all(a[k].shape == b[k].shape for k in a)
