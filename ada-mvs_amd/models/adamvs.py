@@ -32,7 +32,7 @@ def _pooled_context(in_ch, out_ch, pool):
 class FeatureNet0(PackedCache, nn.Module):
     """2D U-Net with pooled-context branches, three output scales (C = 32/16/8 at 1/4, 1/2, 1/1);
     reference models/adamvs.py:49-152.  forward() = adamvs_feature_net0 (csrc/featnet.hip) on GPU tensors whose
-    height and width are multiples of 32 and base_channels = 8; other shapes run the same layers through PyTorch."""
+    height and width are multiples of 32 (the reference's own size rule) and base_channels = 8; anything else raises."""
 
     def __init__(self, base_channels, num_stage=3, stride=4):
         super().__init__()
@@ -67,21 +67,28 @@ class FeatureNet0(PackedCache, nn.Module):
     def hip_supported(self, x):
         return x.is_cuda and self.base_channels == 8 and x.shape[-2] % 32 == 0 and x.shape[-1] % 32 == 0
 
+    def _require_hip(self, x):
+        """forward() / forward_cl() are the HIP kernels or nothing: no PyTorch path is taken silently.  (The reference
+        has the same size rule, quirk Q9: its pooled-context branches and three /2 levels need multiples of 32, which
+        crop_input guarantees; base_channels is 8 in every model it builds.)  forward_torch() is the explicitly named
+        PyTorch evaluation of the same layers, for comparisons."""
+        if not self.hip_supported(x):
+            raise AdaMVSHipError("%s: needs a GPU tensor [N,3,H,W] with H, W multiples of 32 and base_channels 8 (got %s on %s, "
+                                 "base_channels %d); there is no fallback path" % (type(self).__name__, tuple(x.shape), x.device, self.base_channels))
+
     def forward_cl(self, x):
         """[N,3,H,W] -> channel-last stage maps ([N,hw/16,32], [N,hw/4,16], [N,hw,8]) for the plane sweep."""
-        if self.hip_supported(x):
-            # intermediate maps take ~77 floats per pixel and image: bound the workspace, not the batch
-            per_image = hip_ops.feature_net0_workspace_bytes(1, x.shape[-2], x.shape[-1])
-            chunk = max(1, int(self.workspace_limit_bytes // per_image))
-            if x.shape[0] <= chunk:
-                return hip_ops.feature_net0(x, self.packed(x.device))
-            N, H, W = x.shape[0], x.shape[-2], x.shape[-1]      # chunks write into their slices of the whole maps (no concatenation copy)
-            maps = tuple(torch.empty(N, (H // s) * (W // s), c, device=x.device, dtype=torch.float32) for s, c in ((4, 32), (2, 16), (1, 8)))
-            for i in range(0, N, chunk):
-                hip_ops.feature_net0(x[i:i + chunk], self.packed(x.device), out=tuple(m[i:i + chunk] for m in maps))
-            return maps
-        f = self.forward_torch(x)
-        return tuple(hip_ops.pack_features(f["stage%d" % (k + 1)]) for k in range(3))
+        self._require_hip(x)
+        # intermediate maps take ~77 floats per pixel and image: bound the workspace, not the batch
+        per_image = hip_ops.feature_net0_workspace_bytes(1, x.shape[-2], x.shape[-1])
+        chunk = max(1, int(self.workspace_limit_bytes // per_image))
+        if x.shape[0] <= chunk:
+            return hip_ops.feature_net0(x, self.packed(x.device))
+        N, H, W = x.shape[0], x.shape[-2], x.shape[-1]      # chunks write into their slices of the whole maps (no concatenation copy)
+        maps = tuple(torch.empty(N, (H // s) * (W // s), c, device=x.device, dtype=torch.float32) for s, c in ((4, 32), (2, 16), (1, 8)))
+        for i in range(0, N, chunk):
+            hip_ops.feature_net0(x[i:i + chunk], self.packed(x.device), out=tuple(m[i:i + chunk] for m in maps))
+        return maps
 
     @staticmethod
     def _with_context(feat, branch_a, branch_b):
@@ -91,12 +98,11 @@ class FeatureNet0(PackedCache, nn.Module):
         return torch.cat((a, b, feat), 1)
 
     def forward(self, x):
-        if self.hip_supported(x):
-            H, W = x.shape[-2:]
-            s1, s2, s3 = hip_ops.feature_net0(x, self.packed(x.device))
-            return {"stage1": hip_ops.unpack_features(s1, H // 4, W // 4), "stage2": hip_ops.unpack_features(s2, H // 2, W // 2),
-                    "stage3": hip_ops.unpack_features(s3, H, W)}
-        return self.forward_torch(x)
+        self._require_hip(x)
+        H, W = x.shape[-2:]
+        s1, s2, s3 = hip_ops.feature_net0(x, self.packed(x.device))
+        return {"stage1": hip_ops.unpack_features(s1, H // 4, W // 4), "stage2": hip_ops.unpack_features(s2, H // 2, W // 2),
+                "stage3": hip_ops.unpack_features(s3, H, W)}
 
     def forward_torch(self, x):
         c0 = self.conv0(x)
@@ -266,7 +272,6 @@ class Infer_AdaMVSNet(nn.Module):
         self.depth_intervals_ratio = list(depth_intervals_ratio)
         self.cr_base_chs = cr_base_chs
         self.num_stage = len(ndepths)
-        self.feature_chunk = 40                  # images per FeatureNet0 call (extract_features)
         self.materialize_planes = False          # True: hypothesis planes as a [B,D,h,w] tensor instead of generated in the kernels
         self._stage_workspace = {}               # one workspace per (device, tile group) for all stages; shared by DataParallel replicas
         self.view_shard = None                   # (rank, world): latency mode -- pass A of stage 1 over this rank's share of the
@@ -341,12 +346,7 @@ class Infer_AdaMVSNet(nn.Module):
         B, V = imgs.shape[:2]
         x = imgs.transpose(0, 1).reshape(B * V, *imgs.shape[2:]).contiguous()     # view-major
         H, W = x.shape[-2:]
-        if self.feature.hip_supported(x):
-            maps = self.feature.forward_cl(x)                                     # channel-last, no transposes
-        else:
-            # MIOpen has tuned solvers for moderate batches only (very large ones fall to its naive kernels): chunk
-            chunks = [self.feature.forward_cl(x[i:i + self.feature_chunk]) for i in range(0, B * V, self.feature_chunk)]
-            maps = chunks[0] if len(chunks) == 1 else tuple(torch.cat([c[k] for c in chunks], 0) for k in range(3))
+        maps = self.feature.forward_cl(x)                                         # channel-last, no transposes; raises on unsupported input
         feats_cl, shapes = [], []
         for s in range(self.num_stage):
             scale = (4, 2, 1)[s]

@@ -66,17 +66,16 @@ class FeatureNet(FeatureNet0):
     def forward_cl(self, x):
         if self.arch_mode == "unet":
             return FeatureNet0.forward_cl(self, x)
-        if self.hip_supported(x):
-            per_image = hip_ops.feature_net_fpn_workspace_bytes(1, x.shape[-2], x.shape[-1])
-            chunk = max(1, int(self.workspace_limit_bytes // per_image))
-            parts = [self._run_hip(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)]
-            return parts[0] if len(parts) == 1 else tuple(torch.cat([p[k] for p in parts], 0) for k in range(3))
-        f = self.forward_torch(x)
-        return tuple(hip_ops.pack_features(f["stage%d" % (k + 1)]) for k in range(3))
+        self._require_hip(x)
+        per_image = hip_ops.feature_net_fpn_workspace_bytes(1, x.shape[-2], x.shape[-1])
+        chunk = max(1, int(self.workspace_limit_bytes // per_image))
+        parts = [self._run_hip(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)]
+        return parts[0] if len(parts) == 1 else tuple(torch.cat([p[k] for p in parts], 0) for k in range(3))
 
     def forward(self, x):
-        if self.arch_mode == "unet" or not self.hip_supported(x):
+        if self.arch_mode == "unet":
             return FeatureNet0.forward(self, x)
+        self._require_hip(x)
         H, W = x.shape[-2:]
         s1, s2, s3 = self._run_hip(x)
         return {"stage1": hip_ops.unpack_features(s1, H // 4, W // 4), "stage2": hip_ops.unpack_features(s2, H // 2, W // 2),

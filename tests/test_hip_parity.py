@@ -160,6 +160,19 @@ def test_feature_net0_in_chunks_equals_one_call(hip):
         hip.feature_net0(x[:1], m.feature.packed(x.device), out=tuple(t[:1, :, :4] for t in whole))
 
 
+def test_feature_net0_has_no_fallback(hip):
+    """forward() and forward_cl() are the HIP kernels or an error: CPU tensors and sizes that are not multiples of 32 (the
+    reference's own rule, quirk Q9) raise instead of running the layers through PyTorch."""
+    from ada_mvs_amd._lib import AdaMVSHipError
+    m, _ = _model("tiny")
+    with torch.no_grad():
+        for x in (torch.zeros(1, 3, 64, 96), torch.zeros(1, 3, 40, 96).cuda()):
+            with pytest.raises(AdaMVSHipError, match="no fallback"):
+                m.feature(x)
+            with pytest.raises(AdaMVSHipError, match="no fallback"):
+                m.feature.forward_cl(x)
+
+
 def test_feature_net0_golden(hip):
     """Against the reference's own FeatureNet0 outputs (end-to-end fixture, 64x96, 3 views)."""
     g = load_golden("e2e_tiny")
