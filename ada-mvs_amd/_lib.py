@@ -101,10 +101,11 @@ SIGNATURES = {
     "adamvs_soft_argmin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 PLANES_EXPLICIT, PLANES_UNIFORM, PLANES_WINDOW = 0, 1, 2
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15
+PHASE_TIMING_ONLY = 16       # a proper subset of AGGREGATE|RECURRENCE|SOFT_ARGMIN at D > 32: its duration, no maps (adamvs_hip.h)
 _lib = None
 
 

@@ -162,13 +162,19 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   }
 
   // -- per chunk of hypotheses: weighted aggregation + conv1 (state-independent), the recurrence, soft-argmin accumulation.
-  // With the full mask the three are interleaved chunk by chunk and the recurrence runs as a pipeline across chunk
-  // boundaries.  A partial mask (phase-by-phase timing, bench.py) runs the selected phase alone over all chunks on the
-  // same buffers: its duration is that of the phase, only the full mask produces the maps.
+  // With the three bits set they are interleaved chunk by chunk and the recurrence runs as a pipeline across chunk
+  // boundaries.  The workspace holds ONE chunk of conv1 outputs and two of cost slices, so with more than one chunk a
+  // proper subset of the three cannot hand its results to a later call: refused, unless the caller states that it wants
+  // the phase's duration only (ADAMVS_PHASE_TIMING_ONLY, bench.py's phase-by-phase timing), in which case the selected
+  // phase runs alone over all chunks on whatever the buffers hold.
   const bool do_agg = phases & ADAMVS_PHASE_AGGREGATE, do_rec = phases & ADAMVS_PHASE_RECURRENCE, do_arg = phases & ADAMVS_PHASE_SOFT_ARGMIN;
   if (!do_agg && !do_rec && !do_arg) return 0;
   const size_t hw = (size_t)s.h * s.w, hw4 = (size_t)(s.h / 2) * (s.w / 2);
   const int dc = c.dc, nchunks = (s.D + dc - 1) / dc;
+  ADAMVS_CHECK_ARG(nchunks == 1 || (do_agg && do_rec && do_arg) || (phases & ADAMVS_PHASE_TIMING_ONLY),
+                   "stage: phases=%d selects a proper subset of AGGREGATE|RECURRENCE|SOFT_ARGMIN, but D=%d runs in %d chunks of %d "
+                   "hypotheses and the workspace keeps one: pass all three in one call (or add ADAMVS_PHASE_TIMING_ONLY "
+                   "for the duration alone, no maps)", phases, s.D, nchunks, dc);
   const size_t c1_stride = (size_t)s.B * hw * 8;
   GruStateRing rb{{ws + c.h1[0], ws + c.h1[1], ws + c.h1[2], ws + c.h1[3]}, ws + c.rh1, ws + c.u1, {ws + c.c2[0], ws + c.c2[1]},
                   {ws + c.h2[0], ws + c.h2[1]}, ws + c.rh2, ws + c.u2};

@@ -622,11 +622,7 @@ __global__ __launch_bounds__(256) void k_conv_dd_resident(ConvDDArgs a) {
 }
 
 static int small_grid_limit() {          // workgroups up to which the resident form is used (0 disables it)
-  static int limit = -1;
-  if (limit < 0) {
-    const char* e = getenv("ADAMVS_CONV_SMALL_GRID");
-    limit = e ? atoi(e) : 1024;
-  }
+  static const int limit = [] { const char* e = getenv("ADAMVS_CONV_SMALL_GRID"); return e ? atoi(e) : 1024; }();   // once, thread-safely
   return limit;
 }
 

@@ -260,8 +260,7 @@ static int launch_fconv(const FConvArgs& a_in, int N, hipStream_t st, const char
   constexpr size_t lds = (size_t)G * group_pitch(PLANE, G) * sizeof(float);
   static_assert(lds <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
   auto kern = k_fconv<CA, CB, NT, MODE, EPI>;
-  static int capacity = 0;
-  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(a.wo, 16), cdiv(a.ho, 4), N)) return rc;
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;

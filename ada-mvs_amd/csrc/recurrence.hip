@@ -108,8 +108,7 @@ static int launch_slot(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleU
   constexpr size_t lds = max3(R0::LDS_BYTES, R1::LDS_BYTES, R2::LDS_BYTES);
   static_assert(lds <= 64 * 1024, "slot exceeds the default dynamic LDS limit");
   auto kern = k_slot<R0, R1, R2>;
-  static int capacity = 0;                    // per instantiation; a pure function of the kernel and the device
-  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  static const int capacity = resident_blocks(kern, 256, lds);      // per instantiation; once, thread-safely (magic static)
   SlotArgs<R0, R1, R2> s;
   memset(&s, 0, sizeof(s));
   long tiles[3] = {0, 0, 0};
@@ -171,8 +170,7 @@ static int launch_slot4(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const Role
   constexpr size_t lds = max4(R0::LDS_BYTES, R1::LDS_BYTES, R2::LDS_BYTES, R3::LDS_BYTES);
   static_assert(lds <= 64 * 1024, "slot exceeds the default dynamic LDS limit");
   auto kern = k_slot4<R0, R1, R2, R3>;
-  static int capacity = 0;
-  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  static const int capacity = resident_blocks(kern, 256, lds);
   SlotArgs4<R0, R1, R2, R3> s;
   memset(&s, 0, sizeof(s));
   long tiles[4] = {0, 0, 0, 0};
@@ -219,18 +217,22 @@ typedef Gru2FusedBx3Role Gru2Bx;
 // fa, fb: the fused bf16x3 level-1 kernel runs tiles [0,fa) in slot A, [fa,fb) in B, [fb,1) in C; fd: the decoder of the
 // bf16x3 schedule runs [0,fd) in slot B and the rest in C.
 struct RoleCosts { float g1, c1, v2, g2, c2, dec, k1bx, v2bx, g2bx, c2bx, fa, fb, fd; };
-static const RoleCosts& role_costs() {
-  static RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 4.46f, 13.8f, 3.2f, 12.0f, 5.0f, 0.6f, 0.8f, 0.42f};
-  static bool init = false;
-  if (!init) {
-    init = true;
-    if (const char* e = getenv("ADAMVS_RECUR_COSTS")) {
-      float v[13];
-      if (sscanf(e, "%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9, v + 10,
-                 v + 11, v + 12) == 13)
-        c = RoleCosts{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]};
-    }
+static RoleCosts parse_role_costs() {
+  RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 4.46f, 13.8f, 3.2f, 12.0f, 5.0f, 0.6f, 0.8f, 0.42f};
+  if (const char* e = getenv("ADAMVS_RECUR_COSTS")) {
+    float v[13];
+    bool ok = sscanf(e, "%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9, v + 10,
+                     v + 11, v + 12) == 13;
+    for (int i = 0; ok && i < 10; ++i) ok = v[i] > 0.f && v[i] < 1e6f;          // a zero cost would divide the grid by zero work
+    for (int i = 10; ok && i < 13; ++i) ok = v[i] >= 0.f && v[i] <= 1.f;         // tile fractions
+    if (ok) c = RoleCosts{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]};
+    else fprintf(stderr, "adamvs: ADAMVS_RECUR_COSTS ignored (13 comma-separated values: 10 positive costs, 3 fractions in [0,1])\n");
   }
+  return c;
+}
+// initialised once, thread-safely (C++11 magic static): nn.DataParallel calls the stage from one thread per device
+static const RoleCosts& role_costs() {
+  static const RoleCosts c = parse_role_costs();
   return c;
 }
 
@@ -280,9 +282,11 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
   const RecurLags lag = recurrence_lags(schedule, precision);
   const int s2 = t - 1, sc = t - lag.c2, sd = t - lag.dec;            // hypotheses of conv2/gates2, cand2, decoder
   const bool l1 = t < D, l2 = s2 >= 0 && s2 < D, lc = sc >= 0 && sc < D, dec = sd >= 0 && sd < D;
-  auto H1 = [&](int s) { return rb.h1[(s + 4) % 4]; };
-  auto H2 = [&](int s) { return rb.h2[(s + 2) % 2]; };
-  auto C2 = [&](int s) { return rb.c2[(s + 2) % 2]; };
+  // ring slots: s may be as low as -1 - lag.dec while the pipeline fills (roles of hypotheses that do not exist yet are
+  // disabled, but their argument structs are still built): a true modulo, never a negative index
+  auto H1 = [&](int s) { return rb.h1[((s % 4) + 4) % 4]; };
+  auto H2 = [&](int s) { return rb.h2[((s % 2) + 2) % 2]; };
+  auto C2 = [&](int s) { return rb.c2[((s % 2) + 2) % 2]; };
   const RoleCosts& k = role_costs();
   int rc;
   DecoderArgs da{H2(sd), H1(sd), fw.upconv1, fw.upconv1_b, fw.final_w, vol_dec, h, w, D_vol, d_dec};

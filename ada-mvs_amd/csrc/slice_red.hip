@@ -91,8 +91,7 @@ static int launch_small_shape(const SmallConvArgs& a, int B, hipStream_t st, con
   constexpr size_t lds = (size_t)((CA + CB) / 4) * group_pitch(PLANE, (CA + CB) / 4) * sizeof(float);
   static_assert(lds <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
   auto kern = k_conv_small<CA, CB, NT, STRIDE, EPI, TR, RW>;
-  static int capacity = 0;              // per instantiation; a pure function of the kernel and the device
-  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(a.wo, TC), cdiv(a.ho, TR), B)) return rc;
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
@@ -220,8 +219,7 @@ __global__ __launch_bounds__(256) void k_conv1_two_row(const float* __restrict__
 static int launch_cand1_two_row(const SmallConvArgs& a, int B, hipStream_t st) {
   constexpr int G = 4;
   constexpr size_t lds = (size_t)G * group_pitch(plane_pitch16(10 * 18), G) * sizeof(float);
-  static int capacity = 0;
-  if (!capacity) capacity = resident_blocks(k_cand1_two_row, 256, lds);
+  static const int capacity = resident_blocks(k_cand1_two_row, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(a.wo, 16), cdiv(a.ho, 8), B)) return rc;
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
@@ -372,8 +370,7 @@ static int launch_conv1_ksplit32(const float* cost, const float* w, float* c1, i
   constexpr int C = 32;
   constexpr size_t lds = ((size_t)(C / 4) * group_pitch(plane_pitch16(10 * 18), C / 4) + 12 * 64 * 4) * sizeof(float);
   auto kern = k_conv1_ksplit<C>;
-  static int capacity = 0;
-  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(w_, 16), cdiv(h, 8), N)) return rc;
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
@@ -386,8 +383,7 @@ template <int C>
 static int launch_conv1_c(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
   constexpr size_t lds = (size_t)(C / 4) * group_pitch(plane_pitch16(10 * 18), C / 4) * sizeof(float);
   auto kern = k_conv1_two_row<C>;
-  static int capacity = 0;
-  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(w_, 16), cdiv(h, 8), N)) return rc;
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
@@ -450,13 +446,12 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   DecoderArgs da{h2s, h1, fw.upconv1, fw.upconv1_b, fw.final_w, vol, h, w, D, d};
   TileGrid tg;
   if ((rc = make_tile_grid(tg, cdiv(w, 30), cdiv(h, 6), B))) return rc;
-  static int cap_up = 0, cap_flat = 0;          // resident capacity per instantiation (pure function of kernel + device)
   constexpr size_t dlds = DecoderRole<true>::LDS_BYTES;
   if (in_up) {
-    if (!cap_up) cap_up = resident_blocks(k_decoder<true>, 256, dlds);
+    static const int cap_up = resident_blocks(k_decoder<true>, 256, dlds);      // once, thread-safely (magic static)
     hipLaunchKernelGGL((k_decoder<true>), dim3(tg.ntiles < cap_up ? tg.ntiles : cap_up), dim3(256), dlds, st, da, tg);
   } else {
-    if (!cap_flat) cap_flat = resident_blocks(k_decoder<false>, 256, dlds);
+    static const int cap_flat = resident_blocks(k_decoder<false>, 256, dlds);
     hipLaunchKernelGGL((k_decoder<false>), dim3(tg.ntiles < cap_flat ? tg.ntiles : cap_flat), dim3(256), dlds, st, da, tg);
   }
   ADAMVS_CHECK_LAUNCH("decoder");

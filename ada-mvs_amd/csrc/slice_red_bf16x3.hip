@@ -34,8 +34,7 @@ static int launch_bx(const SmallConvArgsBx& a, int N, hipStream_t st, const char
   constexpr size_t lds = (size_t)2 * LR * LC * bx_pixel_pitch(CA + CB) * sizeof(__bf16);
   static_assert(lds <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
   auto kern = k_conv_small_bx3<CA, CB, NT, STRIDE, EPI>;
-  static int capacity = 0;              // per instantiation; a pure function of the kernel and the device
-  if (!capacity) capacity = resident_blocks(kern, 256, lds);
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(a.wo, TC), cdiv(a.ho, TR), N)) return rc;
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
@@ -60,8 +59,7 @@ __global__ __launch_bounds__(256, 2) void k_gru2_fused_bx3(Gru2Args a, TileGrid 
 
 static int launch_gru2_fused(const Gru2Args& a, int B, hipStream_t st) {
   constexpr size_t lds = Gru2FusedBx3Role::LDS_BYTES;
-  static int capacity = 0;
-  if (!capacity) capacity = resident_blocks(k_gru2_fused_bx3, 256, lds);
+  static const int capacity = resident_blocks(k_gru2_fused_bx3, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, Gru2FusedBx3Role::tiles_x(a), Gru2FusedBx3Role::tiles_y(a), B)) return rc;
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
@@ -73,8 +71,7 @@ static int launch_gru2_fused(const Gru2Args& a, int B, hipStream_t st) {
 
 static int launch_gru1_fused(const Gru1Args& a, int B, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * 12 * 34 * 32 + 10 * 32 * 32;
-  static int capacity = 0;
-  if (!capacity) capacity = resident_blocks(k_gru1_fused_bx3, 256, lds);
+  static const int capacity = resident_blocks(k_gru1_fused_bx3, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(a.w, 30), cdiv(a.h, 8), B)) return rc;
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;

@@ -67,12 +67,21 @@ def test_sample(model, sample, num_stage=3, dlossw=(0.5, 1.0, 2.0), detailed_sum
     return tensor2float(loss), tensor2float(scalars), images, saved
 
 
+def _imsave(path, arr, fmt):
+    """plt.imsave as the reference calls it (train_whu.py:252-258): default colormap for 2-D maps, RGB(A) arrays as they are."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    plt.imsave(path, arr, format=fmt)
+
+
 def test(model, loader, output_folder=None, num_stage=3, dlossw=(0.5, 1.0, 2.0), log=print):
-    """The reference's test(): every sample through test_sample, the running mean of the scalars, and -- when
-    `output_folder` is given and the samples carry "outimage" / "outcam" / "out_view" / "out_name" -- the reference's files
-    per sample (<view>/<name>_init.pfm, _prob.pfm, <name>.txt; the colour renderings are predict.py's --display)."""
+    """The reference's test() (train_whu.py:213-262): every sample through test_sample, the running mean of the scalars,
+    and -- when `output_folder` is given and the samples carry "out_view" / "out_name" -- the reference's files per sample:
+    <view>/<name>_init.pfm, _prob.pfm, <name>.txt (with "outcam"), <name>.jpg (with "outimage"; an input of the downstream
+    fusion step) and the renderings <view>/color/<name>_init.png (36000 - depth) and _prob.png."""
     meter = DictAverageMeter()
-    start = time.time()
+    t0 = time.time()
     for i, sample in enumerate(loader):
         t0 = time.time()
         _, scalars, images, saved = test_sample(model, sample, num_stage, dlossw)
@@ -87,7 +96,11 @@ def test(model, loader, output_folder=None, num_stage=3, dlossw=(0.5, 1.0, 2.0),
             name = saved["out_name"][0]
             save_pfm(os.path.join(folder, "%s_init.pfm" % name), depth)
             save_pfm(os.path.join(folder, "%s_prob.pfm" % name), prob)
+            if "outimage" in saved:
+                _imsave(os.path.join(folder, "%s.jpg" % name), np.squeeze(tensor2numpy(saved["outimage"])), "jpg")
             if "outcam" in saved:
                 write_red_cam(os.path.join(folder, "%s.txt" % name), np.squeeze(tensor2numpy(saved["outcam"])), str(name))
-    log("final, time = {:3f}, test results = {}".format(time.time() - start, meter.mean()))
+            _imsave(os.path.join(folder, "color", "%s_init.png" % name), np.float32(36000.0) - depth, "png")
+            _imsave(os.path.join(folder, "color", "%s_prob.png" % name), prob, "png")
+    log("final, time = {:3f}, test results = {}".format(time.time() - t0, meter.mean()))     # the last iteration's time, as the reference prints it
     return meter.mean()

@@ -4,11 +4,13 @@ models/module.py, backed by the HIP library.
 Functions keep the reference names, argument order and tensor layouts
 (homo_warping_float, depth_regression, get_depth_range_samples,
 get_cur_depth_range_samples).  The nn.Module blocks below exist to own
-parameters under the reference's state-dict key names; FeatureNet0's blocks
-(`Conv2d`, `Deconv2d`, `DeConv2dFuse`) run on PyTorch/MIOpen -- they are
-upstream of the hot path -- while the hot-path blocks
-(`ConvReLU`, `ConvBnReLU`, `ConvGRUCell`) have no forward of their own: their
-arithmetic is fused into the HIP kernels of the enclosing network.
+parameters under the reference's state-dict key names.  FeatureNet0 runs on
+the hand-written kernels of csrc/featnet.hip (`FeatureNet0.forward_cl`,
+SURVEY.md section 8f1); its blocks (`Conv2d`, `Deconv2d`, `DeConv2dFuse`)
+keep a PyTorch `forward` only for `FeatureNet0.forward_torch`, the explicit
+reference form used by the tests.  The hot-path blocks (`ConvReLU`,
+`ConvBnReLU`, `ConvGRUCell`) have no forward of their own: their arithmetic
+is fused into the HIP kernels of the enclosing network.
 """
 import torch
 import torch.nn as nn

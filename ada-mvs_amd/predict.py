@@ -114,6 +114,15 @@ def save_outputs(args, output_folder, depth_est, prob, ref_image, ref_cam, ref_p
 
 def predict_depth(args):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    # loader processes come from a fork server, and the server is started HERE, before anything below touches the GPU
+    # (torch.cuda.is_available() already initialises HIP): a child forked from a process with an initialised HIP runtime
+    # must never call into it.  The server is a freshly spawned interpreter; the loader children are forked from IT.
+    ctx = None
+    if args.num_workers > 0:
+        import multiprocessing
+        from multiprocessing import forkserver
+        ctx = multiprocessing.get_context("forkserver")
+        forkserver.ensure_running()
     if not torch.cuda.is_available():
         raise RuntimeError("predict: needs an MI355X (there is no CPU fallback for the Ada-MVS hot path)")
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -121,10 +130,8 @@ def predict_depth(args):
     dataset = find_dataset_def(args.dataset)(args.data_folder, args.view_num, args)
     if world > 1:                                    # independent samples: deal them out, no data-path collective
         dataset = Subset(dataset, list(range(rank, len(dataset), world)))
-    # loader processes come from a fork server started before this process touches the GPU: a child forked from a process
-    # with an initialised HIP runtime must never call into it
     loader = DataLoader(dataset, args.batch_size, shuffle=False, num_workers=args.num_workers, drop_last=False,
-                        multiprocessing_context="forkserver" if args.num_workers > 0 else None)
+                        multiprocessing_context=ctx)
     model = build_model(args, device)
     os.makedirs(args.output_folder, exist_ok=True)
     step, t_first = 0, time.time()

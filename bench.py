@@ -127,9 +127,9 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 mark("s%d.view_weight_resample" % (s + 1), lambda: phase(_lib.PHASE_VIEW_WEIGHTS))
             # the three phases below are interleaved chunk by chunk in a real run; called one by one each runs alone over
             # all chunks (its own duration, no maps), so the maps that feed the next stage come from one untimed full call
-            mark("s%d.aggregate_conv1" % (s + 1), lambda: phase(_lib.PHASE_AGGREGATE))
-            mark("s%d.recurrence" % (s + 1), lambda: phase(_lib.PHASE_RECURRENCE))
-            mark("s%d.soft_argmin" % (s + 1), lambda: phase(_lib.PHASE_SOFT_ARGMIN))
+            mark("s%d.aggregate_conv1" % (s + 1), lambda: phase(_lib.PHASE_AGGREGATE | _lib.PHASE_TIMING_ONLY))
+            mark("s%d.recurrence" % (s + 1), lambda: phase(_lib.PHASE_RECURRENCE | _lib.PHASE_TIMING_ONLY))
+            mark("s%d.soft_argmin" % (s + 1), lambda: phase(_lib.PHASE_SOFT_ARGMIN | _lib.PHASE_TIMING_ONLY))
             phase(_lib.PHASE_AGGREGATE | _lib.PHASE_RECURRENCE | _lib.PHASE_SOFT_ARGMIN)
             depth, conf = outs[2], outs[0]
     torch.cuda.synchronize()
@@ -160,11 +160,11 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0):
     return acts["prob"][0]
 
 
-def cpu_baseline(cfg, sd):
+def cpu_baseline(cfg, sd, baseline=8.0):
     """The CPU oracle (a port of the reference's unfused PyTorch-CPU path) on ONE tile of the workload."""
     from oracle import adamvs_oracle as O          # checker / baseline only
     c = synth.CONFIGS[cfg]
-    imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0)
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0, baseline=baseline)
     sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
     threads = min(os.cpu_count() or 1, 32)          # more threads than that only add scheduling overhead to the small ops
     torch.set_num_threads(threads)
@@ -282,19 +282,165 @@ def bench_msrednet(args):
     print(json.dumps(result))
 
 
+class Workload:
+    """One configuration of the hot path set up for timing on this rank: the model, this rank's tiles (images seeded by
+    their GLOBAL tile index; rig b of the batch for slot b), FeatureNet0 outputs resident in HBM (upstream
+    of the timed region, timed separately) and the captured hipGraph of one step."""
+
+    def __init__(self, cfg, tiles, precision, dev, groups=1, use_graph=True, baseline=8.0, warm=1):
+        self.cfg, self.tiles, self.precision, self.dev, self.G, self.baseline = cfg, list(tiles), precision, dev, groups, baseline
+        self.c = synth.CONFIGS[cfg]
+        self.B = B = len(self.tiles)
+        assert B > 0 and B % groups == 0, "tiles per GPU must be a positive multiple of --groups"
+        self.Bg = Bg = B // groups
+        self.model, self.sd = build_model(cfg, dev, precision)
+        imgs = torch.cat([synth.tile_inputs(cfg, 1, seed=t)[0] for t in self.tiles], 0).to(dev)
+        _, proj, dv = synth.tile_inputs(cfg, batch=B, seed=0, baseline=baseline)
+        proj = {k: v.to(dev) for k, v in proj.items()}
+        dv = dv.to(dev)
+        self.interval = (synth.DEPTH_RANGE[1] - synth.DEPTH_RANGE[0]) / self.c["num_depth"]
+        G = groups
+        with torch.no_grad():
+            self.groups = [self.model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]
+            torch.cuda.synchronize()
+            self.t_feat = float("inf")
+            for _ in range(3):               # steady state: the caching allocator re-uses the workspace of the previous call
+                self.groups = None
+                t0 = time.time()
+                self.groups = [self.model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]
+                torch.cuda.synchronize()
+                self.t_feat = min(self.t_feat, time.time() - t0)
+            del imgs
+            self.projs = [{k: v[g * Bg:(g + 1) * Bg].contiguous() for k, v in proj.items()} for g in range(G)]
+            self.dvs = [dv[g * Bg:(g + 1) * Bg].contiguous() for g in range(G)]
+            self.side = [torch.cuda.Stream() for _ in range(G - 1)]
+            for _ in range(max(warm, 1)):
+                self.depth, self.conf = self.hot_path()
+            torch.cuda.synchronize()
+            self.graph = None
+            if use_graph:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.depth, self.conf = self.hot_path()
+                self.graph.replay()
+                torch.cuda.synchronize()
+
+    def hot_path(self):
+        """All groups, each on its own stream, forked from / joined to the current stream."""
+        cur = torch.cuda.current_stream()
+        G = self.G
+        outs = [None] * G
+        for g in range(G):
+            st = cur if g == 0 else self.side[g - 1]
+            if g:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                o = self.model.infer_from_features(self.groups[g][0], self.groups[g][1], self.projs[g], self.dvs[g], self.interval, group=g)
+                outs[g] = (o["depth"], o["photometric_confidence"])
+        for g in range(1, G):
+            cur.wait_stream(self.side[g - 1])
+        if G == 1:
+            return outs[0]
+        return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
+
+    def step(self):
+        """One pass of the hot path over this rank's tiles -> (depth, confidence) [B,Ho,Wo] (the graph's output buffers)."""
+        if self.graph is not None:
+            self.graph.replay()
+            return self.depth, self.conf
+        return self.hot_path()
+
+    def step_fracs(self, ms_per_step):
+        """algorithmic conv flops and bytes of ALL phases / the measured step, against the bounding roofline
+        (fp32: the fp32 matrix pipe; split-bf16: HBM -- it executes three bf16 products per fp32 product on the bf16 pipe)."""
+        work = algorithmic_work(self.cfg, self.B)
+        split = self.precision == "bf16x3"
+        step_s = 1e-3 * ms_per_step
+        tot_flops = sum(w_.get("costreg_flops", 0) + w_["recurrence_flops"] + w_["conv1_flops"] for w_ in work)
+        tot_bytes = sum(sum(v for k_, v in w_.items() if k_.endswith("_bytes")) for w_ in work)
+        f_mfma = (tot_flops * 3 / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS if split else tot_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+        f_hbm = tot_bytes / step_s / 1e9 / HBM_PEAK_GBS
+        return {"step_frac_mfma": f_mfma, "step_frac_hbm": f_hbm, "step_frac": f_hbm if split else f_mfma,
+                "step_bound": "hbm" if split else "mfma (fp32)",
+                "step_algorithmic": {"conv_gflop_per_tile": tot_flops / self.B / 1e9, "gbytes_per_tile": tot_bytes / self.B / 1e9}}
+
+    def close(self):
+        """Release the graph, the stage workspaces and the features before the next workload is set up."""
+        self.graph = None
+        self.depth = self.conf = None
+        self.groups = self.projs = self.dvs = None
+        self.model._stage_workspace.clear()
+        self.model = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+def time_plain(wl, steps, warmup):
+    """ms per step of a single-rank workload (no gather: with one rank the maps are already where they are wanted)."""
+    with torch.no_grad():
+        for _ in range(warmup):
+            wl.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+# BASELINE.json configs 3 and 4, measured after the headline's timed region (N = 1 only) and reported under "cascade":
+# (key, config, global tile indices of this GPU's batch, precision)
+CASCADE_CASES = (
+    ("cfg3_b32_bf16x3", "cfg3", list(range(32)), "bf16x3"),
+    ("cfg3_b32_fp32", "cfg3", list(range(32)), "fp32"),
+    ("cfg4_share_b4_fp32", "cfg3", adist.tiles_of_rank(32, 0, 8), "fp32"),        # 32 tiles over 8 ranks: rank 0 owns 0, 8, 16, 24
+    ("cfg4_share_b4_bf16x3", "cfg3", adist.tiles_of_rank(32, 0, 8), "bf16x3"),
+)
+
+
+def bench_cascade(dev, steps, warmup, baseline, use_graph=True):
+    """The cascade configurations (BASELINE.json configs[2], configs[3]'s per-GPU share) on one GPU: hipGraph replay, same
+    timing brackets as the headline.  Every case starts with global tile 0 on rig 0, so ONE oracle pass of that tile
+    (cfg3, full size) checks all of them: parity_rel_l1 per case, 1e-3 enforced by the caller."""
+    out, tile0 = {}, {}
+    for key, cfg, tiles, precision in CASCADE_CASES:
+        wl = Workload(cfg, tiles, precision, dev, use_graph=use_graph, baseline=baseline)
+        ms = time_plain(wl, steps, warmup)
+        d, p = wl.step()
+        torch.cuda.synchronize()
+        tile0[key] = (d[0].clone(), p[0].clone())
+        fr = wl.step_fracs(ms)
+        out[key] = {"workload": "%s: 5 views, 768x384, hypotheses 192/64/8, %s, %d tiles per step" % (
+                        "cfg3" if len(tiles) == 32 else "cfg4 (32 cfg3 tiles over 8 GPUs): one GPU's share", precision, len(tiles)),
+                    "maps_per_s": len(tiles) / (ms * 1e-3), "ms_per_step": ms, "ms_per_tile": ms / len(tiles),
+                    "step_frac": fr["step_frac"], "step_bound": fr["step_bound"], "steps": steps, "warmup": warmup}
+        sd = wl.sd
+        wl.close()
+        del wl
+    return out, tile0, sd
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=list(synth.CONFIGS))
-    ap.add_argument("--batch", type=int, default=128, help="reference tiles per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="reference tiles per GPU per step (weak scaling: fixed per GPU)")
+    ap.add_argument("--tiles-total", type=int, default=0,
+                    help="strong scaling: this many tiles per step over ALL ranks (tile t on rank t mod N), e.g. 32 with "
+                         "--workload cfg3 = BASELINE.json configs[3] as stated; overrides --batch")
+    ap.add_argument("--baseline", type=float, default=8.0,
+                    help="camera baseline of the synthetic rig per view index (SURVEY.md 8c recipe: 8; larger = more disparity "
+                         "per hypothesis plane and out-of-bounds warps)")
     ap.add_argument("--groups", type=int, default=1, help="independent tile groups run concurrently on separate HIP streams")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32: exact fp32 MFMA (the cfg2 headline); bf16x3: split-bf16 MFMA for the convolutions (~1e-5 of fp32)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-cascade", action="store_true",
+                    help="skip the cfg3 / cfg4-share measurements that follow the headline (N = 1, default workload only)")
     ap.add_argument("--red-batch", type=int, default=1, help="--model msrednet: tiles per step")
     ap.add_argument("--model", default="adamvs", choices=["adamvs", "msrednet"],
                     help="adamvs: the headline path; msrednet: the sibling model (SURVEY.md 8f row f3), --red-batch tiles per step, 1 GPU")
@@ -311,78 +457,26 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()
-    cfg, B = args.workload, args.batch
+    cfg = args.workload
     c = synth.CONFIGS[cfg]
-    model, sd = build_model(cfg, dev, args.precision)
-    n_tiles = world * B
+    strong = args.tiles_total > 0
+    n_tiles = args.tiles_total if strong else world * args.batch
     my_tiles = adist.tiles_of_rank(n_tiles, rank, world)
-    # per-tile seeds = global tile index; this rank's tiles as one batch
-    imgs = torch.cat([synth.tile_inputs(cfg, 1, seed=t)[0] for t in my_tiles], 0).to(dev)
-    _, proj, dv = synth.tile_inputs(cfg, batch=B, seed=0)
-    proj = {k: v.to(dev) for k, v in proj.items()}
-    dv = dv.to(dev)
-    interval = (synth.DEPTH_RANGE[1] - synth.DEPTH_RANGE[0]) / c["num_depth"]
-
+    if not my_tiles:
+        raise SystemExit("bench.py: --tiles-total %d leaves rank %d of %d without a tile" % (n_tiles, rank, world))
     G = args.groups
-    assert B % G == 0, "--batch must be a multiple of --groups"
-    Bg = B // G
+
     with torch.no_grad():
-        t0 = time.time()
-        groups = [model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]   # upstream of the hot path; untimed, reported
-        torch.cuda.synchronize()
-        t_feat_first = time.time() - t0
-        t_feat = float("inf")
-        for _ in range(3):                   # steady state: the caching allocator re-uses the workspace of the previous call
-            del groups
-            t0 = time.time()
-            groups = [model.extract_features(imgs[g * Bg:(g + 1) * Bg]) for g in range(G)]
-            torch.cuda.synchronize()
-            t_feat = min(t_feat, time.time() - t0)
-        del imgs
-        projs = [{k: v[g * Bg:(g + 1) * Bg].contiguous() for k, v in proj.items()} for g in range(G)]
-        dvs = [dv[g * Bg:(g + 1) * Bg].contiguous() for g in range(G)]
-        side = [torch.cuda.Stream() for _ in range(G - 1)]
-        feats_cl, shapes = groups[0]
-
-        def hot_path():
-            """All groups, each on its own stream, forked from / joined to the current stream."""
-            cur = torch.cuda.current_stream()
-            outs = [None] * G
-            for g in range(G):
-                st = cur if g == 0 else side[g - 1]
-                if g:
-                    st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    o = model.infer_from_features(groups[g][0], groups[g][1], projs[g], dvs[g], interval, group=g)
-                    outs[g] = (o["depth"], o["photometric_confidence"])
-            for g in range(1, G):
-                cur.wait_stream(side[g - 1])
-            if G == 1:
-                return outs[0]
-            return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
-
-        for _ in range(max(args.warmup, 1)):
-            depth, conf = hot_path()
-        torch.cuda.synchronize()
-
-        graph = None
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                depth, conf = hot_path()
-            graph.replay()
-            torch.cuda.synchronize()
-
+        wl = Workload(cfg, my_tiles, args.precision, dev, groups=G, use_graph=not args.no_graph, baseline=args.baseline,
+                      warm=max(args.warmup, 1))
+        B, Bg = wl.B, wl.Bg
+        depth, conf = wl.depth, wl.conf
         # one gather of the finished maps per step, staged through preallocated buffers and issued asynchronously:
         # the collective of step k overlaps the replay of step k+1 (ada_mvs_amd/dist.py)
         gatherer = adist.MapGatherer(n_tiles, B, depth.shape[-2], depth.shape[-1], dev)
 
         def step():
-            if graph is not None:
-                graph.replay()
-                d, p = depth, conf
-            else:
-                d, p = hot_path()
+            d, p = wl.step()
             gatherer.start(d, p)
 
         for _ in range(args.warmup):
@@ -408,124 +502,51 @@ def main():
         if rank == 0:
             assert gathered[0].shape[0] == n_tiles and bool(torch.isfinite(gathered[0]).all())
             tile0 = (gathered[0][0].clone(), gathered[1][0].clone())      # the graph's output buffers are reused below
+            cascade_txt = "x".join(map(str, c["ndepths"]))
             result = {
-                "metric": "depth maps/sec at 768x384x5-view x192-hyp (hot path, features resident in HBM)",
+                "metric": "depth maps/sec at %dx%dx%d-view x%s-hyp (hot path, features resident in HBM)" % (c["W"], c["H"], c["views"], cascade_txt),
                 "value": n_tiles * args.steps / elapsed, "unit": "depth maps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
                 "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA, fp32 accumulate) for the convolutions, f32 elsewhere",
                 "data": "synthetic",
                 "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, %s" % (
                     cfg, c["views"], c["W"], c["H"], "/".join(map(str, c["ndepths"])), args.precision),
-                    "tiles_per_gpu_per_step": B, "concurrent_tile_groups": G, "global_tiles_per_step": n_tiles,
+                    "tiles_per_gpu_per_step": B if not strong else "%d..%d" % (n_tiles // world, -(-n_tiles // world)),
+                    "concurrent_tile_groups": G, "global_tiles_per_step": n_tiles,
                     "parallelism": "tile-sharded x%d, 1 RCCL gather per step" % world,
-                    "launch": "eager" if graph is None else "hipGraph replay"},
+                    "launch": "eager" if wl.graph is None else "hipGraph replay",
+                    "rig_baseline": args.baseline},
                 # upstream of the timed region: FeatureNet0 on all views of a tile (csrc/featnet.hip)
-                "feature_net_ms_per_tile": 1e3 * t_feat / B,
-                "end_to_end_maps_per_s_per_gpu": B / (t_feat + elapsed / args.steps),
+                "feature_net_ms_per_tile": 1e3 * wl.t_feat / B,
+                "end_to_end_maps_per_s_per_gpu": B / (wl.t_feat + elapsed / args.steps),
             }
 
         if rank == 0 and world == 1 and not args.no_roofline:
-            times = timed_phases(model, feats_cl, shapes, projs[0], dvs[0], interval, max(2, min(args.steps, 5)))
-            work = algorithmic_work(cfg, Bg)
-            avg = {k: sum(v[1:]) / max(len(v) - 1, 1) for k, v in times.items()}        # drop the first call
-            phases = {}
-            for k, v in avg.items():                                                   # fold the per-layer marks
-                key = k.split(".costreg.")[0] + ".cost_reg_net_2d" if ".costreg." in k else k
-                phases[key] = phases.get(key, 0.0) + v
-            result["phase_ms_per_step"] = {k: round(v, 4) for k, v in sorted(phases.items())}
-            layers = {k.split(".costreg.")[1]: round(v, 4) for k, v in avg.items() if ".costreg." in k}
-            if layers:
-                result["cost_reg_layers_ms"] = layers          # one launch each: <layer>.mode<0 s1 | 1 s2 | 2 transposed>
-            dom = max(phases, key=phases.get)
-            st = work[int(dom[1]) - 1]
-            kind = dom.split(".", 1)[1]
-            c0 = synth.CONFIGS[cfg]
-            split = args.precision == "bf16x3"
-            if kind == "cost_reg_net_2d":
-                # dominant kernel = the stride-1 instantiation of k_conv_dd (conv0, conv2, conv4, prob; conv6 too unless its grid is small).  The split-bf16
-                # mode EXECUTES three bf16 products per fp32 product on the bf16 matrix pipe: priced against that pipe's peak.
-                hw0, Dd, N = st["h"] * st["w"], st["D"], (c0["views"] - 1) * Bg
-                res = {"conv0": 1, "conv2": 2, "conv4": 4, "conv6": 8, "prob": 1}       # linear down-scale of the layer's maps
-
-                def on_dominant_kernel(layer):
-                    # the fp32 path sends stride-1 layers of at most 2048 blocks of 8 x 16 pixels to the 2-row kernel
-                    # k_conv_dd_rows2 (csrc/costreg2d.hip: small_grid_rows2); those launches are not the dominant kernel's
-                    if split:
-                        return True
-                    e = os.environ.get("ADAMVS_CONV_ROWS2", "")
-                    if e:
-                        return int(e) == 0
-                    r = res[layer]
-                    return -(-(st["w"] // r) // 16) * -(-(st["h"] // r) // 8) * N > 2048
-
-                lay = {k: v for k, v in avg.items() if ".costreg." in k and k.endswith("mode0") and on_dominant_kernel(k.split(".")[2])}
-                flops = sum(2.0 * N * (hw0 // res[k.split(".")[2]] ** 2) * Dd * Dd * 9 for k in lay) * (3 if split else 1)
-                ms = sum(lay.values())
-                ach = flops / (ms * 1e-3) / 1e12
-                peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-                roof = {"kernel": "%s (CostRegNet2D 3x3 stride-1 layers %s, %d launches per step)" % (
-                            "k_conv_dd_bx3<MT,WM,CONV_S1>, executed bf16 flops = 3 x fp32 products" if split else "k_conv_dd<MT,WM,CONV_S1>",
-                            "+".join(k.split(".")[2] for k in lay), len(lay)),
-                        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                        "frac": ach / peak, "launch_ms": ms / len(lay),
-                        "flops_per_launch": flops / len(lay), "traffic": None}
-                stamp = source_stamp()
-                for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
-                    tj = json.load(open(tpath))       # HBM bytes per launch from committed PMC passes (tools/profile_round.sh)
-                    if tj.get("config") != {"workload": cfg, "tiles_per_launch": Bg} or tj.get("precision", "fp32") != args.precision:
-                        continue
-                    if tj.get("source_stamp") != stamp:
-                        roof["traffic_note"] = "%s was measured on another build (stamp %s, this build %s): not quoted" % (
-                            os.path.basename(tpath), tj.get("source_stamp"), stamp)
-                        continue
-                    k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_dd<3, 4, 0") in k]
-                    if k0:
-                        roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
-                        roof["traffic_note"] = ("bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), %s, "
-                                                "same source stamp %s" % (os.path.basename(tpath), stamp))
-                        break
-            elif kind == "recurrence":
-                # executed flops: the split-bf16 mode issues three bf16 products per fp32 product
-                ach = st["recurrence_flops"] * (3 if split else 1) / (avg[dom] * 1e-3) / 1e12
-                peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-                # launches per hypothesis depend on the stage size (csrc/recurrence.hip: 6 / 3 / 2 in fp32, 4 / 2 in bf16x3):
-                # the figure priced here is one hypothesis = one recurrent step of all tiles
-                roof = {"kernel": "the ConvGRU / decoder tile loops of one hypothesis (%d hypotheses per step)" % st["D"], "bound": "mfma",
-                        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                        "launch_ms": avg[dom] / st["D"], "traffic": None}
-                if split:
-                    roof["note"] = ("short K (72-288) convolutions on 8-16 channel maps: bound by launch latency, LDS and the "
-                                    "VALU work of the hi/lo split, not by the bf16 matrix pipe")
-            else:
-                key = {"pair_similarity": "pair_similarity_bytes", "aggregate_conv1": "aggregate_bytes",
-                       "soft_argmin": "softargmin_bytes", "softmax_max_regress": "softmax_bytes",
-                       "view_weight_resample": "softmax_bytes"}[kind]
-                ach = st[key] / (avg[dom] * 1e-3) / 1e9
-                roof = {"kernel": "k_" + kind, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "launch_ms": avg[dom], "traffic": None}
-            # the whole step against both rooflines: algorithmic conv flops and algorithmic bytes of ALL
-            # phases / the measured ms_per_step; fp32 is bound by the fp32 matrix pipe, the split-bf16 mode by HBM
-            step_s = 1e-3 * result["ms_per_step"] * (Bg / float(B))
-            tot_flops = sum(w_.get("costreg_flops", 0) + w_["recurrence_flops"] + w_["conv1_flops"] for w_ in work)
-            tot_bytes = sum(sum(v for k_, v in w_.items() if k_.endswith("_bytes")) for w_ in work)
-            # (the split-bf16 mode executes three bf16 products per fp32 product, on the bf16 pipe)
-            roof["step_frac_mfma"] = (tot_flops * 3 / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS if split
-                                      else tot_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS)
-            roof["step_frac_hbm"] = tot_bytes / step_s / 1e9 / HBM_PEAK_GBS
-            roof["step_frac"] = roof["step_frac_hbm"] if split else roof["step_frac_mfma"]
-            roof["step_bound"] = "hbm" if split else "mfma (fp32)"
-            roof["step_algorithmic"] = {"conv_gflop_per_tile": tot_flops / Bg / 1e9, "gbytes_per_tile": tot_bytes / Bg / 1e9}
-            roof["dominant_phase"] = dom
-            result["roofline"] = roof
+            result.update(roofline_of(wl, args, result["ms_per_step"]))
         parity_ok = True
+        sd = wl.sd
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             # the oracle runs tile 0 of this very workload: its maps are the parity check of the timed run
-            result["cpu_baseline"], ref = cpu_baseline(cfg, sd)
-            result["parity_rel_l1"] = {"depth": rel_l1(tile0[0], ref["depth"][0]),
-                                       "photometric_confidence": rel_l1(tile0[1], ref["photometric_confidence"][0]),
-                                       "tolerance": 1e-3, "tile": 0, "against": "oracle/adamvs_oracle.py (cpu_baseline run)"}
+            result["cpu_baseline"], ref = cpu_baseline(cfg, sd, args.baseline)
+            result["parity_rel_l1"] = parity_of(tile0, ref, c, wl.interval)
             parity_ok = max(result["parity_rel_l1"]["depth"], result["parity_rel_l1"]["photometric_confidence"]) <= 1e-3
+        wl.close()
+        del wl, gatherer, gathered, depth, conf
+
+        # BASELINE.json's cascade configurations beside the headline: cfg3 (configs[2]) and one GPU's share of cfg4
+        # (configs[3]), each with parity against ONE oracle pass of cfg3's tile 0
+        if rank == 0 and world == 1 and cfg == "cfg2" and not strong and not args.no_cascade:
+            cas, tiles0, sd3 = bench_cascade(dev, max(3, min(args.steps, 10)), max(1, min(args.warmup, 3)), args.baseline,
+                                             use_graph=not args.no_graph)
+            if not args.no_cpu_baseline:
+                base3, ref3 = cpu_baseline("cfg3", sd3, args.baseline)
+                c3 = synth.CONFIGS["cfg3"]
+                for key in cas:
+                    cas[key]["parity_rel_l1"] = parity_of(tiles0[key], ref3, c3, (synth.DEPTH_RANGE[1] - synth.DEPTH_RANGE[0]) / c3["num_depth"])
+                    parity_ok = parity_ok and max(cas[key]["parity_rel_l1"]["depth"], cas[key]["parity_rel_l1"]["photometric_confidence"]) <= 1e-3
+                cas["cpu_baseline"] = base3
+            result["cascade"] = cas
         if rank == 0:
             print(json.dumps(result))
         if not parity_ok:
@@ -533,6 +554,107 @@ def main():
             sys.exit(3)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def parity_of(tile0, ref, c, depth_interval):
+    """Tile 0 of the measured run against the oracle's maps: relative L1 (the north-star bar, 1e-3) and the mean depth
+    error in units of the FINEST hypothesis interval (the last stage's ratio x depth_interval) -- relative L1 of a depth map
+    around 500 hides a quarter of an interval behind 5e-4."""
+    d, p = tile0[0].detach().double().cpu(), tile0[1].detach().double().cpu()
+    rd, rp = ref["depth"][0].double(), ref["photometric_confidence"][0].double()
+    finest = synth.DEPTH_INTERVALS_RATIO[len(c["ndepths"]) - 1] * depth_interval
+    return {"depth": rel_l1(d, rd), "photometric_confidence": rel_l1(p, rp),
+            "depth_abs_err_in_finest_intervals": float((d - rd).abs().mean() / finest),
+            "tolerance": 1e-3, "tile": 0, "against": "oracle/adamvs_oracle.py (cpu_baseline run)"}
+
+
+def roofline_of(wl, args, ms_per_step):
+    """roofline + phase tables of the headline workload: HIP-event timing of the stage run phase by phase through the C ABI."""
+    result = {}
+    cfg, Bg, B = wl.cfg, wl.Bg, wl.B
+    feats_cl, shapes = wl.groups[0]
+    times = timed_phases(wl.model, feats_cl, shapes, wl.projs[0], wl.dvs[0], wl.interval, max(2, min(args.steps, 5)))
+    work = algorithmic_work(cfg, Bg)
+    avg = {k: sum(v[1:]) / max(len(v) - 1, 1) for k, v in times.items()}        # drop the first call
+    phases = {}
+    for k, v in avg.items():                                                   # fold the per-layer marks
+        key = k.split(".costreg.")[0] + ".cost_reg_net_2d" if ".costreg." in k else k
+        phases[key] = phases.get(key, 0.0) + v
+    result["phase_ms_per_step"] = {k: round(v, 4) for k, v in sorted(phases.items())}
+    layers = {k.split(".costreg.")[1]: round(v, 4) for k, v in avg.items() if ".costreg." in k}
+    if layers:
+        result["cost_reg_layers_ms"] = layers          # one launch each: <layer>.mode<0 s1 | 1 s2 | 2 transposed>
+    dom = max(phases, key=phases.get)
+    st = work[int(dom[1]) - 1]
+    kind = dom.split(".", 1)[1]
+    c0 = synth.CONFIGS[cfg]
+    split = args.precision == "bf16x3"
+    if kind == "cost_reg_net_2d":
+        # dominant kernel = the stride-1 instantiation of k_conv_dd (conv0, conv2, conv4, prob; conv6 too unless its grid is small).  The split-bf16
+        # mode EXECUTES three bf16 products per fp32 product on the bf16 matrix pipe: priced against that pipe's peak.
+        hw0, Dd, N = st["h"] * st["w"], st["D"], (c0["views"] - 1) * Bg
+        res = {"conv0": 1, "conv2": 2, "conv4": 4, "conv6": 8, "prob": 1}       # linear down-scale of the layer's maps
+
+        def on_dominant_kernel(layer):
+            # the fp32 path sends stride-1 layers of at most 2048 blocks of 8 x 16 pixels to the 2-row kernel
+            # k_conv_dd_rows2 (csrc/costreg2d.hip: small_grid_rows2); those launches are not the dominant kernel's
+            if split:
+                return True
+            e = os.environ.get("ADAMVS_CONV_ROWS2", "")
+            if e:
+                return int(e) == 0
+            r = res[layer]
+            return -(-(st["w"] // r) // 16) * -(-(st["h"] // r) // 8) * N > 2048
+
+        lay = {k: v for k, v in avg.items() if ".costreg." in k and k.endswith("mode0") and on_dominant_kernel(k.split(".")[2])}
+        flops = sum(2.0 * N * (hw0 // res[k.split(".")[2]] ** 2) * Dd * Dd * 9 for k in lay) * (3 if split else 1)
+        ms = sum(lay.values())
+        ach = flops / (ms * 1e-3) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        roof = {"kernel": "%s (CostRegNet2D 3x3 stride-1 layers %s, %d launches per step)" % (
+                    "k_conv_dd_bx3<MT,WM,CONV_S1>, executed bf16 flops = 3 x fp32 products" if split else "k_conv_dd<MT,WM,CONV_S1>",
+                    "+".join(k.split(".")[2] for k in lay), len(lay)),
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "launch_ms": ms / len(lay),
+                "flops_per_launch": flops / len(lay), "traffic": None}
+        stamp = source_stamp()
+        for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+            tj = json.load(open(tpath))       # HBM bytes per launch from committed PMC passes (tools/profile_round.sh)
+            if tj.get("config") != {"workload": cfg, "tiles_per_launch": Bg} or tj.get("precision", "fp32") != args.precision:
+                continue
+            if tj.get("source_stamp") != stamp:
+                roof["traffic_note"] = "%s was measured on another build (stamp %s, this build %s): not quoted" % (
+                    os.path.basename(tpath), tj.get("source_stamp"), stamp)
+                continue
+            k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_dd<3, 4, 0") in k]
+            if k0:
+                roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
+                roof["traffic_note"] = ("bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), %s, "
+                                        "same source stamp %s" % (os.path.basename(tpath), stamp))
+                break
+    elif kind == "recurrence":
+        # executed flops: the split-bf16 mode issues three bf16 products per fp32 product
+        ach = st["recurrence_flops"] * (3 if split else 1) / (avg[dom] * 1e-3) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        # launches per hypothesis depend on the stage size (csrc/recurrence.hip: 6 / 3 / 2 in fp32, 4 / 2 in bf16x3):
+        # the figure priced here is one hypothesis = one recurrent step of all tiles
+        roof = {"kernel": "the ConvGRU / decoder tile loops of one hypothesis (%d hypotheses per step)" % st["D"], "bound": "mfma",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "launch_ms": avg[dom] / st["D"], "traffic": None}
+        if split:
+            roof["note"] = ("short K (72-288) convolutions on 8-16 channel maps: bound by launch latency, LDS and the "
+                            "VALU work of the hi/lo split, not by the bf16 matrix pipe")
+    else:
+        key = {"pair_similarity": "pair_similarity_bytes", "aggregate_conv1": "aggregate_bytes",
+               "soft_argmin": "softargmin_bytes", "softmax_max_regress": "softmax_bytes",
+               "view_weight_resample": "softmax_bytes"}[kind]
+        ach = st[key] / (avg[dom] * 1e-3) / 1e9
+        roof = {"kernel": "k_" + kind, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "launch_ms": avg[dom], "traffic": None}
+    roof.update(wl.step_fracs(ms_per_step))
+    roof["dominant_phase"] = dom
+    result["roofline"] = roof
+    return result
 
 
 if __name__ == "__main__":

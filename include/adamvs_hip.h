@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 9
+#define ADAMVS_ABI_VERSION 10
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -211,19 +211,26 @@ typedef struct adamvs_stage_desc {
 
 size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);
 
-/* phases of a stage; intermediate results live in the workspace between calls */
+/* phases of a stage.  VIEW_WEIGHTS may run in a call of its own: its results are the view_weight / pair_depth OUTPUT
+ * tensors, which a later call reads back.  AGGREGATE, RECURRENCE and SOFT_ARGMIN form one chain over chunks of 32
+ * hypotheses (the workspace holds one chunk of conv1 outputs and two of cost slices, nothing of it grows with D), so
+ * for D > 32 they produce maps only when all three are in ONE call: a call with a proper subset of them returns an
+ * argument error (-1) unless ADAMVS_PHASE_TIMING_ONLY is set, which runs the selected phase alone over all chunks on
+ * whatever the workspace holds -- its duration is the phase's, depth / confidence are NOT valid (bench.py's
+ * phase-by-phase timing).  For D <= 32 (one chunk) every subset is valid without the bit, in order. */
 #define ADAMVS_PHASE_VIEW_WEIGHTS 1  /* pass A (pair similarity, CostRegNet2D, softmax) or resample of prev_conf */
-#define ADAMVS_PHASE_AGGREGATE    2  /* weighted aggregation + conv1 for all hypotheses */
+#define ADAMVS_PHASE_AGGREGATE    2  /* weighted aggregation + conv1 */
 #define ADAMVS_PHASE_RECURRENCE   4  /* D sequential ConvGRU encoder-decoder steps */
 #define ADAMVS_PHASE_SOFT_ARGMIN  8  /* depth / confidence from the regularised slices */
 #define ADAMVS_PHASE_ALL         15
+#define ADAMVS_PHASE_TIMING_ONLY 16  /* allow a proper subset of AGGREGATE|RECURRENCE|SOFT_ARGMIN at D > 32: timing, no maps */
 
 /* feat [V=S+1][B][h*w][C]; rt [B][S][12]; planes: see adamvs_stage_desc.plane_mode;
  * prev_conf [S][B][prev_h*prev_w] (previous stage's view weights; ignored when first_stage);
  * w_reg: packed CostRegNet2D weights (first_stage only);
  * outputs: view_weight [S][B][h*w] (what the next stage consumes as prev_conf),
  *          pair_depth [S][B][h*w] (first_stage only), depth / confidence [B][Ho*Wo].
- * phases: ADAMVS_PHASE_ALL, or a subset to run (and time) the stage piecewise in order. */
+ * phases: ADAMVS_PHASE_ALL, or VIEW_WEIGHTS alone followed by the other three together (see above). */
 int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt, const float* planes,
                                const float* prev_conf, const float* w_reg, const adamvs_fuse_weights* w_fuse,
                                float* view_weight, float* pair_depth, float* depth, float* confidence,

@@ -697,3 +697,57 @@ def test_generated_planes_equal_materialised_planes(hip, precision):
             assert torch.equal(a, b)
     for a, b in zip(outs[0]["stage1"]["pair_result"], outs[1]["stage1"]["pair_result"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D,stage", [(48, 0), (192, 0), (40, 1), (24, 1)])
+def test_piecewise_phase_masks(hip, D, stage):
+    """adamvs_depth_stage_forward's phase mask (include/adamvs_hip.h): VIEW_WEIGHTS in a call of its own followed by
+    AGGREGATE | RECURRENCE | SOFT_ARGMIN in one call equals PHASE_ALL bit for bit at any D.  The workspace keeps ONE chunk of
+    32 hypotheses, so with D > 32 a proper subset of the last three is refused (it cannot hand results to a later call)
+    unless ADAMVS_PHASE_TIMING_ONLY is set, which runs it for its duration alone; with D <= 32 the phases may run one by
+    one and still produce the maps."""
+    from ada_mvs_amd import _lib
+    from ada_mvs_amd._lib import AdaMVSHipError
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    B, V, h, w = 2, 3, 16, 24
+    m = Infer_AdaMVSNet(D if stage == 0 else 48, [D if stage == 0 else 48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.cuda().eval()
+    net = m.DepthNet[stage]
+    C = (32, 16, 8)[stage]
+    feats = [synth.smooth_features(B, C, h, w, seed=70 + v) for v in range(V)]
+    feat_cl = hip.pack_features(dev(torch.stack(feats, 0).reshape(-1, C, h, w)))
+    rt = hip.relative_transforms(dev(synth.rig_projections(V, 4 * h, 4 * w, batch=B)["stage1"]))
+    g = torch.Generator().manual_seed(11)
+    planes = dev((430.0 + 10.0 * torch.rand(B, 1, h, w, generator=g) + (150.0 / D) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).contiguous())
+    prev = None if stage == 0 else dev(torch.rand(V - 1, B, h // 2, w // 2, generator=g))
+    Ho, Wo = (2 * h, 2 * w) if net.in_up else (h, w)
+
+    def outputs():
+        return (torch.zeros(V - 1, B, h, w, device="cuda"), torch.zeros(V - 1, B, h, w, device="cuda") if stage == 0 else None,
+                torch.zeros(B, Ho, Wo, device="cuda"), torch.zeros(B, Ho, Wo, device="cuda"))
+
+    rest = _lib.PHASE_AGGREGATE | _lib.PHASE_RECURRENCE | _lib.PHASE_SOFT_ARGMIN
+    with torch.no_grad():
+        whole = net.run(feat_cl, B, C, h, w, rt, planes, prev)
+        o = outputs()
+        net.run(feat_cl, B, C, h, w, rt, planes, prev, phases=_lib.PHASE_VIEW_WEIGHTS, outputs=o)
+        net.run(feat_cl, B, C, h, w, rt, planes, prev, phases=rest, outputs=o)
+        torch.cuda.synchronize()
+        for a, b in zip(whole, o):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)
+        for sub in (_lib.PHASE_AGGREGATE, _lib.PHASE_RECURRENCE, _lib.PHASE_SOFT_ARGMIN, _lib.PHASE_AGGREGATE | _lib.PHASE_RECURRENCE,
+                    _lib.PHASE_VIEW_WEIGHTS | _lib.PHASE_SOFT_ARGMIN):
+            if D > 32:
+                with pytest.raises(AdaMVSHipError, match="TIMING_ONLY"):
+                    net.run(feat_cl, B, C, h, w, rt, planes, prev, phases=sub, outputs=outputs())
+                net.run(feat_cl, B, C, h, w, rt, planes, prev, phases=sub | _lib.PHASE_TIMING_ONLY, outputs=outputs())    # runs; no maps promised
+        if D <= 32:            # one chunk: the phases one by one, in order, still make the maps
+            o = outputs()
+            for ph in (_lib.PHASE_VIEW_WEIGHTS, _lib.PHASE_AGGREGATE, _lib.PHASE_RECURRENCE, _lib.PHASE_SOFT_ARGMIN):
+                net.run(feat_cl, B, C, h, w, rt, planes, prev, phases=ph, outputs=o)
+            torch.cuda.synchronize()
+            assert torch.equal(whole[2], o[2]) and torch.equal(whole[3], o[3])
+        torch.cuda.synchronize()
