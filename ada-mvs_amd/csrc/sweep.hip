@@ -15,6 +15,7 @@
 // conv1 of SliceCostRegNetRED (adamvs.py:416) runs over it as an ordinary tiled
 // convolution on the matrix cores (slice_red.hip), writing c1[d].
 #include <limits.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "kernels.h"
@@ -151,6 +152,171 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------
+// The weighted aggregation of the hot path (MODE 0 above), restructured around what the plane loop of k_sweep_aggregate
+// spends its time on (round 3; the kernel above stays for the variance mode and as the A/B reference, ADAMVS_SWEEP=0):
+//  * projections are handed around inside a quad with DPP moves (VALU, no LDS crossbar, no lgkmcnt wait) instead of five
+//    ds_bpermute per view and plane: lane q of a quad projects views q, q + 4 (both quads of a C = 32 pixel hold all
+//    views; with C = 8 a quad holds two pixels and lane q of a pair projects views q, q + 2, ...);
+//  * the view weight (already normalised by 1e-5 + sum of weights) is folded into the four bilinear weights by the lane
+//    that projects the view, so a view costs eight packed FMAs into ONE accumulator and the reference vector enters once
+//    per plane:  sim = eps + ref * sum_v sum_t (w_vt wn_v) tap_vt   (reference adamvs.py:497-512, reassociated);
+//  * tap reloads are buffer loads (uniform descriptor per view, 32-bit lane offset: no 64-bit address arithmetic), and
+//    a plane runs in two phases with the NEXT plane's projection in between: phase 1 compares the cells of all views and
+//    issues every reload of the plane, then the next projection is computed, then phase 2 blends -- the reloads of a
+//    plane overlap each other and ~40 vector instructions instead of being waited for one view after the other;
+//  * generated planes (the stage path) cost a multiply and an add per plane; explicit planes are staged through LDS per
+//    group of 8, fetched before the previous group's store burst (vmcnt retires in order).
+template <int CTRL> __device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// the value lane q of the caller's quad holds (G >= 4), or lane q of the caller's pair (G == 2: a quad = two pixels)
+template <int G> __device__ __forceinline__ int quad_bcast_i(int v, int q) {
+  if (G == 2) return q == 0 ? dpp_mov_i<0xA0>(v) : dpp_mov_i<0xF5>(v);          // quad_perm [0,0,2,2] / [1,1,3,3]
+  switch (q) {
+    case 0: return dpp_mov_i<0x00>(v);
+    case 1: return dpp_mov_i<0x55>(v);
+    case 2: return dpp_mov_i<0xAA>(v);
+    default: return dpp_mov_i<0xFF>(v);
+  }
+}
+template <int G> __device__ __forceinline__ float quad_bcast_f(float v, int q) {
+  return __builtin_bit_cast(float, quad_bcast_i<G>(__builtin_bit_cast(int, v), q));
+}
+
+// grid: (ceil(hw / (256/G)), 1, B); block 256.  sim [d1-d0][B][hw][C].  GEN: planes generated (uniform / window).
+template <int C, int SV, bool GEN>
+__global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ feat, const float* __restrict__ rt, PlaneSrc planes,
+                                                     const float* __restrict__ vw, float* __restrict__ sim, int B, int S, int D,
+                                                     int d0, int d1, int h, int w, int eps_num) {
+  constexpr int G = C / 4, PPB = 256 / G, NQ = G < 4 ? G : 4, VPL = (SV + NQ - 1) / NQ, PK = 8, NM = PK / G;
+  const int hw = h * w;
+  const int tid = threadIdx.x, g = tid % G, gq = g % NQ, pib = tid / G;
+  const int pix = blockIdx.x * PPB + pib;
+  const int b = blockIdx.z;
+  const bool live = pix < hw;
+  const int pc = live ? pix : hw - 1;
+  const float x = (float)(pc % w), y = (float)(pc / w);
+  const f32x4 ref4 = *(const f32x4*)(feat + ((size_t)b * hw + pc) * C + 4 * g);
+
+  // normalisation of the view weights (adamvs.py:497-512), per pixel: all lanes
+  float winv, eps_term;
+  {
+    float wsum = eps_num ? 0.f : 1e-5f;
+    for (int s = 0; s < S; ++s) wsum += vw[((size_t)s * B + b) * hw + pc];
+    winv = 1.0f / wsum;
+    eps_term = eps_num ? 1e-5f * winv : 0.f;       // train/test twin (adamvs.py:262-300): (1e-5 + sum) / sum_v w_v
+  }
+  // the views this lane projects: gq, gq + NQ, ... (views past S-1 repeat the last one; never consumed)
+  float ax[VPL], ay[VPL], az[VPL], tx[VPL], ty[VPL], tz[VPL], wn[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int sc = min(gq + k * NQ, S - 1);
+    const float* r = rt + ((size_t)b * S + sc) * 12;
+    ax[k] = r[0] * x + r[1] * y + r[2];              // rot_xyz = R.[x,y,1] (module.py:549)
+    ay[k] = r[3] * x + r[4] * y + r[5];
+    az[k] = r[6] * x + r[7] * y + r[8];
+    tx[k] = r[9]; ty[k] = r[10]; tz[k] = r[11];
+    wn[k] = vw[((size_t)sc * B + b) * hw + pc] * winv;
+  }
+  // cached cell and its four taps (4 channels of this lane) per view.  Named variables, not arrays: an array of SV
+  // float4 is promoted to ONE <16 x float> value, i.e. a 512-bit register tuple that is copied whole after every
+  // conditional reload (measured: 188 registers and 32 v_mov_b64 per view and plane).
+#define ADAMVS_EACH_VIEW(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define ADAMVS_DECL_VIEW(i) int cc##i = -1; f32x4 ta##i = {0.f, 0.f, 0.f, 0.f}, tb##i = ta##i, tc##i = ta##i, td##i = ta##i;
+  ADAMVS_EACH_VIEW(ADAMVS_DECL_VIEW)
+#undef ADAMVS_DECL_VIEW
+  const size_t vstride = (size_t)B * hw * C;
+  const float* src1 = feat + ((size_t)B + b) * (size_t)hw * C;                 // view s: + s * vstride (uniform)
+  const unsigned g16 = 16u * g;
+  const unsigned rowpitch = (unsigned)w * (C * 4);
+  const PlaneLine pl = plane_line(planes, b, pc, D, hw);
+  const unsigned ooff = live ? (unsigned)((((size_t)b * hw + pc) * C + 4 * g) * 4) : BUF_OOB;
+  const size_t ostride = (size_t)B * hw * C;
+
+  __shared__ f32x4 park[PK][256];
+  __shared__ float dstash[GEN ? 1 : PK][GEN ? 1 : PPB];
+
+  auto project = [&](float depth, PlaneTaps (&o)[VPL]) {
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      o[k] = plane_taps_scaled(ax[k], ay[k], az[k], tx[k], ty[k], tz[k], depth, h, w, wn[k]);
+    }
+  };
+  auto depth_of = [&](int d, int j) -> float {          // plane d = plane j of the current group
+    if (GEN) return plane_value(pl.lo, pl.step, d);
+    return dstash[GEN ? 0 : j][GEN ? 0 : pib];
+  };
+
+  float nd[NM];                                     // explicit planes: lane g fetches planes dg + g, dg + G + g, ... of the NEXT group
+  if (!GEN) {
+#pragma unroll
+    for (int k = 0; k < NM; ++k) nd[k] = pl.q[(size_t)min(d0 + k * G + g, d1 - 1) * hw];
+  }
+  for (int dg = d0; dg < d1; dg += PK) {
+    if (!GEN) {
+      __syncthreads();                              // every lane is done with the previous group's planes
+#pragma unroll
+      for (int k = 0; k < NM; ++k) dstash[GEN ? 0 : k * G + g][GEN ? 0 : pib] = nd[k];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NM; ++k) nd[k] = pl.q[(size_t)min(dg + PK + k * G + g, d1 - 1) * hw];     // in flight during the group
+    }
+    PlaneTaps nxt[VPL];
+    project(depth_of(dg, 0), nxt);
+#pragma unroll 1
+    for (int j = 0; j < PK; ++j) {
+      const int d = dg + j;
+      if (d >= d1) break;
+      PlaneTaps cur[VPL];
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) cur[k] = nxt[k];
+      // ---- phase 1: the cells of this plane, every reload issued
+      auto reload = [&](int s, int& cc, f32x4& ta, f32x4& tb, f32x4& tc, f32x4& td) {
+        const int cell = quad_bcast_i<G>(cur[s / NQ].cell, s % NQ);
+        if (cell != -1 && cell != cc) {                            // entered another source cell
+          cc = cell;
+          const buf_rsrc rs = make_rsrc(src1 + (size_t)s * vstride);
+          const int ix = (cell & 0xFFFF) - 1, iy = (cell >> 16) - 1;
+          const unsigned xa = (unsigned)max(ix, 0) * (C * 4) + g16, xb = (unsigned)min(ix + 1, w - 1) * (C * 4) + g16;
+          const unsigned ya = (unsigned)max(iy, 0) * rowpitch, yb = (unsigned)min(iy + 1, h - 1) * rowpitch;
+          ta = buf_load4(rs, ya + xa);
+          tb = buf_load4(rs, ya + xb);
+          tc = buf_load4(rs, yb + xa);
+          td = buf_load4(rs, yb + xb);
+        }
+      };
+#define ADAMVS_RELOAD_VIEW(i) if (i < SV && i < S) reload(i, cc##i, ta##i, tb##i, tc##i, td##i);
+      ADAMVS_EACH_VIEW(ADAMVS_RELOAD_VIEW)
+#undef ADAMVS_RELOAD_VIEW
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- the next plane's projection, under the reloads
+      if (j + 1 < PK) project(depth_of(min(d + 1, d1 - 1), min(j + 1, PK - 1)), nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 2: blend
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};       // even / odd views: two FMA chains
+      auto blend = [&](int s, const f32x4& ta, const f32x4& tb, const f32x4& tc, const f32x4& td) {
+        const PlaneTaps& m = cur[s / NQ];
+        const float w00 = quad_bcast_f<G>(m.w00, s % NQ), w01 = quad_bcast_f<G>(m.w01, s % NQ);
+        const float w10 = quad_bcast_f<G>(m.w10, s % NQ), w11 = quad_bcast_f<G>(m.w11, s % NQ);
+        f32x4& a = acc[s & 1];                                     // all-zero weights when padding
+        a = ta * w00 + a; a = tb * w01 + a; a = tc * w10 + a; a = td * w11 + a;
+      };
+#define ADAMVS_BLEND_VIEW(i) if (i < SV && i < S) blend(i, ta##i, tb##i, tc##i, td##i);
+      ADAMVS_EACH_VIEW(ADAMVS_BLEND_VIEW)
+#undef ADAMVS_BLEND_VIEW
+      park[j][tid] = ref4 * (acc[0] + acc[1]) + eps_term;
+      // every reload of this plane has been consumed; stated explicitly (the builtin, so that the compiler's wait insertion
+      // knows it): without it the reload branches of the next plane, which build their addresses in the dead tap
+      // registers, each start with a conservative s_waitcnt vmcnt and the reloads of a plane serialise
+      wait_vmem_all();
+    }
+    const int nd_ = min(PK, d1 - dg);
+#pragma unroll 1
+    for (int j = 0; j < nd_; ++j)
+      buf_store4(make_rsrc(sim + (size_t)(dg + j - d0) * ostride), ooff, park[j][tid]);
+  }
+#undef ADAMVS_EACH_VIEW
+}
+
 template <int C>
 static int launch_sweep_variance_c(const float* feat, const float* rt, PlaneSrc planes, float* out_a, int Da, float* out_b,
                                    int Db, int B, int S, int D, int h, int w, hipStream_t st) {
@@ -175,10 +341,28 @@ int launch_sweep_variance(const float* feat, const float* rt, const float* plane
   return set_error(-1, "sweep_variance: C=%d unsupported (8, 16 or 32)", C);
 }
 
+// ADAMVS_SWEEP=0: the round-2 kernel (A/B); default: k_sweep_blend
+static bool sweep_blend_enabled() {
+  static const bool on = [] { const char* e = getenv("ADAMVS_SWEEP"); return !(e && *e == '0'); }();
+  return on;
+}
+
 template <int C>
 static int launch_sweep_c(const float* feat, const float* rt, PlaneSrc planes, const float* vw, float* sim, int B, int S,
                           int D, int d0, int d1, int h, int w, int eps_num, hipStream_t st) {
   dim3 grid(cdiv(h * w, 256 / (C / 4)), 1, B);
+  if (sweep_blend_enabled() && (size_t)B * h * w * C * 4 < 0x7fffffffu) {      // 32-bit lane offsets inside one view / one plane
+    const bool gen = planes.mode != PLANES_EXPLICIT;
+    if (S <= 4) {
+      if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 4, true>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+      else hipLaunchKernelGGL((k_sweep_blend<C, 4, false>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+    } else {
+      if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 8, true>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+      else hipLaunchKernelGGL((k_sweep_blend<C, 8, false>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+    }
+    ADAMVS_CHECK_LAUNCH("sweep_blend");
+    return 0;
+  }
   if (S <= 4)
     hipLaunchKernelGGL((k_sweep_aggregate<C, 4>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
   else

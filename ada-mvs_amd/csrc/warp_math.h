@@ -80,6 +80,27 @@ __device__ __forceinline__ PlaneTaps plane_taps(float ax, float ay, float az, fl
   return t;
 }
 
+// The same projection without branches, with a scale folded into the weights (the sweep folds the normalised view weight
+// in here): every quantity is computed for every lane and masked at the end -- in a rolled plane loop the two nested
+// exec-masked regions of plane_taps cost a dozen register initialisations per plane.  Inside the image band ix lies in
+// [-1, w-1] and iy in [-1, h-1], so tap x0 is padding only for ix == -1 and tap x1 only for ix == w-1 (likewise y).
+__device__ __forceinline__ PlaneTaps plane_taps_scaled(float ax, float ay, float az, float tx, float ty, float tz, float depth,
+                                                       int h, int w, float scale) {
+  const float X0 = ax * depth + tx, X1 = ay * depth + ty, X2 = az * depth + tz;      // module.py:550-552
+  const float rz = rcp_nr(X2);
+  const float u = X0 * rz, v = X1 * rz;                                              // module.py:553
+  const bool inside = u > -1.0f && u < (float)w && v > -1.0f && v < (float)h;        // false for NaN / inf as well
+  const float fx0 = floorf(u), fy0 = floorf(v);
+  const int ix = (int)fx0, iy = (int)fy0;
+  const float lx = u - fx0, ly = v - fy0;
+  const float wx0 = (inside && ix >= 0) ? 1.f - lx : 0.f, wx1 = (inside && ix < w - 1) ? lx : 0.f;
+  const float wy0 = (iy >= 0 ? 1.f - ly : 0.f) * scale, wy1 = (iy < h - 1 ? ly : 0.f) * scale;
+  PlaneTaps t;
+  t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
+  t.cell = inside ? ((ix + 1) | ((iy + 1) << 16)) : -1;
+  return t;
+}
+
 // the four taps of a packed cell (clamped to the image; padding taps carry weight 0)
 __device__ __forceinline__ void load_cell_taps(const float* __restrict__ src, int C, int cell, int h, int w, f32x4& t00,
                                                f32x4& t01, f32x4& t10, f32x4& t11) {
