@@ -27,6 +27,15 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// The value the LAST of the G neighbouring lanes of a pixel holds, in every lane of the group (DPP).
+template <int G>
+__device__ __forceinline__ int group_last(int v) {
+  if (G == 2) return __builtin_amdgcn_update_dpp(0, v, 0xF5, 0xF, 0xF, true);                 // quad_perm [1,1,3,3]
+  if (G == 4) return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xF, 0xF, true);                 // quad_perm [3,3,3,3]
+  const int lo = __builtin_amdgcn_update_dpp(0, v, 0x157, 0xF, 0x3, true);                    // row_share:7 -> lanes 0-7 of every row
+  return __builtin_amdgcn_update_dpp(lo, v, 0x15F, 0xF, 0xC, false);                          // row_share:15 -> lanes 8-15
+}
+
 // ---------------------------------------------------------------------------
 // grid: (pixel groups, S, B); block 256.  sim [S][B][hw][D] (channel-last in d).
 template <int C>
@@ -63,8 +72,27 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   for (int d0 = 0; d0 < D; d0 += G) {
     float keep = 0.f;
     const PlaneTaps mine = plane_taps(ax, ay, az, tx, ty, tz, plane_at(planes, pl, min(d0 + g, D - 1), hw), h, w);
+    // The cell of the group's LAST plane, on the VALU (DPP).  Planes are monotone in disparity nearly everywhere, so the G
+    // planes of a group leave the cached cell at most once: every lane then sits in the cached cell or in the last
+    // lane's -- ONE reload per group, no walk through the planes (the walk below costs a ds_bpermute round trip per plane).
+    const int cn = group_last<G>(mine.cell);
     if (__all(mine.cell == ccell || mine.cell == -1)) {            // whole wave still inside its cached cells
       keep = (mine.w00 * d00 + mine.w01 * d01 + mine.w10 * d10 + mine.w11 * d11) * (1.0f / (float)C);
+    } else if (__all(cn != -1 && (mine.cell == ccell || mine.cell == cn || mine.cell == -1))) {
+      float n00 = d00, n01 = d01, n10 = d10, n11 = d11;
+      if (cn != ccell) {                                           // the same decision in all G lanes of a pixel
+        f32x4 t00, t01, t10, t11;
+        load_cell_taps(src, C, cn, h, w, t00, t01, t10, t11);
+        const f32x4 m00 = t00 * ref4, m01 = t01 * ref4, m10 = t10 * ref4, m11 = t11 * ref4;
+        n00 = group_sum<G>((m00.x + m00.y) + (m00.z + m00.w));
+        n01 = group_sum<G>((m01.x + m01.y) + (m01.z + m01.w));
+        n10 = group_sum<G>((m10.x + m10.y) + (m10.z + m10.w));
+        n11 = group_sum<G>((m11.x + m11.y) + (m11.z + m11.w));
+      }
+      const bool old = mine.cell == ccell;                         // a plane off the image has four zero weights: either set
+      keep = (mine.w00 * (old ? d00 : n00) + mine.w01 * (old ? d01 : n01) + mine.w10 * (old ? d10 : n10) + mine.w11 * (old ? d11 : n11)) *
+             (1.0f / (float)C);
+      ccell = cn; d00 = n00; d01 = n01; d10 = n10; d11 = n11;
     } else
 #pragma unroll
     for (int j = 0; j < G; ++j) {                                  // planes past D-1 repeat the last one, never stored
