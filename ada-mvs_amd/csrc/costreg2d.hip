@@ -28,6 +28,9 @@ struct ConvDDArgs {
   const float* skip;   // [N][ho*wo][D] or null; added after the ReLU (adamvs.py:234-236)
   float* out;          // [N][ho*wo][D]
   int D, hi, wi, ho, wo, relu;
+  const float* in2;    // [N][hi*wi][D] or null: the layer convolves in + in2, summed when the window enters LDS.  The
+                       // hourglass's skip additions (x = conv4 + conv7(x), adamvs.py:234-236) run HERE, in the consumer of x:
+                       // in the producer's epilogue a skip operand is a second round of loads that nothing overlaps
 };
 
 enum { CONV_S1 = 0, CONV_S2 = 1, CONV_T2 = 2 };
@@ -53,7 +56,7 @@ template <int BR> struct TileGeom<CONV_T2, BR> { static constexpr int LR = BR + 
 //  * two named register sets for the A fragments and two chunks per loop trip: the fragments and the activation
 //    tile of chunk k+1 are requested before the MFMAs of chunk k and waited for once, after them (vmcnt retires
 //    in order; a single explicit wait keeps the compiler from scheduling its own in the middle of the chain).
-template <int MT, int WM, int MODE, int KB, int PY, int PX, int BR = 8>
+template <int MT, int WM, int MODE, int KB, int PY, int PX, int BR = 8, bool TWO = false>
 __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
   using TG = TileGeom<MODE, BR>;
   constexpr int LR = TG::LR, LC = TG::LC, PLANE = TG::PLANE, GP = group_pitch(PLANE, KB / 4);
@@ -119,16 +122,25 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
           }
       }
   };
+  constexpr bool two = TWO;          // the layer convolves in + in2 (a separate instantiation: the plain chunk loop stays as it was)
+  const buf_rsrc rx2 = make_rsrc((const char*)(two ? a.in2 : a.in) + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
+  f32x4 xs2[two ? NITA : 1];
   auto load_x = [&](f32x4 (&st)[NITA], int ch) {
 #pragma unroll
     for (int it = 0; it < NITA; ++it)
       st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+    if (two) {
+#pragma unroll
+      for (int it = 0; it < NITA; ++it)
+        xs2[two ? it : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, xoff[it], (unsigned)ch * 4u, 0));
+    }
   };
   auto store_x = [&](const f32x4 (&st)[NITA]) {
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
       float* dl = (float*)((char*)lds + xlds[it]);
-      dl[0] = st[it].x; dl[PLANE] = st[it].y; dl[2 * PLANE] = st[it].z; dl[3 * PLANE] = st[it].w;
+      const f32x4 v = two ? st[it] + xs2[two ? it : 0] : st[it];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
     }
   };
   auto mfma_chunk = [&](const float (&wf)[NTAP][KB / 4][MT]) {
@@ -210,6 +222,8 @@ __device__ __forceinline__ void conv_dd_t2_all(const ConvDDArgs& a, float* lds, 
   constexpr int NITEMS = LR * LC * (KB / 4), NITA = (NITEMS + 255) / 256;
 
   const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.hi + r0) * a.wi + c0) * (long)D * 4);
+  const bool two = a.in2 != nullptr;                         // uniform: the layer convolves in + in2
+  const buf_rsrc rx2 = make_rsrc((const char*)(two ? a.in2 : a.in) + (((long)n * a.hi + r0) * a.wi + c0) * (long)D * 4);
   unsigned xoff[NITA], xlds[NITA];
 #pragma unroll
   for (int it = 0; it < NITA; ++it) {
@@ -229,21 +243,39 @@ __device__ __forceinline__ void conv_dd_t2_all(const ConvDDArgs& a, float* lds, 
     xb[kc] = (unsigned)((kc * GP + q * PLANE + (wn * NTR) * LC + p) * 4);
     pin(xb[kc]);
   }
+  // epilogue: the lane's output pixel of class (0, 0) in row r of its wave, as a byte offset from the image (the class and
+  // the channel tile are added as uniform terms); BUF_OOB outside the map, so that EVERY lane issues every store and
+  // the number of stores in flight after an epilogue is known: the next class does not wait for them
+  const buf_rsrc ro = make_rsrc((char*)a.out + (long)n * a.ho * a.wo * (long)D * 4);
+  const buf_rsrc rk = make_rsrc((const char*)(a.skip ? a.skip : a.out) + (long)n * a.ho * a.wo * (long)D * 4);
+  unsigned ooff[NTR];
+#pragma unroll
+  for (int r = 0; r < NTR; ++r) {
+    const int row = r0 + wn * NTR + r, col = c0 + p;
+    ooff[r] = (row < a.hi && col < a.wi) ? (unsigned)((((2 * row) * a.wo + 2 * col) * D + wm * MT * 16 + 4 * q) * 4) : BUF_OOB;
+    pin(ooff[r]);
+  }
 
   float wfA[4][KB / 4][MT], wfB[4][KB / 4][MT];              // up to 4 taps
-  f32x4 xs[NITA];
+  f32x4 xs[NITA], xs2[NITA];
   f32x4 acc[MT][NTR];
 
   auto load_x = [&](int ch) {
 #pragma unroll
     for (int it = 0; it < NITA; ++it)
       xs[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+    if (two) {
+#pragma unroll
+      for (int it = 0; it < NITA; ++it)
+        xs2[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, xoff[it], (unsigned)ch * 4u, 0));
+    }
   };
   auto store_x = [&]() {
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
       float* dl = (float*)((char*)lds + xlds[it]);
-      dl[0] = xs[it].x; dl[PLANE] = xs[it].y; dl[2 * PLANE] = xs[it].z; dl[3 * PLANE] = xs[it].w;
+      const f32x4 v = two ? xs[it] + xs2[it] : xs[it];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
     }
   };
   auto load_w = [&](auto pyc, auto pxc, float (&wf)[4][KB / 4][MT], int ch) {
@@ -279,15 +311,17 @@ __device__ __forceinline__ void conv_dd_t2_all(const ConvDDArgs& a, float* lds, 
             for (int r = 0; r < NTR; ++r) acc[mt][r] = mfma16(wf[ty * (1 + PX) + tx][kc][mt], bv[r], acc[mt][r]);
         }
   };
-  // one class; wfA and xs hold its first chunk on entry; on exit they hold the first chunk of class (nyc, nxc), if any
-  auto run_class = [&](auto pyc, auto pxc, auto nyc, auto nxc, auto has_next) {
+  // one class; wfA and xs hold its first chunk on entry; on exit they hold the first chunk of class (nyc, nxc), if any.
+  // `first`: nothing but that first chunk is in flight (block entry); otherwise the previous class's stores are, and the
+  // wait for the chunk -- requested BEFORE them, vmcnt retires in order -- is left to the compiler, which counts them.
+  auto run_class = [&](auto pyc, auto pxc, auto nyc, auto nxc, auto has_next, auto first) {
     constexpr int PY = decltype(pyc)::value, PX = decltype(pxc)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < NTR; ++r) acc[mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ch = 0; ch < D; ch += 2 * KB) {
-      wait_vmem_all();
+      if (decltype(first)::value || ch > 0) wait_vmem_all();
       __syncthreads();
       store_x();
       __syncthreads();
@@ -308,29 +342,26 @@ __device__ __forceinline__ void conv_dd_t2_all(const ConvDDArgs& a, float* lds, 
       }
       mfma_chunk(pyc, pxc, wfB);
     }
+    const unsigned cls = (unsigned)((PY * a.wo + PX) * D * 4);           // uniform: the class's pixel offset
 #pragma unroll
-    for (int r = 0; r < NTR; ++r) {
-      const int row = r0 + wn * NTR + r, col = c0 + p;
-      if (!(row < a.hi && col < a.wi)) continue;
-      const size_t opix = ((size_t)n * a.ho + 2 * row + PY) * a.wo + 2 * col + PX;
+    for (int r = 0; r < NTR; ++r)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int co4 = (wm * MT + mt) * 16 + 4 * q;
-        f32x4 v = acc[mt][r] + *(const f32x4*)(a.bias + co4);
+        f32x4 v = acc[mt][r] + *(const f32x4*)(a.bias + (wm * MT + mt) * 16 + 4 * q);
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (a.skip) v += *(const f32x4*)(a.skip + opix * D + co4);
-        *(f32x4*)(a.out + opix * D + co4) = v;
+        const unsigned o = ooff[r] == BUF_OOB ? BUF_OOB : ooff[r] + cls + (unsigned)(mt * 64);
+        if (a.skip) v += buf_load4(rk, o);
+        buf_store4(ro, o, v);
       }
-    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   load_w(I1{}, I1{}, wfA, 0);
   load_x(0);
-  run_class(I1{}, I1{}, I1{}, I0{}, std::true_type{});
-  run_class(I1{}, I0{}, I0{}, I1{}, std::true_type{});
-  run_class(I0{}, I1{}, I0{}, I0{}, std::true_type{});
-  run_class(I0{}, I0{}, I0{}, I0{}, std::false_type{});
+  run_class(I1{}, I1{}, I1{}, I0{}, std::true_type{}, std::true_type{});
+  run_class(I1{}, I0{}, I0{}, I1{}, std::true_type{}, std::false_type{});
+  run_class(I0{}, I1{}, I0{}, I0{}, std::true_type{}, std::false_type{});
+  run_class(I0{}, I0{}, I0{}, I0{}, std::false_type{}, std::false_type{});
 }
 
 // ConvTranspose2d(k3, s2, p1, op1) with the four output parity classes of a block of input positions advanced TOGETHER,
@@ -397,16 +428,25 @@ __device__ __forceinline__ void conv_dd_t2_fused(const ConvDDArgs& a, float* lds
           wf[t][kc][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, frag, 0));
         }
   };
+  const bool two = a.in2 != nullptr;                         // uniform: the layer convolves in + in2
+  const buf_rsrc rx2 = make_rsrc((const char*)(two ? a.in2 : a.in) + (((long)n * a.hi + r0) * a.wi + c0) * (long)D * 4);
+  f32x4 xs2[NITA];
   auto load_x = [&](f32x4 (&st)[NITA], int ch) {
 #pragma unroll
     for (int it = 0; it < NITA; ++it)
       st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+    if (two) {
+#pragma unroll
+      for (int it = 0; it < NITA; ++it)
+        xs2[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, xoff[it], (unsigned)ch * 4u, 0));
+    }
   };
   auto store_x = [&](const f32x4 (&st)[NITA]) {
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
       float* dl = (float*)((char*)lds + xlds[it]);
-      dl[0] = st[it].x; dl[PLANE] = st[it].y; dl[2 * PLANE] = st[it].z; dl[3 * PLANE] = st[it].w;
+      const f32x4 v = two ? st[it] + xs2[it] : st[it];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
     }
   };
   auto mfma_chunk = [&](const float (&wf)[9][KB / 4][MT]) {
@@ -483,23 +523,24 @@ __global__ __launch_bounds__(256, OCC) void k_conv_dd_t2_fused(ConvDDArgs a) {
 }
 
 // grid: (ceil(cols/16), ceil(rows/8), N); block 256
-template <int MT, int WM, int MODE, int KB>
+// TWO (stride-1 layers only): the layer convolves in + in2; the transposed kernel takes in2 as a uniform run-time switch
+template <int MT, int WM, int MODE, int KB, bool TWO = false>
 __global__ __launch_bounds__(256, (MT == 4 && WM == 4) ? 1 : 2) void k_conv_dd(ConvDDArgs a) {
   __shared__ float lds[(KB / 4) * group_pitch(TileGeom<MODE>::PLANE, KB / 4)];
   if (MODE == CONV_T2) {
     conv_dd_t2_all<MT, WM, KB>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
   } else {
-    conv_dd_body<MT, WM, MODE, KB, 0, 0>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+    conv_dd_body<MT, WM, MODE, KB, 0, 0, 8, TWO>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
   }
 }
 
 // Stride-1 / stride-2 layers on a SMALL grid (the deep levels of the hourglass when few maps are in flight: 12 x 24 maps
 // of 16 tiles are 64 blocks of 8 x 16 on 256 CUs, a third of each block padding): blocks of 2 output rows, four times the
 // workgroups, no padded rows.  54 MFMAs per wave and barrier pair instead of 216 -- it pays only while the chip is not full.
-template <int MT, int WM, int MODE, int KB>
+template <int MT, int WM, int MODE, int KB, bool TWO = false>
 __global__ __launch_bounds__(256, 2) void k_conv_dd_rows2(ConvDDArgs a) {
   __shared__ float lds[(KB / 4) * group_pitch(TileGeom<MODE, 2>::PLANE, KB / 4)];
-  conv_dd_body<MT, WM, MODE, KB, 0, 0, 2>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+  conv_dd_body<MT, WM, MODE, KB, 0, 0, 2, TWO>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
 }
 
 // Measured (cfg3, 4 / 32 tiles per step): 64 blocks of 8 rows 0.185 -> 0.073 ms, 144: 0.193 -> 0.139, 576: 0.49 -> 0.38, 512: 0.33 -> 0.25,
@@ -523,11 +564,23 @@ static bool t2_fused(long blocks_class_by_class) {
   return blocks_class_by_class <= 2048;
 }
 
+// ADAMVS_T2_KB8=0: one k-step per chunk in the transposed kernel at D = 192, as in rounds 1-2 (A/B).  Two k-steps halve
+// the barrier pairs per class (a class has at most four taps, so the fragments still fit two waves per SIMD):
+// measured conv11 of cfg2 14.2 -> 13.8 ms, with the epilogue freed of the skip operand 14.5 -> 12.3.
+static bool t2_kb8() { const char* e = getenv("ADAMVS_T2_KB8"); return !(e && *e == '0'); }
+// ADAMVS_COSTREG_DEFER_SKIPS=0: the skip additions in the producing layer's epilogue, as in rounds 1-2 (A/B)
+static bool costreg_deferred_skips() { const char* e = getenv("ADAMVS_COSTREG_DEFER_SKIPS"); return !(e && *e == '0'); }
+
 template <int MT, int WM>
-static int launch_conv_dd_cfg(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
+static int launch_conv_dd_cfg(const ConvDDArgs& a_, int N, int mode, hipStream_t st) {
+  const ConvDDArgs& a = a_;
   constexpr int KB = (WM == 4 || (MT == 4 && WM == 2)) ? 4 : 8;
   const bool rows2 = WM >= 2 && mode != CONV_T2 && small_grid_rows2((long)cdiv(a.wo, 16) * cdiv(a.ho, 8) * N);
-  if (mode == CONV_S1 && rows2)
+  if (mode == CONV_S1 && rows2 && a.in2)
+    hipLaunchKernelGGL((k_conv_dd_rows2<MT, (WM >= 2 ? WM : 2), CONV_S1, KB, true>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 2), N), dim3(256), 0, st, a);
+  else if (mode == CONV_S1 && a.in2)
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S1, KB, true>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
+  else if (mode == CONV_S1 && rows2)
     hipLaunchKernelGGL((k_conv_dd_rows2<MT, (WM >= 2 ? WM : 2), CONV_S1, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 2), N), dim3(256), 0, st, a);
   else if (mode == CONV_S2 && rows2)
     hipLaunchKernelGGL((k_conv_dd_rows2<MT, (WM >= 2 ? WM : 2), CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 2), N), dim3(256), 0, st, a);
@@ -537,6 +590,8 @@ static int launch_conv_dd_cfg(const ConvDDArgs& a, int N, int mode, hipStream_t 
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
   else if (WM >= 2 && t2_fused((long)cdiv(a.wi, 16) * cdiv(a.hi, 8) * N))      // small grids: 2-row blocks, all classes per chunk
     hipLaunchKernelGGL((k_conv_dd_t2_fused<MT, (WM >= 2 ? WM : 2), 4, 2, 2>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 2), N), dim3(256), 0, st, a);
+  else if (WM == 4 && MT == 3 && t2_kb8())     // at most four taps per class: two k-steps per chunk fit the register budget
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_T2, 8>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_T2, KB>), dim3(cdiv(a.wi, 16), cdiv(a.hi, 8), N), dim3(256), 0, st, a);
   ADAMVS_CHECK_LAUNCH("conv_dd");
@@ -585,6 +640,16 @@ __global__ __launch_bounds__(256) void k_conv_dd_resident(ConvDDArgs a) {
     const int g = i % KCT, pp = i / KCT, r = pp / LC, c = pp % LC;
     const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi;
     xs[it] = buf_load4(rx, ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB);
+  }
+  if (a.in2) {                                               // uniform: the layer convolves in + in2
+    const buf_rsrc rx2 = make_rsrc((const char*)a.in2 + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = min(tid + it * 256, NITEMS - 1);
+      const int g = i % KCT, pp = i / KCT, r = pp / LC, c = pp % LC;
+      const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi;
+      xs[it] += buf_load4(rx2, ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB);
+    }
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -757,6 +822,10 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
   float* x9 = x7 + F / 16;            // F/4
   float* x11 = x9 + F / 4;            // F
   const int h2 = h / 2, w2 = w / 2, h4 = h / 4, w4 = w / 4, h8 = h / 8, w8 = w / 8;
+  // The three skip additions of the hourglass (x = conv4 + conv7(x); x = conv2 + conv9(x); x = conv0 + conv11(x),
+  // adamvs.py:233-236).  bf16x3: in the epilogue of the transposed layer that produces x (`skip`).  fp32: in the layer
+  // that CONSUMES x (`in2`: the sum is formed when the window enters LDS, one chunk ahead of its use) -- the transposed
+  // kernel's epilogue is then bias + ReLU + stores and nothing waits for it.  The same two addends, one fp32 add: same bits.
   struct L { const float* in; float* out; const float* skip; int hi, wi, ho, wo, mode, relu; };
   const L plan[11] = {
       {x, conv0, nullptr, h, w, h, w, CONV_S1, 1},
@@ -771,6 +840,10 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
       {x9, x11, conv0, h2, w2, h, w, CONV_T2, 1},
       {x11, score, nullptr, h, w, h, w, CONV_S1, 0},
   };
+  // deferred where the CONSUMER is a transposed layer (conv7 -> conv9 -> conv11: its window is small and re-read per
+  // class anyway); conv11 keeps its own skip: in the stride-1 kernel of `prob` a second input costs more than the epilogue
+  // of conv11 gains (measured at cfg2: prob 42.9 -> 45.4 ms against conv11 13.6 -> 12.3)
+  const bool defer = precision == PRECISION_FP32 && costreg_deferred_skips();
   for (int i = 0; i < 11; ++i) {
     const float* wl = wpk + (size_t)i * LW;
     int rc;
@@ -778,8 +851,10 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
       rc = launch_conv_dd_bf16x3(plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, N, D, plan[i].hi,
                                  plan[i].wi, plan[i].ho, plan[i].wo, plan[i].mode, plan[i].relu, st);
     } else {
-      ConvDDArgs a{plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, D,
-                   plan[i].hi, plan[i].wi, plan[i].ho, plan[i].wo, plan[i].relu};
+      const bool give = defer && i + 1 < 11 && plan[i + 1].mode == CONV_T2;        // layer i + 1 adds this layer's skip to its input
+      const bool take = defer && i > 0 && plan[i].mode == CONV_T2 && plan[i - 1].skip;
+      ConvDDArgs a{plan[i].in, wl, wl + (size_t)9 * D * D, give ? nullptr : plan[i].skip, plan[i].out, D,
+                   plan[i].hi, plan[i].wi, plan[i].ho, plan[i].wo, plan[i].relu, take ? plan[i - 1].skip : nullptr};
       rc = launch_conv_dd(a, N, plan[i].mode, st);
     }
     if (rc) return rc;
@@ -830,8 +905,8 @@ extern "C" int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* s
   return launch_cost_reg_net_2d(x, wpk, (float*)workspace, score, N, D, h, w, precision, (hipStream_t)stream);
 }
 
-extern "C" int adamvs_conv3x3_dd(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N,
-                                 int D, int hi, int wi, int mode, int relu, int precision, void* stream) {
+extern "C" int adamvs_conv3x3_dd(const float* in, const float* in2, const float* wpk, const float* bias, const float* skip,
+                                 float* out, int N, int D, int hi, int wi, int mode, int relu, int precision, void* stream) {
   if (int rc = check_precision(precision, D, "conv3x3_dd")) return rc;
   ADAMVS_CHECK_ARG(in && wpk && bias && out && N > 0 && hi > 0 && wi > 0, "conv3x3_dd: bad arguments");
   ADAMVS_CHECK_ARG(costreg_depth_supported(D), "conv3x3_dd: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
@@ -840,9 +915,11 @@ extern "C" int adamvs_conv3x3_dd(const float* in, const float* wpk, const float*
   ADAMVS_CHECK_ARG((size_t)N * 4 <= 65535, "conv3x3_dd: N=%d exceeds the grid z limit", N);
   int ho = mode == CONV_S2 ? hi / 2 : (mode == CONV_T2 ? 2 * hi : hi);
   int wo = mode == CONV_S2 ? wi / 2 : (mode == CONV_T2 ? 2 * wi : wi);
+  ADAMVS_CHECK_ARG(!(in2 && (precision == PRECISION_BF16X3 || mode == CONV_S2)),
+                   "conv3x3_dd: in2 is implemented for fp32, modes 0 and 2 (otherwise pass the addition as the producer's skip)");
   if (precision == PRECISION_BF16X3)
     return launch_conv_dd_bf16x3(in, wpk, bias, skip, out, N, D, hi, wi, ho, wo, mode, relu, (hipStream_t)stream);
-  ConvDDArgs a{in, wpk, bias, skip, out, D, hi, wi, ho, wo, relu};
+  ConvDDArgs a{in, wpk, bias, skip, out, D, hi, wi, ho, wo, relu, in2};
   return launch_conv_dd(a, N, mode, (hipStream_t)stream);
 }
 

@@ -353,11 +353,11 @@ extern "C" int adamvs_red_recur_split(const float* gxr, const float* gxu, const 
   for (int d = 0; d < D; ++d) {
     int rc;
     // Wh.h + (Wx.x + b): the x halves of all planes were computed before the recurrence and enter as `skip`
-    if ((rc = adamvs_conv3x3_dd(r.state, w_ghr, w_ghr + wsz, gxr + d * plane, r.f, B, W, h, w, 0, 0, 0, stream))) return rc;
-    if ((rc = adamvs_conv3x3_dd(r.state, w_ghu, w_ghu + wsz, gxu + d * plane, r.fu, B, W, h, w, 0, 0, 0, stream))) return rc;
+    if ((rc = adamvs_conv3x3_dd(r.state, nullptr, w_ghr, w_ghr + wsz, gxr + d * plane, r.f, B, W, h, w, 0, 0, 0, stream))) return rc;
+    if ((rc = adamvs_conv3x3_dd(r.state, nullptr, w_ghu, w_ghu + wsz, gxu + d * plane, r.fu, B, W, h, w, 0, 0, 0, stream))) return rc;
     if ((rc = adamvs_group_stats_partial(r.f, r.fu, B, npix, W, HC, r.part, pbytes, stream))) return rc;
     if ((rc = adamvs_gru2_gates_apply(r.f, r.fu, W, r.part, gn, r.state, r.rh, r.u, B, npix, W, HC, eps, stream))) return rc;
-    if ((rc = adamvs_conv3x3_dd(r.rh, w_ch, w_ch + wsz, cx + d * plane, r.o, B, W, h, w, 0, 0, 0, stream))) return rc;
+    if ((rc = adamvs_conv3x3_dd(r.rh, nullptr, w_ch, w_ch + wsz, cx + d * plane, r.o, B, W, h, w, 0, 0, 0, stream))) return rc;
     if ((rc = adamvs_group_stats_partial(r.o, nullptr, B, npix, W, HC, r.part, pbytes, stream))) return rc;
     if ((rc = adamvs_gru2_out_apply(r.o, r.part, gn + 4 * HC, r.u, r.state, R + (size_t)d * B * npix * RW, RW, B, npix, W, HC, eps,
                                     stream)))

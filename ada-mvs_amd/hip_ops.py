@@ -295,12 +295,15 @@ def depth_stage_workspace_bytes(desc):
     return n
 
 
-def conv3x3_dd(x_cl, wpk_layer, bias, skip, N, D, hi, wi, mode, relu, out=None, precision=0):
-    """One CostRegNet2D layer on channel-last maps (mode 0 stride 1, 1 stride 2, 2 transposed stride 2)."""
+def conv3x3_dd(x_cl, wpk_layer, bias, skip, N, D, hi, wi, mode, relu, out=None, precision=0, in2=None):
+    """One CostRegNet2D layer on channel-last maps (mode 0 stride 1, 1 stride 2, 2 transposed stride 2).
+    skip: added to the output after the ReLU; in2: added to the input (the layer convolves x_cl + in2; fp32 only)."""
     ho, wo = (hi // 2, wi // 2) if mode == 1 else ((2 * hi, 2 * wi) if mode == 2 else (hi, wi))
     if out is None:
         out = torch.empty(N, ho * wo, D, device=x_cl.device, dtype=torch.float32)
-    check(_lib.load().adamvs_conv3x3_dd(_p(x_cl), _p(wpk_layer), _p(bias), _p(skip) if skip is not None else ctypes.c_void_p(0),
+    null = ctypes.c_void_p(0)
+    check(_lib.load().adamvs_conv3x3_dd(_p(x_cl), _p(_dev(in2, "in2")) if in2 is not None else null, _p(wpk_layer), _p(bias),
+                                        _p(skip) if skip is not None else null,
                                         _p(out), N, D, hi, wi, mode, int(relu), int(precision), _stream()), "conv3x3_dd")
     return out
 

@@ -149,12 +149,19 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0):
     """CostRegNet2D through the one-layer C-ABI op, one timing mark per launch."""
     LW = 9 * D * D + D
     acts = {"x": (x, h, w)}
+    # fp32: conv7's and conv9's skip additions run in the CONSUMING transposed layer (in2), as adamvs_cost_reg_net_2d issues
+    # them (csrc/costreg2d.hip); conv11's, and all of them in bf16x3, in the producing layer's epilogue (skip)
+    defer = precision == 0 and os.environ.get("ADAMVS_COSTREG_DEFER_SKIPS", "1") != "0"
+    pending = None                       # the addend the next layer has to add to its input
     for i, (name, mode, relu, src, skip) in enumerate(COSTREG_PLAN):
         xin, hi, wi = acts[src]
         wl = wpk[i * LW:(i + 1) * LW]
         sk = acts[skip][0] if skip else None
+        give = defer and i + 1 < len(COSTREG_PLAN) and COSTREG_PLAN[i + 1][1] == 2      # only a transposed consumer takes the addend
+        in2, pending = pending, (sk if give else None)
         out = mark("s%d.costreg.%s.mode%d" % (stage, name, mode),
-                   lambda: hip_ops.conv3x3_dd(xin, wl, wl[9 * D * D:], sk, N, D, hi, wi, mode, relu, precision=precision))
+                   lambda: hip_ops.conv3x3_dd(xin, wl, wl[9 * D * D:], None if give else sk, N, D, hi, wi, mode, relu,
+                                              precision=precision, in2=in2))
         ho, wo = (hi // 2, wi // 2) if mode == 1 else ((2 * hi, 2 * wi) if mode == 2 else (hi, wi))
         acts[name] = (out, ho, wo)
     return acts["prob"][0]

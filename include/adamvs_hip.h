@@ -92,11 +92,16 @@ int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N
                            int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One layer of CostRegNet2D: ConvBnReLU.forward (models/module.py:254-261) or the
- * ConvTranspose2d-BN-ReLU blocks of models/adamvs.py:212-225, BN folded into wpk/bias,
- * optional skip added after the ReLU.  mode 0: 3x3 stride 1; 1: stride 2; 2: transposed
- * stride 2 (k3 p1 op1).  in [N][hi*wi][D] -> out [N][ho*wo][D]; wpk as one layer above. */
-int adamvs_conv3x3_dd(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
-                      int hi, int wi, int mode, int relu, int precision, void* stream);
+ * ConvTranspose2d-BN-ReLU blocks of models/adamvs.py:212-225, BN folded into wpk/bias.
+ * mode 0: 3x3 stride 1; 1: stride 2; 2: transposed stride 2 (k3 p1 op1).
+ * in [N][hi*wi][D] -> out [N][ho*wo][D]; wpk as one layer above.  The hourglass's additions
+ * (x = conv4 + conv7(x), adamvs.py:233-236) can sit on either side of a layer:
+ *   skip [N][ho*wo][D] or NULL: added to this layer's output after the ReLU (producer side);
+ *   in2  [N][hi*wi][D] or NULL: the layer convolves in + in2 (consumer side: the sum is formed while the
+ *        window is staged, so a transposed layer's epilogue carries no second round of loads).
+ * adamvs_cost_reg_net_2d uses in2 in fp32 and skip in bf16x3; the result is the same fp32 sum either way. */
+int adamvs_conv3x3_dd(const float* in, const float* in2, const float* wpk, const float* bias, const float* skip, float* out,
+                      int N, int D, int hi, int wi, int mode, int relu, int precision, void* stream);
 
 /* models/adamvs.py:481-486 + module.py:617-625: softmax over D, its maximum (view
  * weight) and the expectation of the hypothesis planes (pair depth).
