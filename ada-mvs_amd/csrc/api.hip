@@ -155,8 +155,14 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   if (!(phases & ADAMVS_PHASE_VIEW_WEIGHTS)) {
   } else if (s.first_stage) {
     if ((rc = launch_pair_similarity(feat, rt, ps, ws + c.sim, s.B, s.S, s.C, s.D, s.h, s.w, st))) return rc;
-    if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, s.precision, st))) return rc;
-    if ((rc = launch_softmax_regress(ws + c.score, ps, view_weight, pair_depth, s.S, s.B, s.D, s.h, s.w, st))) return rc;
+    if (cost_reg_softmax_fusable(s.D, s.precision, ps)) {       // softmax / max / regression in the epilogue of the last layer
+      if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, s.precision, st,
+                                       view_weight, pair_depth, &ps, s.B)))
+        return rc;
+    } else {
+      if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, s.precision, st))) return rc;
+      if ((rc = launch_softmax_regress(ws + c.score, ps, view_weight, pair_depth, s.S, s.B, s.D, s.h, s.w, st))) return rc;
+    }
   } else {
     if ((rc = adamvs_resize_bilinear(prev_conf, view_weight, s.S * s.B, s.prev_h, s.prev_w, s.h, s.w, stream))) return rc;
   }

@@ -28,6 +28,11 @@ struct ConvDDArgs {
   const float* skip;   // [N][ho*wo][D] or null; added after the ReLU (adamvs.py:234-236)
   float* out;          // [N][ho*wo][D]
   int D, hi, wi, ho, wo, relu;
+  // softmax epilogue (the `prob` layer inside a stage, reference adamvs.py:481-486): when sm_vw != null the scores are not
+  // stored; the block reduces them over D and writes view_weight = max_d softmax and pair_depth = sum_d softmax * depth_d
+  float* sm_vw; float* sm_pd;   // [N][ho*wo]
+  PlaneSrc sm_planes;           // image n belongs to tile n % sm_B
+  int sm_B;
   const float* in2;    // [N][hi*wi][D] or null: the layer convolves in + in2, summed when the window enters LDS.  The
                        // hourglass's skip additions (x = conv4 + conv7(x), adamvs.py:234-236) run HERE, in the consumer of x:
                        // in the producer's epilogue a skip operand is a second round of loads that nothing overlaps
@@ -56,7 +61,7 @@ template <int BR> struct TileGeom<CONV_T2, BR> { static constexpr int LR = BR + 
 //  * two named register sets for the A fragments and two chunks per loop trip: the fragments and the activation
 //    tile of chunk k+1 are requested before the MFMAs of chunk k and waited for once, after them (vmcnt retires
 //    in order; a single explicit wait keeps the compiler from scheduling its own in the middle of the chain).
-template <int MT, int WM, int MODE, int KB, int PY, int PX, int BR = 8, bool TWO = false>
+template <int MT, int WM, int MODE, int KB, int PY, int PX, int BR = 8, bool TWO = false, bool SOFTMAX = false>
 __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
   using TG = TileGeom<MODE, BR>;
   constexpr int LR = TG::LR, LC = TG::LC, PLANE = TG::PLANE, GP = group_pitch(PLANE, KB / 4);
@@ -184,6 +189,63 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
     mfma_chunk(wfB);
   }
 
+  if (SOFTMAX) {
+    // softmax over the D scores of every pixel of the block, without the score volume: a lane holds 4 MT of a pixel's
+    // scores per row -> its own (max, sum of exp, sum of exp * depth); the 4 WM partials of a pixel meet in LDS and one
+    // thread per pixel merges them (the online-softmax merge): view weight = 1 / sum, pair depth = weighted sum / sum
+    // (adamvs.py:481-486: softmax, max over D, depth_regression).
+    constexpr int NPART = 4 * WM;
+    __syncthreads();                                   // the last chunk's readers are done: the tile space is reused
+    float* part = lds;                                 // [BR rows][16 columns][NPART][3]
+    const int b = n % a.sm_B;
+#pragma unroll
+    for (int r = 0; r < NTR; ++r) {
+      const int row = wn * NTR + r;
+      const int oy = min(r0 + row, a.ho - 1), ox = min(c0 + p, a.wo - 1);
+      const PlaneLine pl = plane_line(a.sm_planes, b, (size_t)oy * a.wo + ox, D, (size_t)a.ho * a.wo);
+      f32x4 v[MT];
+      float m = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        v[mt] = acc[mt][r] + *(const f32x4*)(a.bias + (wm * MT + mt) * 16 + 4 * q);
+        m = fmaxf(m, fmaxf(fmaxf(v[mt].x, v[mt].y), fmaxf(v[mt].z, v[mt].w)));
+      }
+      float se = 0.f, sd = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int d = (wm * MT + mt) * 16 + 4 * q;
+        const float e0 = __expf(v[mt].x - m), e1 = __expf(v[mt].y - m), e2 = __expf(v[mt].z - m), e3 = __expf(v[mt].w - m);
+        se += (e0 + e1) + (e2 + e3);
+        const size_t hw = (size_t)a.ho * a.wo;         // explicit planes: four loads; generated: a multiply and an add each
+        sd = __fmaf_rn(e3, plane_at(a.sm_planes, pl, d + 3, hw), __fmaf_rn(e2, plane_at(a.sm_planes, pl, d + 2, hw),
+             __fmaf_rn(e1, plane_at(a.sm_planes, pl, d + 1, hw), __fmaf_rn(e0, plane_at(a.sm_planes, pl, d, hw), sd))));
+      }
+      float* o = part + ((row * 16 + p) * NPART + wm * 4 + q) * 3;
+      o[0] = m; o[1] = se; o[2] = sd;
+    }
+    __syncthreads();
+    if (tid < BR * 16) {
+      const int row = tid >> 4, col = tid & 15;
+      const float* pp = part + (row * 16 + col) * NPART * 3;
+      float M = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NPART; ++j) M = fmaxf(M, pp[3 * j]);
+      float Z = 0.f, P = 0.f;
+#pragma unroll
+      for (int j = 0; j < NPART; ++j) {
+        const float sc = __expf(pp[3 * j] - M);
+        Z = __fmaf_rn(pp[3 * j + 1], sc, Z);
+        P = __fmaf_rn(pp[3 * j + 2], sc, P);
+      }
+      const int oy = r0 + row, ox = c0 + col;
+      if (oy < a.ho && ox < a.wo) {
+        const size_t opix = ((size_t)n * a.ho + oy) * a.wo + ox;
+        a.sm_vw[opix] = 1.0f / Z;                      // max_d softmax = exp(max - max) / sum
+        a.sm_pd[opix] = P / Z;
+      }
+    }
+    return;
+  }
   // epilogue: lane owns channels co4..co4+3 of the pixel in column p
 #pragma unroll
   for (int r = 0; r < NTR; ++r) {
@@ -524,13 +586,15 @@ __global__ __launch_bounds__(256, OCC) void k_conv_dd_t2_fused(ConvDDArgs a) {
 
 // grid: (ceil(cols/16), ceil(rows/8), N); block 256
 // TWO (stride-1 layers only): the layer convolves in + in2; the transposed kernel takes in2 as a uniform run-time switch
-template <int MT, int WM, int MODE, int KB, bool TWO = false>
+// SM (stride-1 layers only): the softmax epilogue of the `prob` layer (conv_dd_body)
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+template <int MT, int WM, int MODE, int KB, bool TWO = false, bool SM = false>
 __global__ __launch_bounds__(256, (MT == 4 && WM == 4) ? 1 : 2) void k_conv_dd(ConvDDArgs a) {
-  __shared__ float lds[(KB / 4) * group_pitch(TileGeom<MODE>::PLANE, KB / 4)];
+  __shared__ float lds[imax((KB / 4) * group_pitch(TileGeom<MODE>::PLANE, KB / 4), SM ? 8 * 16 * 4 * WM * 3 : 0)];
   if (MODE == CONV_T2) {
     conv_dd_t2_all<MT, WM, KB>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
   } else {
-    conv_dd_body<MT, WM, MODE, KB, 0, 0, 8, TWO>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+    conv_dd_body<MT, WM, MODE, KB, 0, 0, 8, TWO, SM>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
   }
 }
 
@@ -576,6 +640,11 @@ static int launch_conv_dd_cfg(const ConvDDArgs& a_, int N, int mode, hipStream_t
   const ConvDDArgs& a = a_;
   constexpr int KB = (WM == 4 || (MT == 4 && WM == 2)) ? 4 : 8;
   const bool rows2 = WM >= 2 && mode != CONV_T2 && small_grid_rows2((long)cdiv(a.wo, 16) * cdiv(a.ho, 8) * N);
+  if (a.sm_vw) {                // the caller has checked cost_reg_softmax_fusable(): stride 1, no second input
+    hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S1, KB, false, true>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
+    ADAMVS_CHECK_LAUNCH("conv_dd (softmax epilogue)");
+    return 0;
+  }
   if (mode == CONV_S1 && rows2 && a.in2)
     hipLaunchKernelGGL((k_conv_dd_rows2<MT, (WM >= 2 ? WM : 2), CONV_S1, KB, true>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 2), N), dim3(256), 0, st, a);
   else if (mode == CONV_S1 && a.in2)
@@ -711,7 +780,7 @@ static int launch_conv_dd_resident(const ConvDDArgs& a, int N, hipStream_t st) {
 }
 
 static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
-  if (mode == CONV_S1 && (a.D == 32 || a.D == 64)) {
+  if (mode == CONV_S1 && (a.D == 32 || a.D == 64) && !a.sm_vw) {
     const int rc = a.D == 32 ? launch_conv_dd_resident<32>(a, N, st) : launch_conv_dd_resident<64>(a, N, st);
     if (rc >= 0) return rc;
   }
@@ -807,8 +876,16 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
 // ---------------------------------------------------------------------------
 // Layer plan.  Packed weights: 11 layers x (9*D*D fragment floats + D bias floats), in the order
 // conv0..conv6, conv7, conv9, conv11, prob.  Workspace: 3 * N*h*w*D floats.
+// sm_vw != null (fp32, generated planes): the `prob` layer reduces its scores over D in its epilogue and writes the view
+// weights / pair depths of softmax_max_regress directly (score is not written); the caller skips launch_softmax_regress.
+bool cost_reg_softmax_fusable(int D, int precision, const PlaneSrc& planes) {
+  static const bool on = [] { const char* e = getenv("ADAMVS_FUSE_SOFTMAX"); return !(e && *e == '0'); }();
+  return on && precision == PRECISION_FP32 && D >= 16;      // any plane source: the same code path, so generated == materialised bit for bit
+}
+
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
-                           int precision, hipStream_t st) {
+                           int precision, hipStream_t st, float* sm_vw, float* sm_pd, const PlaneSrc* sm_planes, int sm_B) {
+  const bool fuse_softmax = sm_vw != nullptr;
   const size_t F = (size_t)N * h * w * D;
   const size_t LW = (size_t)9 * D * D + D;
   float* conv0 = ws;                  // F
@@ -854,7 +931,9 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
       const bool give = defer && i + 1 < 11 && plan[i + 1].mode == CONV_T2;        // layer i + 1 adds this layer's skip to its input
       const bool take = defer && i > 0 && plan[i].mode == CONV_T2 && plan[i - 1].skip;
       ConvDDArgs a{plan[i].in, wl, wl + (size_t)9 * D * D, give ? nullptr : plan[i].skip, plan[i].out, D,
-                   plan[i].hi, plan[i].wi, plan[i].ho, plan[i].wo, plan[i].relu, take ? plan[i - 1].skip : nullptr};
+                   plan[i].hi, plan[i].wi, plan[i].ho, plan[i].wo, plan[i].relu, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1,
+                   take ? plan[i - 1].skip : nullptr};
+      if (i == 10 && fuse_softmax) { a.sm_vw = sm_vw; a.sm_pd = sm_pd; a.sm_planes = *sm_planes; a.sm_B = sm_B; }
       rc = launch_conv_dd(a, N, plan[i].mode, st);
     }
     if (rc) return rc;
@@ -919,8 +998,18 @@ extern "C" int adamvs_conv3x3_dd(const float* in, const float* in2, const float*
                    "conv3x3_dd: in2 is implemented for fp32, modes 0 and 2 (otherwise pass the addition as the producer's skip)");
   if (precision == PRECISION_BF16X3)
     return launch_conv_dd_bf16x3(in, wpk, bias, skip, out, N, D, hi, wi, ho, wo, mode, relu, (hipStream_t)stream);
-  ConvDDArgs a{in, wpk, bias, skip, out, D, hi, wi, ho, wo, relu, in2};
+  ConvDDArgs a{in, wpk, bias, skip, out, D, hi, wi, ho, wo, relu, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, in2};
   return launch_conv_dd(a, N, mode, (hipStream_t)stream);
+}
+
+extern "C" int adamvs_prob_softmax_regress(const float* in, const float* wpk, const float* bias, const float* planes,
+                                           float* view_weight, float* pair_depth, int S, int B, int D, int h, int w, void* stream) {
+  ADAMVS_CHECK_ARG(in && wpk && bias && planes && view_weight && pair_depth && S > 0 && B > 0 && h > 0 && w > 0,
+                   "prob_softmax_regress: bad arguments");
+  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "prob_softmax_regress: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
+  ADAMVS_CHECK_ARG((size_t)S * B <= 65535, "prob_softmax_regress: S*B=%d exceeds the grid z limit", S * B);
+  ConvDDArgs a{in, wpk, bias, nullptr, nullptr, D, h, w, h, w, 0, view_weight, pair_depth, explicit_planes(planes), B, nullptr};
+  return launch_conv_dd(a, S * B, CONV_S1, (hipStream_t)stream);
 }
 
 extern "C" int adamvs_softmax_max_regress(const float* score, const float* planes, float* view_weight, float* pair_depth,

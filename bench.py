@@ -119,8 +119,13 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 # the op-level entry points of pass A take a planes tensor; inside the stage call they are generated
                 planes_t = hip_ops.depth_range_samples(cur, D, 0.0, [B, h, w])
                 sim = mark("s%d.pair_similarity" % (s + 1), lambda: hip_ops.pair_similarity(feats_cl[s], rt, planes_t, B, S, C, D, h, w))
-                score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w, _lib.PRECISIONS[net.reg.effective_precision()])
-                vw_pd = mark("s%d.softmax_max_regress" % (s + 1), lambda: hip_ops.softmax_max_regress(score, planes_t, S, B, D, h, w))
+                prec = _lib.PRECISIONS[net.reg.effective_precision()]
+                # fp32: softmax / max / regression run in the epilogue of the last layer (csrc/costreg2d.hip), as in the stage
+                fused_sm = prec == 0 and os.environ.get("ADAMVS_FUSE_SOFTMAX", "1") != "0"
+                score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w, prec,
+                                              softmax=(planes_t, S, B) if fused_sm else None)
+                vw_pd = score if fused_sm else mark("s%d.softmax_max_regress" % (s + 1),
+                                                    lambda: hip_ops.softmax_max_regress(score, planes_t, S, B, D, h, w))
                 outs[0].copy_(vw_pd[0])
                 del sim, score, planes_t
             else:
@@ -145,8 +150,9 @@ COSTREG_PLAN = (  # (layer, mode 0 s1 / 1 s2 / 2 transposed, relu, input, skip),
     ("prob", 0, 0, "conv11", None))
 
 
-def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0):
-    """CostRegNet2D through the one-layer C-ABI op, one timing mark per launch."""
+def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=None):
+    """CostRegNet2D through the one-layer C-ABI op, one timing mark per launch.  softmax = (planes, S, B): the last layer runs
+    with the softmax / max / regression epilogue and (view_weight, pair_depth) is returned instead of the scores."""
     LW = 9 * D * D + D
     acts = {"x": (x, h, w)}
     # fp32: conv7's and conv9's skip additions run in the CONSUMING transposed layer (in2), as adamvs_cost_reg_net_2d issues
@@ -159,6 +165,10 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0):
         sk = acts[skip][0] if skip else None
         give = defer and i + 1 < len(COSTREG_PLAN) and COSTREG_PLAN[i + 1][1] == 2      # only a transposed consumer takes the addend
         in2, pending = pending, (sk if give else None)
+        if name == "prob" and softmax is not None:
+            planes_t, S, B = softmax
+            return mark("s%d.costreg.prob+softmax.mode0" % stage,
+                        lambda: hip_ops.prob_softmax_regress(xin, wl, wl[9 * D * D:], planes_t, S, B, D, hi, wi))
         out = mark("s%d.costreg.%s.mode%d" % (stage, name, mode),
                    lambda: hip_ops.conv3x3_dd(xin, wl, wl[9 * D * D:], None if give else sk, N, D, hi, wi, mode, relu,
                                               precision=precision, in2=in2))
@@ -600,11 +610,13 @@ def roofline_of(wl, args, ms_per_step):
         # dominant kernel = the stride-1 instantiation of k_conv_dd (conv0, conv2, conv4, prob; conv6 too unless its grid is small).  The split-bf16
         # mode EXECUTES three bf16 products per fp32 product on the bf16 matrix pipe: priced against that pipe's peak.
         hw0, Dd, N = st["h"] * st["w"], st["D"], (c0["views"] - 1) * Bg
-        res = {"conv0": 1, "conv2": 2, "conv4": 4, "conv6": 8, "prob": 1}       # linear down-scale of the layer's maps
+        res = {"conv0": 1, "conv2": 2, "conv4": 4, "conv6": 8, "prob": 1, "prob+softmax": 1}       # linear down-scale of the layer's maps
 
         def on_dominant_kernel(layer):
             # the fp32 path sends stride-1 layers of at most 2048 blocks of 8 x 16 pixels to the 2-row kernel
             # k_conv_dd_rows2 (csrc/costreg2d.hip: small_grid_rows2); those launches are not the dominant kernel's
+            if layer == "prob+softmax":          # the last layer's own instantiation (softmax epilogue): timed, not part of this kernel's launches
+                return False
             if split:
                 return True
             e = os.environ.get("ADAMVS_CONV_ROWS2", "")

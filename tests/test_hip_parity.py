@@ -751,3 +751,22 @@ def test_piecewise_phase_masks(hip, D, stage):
             torch.cuda.synchronize()
             assert torch.equal(whole[2], o[2]) and torch.equal(whole[3], o[3])
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("D,h,w", [(192, 16, 32), (48, 24, 40), (64, 8, 16), (256, 8, 16)])
+def test_prob_softmax_regress_fused(hip, D, h, w):
+    """adamvs_prob_softmax_regress -- the last CostRegNet2D layer with softmax / max / depth regression in its epilogue
+    (reference adamvs.py:238, 481-486; what the fp32 stage runs) -- against the two separate ops, whose parity with the
+    oracle the tests above hold: same view weights and pair depths to fp32 summation order, on maps whose sizes are not
+    multiples of the 8 x 16 block (h = 24) and with per-pixel planes."""
+    S, B = 2, 2
+    g = torch.Generator().manual_seed(D + h)
+    x = dev(torch.randn(S * B, h * w, D, generator=g))
+    wl = dev(torch.randn(9 * D * D + D, generator=g) * (2.0 / (9 * D)) ** 0.5 * 3.0)        # gain 3 on the logits layer, as in synth
+    planes = dev((400.0 + 20.0 * torch.rand(B, 1, h, w, generator=g) + (180.0 / D) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).contiguous())
+    score = hip.conv3x3_dd(x, wl, wl[9 * D * D:], None, S * B, D, h, w, 0, False)
+    vw0, pd0 = hip.softmax_max_regress(score, planes, S, B, D, h, w)
+    vw1, pd1 = hip.prob_softmax_regress(x, wl, wl[9 * D * D:], planes, S, B, D, h, w)
+    torch.cuda.synchronize()
+    assert rel_l1(vw1, vw0) < 2e-6 and rel_l1(pd1, pd0) < 2e-6
+    assert float((vw1 - vw0).abs().max()) < 1e-5 and float((pd1 - pd0).abs().max() / 500.0) < 1e-5
