@@ -645,7 +645,7 @@ def roofline_of(wl, args, ms_per_step):
                 roof["traffic_note"] = "%s was measured on another build (stamp %s, this build %s): not quoted" % (
                     os.path.basename(tpath), tj.get("source_stamp"), stamp)
                 continue
-            k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_dd<3, 4, 0") in k]
+            k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_dd<3, 4, 0, 4, false, false>") in k]
             if k0:
                 roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
                 roof["traffic_note"] = ("bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), %s, "
