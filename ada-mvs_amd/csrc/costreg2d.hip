@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "conv_frag.h"
+#include "costreg_softmax.h"
 #include "kernels.h"
 
 namespace adamvs {
@@ -190,60 +191,8 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
   }
 
   if (SOFTMAX) {
-    // softmax over the D scores of every pixel of the block, without the score volume: a lane holds 4 MT of a pixel's
-    // scores per row -> its own (max, sum of exp, sum of exp * depth); the 4 WM partials of a pixel meet in LDS and one
-    // thread per pixel merges them (the online-softmax merge): view weight = 1 / sum, pair depth = weighted sum / sum
-    // (adamvs.py:481-486: softmax, max over D, depth_regression).
-    constexpr int NPART = 4 * WM;
     __syncthreads();                                   // the last chunk's readers are done: the tile space is reused
-    float* part = lds;                                 // [BR rows][16 columns][NPART][3]
-    const int b = n % a.sm_B;
-#pragma unroll
-    for (int r = 0; r < NTR; ++r) {
-      const int row = wn * NTR + r;
-      const int oy = min(r0 + row, a.ho - 1), ox = min(c0 + p, a.wo - 1);
-      const PlaneLine pl = plane_line(a.sm_planes, b, (size_t)oy * a.wo + ox, D, (size_t)a.ho * a.wo);
-      f32x4 v[MT];
-      float m = -INFINITY;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        v[mt] = acc[mt][r] + *(const f32x4*)(a.bias + (wm * MT + mt) * 16 + 4 * q);
-        m = fmaxf(m, fmaxf(fmaxf(v[mt].x, v[mt].y), fmaxf(v[mt].z, v[mt].w)));
-      }
-      float se = 0.f, sd = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int d = (wm * MT + mt) * 16 + 4 * q;
-        const float e0 = __expf(v[mt].x - m), e1 = __expf(v[mt].y - m), e2 = __expf(v[mt].z - m), e3 = __expf(v[mt].w - m);
-        se += (e0 + e1) + (e2 + e3);
-        const size_t hw = (size_t)a.ho * a.wo;         // explicit planes: four loads; generated: a multiply and an add each
-        sd = __fmaf_rn(e3, plane_at(a.sm_planes, pl, d + 3, hw), __fmaf_rn(e2, plane_at(a.sm_planes, pl, d + 2, hw),
-             __fmaf_rn(e1, plane_at(a.sm_planes, pl, d + 1, hw), __fmaf_rn(e0, plane_at(a.sm_planes, pl, d, hw), sd))));
-      }
-      float* o = part + ((row * 16 + p) * NPART + wm * 4 + q) * 3;
-      o[0] = m; o[1] = se; o[2] = sd;
-    }
-    __syncthreads();
-    if (tid < BR * 16) {
-      const int row = tid >> 4, col = tid & 15;
-      const float* pp = part + (row * 16 + col) * NPART * 3;
-      float M = -INFINITY;
-#pragma unroll
-      for (int j = 0; j < NPART; ++j) M = fmaxf(M, pp[3 * j]);
-      float Z = 0.f, P = 0.f;
-#pragma unroll
-      for (int j = 0; j < NPART; ++j) {
-        const float sc = __expf(pp[3 * j] - M);
-        Z = __fmaf_rn(pp[3 * j + 1], sc, Z);
-        P = __fmaf_rn(pp[3 * j + 2], sc, P);
-      }
-      const int oy = r0 + row, ox = c0 + col;
-      if (oy < a.ho && ox < a.wo) {
-        const size_t opix = ((size_t)n * a.ho + oy) * a.wo + ox;
-        a.sm_vw[opix] = 1.0f / Z;                      // max_d softmax = exp(max - max) / sum
-        a.sm_pd[opix] = P / Z;
-      }
-    }
+    softmax_epilogue<MT, WM, NTR, BR>(acc, a.bias, a.sm_planes, a.sm_B, n, r0, c0, a.ho, a.wo, D, a.sm_vw, a.sm_pd, lds);
     return;
   }
   // epilogue: lane owns channels co4..co4+3 of the pixel in column p
@@ -876,11 +825,12 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
 // ---------------------------------------------------------------------------
 // Layer plan.  Packed weights: 11 layers x (9*D*D fragment floats + D bias floats), in the order
 // conv0..conv6, conv7, conv9, conv11, prob.  Workspace: 3 * N*h*w*D floats.
-// sm_vw != null (fp32, generated planes): the `prob` layer reduces its scores over D in its epilogue and writes the view
+// sm_vw != null: the `prob` layer reduces its scores over D in its epilogue (costreg_softmax.h) and writes the view
 // weights / pair depths of softmax_max_regress directly (score is not written); the caller skips launch_softmax_regress.
 bool cost_reg_softmax_fusable(int D, int precision, const PlaneSrc& planes) {
   static const bool on = [] { const char* e = getenv("ADAMVS_FUSE_SOFTMAX"); return !(e && *e == '0'); }();
-  return on && precision == PRECISION_FP32 && D >= 16;      // any plane source: the same code path, so generated == materialised bit for bit
+  (void)planes; (void)precision;      // any plane source, both precisions: one code path, so generated == materialised bit for bit
+  return on && D >= 16;
 }
 
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
@@ -925,8 +875,10 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
     const float* wl = wpk + (size_t)i * LW;
     int rc;
     if (precision == PRECISION_BF16X3) {
+      const bool sm = i == 10 && fuse_softmax;
       rc = launch_conv_dd_bf16x3(plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, N, D, plan[i].hi,
-                                 plan[i].wi, plan[i].ho, plan[i].wo, plan[i].mode, plan[i].relu, st);
+                                 plan[i].wi, plan[i].ho, plan[i].wo, plan[i].mode, plan[i].relu, st, sm ? sm_vw : nullptr,
+                                 sm ? sm_pd : nullptr, sm ? sm_planes : nullptr, sm_B);
     } else {
       const bool give = defer && i + 1 < 11 && plan[i + 1].mode == CONV_T2;        // layer i + 1 adds this layer's skip to its input
       const bool take = defer && i > 0 && plan[i].mode == CONV_T2 && plan[i - 1].skip;
@@ -1003,12 +955,18 @@ extern "C" int adamvs_conv3x3_dd(const float* in, const float* in2, const float*
 }
 
 extern "C" int adamvs_prob_softmax_regress(const float* in, const float* wpk, const float* bias, const float* planes,
-                                           float* view_weight, float* pair_depth, int S, int B, int D, int h, int w, void* stream) {
+                                           float* view_weight, float* pair_depth, int S, int B, int D, int h, int w, int precision,
+                                           void* stream) {
+  if (int rc = check_precision(precision, D, "prob_softmax_regress")) return rc;
   ADAMVS_CHECK_ARG(in && wpk && bias && planes && view_weight && pair_depth && S > 0 && B > 0 && h > 0 && w > 0,
                    "prob_softmax_regress: bad arguments");
   ADAMVS_CHECK_ARG(costreg_depth_supported(D), "prob_softmax_regress: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
   ADAMVS_CHECK_ARG((size_t)S * B <= 65535, "prob_softmax_regress: S*B=%d exceeds the grid z limit", S * B);
-  ConvDDArgs a{in, wpk, bias, nullptr, nullptr, D, h, w, h, w, 0, view_weight, pair_depth, explicit_planes(planes), B, nullptr};
+  const PlaneSrc ps = explicit_planes(planes);
+  if (precision == PRECISION_BF16X3)
+    return launch_conv_dd_bf16x3(in, wpk, bias, nullptr, nullptr, S * B, D, h, w, h, w, CONV_S1, 0, (hipStream_t)stream, view_weight,
+                                 pair_depth, &ps, B);
+  ConvDDArgs a{in, wpk, bias, nullptr, nullptr, D, h, w, h, w, 0, view_weight, pair_depth, ps, B, nullptr};
   return launch_conv_dd(a, S * B, CONV_S1, (hipStream_t)stream);
 }
 

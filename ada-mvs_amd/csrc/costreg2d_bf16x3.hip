@@ -11,6 +11,7 @@
 // MFMA operand layout (16x16x32): lane l holds A[row l&15][k = 8(l>>4)+j] and B[k = 8(l>>4)+j][col l&15],
 // j = 0..7 (one 16-byte register quad each); rows = output channels, cols = 16 pixels, k = 32 input channels.
 #include "common.h"
+#include "costreg_softmax.h"
 #include "kernels.h"
 
 namespace adamvs {
@@ -25,6 +26,9 @@ struct ConvDDArgs16 {
   const float* skip;      // [N][ho*wo][D] or null
   float* out;             // [N][ho*wo][D]
   int D, hi, wi, ho, wo, relu;
+  float* sm_vw; float* sm_pd;   // softmax epilogue (stride-1 `prob` layer): see costreg_softmax.h; null = store the scores
+  PlaneSrc sm_planes;
+  int sm_B;
 };
 
 enum { BX_S1 = 0, BX_S2 = 1, BX_T2 = 2 };
@@ -48,7 +52,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 
 // Block = BR rows x 16 columns of output positions x all D channels; waves WM along channels (MT tiles each),
 // WN = 4/WM along rows -- the geometry of conv_dd_body in costreg2d.hip with taller blocks.
-template <int MT, int WM, int MODE, int PY, int PX>
+template <int MT, int WM, int MODE, int PY, int PX, bool SOFTMAX = false>
 __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* lds, int n, int by, int bx) {
   using TG = BxGeom<MODE>;
   constexpr int LR = TG::LR, LC = TG::LC, NPIX = LR * LC;
@@ -174,6 +178,11 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
     }
   }
 
+  if (SOFTMAX) {                         // the last layer inside a stage: scores reduced over D here, never stored
+    __syncthreads();                     // the last chunk's readers are done: the tile space is reused for the partials
+    softmax_epilogue<MT, WM, NTR, BR>(acc, a.bias, a.sm_planes, a.sm_B, n, r0, c0, a.ho, a.wo, D, a.sm_vw, a.sm_pd, (float*)lds);
+    return;
+  }
   // epilogue (C/D layout of the 16x16 MFMA family is shape-independent: lane owns channels co4..co4+3 of pixel p)
 #pragma unroll
   for (int r = 0; r < NTR; ++r) {
@@ -194,10 +203,14 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
   }
 }
 
-template <int MT, int WM, int MODE>
+template <int MT, int WM, int MODE, bool SM = false>
 __global__ __launch_bounds__(256, (MODE == BX_S2 || (MT == 4 && WM == 4)) ? 1 : 2) void k_conv_dd_bx3(ConvDDArgs16 a) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];     // [2 (hi,lo)][LR*LC][BX_PIX]
-  if (MODE == BX_T2) {
+  static_assert(!SM || (MODE == BX_S1 && (size_t)2 * BxGeom<BX_S1>::LR * BxGeom<BX_S1>::LC * BX_PIX * 2 >= (size_t)8 * 16 * 4 * WM * 3 * 4),
+                "softmax partials must fit the tile space");
+  if (SM) {
+    conv_dd_bx3_body<MT, WM, MODE, 0, 0, true>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+  } else if (MODE == BX_T2) {
     int n = blockIdx.z >> 2, cls = blockIdx.z & 3;
     switch (cls) {
       case 0: conv_dd_bx3_body<MT, WM, MODE, 0, 0>(a, lds, n, blockIdx.y, blockIdx.x); break;
@@ -210,10 +223,10 @@ __global__ __launch_bounds__(256, (MODE == BX_S2 || (MT == 4 && WM == 4)) ? 1 : 
   }
 }
 
-template <int MT, int WM, int MODE>
+template <int MT, int WM, int MODE, bool SM = false>
 static int launch_bx3_mode(const ConvDDArgs16& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * BxGeom<MODE>::LR * BxGeom<MODE>::LC * BX_PIX * sizeof(__bf16);
-  auto kern = k_conv_dd_bx3<MT, WM, MODE>;
+  auto kern = k_conv_dd_bx3<MT, WM, MODE, SM>;
   static bool attr_set = false;          // idempotent per-kernel attribute (not a stream operation)
   if (lds > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -227,6 +240,7 @@ static int launch_bx3_mode(const ConvDDArgs16& a, dim3 grid, hipStream_t st) {
 
 template <int MT, int WM>
 static int launch_bx3_cfg(const ConvDDArgs16& a, int N, int mode, hipStream_t st) {
+  if (mode == BX_S1 && a.sm_vw) return launch_bx3_mode<MT, WM, BX_S1, true>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, BxGeom<BX_S1>::BR), N), st);
   if (mode == BX_S1) return launch_bx3_mode<MT, WM, BX_S1>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, BxGeom<BX_S1>::BR), N), st);
   if (mode == BX_S2) return launch_bx3_mode<MT, WM, BX_S2>(a, dim3(cdiv(a.wo, 16), cdiv(a.ho, BxGeom<BX_S2>::BR), N), st);
   return launch_bx3_mode<MT, WM, BX_T2>(a, dim3(cdiv(a.wi, 16), cdiv(a.hi, BxGeom<BX_T2>::BR), N * 4), st);
@@ -236,8 +250,10 @@ bool costreg_bf16x3_depth_supported(int D) { return D == 32 || D == 64 || D == 9
 
 // `wpk` is the layer's packed block reinterpreted: 9*D*D floats worth of bf16 fragments (hi half, then lo half)
 int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
-                          int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st) {
-  ConvDDArgs16 a{in, (const bf16x8*)wpk, bias, skip, out, D, hi, wi, ho, wo, relu};
+                          int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st, float* sm_vw, float* sm_pd,
+                          const PlaneSrc* sm_planes, int sm_B) {
+  ConvDDArgs16 a{in, (const bf16x8*)wpk, bias, skip, out, D, hi, wi, ho, wo, relu, sm_vw, sm_pd,
+                 sm_planes ? *sm_planes : PlaneSrc{nullptr, 0, 0.f}, sm_B};
   switch (D) {
     case 32: return launch_bx3_cfg<2, 1>(a, N, mode, st);
     case 64: return launch_bx3_cfg<4, 1>(a, N, mode, st);

@@ -64,7 +64,8 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
                            const PlaneSrc* sm_planes = nullptr, int sm_B = 1);
 bool cost_reg_softmax_fusable(int D, int precision, const PlaneSrc& planes);
 int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
-                          int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st);
+                          int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st, float* sm_vw = nullptr,
+                          float* sm_pd = nullptr, const PlaneSrc* sm_planes = nullptr, int sm_B = 1);
 bool costreg_bf16x3_depth_supported(int D);
 
 int launch_pair_similarity(const float* feat, const float* rt, PlaneSrc planes, float* sim, int B, int S, int C, int D, int h,

@@ -139,13 +139,13 @@ def softmax_max_regress(score, planes, S, B, D, h, w):
     return vw, pd
 
 
-def prob_softmax_regress(x_cl, wpk_layer, bias, planes, S, B, D, h, w):
-    """The `prob` layer of CostRegNet2D with softmax / max / depth regression in its epilogue (fp32; what the stage runs):
+def prob_softmax_regress(x_cl, wpk_layer, bias, planes, S, B, D, h, w, precision=0):
+    """The `prob` layer of CostRegNet2D with softmax / max / depth regression in its epilogue (what the stage runs):
     x_cl [S*B, h*w, D], planes [B, D, h, w] -> (view_weight, pair_depth) [S, B, h, w]."""
     vw = torch.empty(S, B, h, w, device=x_cl.device, dtype=torch.float32)
     pd = torch.empty(S, B, h, w, device=x_cl.device, dtype=torch.float32)
     check(_lib.load().adamvs_prob_softmax_regress(_p(_dev(x_cl, "x")), _p(wpk_layer), _p(bias), _p(_dev(planes, "planes")), _p(vw), _p(pd),
-                                                  S, B, D, h, w, _stream()), "prob_softmax_regress")
+                                                  S, B, D, h, w, int(precision), _stream()), "prob_softmax_regress")
     return vw, pd
 
 

@@ -120,8 +120,8 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 planes_t = hip_ops.depth_range_samples(cur, D, 0.0, [B, h, w])
                 sim = mark("s%d.pair_similarity" % (s + 1), lambda: hip_ops.pair_similarity(feats_cl[s], rt, planes_t, B, S, C, D, h, w))
                 prec = _lib.PRECISIONS[net.reg.effective_precision()]
-                # fp32: softmax / max / regression run in the epilogue of the last layer (csrc/costreg2d.hip), as in the stage
-                fused_sm = prec == 0 and os.environ.get("ADAMVS_FUSE_SOFTMAX", "1") != "0"
+                # softmax / max / regression run in the epilogue of the last layer (csrc/costreg_softmax.h), as in the stage
+                fused_sm = os.environ.get("ADAMVS_FUSE_SOFTMAX", "1") != "0"
                 score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w, prec,
                                               softmax=(planes_t, S, B) if fused_sm else None)
                 vw_pd = score if fused_sm else mark("s%d.softmax_max_regress" % (s + 1),
@@ -168,7 +168,7 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=
         if name == "prob" and softmax is not None:
             planes_t, S, B = softmax
             return mark("s%d.costreg.prob+softmax.mode0" % stage,
-                        lambda: hip_ops.prob_softmax_regress(xin, wl, wl[9 * D * D:], planes_t, S, B, D, hi, wi))
+                        lambda: hip_ops.prob_softmax_regress(xin, wl, wl[9 * D * D:], planes_t, S, B, D, hi, wi, precision=precision))
         out = mark("s%d.costreg.%s.mode%d" % (stage, name, mode),
                    lambda: hip_ops.conv3x3_dd(xin, wl, wl[9 * D * D:], None if give else sk, N, D, hi, wi, mode, relu,
                                               precision=precision, in2=in2))

@@ -110,11 +110,12 @@ int adamvs_softmax_max_regress(const float* score, const float* planes, float* v
                                int S, int B, int D, int h, int w, void* stream);
 
 /* The last layer of CostRegNet2D (`prob`, adamvs.py:227, 238) with the view weighting above fused into its epilogue, the
- * way adamvs_depth_stage_forward runs the fp32 path: score = conv3x3(in) + bias is reduced over D by the workgroup that
+ * way adamvs_depth_stage_forward runs it: score = conv3x3(in) + bias is reduced over D by the workgroup that
  * computes it and never stored.  in [S*B][h*w][D]; wpk / bias: the `prob` block of the packed weights (9*D*D + D floats);
- * planes [B][D][h*w] -> view_weight, pair_depth [S][B][h*w].  fp32 only. */
+ * planes [B][D][h*w] -> view_weight, pair_depth [S][B][h*w].  precision as adamvs_cost_reg_net_2d (wpk packed accordingly). */
 int adamvs_prob_softmax_regress(const float* in, const float* wpk, const float* bias, const float* planes,
-                                float* view_weight, float* pair_depth, int S, int B, int D, int h, int w, void* stream);
+                                float* view_weight, float* pair_depth, int S, int B, int D, int h, int w, int precision,
+                                void* stream);
 
 /* ---- aggregation + recurrent regularisation (pass B) --------------------- */
 

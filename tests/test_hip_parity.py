@@ -754,7 +754,7 @@ def test_piecewise_phase_masks(hip, D, stage):
 
 
 @pytest.mark.parametrize("D,h,w", [(192, 16, 32), (48, 24, 40), (64, 8, 16), (256, 8, 16)])
-def test_prob_softmax_regress_fused(hip, D, h, w):
+def test_prob_softmax_regress_fused(hip, D, h, w):  # fp32; the bf16x3 twin is held by the stage / end-to-end bf16x3 tests
     """adamvs_prob_softmax_regress -- the last CostRegNet2D layer with softmax / max / depth regression in its epilogue
     (reference adamvs.py:238, 481-486; what the fp32 stage runs) -- against the two separate ops, whose parity with the
     oracle the tests above hold: same view weights and pair depths to fp32 summation order, on maps whose sizes are not
