@@ -247,6 +247,160 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// conv0 of both feature nets in ONE kernel (reference models/adamvs.py:57-59: Conv2d(3, 8, 3, 1) + BN + ReLU, Conv2d(8, 8, 3, 1) +
+// BN + ReLU at full resolution), straight from the reference's [N][3][H][W] images.  As separate launches the two layers
+// and the RGB repack moved 173 B per pixel (the 8-channel intermediate out and back in with its halo) at 3.3 - 3.5 TB/s;
+// fused, a tile reads its 12 x 18 window of the image (23 B per output pixel) and writes its 8 x 14 outputs (32 B).  Fused they
+// would be bound by matrix issue instead -- 8 output channels fill half an MFMA tile -- so both layers run in the two-row
+// form of conv1 (slice_red.hip): MFMA rows 0-7 = the 8 channels of output row y, rows 8-15 = those of row y+1, fed by the
+// same input-row fragment: 12 fragment passes per two rows instead of 18.
+//   LDS: image window [4 planes: R, G, B, zero][12 x 18]; intermediate [2 channel groups][4][10 x 16] (the tile grown by one
+//   pixel: zero outside the image, which is the second layer's padding).
+//   stage A: five row pairs of the 10 x 16 region, one per wave (the fifth goes round the waves with the tile index);
+//   stage B: four row pairs of the 8 x 14 tile (columns 14, 15 of a run are surplus), one per wave.
+struct Conv0Args {
+  const float* imgs;     // [N][3][H][W]
+  const float* w0;       // two-row A fragments of conv0.0 [12][1][64] (RGB + a zero channel), BatchNorm scale folded in
+  const float* b0;       // [16] BatchNorm shift (8 real)
+  const float* w1;       // two-row A fragments of conv0.1 [12][2][64]
+  const float* b1;       // [16]
+  float* out;            // [N][H*W][8]
+  int H, W;
+};
+
+__global__ __launch_bounds__(256) void k_conv0_fused(Conv0Args a, TileGrid tg) {
+  constexpr int TR = 8, TC = 14, WR = TR + 4, WC = TC + 4, RR = TR + 2, RC = TC + 2;
+  constexpr int PA = plane_pitch16(WR * WC), PLB = plane_pitch16(RR * RC), GPB = group_pitch(PLB, 2);
+  __shared__ float lds[4 * PA + 2 * GPB];
+  float* la = lds;               // image window, planar
+  float* lb = lds + 4 * PA;      // intermediate, planar in two groups of four channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int H = a.H, W = a.W;
+  const unsigned plane_bytes = (unsigned)((size_t)H * W * 4);
+
+  float w0[12], w1[12][2];
+#pragma unroll
+  for (int t = 0; t < 12; ++t) {
+    w0[t] = a.w0[t * 64 + lane];
+    w1[t][0] = a.w1[(t * 2 + 0) * 64 + lane];
+    w1[t][1] = a.w1[(t * 2 + 1) * 64 + lane];
+  }
+  const f32x4 bias0 = *(const f32x4*)(a.b0 + 4 * (q & 1)), bias1 = *(const f32x4*)(a.b1 + 4 * (q & 1));
+  if (tid < PA) la[3 * PA + tid] = 0.f;                  // the fourth input channel (visible after the first barrier)
+
+  // ---- per-lane constants
+  const bool loader = tid < WR * WC;                      // one window pixel per thread: three channel planes
+  const int lr = min(tid, WR * WC - 1) / WC, lc = min(tid, WR * WC - 1) % WC;
+  unsigned goff = (unsigned)((lr * W + lc) * 4);
+  pin(goff);
+  // stage A: B-fragment origin of row pair 0 (k-row q = channel q); pair rp adds rp * 2 * WC
+  unsigned xa = (unsigned)((q * PA + p) * 4);
+  // its result: region pixel (2 rp + (q >> 1), p), channels 4 (q & 1) ..: planes of group q & 1
+  unsigned sb = (unsigned)((((q & 1) * GPB) + (q >> 1) * RC + p) * 4);
+  // stage B: B-fragment origin of the wave's row pair, per k-chunk
+  unsigned xb[2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) { xb[kc] = (unsigned)((kc * GPB + q * PLB + (2 * wave) * RC + p) * 4); pin(xb[kc]); }
+  pin(xa); pin(sb);
+  const int orow = 2 * wave + (q >> 1);
+  unsigned ooff = p < TC ? (unsigned)(((orow * W + p) * 8 + 4 * (q & 1)) * 4) : BUF_OOB;
+  pin(ooff);
+
+  auto load_tile = [&](float (&st)[3], int n, int tx, int ty) {
+    const int ix0 = tx * TC - 2, iy0 = ty * TR - 2;
+    const buf_rsrc ri = make_rsrc((const char*)a.imgs + (((long)n * 3 * H + iy0) * W + ix0) * 4);
+    const bool ok = loader && (unsigned)(iy0 + lr) < (unsigned)H && (unsigned)(ix0 + lc) < (unsigned)W;
+    const unsigned o = ok ? goff : BUF_OOB;               // zero padding of the first layer
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      st[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, o, (unsigned)ch * plane_bytes, 0));
+  };
+  auto store_tile = [&](const float (&st)[3]) {
+    if (loader) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) la[ch * PA + tid] = st[ch];
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  float stage[3];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int y0 = ty * TR, x0 = tx * TC;
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);                     // in flight during both stages
+    }
+    // ---- stage A: conv0.0 on the region, row pairs wave and (for one wave per tile) 4
+    const int extra = t & 3;                               // uniform
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j == 1 && wave != extra) break;                  // wave-uniform
+      const int rp = j ? 4 : wave;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const char* at = (const char*)la + xa + rp * (2 * WC * 4);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc = mfma16(w0[rr * 3 + kx], *(const float*)(at + (rr * WC + kx) * 4), acc);
+      drain(acc);
+      f32x4 v = acc + bias0;
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      const int gy = y0 - 1 + 2 * rp + (q >> 1), gx = x0 - 1 + p;
+      if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) v = f32x4{0.f, 0.f, 0.f, 0.f};      // padding of conv0.1
+      float* d = (float*)((char*)lb + sb + rp * (2 * RC * 4));
+      d[0] = v.x; d[PLB] = v.y; d[2 * PLB] = v.z; d[3 * PLB] = v.w;
+    }
+    __syncthreads();                                       // the intermediate is complete; the image window is free
+    // ---- stage B: conv0.1 on the tile
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+          acc = mfma16(w1[rr * 3 + kx][kc], *(const float*)((const char*)lb + xb[kc] + (rr * RC + kx) * 4), acc);
+    drain(acc);
+    wait_vmem_all();                                       // the next window has arrived (nothing else is pending)
+    if (more) store_tile(stage);
+    {
+      f32x4 v = acc + bias1;
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      const buf_rsrc ro = make_rsrc((char*)a.out + (((long)n * H + y0) * W + x0) * 32);
+      const bool valid = y0 + orow < H && x0 + p < W;
+      buf_store4(ro, valid ? ooff : BUF_OOB, v);
+    }
+    if (!more) break;
+    __syncthreads();                                       // next window visible; every wave is done with the intermediate
+    t = tn; n = nn; tx = txn; ty = tyn;
+  }
+}
+
+static int launch_conv0_fused(const float* imgs, const adamvs_fconv_weights& c00, const adamvs_fconv_weights& c01, float* out, int N,
+                              int H, int W, hipStream_t st) {
+  static const int capacity = resident_blocks(k_conv0_fused, 256, 0);
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(W, 14), cdiv(H, 8), N)) return rc;
+  if ((size_t)H * W * 4 * 3 >= 0x7fffffffu) return set_error(-1, "feature net conv0: image too large for 32-bit plane offsets (%d x %d)", H, W);
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  Conv0Args a{imgs, c00.w, c00.b, c01.w, c01.b, out, H, W};
+  hipLaunchKernelGGL(k_conv0_fused, dim3(grid), dim3(256), 0, st, a, tg);
+  ADAMVS_CHECK_LAUNCH("feature net conv0 (fused)");
+  return 0;
+}
+
 template <int CA, int CB, int NT, int MODE, int EPI>
 static int launch_fconv(const FConvArgs& a_in, int N, hipStream_t st, const char* name) {
   using GM = FGeom<MODE>;
@@ -351,15 +505,6 @@ static int launch_context(const float* feat, const adamvs_context_weights& wa, c
   return 0;
 }
 
-// imgs [N][3][H][W] (the reference's layout) -> [N][H*W][4], fourth channel zero
-__global__ void k_pack_rgb(const float* __restrict__ in, float* __restrict__ out, size_t hw, size_t total) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const size_t n = i / hw, p = i % hw;
-  const float* s = in + n * 3 * hw + p;
-  *(f32x4*)(out + i * 4) = f32x4{s[0], s[hw], s[2 * hw], 0.f};
-}
-
 static inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 }  // namespace adamvs
@@ -367,36 +512,30 @@ static inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 using namespace adamvs;
 
 // Workspace layout (floats), N images of H x W (both multiples of 32: three /2 levels, AvgPool 8 at the coarsest):
-//   rgb4 [N][HW][4], c0a, c0 [N][HW][8], c1a, c1b, c1 [N][HW/4][16], c2a, c2b, c2 [N][HW/16][32],
+//   c0 [N][HW][8], c1a, c1b, c1 [N][HW/4][16], c2a, c2b, c2 [N][HW/16][32],
 //   d1 [N][HW/4][16] (deconv1.deconv), f1 [N][HW/4][16], d2 [N][HW][8], f2 [N][HW][8], context maps.
 extern "C" size_t adamvs_feature_net0_workspace_bytes(int N, int H, int W) {
   const size_t hw = (size_t)H * W, n = (size_t)N;
-  size_t f = al64(n * hw * 4) + 2 * al64(n * hw * 8) + 3 * al64(n * hw / 4 * 16) + 3 * al64(n * hw / 16 * 32) +
+  size_t f = al64(n * hw * 8) + 3 * al64(n * hw / 4 * 16) + 3 * al64(n * hw / 16 * 32) +
              2 * al64(n * hw / 4 * 16) + 2 * al64(n * hw * 8);
   f += 2 * al64(n * (hw / 16 / 16) * 32) + 2 * al64(n * (hw / 4 / 16) * 16) + 2 * al64(n * (hw / 16) * 8);      // pooled by 4 (x2 for 8: smaller)
   return f * sizeof(float);
 }
 
 // conv0 / conv1 / conv2 of both feature nets (reference models/adamvs.py:57-76 = models/msrednet.py:38-54): imgs -> c0 [N][HW][8],
-// c1 [N][HW/4][16], c2 [N][HW/16][32]; rgb4, c0a, c1a, c1b, c2a, c2b are scratch.
+// c1 [N][HW/4][16], c2 [N][HW/16][32]; c1a, c1b, c2a, c2b are scratch.
 struct EncoderWeights { adamvs_fconv_weights conv0_0, conv0_1, conv1_0, conv1_1, conv1_2, conv2_0, conv2_1, conv2_2; };
 static FConvArgs fconv_args(const float* sa, const float* sb, const adamvs_fconv_weights& w, float* out, int hi, int wi, int ho, int wo,
                             int cout, int ctot, int co0) {
   return FConvArgs{sa, sb, w.w, w.b, out, nullptr, nullptr, hi, wi, ho, wo, cout, ctot, co0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
 }
-static int run_encoder(const float* imgs, const EncoderWeights& fw, float* rgb4, float* c0a, float* c0, float* c1a, float* c1b, float* c1,
+static int run_encoder(const float* imgs, const EncoderWeights& fw, float* c0, float* c1a, float* c1b, float* c1,
                        float* c2a, float* c2b, float* c2, int N, int H, int W, hipStream_t st) {
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
   int rc;
-  {
-    const size_t hw = (size_t)H * W, total = (size_t)N * hw;
-    hipLaunchKernelGGL(k_pack_rgb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, imgs, rgb4, hw, total);
-    ADAMVS_CHECK_LAUNCH("feature net pack_rgb");
-  }
   auto A = fconv_args;
-  // conv0: 3(+1) -> 8 -> 8 at full resolution
-  if ((rc = launch_fconv<4, 0, 1, FM_K3, FE_RELU>(A(rgb4, nullptr, fw.conv0_0, c0a, H, W, H, W, 8, 8, 0), N, st, "conv0.0"))) return rc;
-  if ((rc = launch_fconv<8, 0, 1, FM_K3, FE_RELU>(A(c0a, nullptr, fw.conv0_1, c0, H, W, H, W, 8, 8, 0), N, st, "conv0.1"))) return rc;
+  // conv0: 3 -> 8 -> 8 at full resolution, one kernel straight from the [N][3][H][W] images
+  if ((rc = launch_conv0_fused(imgs, fw.conv0_0, fw.conv0_1, c0, N, H, W, st))) return rc;
   // conv1: 5x5 stride 2 (8 -> 16), two 3x3
   if ((rc = launch_fconv<8, 0, 1, FM_K5S2, FE_RELU>(A(c0, nullptr, fw.conv1_0, c1a, H, W, H2, W2, 16, 16, 0), N, st, "conv1.0"))) return rc;
   if ((rc = launch_fconv<16, 0, 1, FM_K3, FE_RELU>(A(c1a, nullptr, fw.conv1_1, c1b, H2, W2, H2, W2, 16, 16, 0), N, st, "conv1.1"))) return rc;
@@ -415,7 +554,7 @@ static int run_encoder(const float* imgs, const EncoderWeights& fw, float* rgb4,
 // Workspace (floats): the encoder's maps, then t1 [N][HW/4][32] and t2 [N][HW][32] (the top-down maps).
 extern "C" size_t adamvs_feature_net_fpn_workspace_bytes(int N, int H, int W) {
   const size_t hw = (size_t)H * W, n = (size_t)N;
-  const size_t f = al64(n * hw * 4) + 2 * al64(n * hw * 8) + 3 * al64(n * hw / 4 * 16) + 3 * al64(n * hw / 16 * 32) +
+  const size_t f = al64(n * hw * 8) + 3 * al64(n * hw / 4 * 16) + 3 * al64(n * hw / 16 * 32) +
                    al64(n * hw / 4 * 32) + al64(n * hw * 32);
   return f * sizeof(float);
 }
@@ -432,14 +571,13 @@ extern "C" int adamvs_feature_net_fpn(const float* imgs, const adamvs_feature_fp
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
   float* p = (float*)workspace;
   auto take = [&](size_t floats) { float* r = p; p += al64(floats); return r; };
-  float* rgb4 = take(n * hw * 4);
-  float* c0a = take(n * hw * 8); float* c0 = take(n * hw * 8);
+  float* c0 = take(n * hw * 8);
   float* c1a = take(n * hw / 4 * 16); float* c1b = take(n * hw / 4 * 16); float* c1 = take(n * hw / 4 * 16);
   float* c2a = take(n * hw / 16 * 32); float* c2b = take(n * hw / 16 * 32); float* c2 = take(n * hw / 16 * 32);
   float* t1 = take(n * hw / 4 * 32); float* t2 = take(n * hw * 32);
   int rc;
   const EncoderWeights enc{fw.conv0_0, fw.conv0_1, fw.conv1_0, fw.conv1_1, fw.conv1_2, fw.conv2_0, fw.conv2_1, fw.conv2_2};
-  if ((rc = run_encoder(imgs, enc, rgb4, c0a, c0, c1a, c1b, c1, c2a, c2b, c2, N, H, W, st))) return rc;
+  if ((rc = run_encoder(imgs, enc, c0, c1a, c1b, c1, c2a, c2b, c2, N, H, W, st))) return rc;
   auto A = fconv_args;
   // stage 1: out1 (1x1, 32 -> 32) on conv2
   if ((rc = launch_fconv<32, 0, 2, FM_K1, 0>(A(c2, nullptr, fw.out1, stage1, H4, W4, H4, W4, 32, 32, 0), N, st, "fpn out1"))) return rc;
@@ -472,8 +610,7 @@ extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weigh
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
   float* p = (float*)workspace;
   auto take = [&](size_t floats) { float* r = p; p += al64(floats); return r; };
-  float* rgb4 = take(n * hw * 4);
-  float* c0a = take(n * hw * 8); float* c0 = take(n * hw * 8);
+  float* c0 = take(n * hw * 8);
   float* c1a = take(n * hw / 4 * 16); float* c1b = take(n * hw / 4 * 16); float* c1 = take(n * hw / 4 * 16);
   float* c2a = take(n * hw / 16 * 32); float* c2b = take(n * hw / 16 * 32); float* c2 = take(n * hw / 16 * 32);
   float* d1 = take(n * hw / 4 * 16); float* f1 = take(n * hw / 4 * 16);
@@ -483,7 +620,7 @@ extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weigh
   float* x3a = take(n * (hw / 16) * 8); float* x3b = take(n * (hw / 16) * 8);
   int rc;
   const EncoderWeights enc{fw.conv0_0, fw.conv0_1, fw.conv1_0, fw.conv1_1, fw.conv1_2, fw.conv2_0, fw.conv2_1, fw.conv2_2};
-  if ((rc = run_encoder(imgs, enc, rgb4, c0a, c0, c1a, c1b, c1, c2a, c2b, c2, N, H, W, st))) return rc;
+  if ((rc = run_encoder(imgs, enc, c0, c1a, c1b, c1, c2a, c2b, c2, N, H, W, st))) return rc;
   auto A = fconv_args;
   // stage 1 output: out1 . cat(up(branch1_1), up(branch1_2), c2)
   if ((rc = launch_context<32>(c2, fw.br1_1, fw.br1_2, x1a, x1b, N, H4, W4, st))) return rc;

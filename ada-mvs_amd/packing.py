@@ -219,6 +219,19 @@ def pack_taps(w):
     return wp.reshape(nt, 16, cin4 // 4, 4, nt_).permute(0, 4, 2, 3, 1).contiguous().reshape(-1)
 
 
+def conv0_two_row(sd, pre, parts):
+    """conv0.0 (3 -> 8; the input padded to RGB + a zero channel) and conv0.1 (8 -> 8) of both feature nets as two-row
+    fragments [12][cin/4][64] (pack_conv1_two_row), BatchNorm scale folded in, shift -> bias: the layout of k_conv0_fused."""
+    for name, key in (("conv0_0", "conv0.0."), ("conv0_1", "conv0.1.")):
+        w = sd[pre + key + "conv.weight"].detach().float().cpu()
+        scale, shift = _bn_scale_shift(sd, pre + key + "bn.")
+        w = w * scale.reshape(-1, 1, 1, 1)
+        if w.shape[1] % 4:
+            w = torch.cat([w, torch.zeros(w.shape[0], 4 - w.shape[1] % 4, 3, 3)], 1)
+        parts[name + ".w"] = pack_conv1_two_row(w)
+        parts[name + ".b"] = pad_bias(shift, 16)
+
+
 def pack_feature_net(sd, pre="feature.", context=True):
     """FeatureNet0 of `pre` -> (flat fp32 tensor, {field: offset}); fields 'name.w' / 'name.b' for the convolutions,
     'name.w1' / 'name.b1' / 'name.w2' for the pooled-context branches.  context=False: the plain U-Net `FeatureNet`
@@ -233,8 +246,7 @@ def pack_feature_net(sd, pre="feature.", context=True):
         parts[name + ".w"] = pack_taps(w)
         parts[name + ".b"] = pad_bias(shift, (w.shape[0] + 15) // 16 * 16)
 
-    conv_bn("conv0_0", "conv0.0.", 9)
-    conv_bn("conv0_1", "conv0.1.", 9)
+    conv0_two_row(sd, pre, parts)
     conv_bn("conv1_0", "conv1.0.", 25)
     conv_bn("conv1_1", "conv1.1.", 9)
     conv_bn("conv1_2", "conv1.2.", 9)
@@ -301,7 +313,8 @@ def pack_feature_net_fpn(sd, pre="feature."):
         parts[name + ".w"] = pack_taps(w)
         parts[name + ".b"] = pad_bias(shift, (w.shape[0] + 15) // 16 * 16)
 
-    for name, key, taps in (("conv0_0", "conv0.0.", 9), ("conv0_1", "conv0.1.", 9), ("conv1_0", "conv1.0.", 25), ("conv1_1", "conv1.1.", 9),
+    conv0_two_row(sd, pre, parts)
+    for name, key, taps in (("conv1_0", "conv1.0.", 25), ("conv1_1", "conv1.1.", 9),
                             ("conv1_2", "conv1.2.", 9), ("conv2_0", "conv2.0.", 25), ("conv2_1", "conv2.1.", 9), ("conv2_2", "conv2.2.", 9)):
         conv_bn(name, key, taps)
     for name in ("out1", "inner1", "out2", "inner2", "out3"):

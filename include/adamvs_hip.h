@@ -150,7 +150,9 @@ typedef struct adamvs_fuse_weights {
  * Weights (ada-mvs_amd/packing.py::pack_feature_net): every convolution as fp32 MFMA A fragments with the eval-mode
  * BatchNorm scale folded in, w = [cout tile][tap][cin/4][64 lanes], lane l = W[16*tile + (l&15)][4*kc + (l>>4)][tap]
  * (rows beyond cout zero), and b = the BatchNorm shift padded to 16 per tile (zeros for the plain output convs).
- * conv0_0 takes 4 input channels (RGB + a zero).  The 5x5 stride-2 convolutions hold 25 taps; conv2_0 is stored as two
+ * conv0_0 (RGB + a zero channel) and conv0_1 run fused in one kernel and are stored as TWO-ROW fragments [12][cin/4][64], the
+ * layout of adamvs_fuse_weights.conv1 (rows 0-7: output row y, tap ky = rr; rows 8-15: row y+1, tap ky = rr-1; rr = 0..3).
+ * The 5x5 stride-2 convolutions hold 25 taps; conv2_0 is stored as two
  * 16-channel halves.  deconv*_t hold the ConvTranspose2d(k3,s2,p1,op1) weights per output parity class (py,px):
  * 1 + 2 + 2 + 4 taps in the order 00, 01, 10, 11, tap (ty,tx) = kernel index (py ? (ty ? 0 : 2) : 1, same in x) applied
  * to input pixel (i+ty, j+tx).  deconv*_c convolve cat(deconv output, skip).  out_k multiply the feature map only;
