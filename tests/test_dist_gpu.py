@@ -91,3 +91,23 @@ def test_latency_mode_source_views_sharded_over_three_ranks(tmp_path):
         assert np.array_equal(z["vw"], vw) and np.array_equal(z["pd"], torch.stack(o["stage1"]["pair_result"]).cpu().numpy())
         assert np.array_equal(z["depth"], o["depth"].cpu().numpy())
         assert np.array_equal(z["conf"], o["photometric_confidence"].cpu().numpy())
+
+
+def test_bench_two_ranks_strong_scaling_dry_run(tmp_path):
+    """bench.py under torch.distributed.run with two ranks, `--tiles-total 5` (strong scaling: tile t on rank t mod 2, an uneven deal), both
+    ranks on device 0 over gloo -- the N > 1 code path of the bench (tile ownership, the asynchronous gather, the max-over-ranks
+    clock, one JSON line from rank 0) on a 1-GPU box.  Not a scaling point."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, ADAMVS_BENCH_ONE_DEVICE="1", ADAMVS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "cfg1", "--tiles-total", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_tiles_per_step"] == 5
+    assert d["value"] > 0 and d["steps"] == 2

@@ -770,3 +770,30 @@ def test_prob_softmax_regress_fused(hip, D, h, w):  # fp32; the bf16x3 twin is h
     torch.cuda.synchronize()
     assert rel_l1(vw1, vw0) < 2e-6 and rel_l1(pd1, pd0) < 2e-6
     assert float((vw1 - vw0).abs().max()) < 1e-5 and float((pd1 - pd0).abs().max() / 500.0) < 1e-5
+
+
+@pytest.mark.parametrize("C,S", [(32, 1), (32, 4), (32, 5), (32, 8), (16, 2), (16, 4), (16, 7), (8, 1), (8, 3), (8, 4), (8, 8)])
+def test_sweep_blend_views_and_widths(hip, O, C, S):
+    """The aggregation sweep (k_sweep_blend, reference adamvs.py:495-512) for every channel width and 1 ... 8 source views
+    (lane q of a quad projects views q, q + 4; with C = 8 a quad holds two pixels and a lane projects up to four views),
+    on a map whose width is no multiple of the pixels a workgroup takes, 19 planes (two full groups of 8 and a ragged one)
+    with per-pixel spacing, a baseline that sends the far views out of bounds: against the oracle."""
+    import torch.nn.functional as F
+    from ada_mvs_amd import packing
+    B, D, h, w = 2, 19, 14, 42
+    feats = [synth.smooth_features(B, C, h, w, seed=30 + v) for v in range(S + 1)]
+    proj = synth.rig_projections(S + 1, 4 * h, 4 * w, batch=B, baseline=20.0)["stage1"]
+    g = torch.Generator().manual_seed(100 * C + S)
+    lo = 380 + 40 * torch.rand(B, 1, h, w, generator=g)
+    step = (200 + 40 * torch.rand(B, 1, h, w, generator=g)) / (D - 1)
+    planes = (lo + step * torch.arange(D, dtype=torch.float32).reshape(1, D, 1, 1)).contiguous()
+    vw = torch.rand(S, B, h, w, generator=g)
+    w1 = torch.randn(8, C, 3, 3, generator=g) * 0.1
+    args = (hip.pack_features(dev(torch.stack(feats, 0).reshape(-1, C, h, w))), hip.relative_transforms(dev(proj)), dev(planes), dev(vw),
+            packing.pack_conv1_two_row(w1).cuda(), B, S, C, D, h, w)
+    c1 = hip.aggregate_conv1(*args).cpu()
+    Rs, ts = zip(*[O.relative_transform(proj[:, s + 1], proj[:, 0]) for s in range(S)])
+    for d in (0, 7, 8, 18):
+        sim = O.aggregate_similarity(feats[0], feats[1:], Rs, ts, planes[:, d], [vw[s].unsqueeze(1) for s in range(S)])
+        ref = F.relu(F.conv2d(sim, w1, None, 1, 1))
+        assert rel_l1(c1[d].reshape(B, h, w, 8).permute(0, 3, 1, 2), ref) < OP_TOL, "plane %d" % d
