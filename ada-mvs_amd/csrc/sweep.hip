@@ -182,22 +182,29 @@ template <int G> __device__ __forceinline__ float quad_bcast_f(float v, int q) {
   return __builtin_bit_cast(float, quad_bcast_i<G>(__builtin_bit_cast(int, v), q));
 }
 
-// grid: (ceil(hw / (256/G)), 1, B); block 256.  sim [d1-d0][B][hw][C].  GEN: planes generated (uniform / window).
-template <int C, int SV, bool GEN>
+// grid: (ceil(hw / PPB), 1, B); block 256.  sim [d1-d0][B][hw][C].  GEN: planes generated (uniform / window).
+// HALVES = 1: S <= 4 source views, 256 / G pixels per workgroup.  HALVES = 2 (5 ... 8 views, BASELINE cfg5): waves 0, 1 take
+// views 0-3 and waves 2, 3 views 4-7 of the SAME 128 / G pixels; each half parks its partial sum of a group of 8 planes in
+// LDS and the halves meet at the flush (one barrier pair per 8 planes).  Eight views in one lane need 128 registers of taps
+// (208 in all: two waves per SIMD); split, a lane keeps the 122 of the four-view kernel and four waves cover the reloads.
+template <int C, int HALVES, bool GEN>
 __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ feat, const float* __restrict__ rt, PlaneSrc planes,
                                                      const float* __restrict__ vw, float* __restrict__ sim, int B, int S, int D,
                                                      int d0, int d1, int h, int w, int eps_num) {
-  constexpr int G = C / 4, PPB = 256 / G, NQ = G < 4 ? G : 4, VPL = (SV + NQ - 1) / NQ, PK = 8, NM = PK / G;
+  constexpr int SV = 4, G = C / 4, NT = 256 / HALVES, PPB = NT / G, NQ = G < 4 ? G : 4, VPL = (SV + NQ - 1) / NQ, PK = 8, NM = PK / G;
   const int hw = h * w;
-  const int tid = threadIdx.x, g = tid % G, gq = g % NQ, pib = tid / G;
+  const int tid = threadIdx.x, half = __builtin_amdgcn_readfirstlane(tid / NT), ltid = tid % NT;      // half: wave-uniform
+  const int g = ltid % G, gq = g % NQ, pib = ltid / G;
   const int pix = blockIdx.x * PPB + pib;
   const int b = blockIdx.z;
   const bool live = pix < hw;
   const int pc = live ? pix : hw - 1;
   const float x = (float)(pc % w), y = (float)(pc / w);
   const f32x4 ref4 = *(const f32x4*)(feat + ((size_t)b * hw + pc) * C + 4 * g);
+  const int v0 = SV * half;                              // first view of this half
+  const int Sm = min(S - v0, SV);                        // views of this half (>= 1: HALVES = 2 only when S > 4)
 
-  // normalisation of the view weights (adamvs.py:497-512), per pixel: all lanes
+  // normalisation of the view weights (adamvs.py:497-512), per pixel: all lanes, all S views
   float winv, eps_term;
   {
     float wsum = eps_num ? 0.f : 1e-5f;
@@ -205,11 +212,11 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
     winv = 1.0f / wsum;
     eps_term = eps_num ? 1e-5f * winv : 0.f;       // train/test twin (adamvs.py:262-300): (1e-5 + sum) / sum_v w_v
   }
-  // the views this lane projects: gq, gq + NQ, ... (views past S-1 repeat the last one; never consumed)
+  // the views this lane projects: v0 + gq, v0 + gq + NQ, ... (views past S-1 repeat the last one; never consumed)
   float ax[VPL], ay[VPL], az[VPL], tx[VPL], ty[VPL], tz[VPL], wn[VPL];
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
-    const int sc = min(gq + k * NQ, S - 1);
+    const int sc = min(v0 + gq + k * NQ, S - 1);
     const float* r = rt + ((size_t)b * S + sc) * 12;
     ax[k] = r[0] * x + r[1] * y + r[2];              // rot_xyz = R.[x,y,1] (module.py:549)
     ay[k] = r[3] * x + r[4] * y + r[5];
@@ -220,12 +227,12 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
   // cached cell and its four taps (4 channels of this lane) per view.  Named variables, not arrays: an array of SV
   // float4 is promoted to ONE <16 x float> value, i.e. a 512-bit register tuple that is copied whole after every
   // conditional reload (measured: 188 registers and 32 v_mov_b64 per view and plane).
-#define ADAMVS_EACH_VIEW(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define ADAMVS_EACH_VIEW(X) X(0) X(1) X(2) X(3)
 #define ADAMVS_DECL_VIEW(i) int cc##i = -1; f32x4 ta##i = {0.f, 0.f, 0.f, 0.f}, tb##i = ta##i, tc##i = ta##i, td##i = ta##i;
   ADAMVS_EACH_VIEW(ADAMVS_DECL_VIEW)
 #undef ADAMVS_DECL_VIEW
   const size_t vstride = (size_t)B * hw * C;
-  const float* src1 = feat + ((size_t)B + b) * (size_t)hw * C;                 // view s: + s * vstride (uniform)
+  const float* src1 = feat + ((size_t)B + b) * (size_t)hw * C + (size_t)v0 * vstride;      // view v0 + s: + s * vstride (uniform)
   const unsigned g16 = 16u * g;
   const unsigned rowpitch = (unsigned)w * (C * 4);
   const PlaneLine pl = plane_line(planes, b, pc, D, hw);
@@ -254,8 +261,10 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
   for (int dg = d0; dg < d1; dg += PK) {
     if (!GEN) {
       __syncthreads();                              // every lane is done with the previous group's planes
+      if (half == 0) {
 #pragma unroll
-      for (int k = 0; k < NM; ++k) dstash[GEN ? 0 : k * G + g][GEN ? 0 : pib] = nd[k];
+        for (int k = 0; k < NM; ++k) dstash[GEN ? 0 : k * G + g][GEN ? 0 : pib] = nd[k];
+      }
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < NM; ++k) nd[k] = pl.q[(size_t)min(dg + PK + k * G + g, d1 - 1) * hw];     // in flight during the group
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
           td = buf_load4(rs, yb + xb);
         }
       };
-#define ADAMVS_RELOAD_VIEW(i) if (i < SV && i < S) reload(i, cc##i, ta##i, tb##i, tc##i, td##i);
+#define ADAMVS_RELOAD_VIEW(i) if (i < Sm) reload(i, cc##i, ta##i, tb##i, tc##i, td##i);
       ADAMVS_EACH_VIEW(ADAMVS_RELOAD_VIEW)
 #undef ADAMVS_RELOAD_VIEW
       __builtin_amdgcn_sched_barrier(0);
@@ -300,19 +309,28 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
         f32x4& a = acc[s & 1];                                     // all-zero weights when padding
         a = ta * w00 + a; a = tb * w01 + a; a = tc * w10 + a; a = td * w11 + a;
       };
-#define ADAMVS_BLEND_VIEW(i) if (i < SV && i < S) blend(i, ta##i, tb##i, tc##i, td##i);
+#define ADAMVS_BLEND_VIEW(i) if (i < Sm) blend(i, ta##i, tb##i, tc##i, td##i);
       ADAMVS_EACH_VIEW(ADAMVS_BLEND_VIEW)
 #undef ADAMVS_BLEND_VIEW
-      park[j][tid] = ref4 * (acc[0] + acc[1]) + eps_term;
+      // one half: the finished value; two halves: this half's partial sum (the halves meet at the flush)
+      park[j][tid] = HALVES == 1 ? ref4 * (acc[0] + acc[1]) + eps_term : acc[0] + acc[1];
       // every reload of this plane has been consumed; stated explicitly (the builtin, so that the compiler's wait insertion
       // knows it): without it the reload branches of the next plane, which build their addresses in the dead tap
       // registers, each start with a conservative s_waitcnt vmcnt and the reloads of a plane serialise
       wait_vmem_all();
     }
     const int nd_ = min(PK, d1 - dg);
+    if (HALVES == 1) {
 #pragma unroll 1
-    for (int j = 0; j < nd_; ++j)
-      buf_store4(make_rsrc(sim + (size_t)(dg + j - d0) * ostride), ooff, park[j][tid]);
+      for (int j = 0; j < nd_; ++j)
+        buf_store4(make_rsrc(sim + (size_t)(dg + j - d0) * ostride), ooff, park[j][tid]);
+    } else {
+      __syncthreads();                              // both halves have parked the group
+#pragma unroll 1
+      for (int j = half; j < nd_; j += 2)           // half h finishes planes h, h + 2, ...: views 0-3 first, then 4-7 (fixed order)
+        buf_store4(make_rsrc(sim + (size_t)(dg + j - d0) * ostride), ooff, ref4 * (park[j][ltid] + park[j][NT + ltid]) + eps_term);
+      __syncthreads();                              // before the next group overwrites the parked sums
+    }
   }
 #undef ADAMVS_EACH_VIEW
 }
@@ -354,11 +372,12 @@ static int launch_sweep_c(const float* feat, const float* rt, PlaneSrc planes, c
   if (sweep_blend_enabled() && (size_t)B * h * w * C * 4 < 0x7fffffffu) {      // 32-bit lane offsets inside one view / one plane
     const bool gen = planes.mode != PLANES_EXPLICIT;
     if (S <= 4) {
-      if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 4, true>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
-      else hipLaunchKernelGGL((k_sweep_blend<C, 4, false>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
-    } else {
-      if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 8, true>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
-      else hipLaunchKernelGGL((k_sweep_blend<C, 8, false>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+      if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 1, true>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+      else hipLaunchKernelGGL((k_sweep_blend<C, 1, false>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+    } else {                    // 5 ... 8 views: two halves of the workgroup share 128 / G pixels
+      const dim3 grid2(cdiv(h * w, 128 / (C / 4)), 1, B);
+      if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 2, true>), grid2, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+      else hipLaunchKernelGGL((k_sweep_blend<C, 2, false>), grid2, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
     }
     ADAMVS_CHECK_LAUNCH("sweep_blend");
     return 0;
