@@ -728,6 +728,11 @@ static int launch_conv_dd_resident(const ConvDDArgs& a, int N, hipStream_t st) {
   return -1;
 }
 
+static bool conv256_split() {
+  static const bool on = [] { const char* e = getenv("ADAMVS_CONV256_SPLIT"); return !(e && *e == '0'); }();
+  return on;
+}
+
 static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
   if (mode == CONV_S1 && (a.D == 32 || a.D == 64) && !a.sm_vw) {
     const int rc = a.D == 32 ? launch_conv_dd_resident<32>(a, N, st) : launch_conv_dd_resident<64>(a, N, st);
@@ -741,7 +746,25 @@ static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) 
     case 96: return launch_conv_dd_cfg<3, 2>(a, N, mode, st);
     case 128: return launch_conv_dd_cfg<4, 2>(a, N, mode, st);
     case 192: return launch_conv_dd_cfg<3, 4>(a, N, mode, st);
-    case 256: return launch_conv_dd_cfg<4, 4>(a, N, mode, st);
+    case 256:
+      // 16 output tiles per block need 256 accumulator registers: one wave per SIMD, which feeds the matrix pipe at 83 % (DESIGN
+      // section 4, lesson 2; measured 74.5 % of the fp32 MFMA peak for the whole network at cfg5 against 88.5 % at D = 192).  The
+      // 128-channel tiling (two waves per SIMD) run twice instead: the second launch sees the weights, bias, skip and output
+      // moved by 8 channel tiles and contracts over all 256 input channels like the first.  The softmax epilogue needs all the
+      // channels of a pixel in one workgroup and keeps the wide tiling.  ADAMVS_CONV256_SPLIT=0: the wide tiling everywhere.
+      // Measured at cfg5 (8 tiles): 291.9 -> 279.5 ms per step.
+      if (!a.sm_vw && conv256_split()) {
+        ConvDDArgs h = a;
+        for (int half = 0; half < 2; ++half) {
+          h.wpk = a.wpk + (size_t)half * 8 * 64;       // fragment index = (... * D/16 + tile) * 64 floats
+          h.bias = a.bias + half * 128;
+          h.out = a.out + half * 128;
+          h.skip = a.skip ? a.skip + half * 128 : nullptr;
+          if (int rc = launch_conv_dd_cfg<4, 2>(h, N, mode, st)) return rc;
+        }
+        return 0;
+      }
+      return launch_conv_dd_cfg<4, 4>(a, N, mode, st);
   }
   return set_error(-1, "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", a.D);
 }

@@ -260,7 +260,7 @@ int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, 
     case 96: return launch_bx3_cfg<3, 2>(a, N, mode, st);
     case 128: return launch_bx3_cfg<4, 2>(a, N, mode, st);
     case 192: return launch_bx3_cfg<3, 4>(a, N, mode, st);
-    case 256: return launch_bx3_cfg<4, 4>(a, N, mode, st);
+    case 256: return launch_bx3_cfg<4, 4>(a, N, mode, st);      // (the two-launch 128-channel form of the fp32 path does not pay here: 155.0 -> 156.0 ms at cfg5)
   }
   return set_error(-1, "cost_reg_net_2d (bf16x3): D=%d unsupported (32, 64, 96, 128, 192 or 256)", D);
 }
