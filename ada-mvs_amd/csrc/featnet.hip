@@ -20,6 +20,7 @@
 #include "conv_frag.h"
 #include "kernels.h"
 #include "persistent.h"
+#include "slice_roles.h"
 
 namespace adamvs {
 
@@ -401,6 +402,28 @@ static int launch_conv0_fused(const float* imgs, const adamvs_fconv_weights& c00
   return 0;
 }
 
+// deconv2.conv (reference models/module.py:506-524, DeConv2dFuse: 3x3 on cat(deconv output, skip), 16 -> 8, BN, ReLU) at full
+// resolution on the two-row tile loop of the level-1 candidate convolution (slice_roles.h): 8 output channels fill half an
+// MFMA tile in the one-row form of k_fconv (36 MFMAs per 16-pixel run); two rows share the input-row fragments (24 per run),
+// and the 8 x 16 tile re-reads less halo than k_fconv's 4 x 16 (1.41 x instead of 1.69 x).
+__global__ __launch_bounds__(256) void k_fconv_pair_two_row(SmallConvArgs a, TileGrid tg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  TwoRowPairRole<TR_BIAS_RELU>::run(a, tg, TileRange{0, tg.ntiles}, blockIdx.x, gridDim.x, lds);
+}
+
+static int launch_pair_two_row(const float* srcA, const float* srcB, const adamvs_fconv_weights& w, float* out, int N, int h, int wd,
+                               hipStream_t st) {
+  constexpr size_t lds = TwoRowPairRole<TR_BIAS_RELU>::LDS_BYTES;
+  static const int capacity = resident_blocks(k_fconv_pair_two_row, 256, lds);
+  SmallConvArgs a{srcA, srcB, w.w, w.b, out, nullptr, h, wd, h, wd, 8, nullptr};
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(wd, 16), cdiv(h, 8), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(k_fconv_pair_two_row, dim3(grid), dim3(256), lds, st, a, tg);
+  ADAMVS_CHECK_LAUNCH("feature net deconv2.conv (two-row)");
+  return 0;
+}
+
 template <int CA, int CB, int NT, int MODE, int EPI>
 static int launch_fconv(const FConvArgs& a_in, int N, hipStream_t st, const char* name) {
   using GM = FGeom<MODE>;
@@ -639,7 +662,7 @@ extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weigh
   }
   // deconv2: ConvTranspose2d 16 -> 8, cat with conv0, 3x3 16 -> 8
   if ((rc = launch_fconv<16, 0, 1, FM_TALL, FE_RELU>(A(f1, nullptr, fw.deconv2_t, d2, H2, W2, H2, W2, 8, 8, 0), N, st, "deconv2.deconv"))) return rc;
-  if ((rc = launch_fconv<8, 8, 1, FM_K3, FE_RELU>(A(d2, c0, fw.deconv2_c, f2, H, W, H, W, 8, 8, 0), N, st, "deconv2.conv"))) return rc;
+  if ((rc = launch_pair_two_row(d2, c0, fw.deconv2_c, f2, N, H, W, st))) return rc;
   // stage 3 output
   if ((rc = launch_context<8>(f2, fw.br3_1, fw.br3_2, x3a, x3b, N, H, W, st))) return rc;
   {

@@ -702,7 +702,11 @@ struct DecoderRole {
 // MFMAs per 16-pixel run, half of the rows zero); with rows 8-15 = the same channels of the next output row it is
 // 24 per run.  Two sources like k_conv_small (x = c1, r*h: 2 + 2 channel groups), its fused epilogue (u and h of the
 // lane's own pixel requested before the chain; h updated in place), the tile and pipeline of k_conv1_two_row.
-struct Cand1TwoRowRole {
+// EPI2 = TR_CAND: that epilogue.  EPI2 = TR_BIAS_RELU: out = ReLU(conv + bias) -- the same two-source, two-row convolution as a
+// plain layer (FeatureNet0's deconv2.conv: 3x3 on cat(deconv output, skip), 16 -> 8 channels + folded BatchNorm + ReLU).
+enum { TR_CAND = 0, TR_BIAS_RELU = 1 };
+template <int EPI2>
+struct TwoRowPairRole {
   typedef SmallConvArgs Args;
   static constexpr int CA = 8, CB = 8, C = 16, KC = C / 4, G = C / 4, GA = CA / 4, TR = 8, TC = 16, LR = TR + 2, LC = TC + 2;
   static constexpr int NPIX = LR * LC, PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
@@ -787,7 +791,8 @@ struct Cand1TwoRowRole {
     const buf_rsrc ru = make_rsrc((const char*)a.dst1 + opix0 * 32);    // u
     unsigned oo = ooff;
     if (!(y0 + TR <= h && x0 + TC <= w)) oo = (y0 + orow < h && x0 + p < w) ? ooff : BUF_OOB;
-    const f32x4 pre_u = buf_load4(ru, oo), pre_h = buf_load4(rin, oo);  // epilogue operands first, then the next tile
+    f32x4 pre_u = {0.f, 0.f, 0.f, 0.f}, pre_h = pre_u;
+    if (EPI2 == TR_CAND) { pre_u = buf_load4(ru, oo); pre_h = buf_load4(rin, oo); }      // epilogue operands first, then the next tile
     const int tn = t + nwg;
     const bool more = tn < tr.end;
     int nn = 0, txn = 0, tyn = 0;
@@ -810,13 +815,18 @@ struct Cand1TwoRowRole {
     if (more) store_tile(stage);
 
     const f32x4 v = acc + bias;
-    const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
-    buf_store4(rh, oo, pre_u * pre_h + (1.0f - pre_u) * cnd);
+    if (EPI2 == TR_CAND) {
+      const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+      buf_store4(rh, oo, pre_u * pre_h + (1.0f - pre_u) * cnd);
+    } else {
+      buf_store4(rh, oo, f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)});
+    }
     if (!more) break;
     __syncthreads();                                // next tile visible
     t = tn; n = nn; tx = txn; ty = tyn;
   }
   }
 };
+typedef TwoRowPairRole<TR_CAND> Cand1TwoRowRole;
 
 }  // namespace adamvs

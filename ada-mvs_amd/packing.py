@@ -254,7 +254,11 @@ def pack_feature_net(sd, pre="feature.", context=True):
     conv_bn("conv2_1", "conv2.1.", 9)
     conv_bn("conv2_2", "conv2.2.", 9)
     conv_bn("deconv1_c", "deconv1.conv.", 9)
-    conv_bn("deconv2_c", "deconv2.conv.", 9)
+    # deconv2.conv has 8 output channels: two-row fragments [12][4][64] (k_fconv_pair_two_row), like conv0
+    w = sd[pre + "deconv2.conv.conv.weight"].detach().float().cpu()
+    scale, shift = _bn_scale_shift(sd, pre + "deconv2.conv.bn.")
+    parts["deconv2_c.w"] = pack_conv1_two_row(w * scale.reshape(-1, 1, 1, 1))
+    parts["deconv2_c.b"] = pad_bias(shift, 16)
     for name, key in (("deconv1_t", "deconv1.deconv."), ("deconv2_t", "deconv2.deconv.")):
         w = sd[pre + key + "conv.weight"].detach().float().cpu().permute(1, 0, 2, 3)        # -> [cout][cin][ky][kx]
         scale, shift = _bn_scale_shift(sd, pre + key + "bn.")

@@ -155,7 +155,8 @@ typedef struct adamvs_fuse_weights {
  * The 5x5 stride-2 convolutions hold 25 taps; conv2_0 is stored as two
  * 16-channel halves.  deconv*_t hold the ConvTranspose2d(k3,s2,p1,op1) weights per output parity class (py,px):
  * 1 + 2 + 2 + 4 taps in the order 00, 01, 10, 11, tap (ty,tx) = kernel index (py ? (ty ? 0 : 2) : 1, same in x) applied
- * to input pixel (i+ty, j+tx).  deconv*_c convolve cat(deconv output, skip).  out_k multiply the feature map only;
+ * to input pixel (i+ty, j+tx).  deconv*_c convolve cat(deconv output, skip); deconv2_c (8 output channels) is stored as
+ * two-row fragments [12][4][64] like conv0.  out_k multiply the feature map only;
  * the pooled-context branches br_k_j = {w1 [C/2][C] (BN folded), b1 [C/2], w2 [C][C/2] = columns of out_k for that
  * branch} are applied at pooled resolution and their bilinear upsampling (align_corners=False) is added in the
  * epilogue of out_k (the 1x1 convolution and the upsampling are both linear). */
