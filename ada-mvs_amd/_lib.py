@@ -84,6 +84,7 @@ SIGNATURES = {
                                          c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_feature_net0_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "adamvs_feature_net0": (c_i, [c_f, ctypes.POINTER(FeatureWeights), c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_feature_net0_views": (c_i, [c_f, ctypes.POINTER(FeatureWeights), c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_feature_net_fpn_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "adamvs_feature_net_fpn": (c_i, [c_f, ctypes.POINTER(FeatureFpnWeights), c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_red_variance_cost": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),

@@ -268,6 +268,8 @@ struct Conv0Args {
   const float* b1;       // [16]
   float* out;            // [N][H*W][8]
   int H, W;
+  int B, V, n0;          // V > 0: imgs is [B][V][3][H][W] (the reference's forward() argument) and image n of this launch is view-major
+                         // image m = n0 + n = v * B + b, read in place from imgs[b][v]; V == 0: imgs is [N][3][H][W]
 };
 
 __global__ __launch_bounds__(256) void k_conv0_fused(Conv0Args a, TileGrid tg) {
@@ -311,7 +313,9 @@ __global__ __launch_bounds__(256) void k_conv0_fused(Conv0Args a, TileGrid tg) {
 
   auto load_tile = [&](float (&st)[3], int n, int tx, int ty) {
     const int ix0 = tx * TC - 2, iy0 = ty * TR - 2;
-    const buf_rsrc ri = make_rsrc((const char*)a.imgs + (((long)n * 3 * H + iy0) * W + ix0) * 4);
+    const int m = a.n0 + n;
+    const long img = a.V ? (long)(m % a.B) * a.V + m / a.B : (long)m;        // uniform
+    const buf_rsrc ri = make_rsrc((const char*)a.imgs + ((img * 3 * H + iy0) * W + ix0) * 4);
     const bool ok = loader && (unsigned)(iy0 + lr) < (unsigned)H && (unsigned)(ix0 + lc) < (unsigned)W;
     const unsigned o = ok ? goff : BUF_OOB;               // zero padding of the first layer
 #pragma unroll
@@ -389,14 +393,15 @@ __global__ __launch_bounds__(256) void k_conv0_fused(Conv0Args a, TileGrid tg) {
   }
 }
 
+struct ViewOrder { int B, V, n0; };      // how the N images of a launch are found in `imgs` (Conv0Args)
 static int launch_conv0_fused(const float* imgs, const adamvs_fconv_weights& c00, const adamvs_fconv_weights& c01, float* out, int N,
-                              int H, int W, hipStream_t st) {
+                              int H, int W, ViewOrder vo, hipStream_t st) {
   static const int capacity = resident_blocks(k_conv0_fused, 256, 0);
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(W, 14), cdiv(H, 8), N)) return rc;
   if ((size_t)H * W * 4 * 3 >= 0x7fffffffu) return set_error(-1, "feature net conv0: image too large for 32-bit plane offsets (%d x %d)", H, W);
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
-  Conv0Args a{imgs, c00.w, c00.b, c01.w, c01.b, out, H, W};
+  Conv0Args a{imgs, c00.w, c00.b, c01.w, c01.b, out, H, W, vo.B, vo.V, vo.n0};
   hipLaunchKernelGGL(k_conv0_fused, dim3(grid), dim3(256), 0, st, a, tg);
   ADAMVS_CHECK_LAUNCH("feature net conv0 (fused)");
   return 0;
@@ -553,12 +558,12 @@ static FConvArgs fconv_args(const float* sa, const float* sb, const adamvs_fconv
   return FConvArgs{sa, sb, w.w, w.b, out, nullptr, nullptr, hi, wi, ho, wo, cout, ctot, co0, 0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
 }
 static int run_encoder(const float* imgs, const EncoderWeights& fw, float* c0, float* c1a, float* c1b, float* c1,
-                       float* c2a, float* c2b, float* c2, int N, int H, int W, hipStream_t st) {
+                       float* c2a, float* c2b, float* c2, int N, int H, int W, hipStream_t st, ViewOrder vo = ViewOrder{0, 0, 0}) {
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
   int rc;
   auto A = fconv_args;
   // conv0: 3 -> 8 -> 8 at full resolution, one kernel straight from the [N][3][H][W] images
-  if ((rc = launch_conv0_fused(imgs, fw.conv0_0, fw.conv0_1, c0, N, H, W, st))) return rc;
+  if ((rc = launch_conv0_fused(imgs, fw.conv0_0, fw.conv0_1, c0, N, H, W, vo, st))) return rc;
   // conv1: 5x5 stride 2 (8 -> 16), two 3x3
   if ((rc = launch_fconv<8, 0, 1, FM_K5S2, FE_RELU>(A(c0, nullptr, fw.conv1_0, c1a, H, W, H2, W2, 16, 16, 0), N, st, "conv1.0"))) return rc;
   if ((rc = launch_fconv<16, 0, 1, FM_K3, FE_RELU>(A(c1a, nullptr, fw.conv1_1, c1b, H2, W2, H2, W2, 16, 16, 0), N, st, "conv1.1"))) return rc;
@@ -621,8 +626,23 @@ extern "C" int adamvs_feature_net_fpn(const float* imgs, const adamvs_feature_fp
   return 0;
 }
 
+static int feature_net0_impl(const float* imgs, const adamvs_feature_weights* wts, float* stage1, float* stage2, float* stage3, int N,
+                             int H, int W, void* workspace, size_t workspace_bytes, void* stream, ViewOrder vo);
+
 extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weights* wts, float* stage1, float* stage2,
                                    float* stage3, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+  return feature_net0_impl(imgs, wts, stage1, stage2, stage3, N, H, W, workspace, workspace_bytes, stream, ViewOrder{0, 0, 0});
+}
+
+extern "C" int adamvs_feature_net0_views(const float* imgs, const adamvs_feature_weights* wts, float* stage1, float* stage2,
+                                         float* stage3, int B, int V, int n0, int n, int H, int W, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(B > 0 && V > 0 && n0 >= 0 && n > 0 && n0 + n <= B * V, "feature_net0_views: B=%d V=%d n0=%d n=%d", B, V, n0, n);
+  return feature_net0_impl(imgs, wts, stage1, stage2, stage3, n, H, W, workspace, workspace_bytes, stream, ViewOrder{B, V, n0});
+}
+
+static int feature_net0_impl(const float* imgs, const adamvs_feature_weights* wts, float* stage1, float* stage2, float* stage3, int N,
+                             int H, int W, void* workspace, size_t workspace_bytes, void* stream, ViewOrder vo) {
   ADAMVS_CHECK_ARG(imgs && wts && stage1 && stage2 && stage3 && workspace, "feature_net0: null pointer");
   ADAMVS_CHECK_ARG(N > 0 && H >= 32 && W >= 32 && (H % 32) == 0 && (W % 32) == 0,
                    "feature_net0: N=%d H=%d W=%d (H, W multiples of 32)", N, H, W);
@@ -643,7 +663,7 @@ extern "C" int adamvs_feature_net0(const float* imgs, const adamvs_feature_weigh
   float* x3a = take(n * (hw / 16) * 8); float* x3b = take(n * (hw / 16) * 8);
   int rc;
   const EncoderWeights enc{fw.conv0_0, fw.conv0_1, fw.conv1_0, fw.conv1_1, fw.conv1_2, fw.conv2_0, fw.conv2_1, fw.conv2_2};
-  if ((rc = run_encoder(imgs, enc, c0, c1a, c1b, c1, c2a, c2b, c2, N, H, W, st))) return rc;
+  if ((rc = run_encoder(imgs, enc, c0, c1a, c1b, c1, c2a, c2b, c2, N, H, W, st, vo))) return rc;
   auto A = fconv_args;
   // stage 1 output: out1 . cat(up(branch1_1), up(branch1_2), c2)
   if ((rc = launch_context<32>(c2, fw.br1_1, fw.br1_2, x1a, x1b, N, H4, W4, st))) return rc;

@@ -200,12 +200,18 @@ def feature_net0_workspace_bytes(N, H, W):
     return int(_lib.load().adamvs_feature_net0_workspace_bytes(int(N), int(H), int(W)))
 
 
-def feature_net0(imgs, packed, workspace=None, out=None):
+def feature_net0(imgs, packed, workspace=None, out=None, views=None):
     """FeatureNet0.forward on [N,3,H,W] images -> channel-last (stage1 [N,hw/16,32], stage2 [N,hw/4,16], stage3 [N,hw,8]).
-    out: the three (contiguous) result tensors, e.g. slices of the maps of a larger batch run in chunks."""
+    out: the three (contiguous) result tensors, e.g. slices of the maps of a larger batch run in chunks.
+    views = (n0, n): imgs is [B,V,3,H,W] as the reference's forward() receives it; images n0 .. n0+n-1 of the V*B images in
+    view-major order (m = v*B + b) are computed, read in place (no transposed copy)."""
     lib = _lib.load()
     imgs = _dev(imgs, "imgs")
-    N, c, H, W = imgs.shape
+    if views is not None:
+        Bv, Vv, c, H, W = imgs.shape
+        n0, N = views
+    else:
+        N, c, H, W = imgs.shape
     if c != 3:
         check(-1, "feature_net0")
     dev = imgs.device
@@ -221,8 +227,12 @@ def feature_net0(imgs, packed, workspace=None, out=None):
     nbytes = lib.adamvs_feature_net0_workspace_bytes(N, H, W)
     if workspace is None or workspace.numel() * 4 < nbytes:
         workspace = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
-    check(lib.adamvs_feature_net0(_p(imgs), packed.ptr(), _p(s1), _p(s2), _p(s3), N, H, W, _p(workspace), nbytes, _stream()),
-          "feature_net0")
+    if views is not None:
+        check(lib.adamvs_feature_net0_views(_p(imgs), packed.ptr(), _p(s1), _p(s2), _p(s3), Bv, Vv, n0, N, H, W, _p(workspace), nbytes,
+                                            _stream()), "feature_net0_views")
+    else:
+        check(lib.adamvs_feature_net0(_p(imgs), packed.ptr(), _p(s1), _p(s2), _p(s3), N, H, W, _p(workspace), nbytes, _stream()),
+              "feature_net0")
     return s1, s2, s3
 
 

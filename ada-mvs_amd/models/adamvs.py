@@ -77,17 +77,23 @@ class FeatureNet0(PackedCache, nn.Module):
                                  "base_channels %d); there is no fallback path" % (type(self).__name__, tuple(x.shape), x.device, self.base_channels))
 
     def forward_cl(self, x):
-        """[N,3,H,W] -> channel-last stage maps ([N,hw/16,32], [N,hw/4,16], [N,hw,8]) for the plane sweep."""
+        """[N,3,H,W] -> channel-last stage maps ([N,hw/16,32], [N,hw/4,16], [N,hw,8]) for the plane sweep.
+        x may also be [B,V,3,H,W], as the reference's forward() receives the images: the maps then hold the V*B images in
+        view-major order (image v*B + b), the order the plane sweep takes, read in place -- no transposed copy."""
         self._require_hip(x)
-        # intermediate maps take ~77 floats per pixel and image: bound the workspace, not the batch
+        by_view = x.dim() == 5
+        N = x.shape[0] * x.shape[1] if by_view else x.shape[0]
+        # intermediate maps take ~65 floats per pixel and image: bound the workspace, not the batch
         per_image = hip_ops.feature_net0_workspace_bytes(1, x.shape[-2], x.shape[-1])
         chunk = max(1, int(self.workspace_limit_bytes // per_image))
-        if x.shape[0] <= chunk:
-            return hip_ops.feature_net0(x, self.packed(x.device))
-        N, H, W = x.shape[0], x.shape[-2], x.shape[-1]      # chunks write into their slices of the whole maps (no concatenation copy)
+        if N <= chunk:
+            return hip_ops.feature_net0(x, self.packed(x.device), views=(0, N) if by_view else None)
+        H, W = x.shape[-2], x.shape[-1]      # chunks write into their slices of the whole maps (no concatenation copy)
         maps = tuple(torch.empty(N, (H // s) * (W // s), c, device=x.device, dtype=torch.float32) for s, c in ((4, 32), (2, 16), (1, 8)))
         for i in range(0, N, chunk):
-            hip_ops.feature_net0(x[i:i + chunk], self.packed(x.device), out=tuple(m[i:i + chunk] for m in maps))
+            n = min(chunk, N - i)
+            hip_ops.feature_net0(x if by_view else x[i:i + n], self.packed(x.device), out=tuple(m[i:i + n] for m in maps),
+                                 views=(i, n) if by_view else None)
         return maps
 
     @staticmethod
@@ -344,9 +350,8 @@ class Infer_AdaMVSNet(nn.Module):
     def extract_features(self, imgs):
         """-> (feats_cl, shapes) for infer_from_features; FeatureNet0 on all B*V images in one batch."""
         B, V = imgs.shape[:2]
-        x = imgs.transpose(0, 1).reshape(B * V, *imgs.shape[2:]).contiguous()     # view-major
-        H, W = x.shape[-2:]
-        maps = self.feature.forward_cl(x)                                         # channel-last, no transposes; raises on unsupported input
+        H, W = imgs.shape[-2:]
+        maps = self.feature.forward_cl(imgs.contiguous())      # view-major, channel-last maps straight from [B,V,3,H,W]; raises on unsupported input
         feats_cl, shapes = [], []
         for s in range(self.num_stage):
             scale = (4, 2, 1)[s]

@@ -170,6 +170,12 @@ typedef struct adamvs_feature_weights {
 size_t adamvs_feature_net0_workspace_bytes(int N, int H, int W);
 int adamvs_feature_net0(const float* imgs, const adamvs_feature_weights* weights, float* stage1, float* stage2, float* stage3,
                         int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+/* The same network on the images as reference Infer_AdaMVSNet.forward receives them, imgs [B][V][3][H][W] (adamvs.py:574-577
+ * runs the net view by view), without the view-major copy: the launch computes images m = n0 .. n0+n-1 of the V*B images in
+ * view-major order (m = v * B + b, the order of the feature maps every entry point above takes), reading imgs[b][v] in place;
+ * stage1..3 receive those n images.  n0 / n let a caller bound the workspace (adamvs_feature_net0_workspace_bytes(n, H, W)). */
+int adamvs_feature_net0_views(const float* imgs, const adamvs_feature_weights* weights, float* stage1, float* stage2, float* stage3,
+                              int B, int V, int n0, int n, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The FPN variant of MS-REDNet's FeatureNet, reference models/msrednet.py:74-91 (constructor), 115-125 (forward), arch_mode
  * "fpn" with three stages: stage1 = out1(conv2); t1 = nearest2x(conv2) + inner1(conv1); stage2 = out2(t1);

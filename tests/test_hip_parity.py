@@ -797,3 +797,23 @@ def test_sweep_blend_views_and_widths(hip, O, C, S):
         sim = O.aggregate_similarity(feats[0], feats[1:], Rs, ts, planes[:, d], [vw[s].unsqueeze(1) for s in range(S)])
         ref = F.relu(F.conv2d(sim, w1, None, 1, 1))
         assert rel_l1(c1[d].reshape(B, h, w, 8).permute(0, 3, 1, 2), ref) < OP_TOL, "plane %d" % d
+
+
+def test_feature_net0_reads_views_in_place(hip):
+    """FeatureNet0.forward_cl on the [B,V,3,H,W] tensor Infer_AdaMVSNet.forward receives (adamvs_feature_net0_views: image
+    m = v*B + b read from imgs[b][v], reference adamvs.py:574-577 runs the net view by view) equals, bit for bit, the
+    maps of the view-major copy -- in one call and in chunks of three images (an uneven split of the 2 x 3 = 6)."""
+    from ada_mvs_amd.models.adamvs import FeatureNet0
+    B, V, H, W = 2, 3, 64, 96
+    net = FeatureNet0(base_channels=8, stride=4, num_stage=3)
+    net.load_state_dict(synth.seeded_state_dict(net, seed=2))
+    net = net.cuda().eval()
+    imgs = dev(torch.randn(B, V, 3, H, W, generator=torch.Generator().manual_seed(9)))
+    want = net.forward_cl(imgs.transpose(0, 1).reshape(B * V, 3, H, W).contiguous())
+    got = net.forward_cl(imgs)
+    net.workspace_limit_bytes = 4 * hip.feature_net0_workspace_bytes(1, H, W)          # chunks of 4 and 2 images
+    got_chunked = net.forward_cl(imgs)
+    torch.cuda.synchronize()
+    for a, b, c in zip(want, got, got_chunked):
+        assert a.shape == b.shape == c.shape
+        assert torch.equal(a, b) and torch.equal(a, c)
