@@ -580,9 +580,15 @@ static bool t2_fused(long blocks_class_by_class) {
 // ADAMVS_T2_KB8=0: one k-step per chunk in the transposed kernel at D = 192, as in rounds 1-2 (A/B).  Two k-steps halve
 // the barrier pairs per class (a class has at most four taps, so the fragments still fit two waves per SIMD):
 // measured conv11 of cfg2 14.2 -> 13.8 ms, with the epilogue freed of the skip operand 14.5 -> 12.3.
-static bool t2_kb8() { const char* e = getenv("ADAMVS_T2_KB8"); return !(e && *e == '0'); }
+static bool t2_kb8() {
+  static const bool on = [] { const char* e = getenv("ADAMVS_T2_KB8"); return !(e && *e == '0'); }();      // once, thread-safely
+  return on;
+}
 // ADAMVS_COSTREG_DEFER_SKIPS=0: the skip additions in the producing layer's epilogue, as in rounds 1-2 (A/B)
-static bool costreg_deferred_skips() { const char* e = getenv("ADAMVS_COSTREG_DEFER_SKIPS"); return !(e && *e == '0'); }
+static bool costreg_deferred_skips() {
+  static const bool on = [] { const char* e = getenv("ADAMVS_COSTREG_DEFER_SKIPS"); return !(e && *e == '0'); }();
+  return on;
+}
 
 template <int MT, int WM>
 static int launch_conv_dd_cfg(const ConvDDArgs& a_, int N, int mode, hipStream_t st) {
