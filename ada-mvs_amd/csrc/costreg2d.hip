@@ -853,7 +853,9 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
 
 // ---------------------------------------------------------------------------
 // Layer plan.  Packed weights: 11 layers x (9*D*D fragment floats + D bias floats), in the order
-// conv0..conv6, conv7, conv9, conv11, prob.  Workspace: 3 * N*h*w*D floats.
+// conv0..conv6, conv7, conv9, conv11, prob; fp32 with D in {64, 128, 192, 256}: followed by the five stride-1 layers
+// (conv0, conv2, conv4, conv6, prob) in the F(2x2, 3x3) form, 16*D*D floats each (costreg2d_wino.hip).
+// Workspace: 3 * N*h*w*D floats.
 // sm_vw != null: the `prob` layer reduces its scores over D in its epilogue (costreg_softmax.h) and writes the view
 // weights / pair depths of softmax_max_regress directly (score is not written); the caller skips launch_softmax_regress.
 bool cost_reg_softmax_fusable(int D, int precision, const PlaneSrc& planes) {
@@ -862,9 +864,16 @@ bool cost_reg_softmax_fusable(int D, int precision, const PlaneSrc& planes) {
   return on && D >= 16;
 }
 
+// ADAMVS_WINOGRAD=0: the stride-1 layers on the direct kernel, as in rounds 1-2 (A/B)
+bool cost_reg_winograd(int D, int precision) {
+  static const bool on = [] { const char* e = getenv("ADAMVS_WINOGRAD"); return !(e && *e == '0'); }();
+  return on && precision == PRECISION_FP32 && wino_depth_supported(D);
+}
+
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
                            int precision, hipStream_t st, float* sm_vw, float* sm_pd, const PlaneSrc* sm_planes, int sm_B) {
   const bool fuse_softmax = sm_vw != nullptr;
+  const bool wino = cost_reg_winograd(D, precision);
   const size_t F = (size_t)N * h * w * D;
   const size_t LW = (size_t)9 * D * D + D;
   float* conv0 = ws;                  // F
@@ -908,6 +917,12 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
       rc = launch_conv_dd_bf16x3(plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, N, D, plan[i].hi,
                                  plan[i].wi, plan[i].ho, plan[i].wo, plan[i].mode, plan[i].relu, st, sm ? sm_vw : nullptr,
                                  sm ? sm_pd : nullptr, sm ? sm_planes : nullptr, sm_B);
+    } else if (wino && plan[i].mode == CONV_S1) {
+      // stride-1 layers in the minimal-filtering form (none of them carries a skip or takes a second input); the scores of the
+      // last one go through the score volume to k_softmax_regress: its channel groups are different workgroups
+      const float* ww = wpk + (size_t)11 * LW + (size_t)(i == 10 ? 4 : i / 2) * 16 * D * D;
+      rc = launch_conv_wino(plan[i].in, ww, wl + (size_t)9 * D * D, nullptr, plan[i].out, N, D, plan[i].hi, plan[i].wi, plan[i].relu, st);
+      if (!rc && i == 10 && fuse_softmax) rc = launch_softmax_regress(score, *sm_planes, sm_vw, sm_pd, N / sm_B, sm_B, D, h, w, st);
     } else {
       const bool give = defer && i + 1 < 11 && plan[i + 1].mode == CONV_T2;        // layer i + 1 adds this layer's skip to its input
       const bool take = defer && i > 0 && plan[i].mode == CONV_T2 && plan[i - 1].skip;

@@ -1,0 +1,261 @@
+// Stride-1 layers of CostRegNet2D (reference models/adamvs.py:198-238: conv0, conv2, conv4, conv6, prob; blocks
+// models/module.py:254-261) in the minimal-filtering form F(2x2, 3x3) of a 3x3 convolution, fp32 throughout.
+//
+// The direct kernel (costreg2d.hip) runs at 92 % of the fp32 matrix rate: what is left to gain is the number of
+// multiplications.  A 2 x 2 output tile of a 3 x 3 convolution needs 16 products per (cin, cout) pair instead of 36:
+//     Y = At [ (G g Gt) .* (Bt d B) ] A,      d = the 4 x 4 input patch, g = the 3 x 3 filter,
+//     Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  At = [1 1 1 0; 0 1 -1 -1]
+// i.e. 16 independent channel contractions U[i][j][cout][cin] . V[i][j][cin][tile], one per position (i, j) of the
+// transformed patch, each an implicit GEMM on v_mfma_f32_16x16x4_f32 with columns = 16 output tiles of one tile row.
+// U = G g Gt is formed on the host in double precision (packing.py::pack_reg_layer_wino); Bt d B and At M A are additions.
+//
+// Mapping.  fp32 MFMA shares the vector lanes (lesson 1), so the input transform must cost few vector
+// instructions per MFMA, and each weight fragment (one per MFMA) must be reused over as many tiles as the accumulators
+// allow.  A workgroup = 4 waves = the 4 ROWS i of the transformed patch: wave i needs two raw patch rows (d0-d2 | d1+d2 |
+// d2-d1 | d1-d3: 4 vector instructions), the column transform of that row (4 more), and owns the accumulators of its
+// four positions (i, 0..3) for MT channel tiles x NT tile rows: 8 vector instructions per 4 MT MFMAs.  One wave per SIMD
+// (up to 512 registers: 4 x MT x NT accumulator tiles = 288 registers at MT 6, NT 3), LDS double-buffered in chunks
+// of 16 input channels with ONE barrier per chunk, weight fragments L2 -> VGPR as one 16-byte load per (k-step, channel
+// tile) carrying the four positions of the wave's row.  A workgroup covers 2 NT x 32 output pixels x 16 MT channels;
+// the channel groups of a pixel block are neighbouring workgroups (they share the input window in L2).
+// The four rows meet in the epilogue: Z_i[b] = sum_j M[i][j] At[b][j] in registers, then through LDS, wave (a, b) forms
+// Y[a][b] = sum_i At[a][i] Z_i[b], adds bias / ReLU / skip and stores.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace adamvs {
+
+struct WinoArgs {
+  const float* in;     // [N][h*w][D]
+  const float* wpk;    // [D/4][4][D/16][64][4]: k-step, patch row i, channel tile, lane (A-fragment order), patch column j
+  const float* bias;   // [D]
+  const float* skip;   // [N][h*w][D] or null; added after the ReLU
+  float* out;          // [N][h*w][D]
+  int D, h, w, relu;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int MT, int NT>
+struct WinoGeom {
+  static constexpr int KC = 16, KS = KC / 4;                 // input channels per LDS chunk, k-steps per chunk
+  static constexpr int LR = 2 * NT + 2, LC = 34, NPIX = LR * LC;
+  static constexpr int PLANE = ((NPIX + 31) / 64) * 64 + 32;  // == 32 (mod 64): the k-rows q, q+1 of a 32-lane ds_read_b64 group on disjoint banks
+  static constexpr int GP = 4 * PLANE + 8;                   // channel-group pitch: the 4 groups of a pixel on different banks when the tile is filled
+  static constexpr int CHUNK = KS * GP;                      // floats per buffer
+  static constexpr int ZFLOATS = 4 * 2 * MT * 64 * 4;        // epilogue exchange of one tile row
+  static constexpr int LDS_FLOATS = (2 * CHUNK > ZFLOATS) ? 2 * CHUNK : ZFLOATS;
+  static_assert(PLANE >= NPIX, "plane pitch");
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, int groups) {
+  using G = WinoGeom<MT, NT>;
+  constexpr int KC = G::KC, KS = G::KS, LC = G::LC, NPIX = G::NPIX, PLANE = G::PLANE, GP = G::GP, CHUNK = G::CHUNK;
+  constexpr int NITEMS = NPIX * (KC / 4), NITA = (NITEMS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = patch row i
+  const int p = lane & 15, q = lane >> 4;
+  const int D = a.D, NTILES = D / 16, NC = D / KC;
+  const int cg = blockIdx.x % groups, bx = blockIdx.x / groups, by = blockIdx.y, n = blockIdx.z;
+  const int r0 = by * 2 * NT, c0 = bx * 32;                  // block origin (output pixels); the window starts one pixel up / left
+
+  // ---- per-lane constants
+  // window fill: item = (pixel of the window, group of 4 channels of the chunk); out-of-image pixels read as zero
+  const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.h + (r0 - 1)) * a.w + (c0 - 1)) * (long)D * 4);
+  unsigned xoff[NITA], xlds[NITA];
+#pragma unroll
+  for (int it = 0; it < NITA; ++it) {
+    const int i = min(tid + it * 256, NITEMS - 1);           // surplus lanes repeat the last item
+    const int g = i % (KC / 4), pp = i / (KC / 4), r = pp / LC, c = pp % LC;
+    const bool ok = (unsigned)(r0 - 1 + r) < (unsigned)a.h && (unsigned)(c0 - 1 + c) < (unsigned)a.w;
+    xoff[it] = ok ? (unsigned)(((r * a.w + c) * D + 4 * g) * 4) : BUF_OOB;
+    xlds[it] = (unsigned)((g * GP + pp) * 4);
+    pin(xoff[it]); pin(xlds[it]);
+  }
+  // raw patch rows of the wave: T = rowA + sgn * rowB  (i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
+  const int rowA = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+  const int rowB = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+  const float sgn = wave == 1 ? 1.0f : -1.0f;
+  const f32x2 sgn2 = {sgn, sgn}, pm = {1.0f, -1.0f};
+  unsigned pa = (unsigned)((q * PLANE + rowA * LC + 2 * p) * 4), pb = (unsigned)((q * PLANE + rowB * LC + 2 * p) * 4);
+  unsigned pa2 = pa + 8, pb2 = pb + 8;
+  pin(pa); pin(pb); pin(pa2); pin(pb2);
+  // A fragments: 16 bytes per lane = the four positions (i, 0..3) of one (k-step, channel tile)
+  const buf_rsrc rw = make_rsrc(a.wpk);
+  unsigned woff = (unsigned)(lane * 16);
+  pin(woff);
+
+  f32x4 acc[4][MT][NT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[j][mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_w = [&](f32x4 (&wf)[MT], int ks) {               // ks: global k-step
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const unsigned frag = (unsigned)(((ks * 4 + wave) * NTILES + cg * MT + mt) * 1024);                 // uniform
+      wf[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, frag, 0));
+    }
+  };
+  auto load_x = [&](f32x4 (&st)[NITA], int ch) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it)
+      st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+  };
+  // The raw patch rows of tile row t, k-step ks of the chunk in buffer `buf`: four ds_read_b64 at pinned base + immediate
+  // (the halves of a row go through two separately pinned bases: merged into one ds_read2_b64, whose offset field is 8 bits,
+  // the pair would need a vector add per read for its address).
+  struct Raw { f32x2 a01, a23, b01, b23; };
+  auto read_raw = [&](Raw& r, int buf, int ks, int t) {
+    const int off = (buf * CHUNK + ks * GP + 2 * t * LC) * 4;
+    r.a01 = *(const f32x2*)((const char*)lds + pa + off); r.a23 = *(const f32x2*)((const char*)lds + pa2 + off);
+    r.b01 = *(const f32x2*)((const char*)lds + pb + off); r.b23 = *(const f32x2*)((const char*)lds + pb2 + off);
+  };
+  // one tile row of one k-step: 4 packed vector instructions, 4 MT MFMAs
+  auto tile_row = [&](const f32x4 (&wf)[MT], const Raw& r, int t) {
+    // T = A + sgn B; (v0, v3) = (t0 - t2, t1 - t3); (v1, v2) = (t2 + t1, t2 - t1)
+    const f32x2 t01 = __builtin_elementwise_fma(sgn2, r.b01, r.a01), t23 = __builtin_elementwise_fma(sgn2, r.b23, r.a23);
+    const f32x2 v03 = t01 - t23;
+    const f32x2 v12 = __builtin_elementwise_fma(__builtin_shufflevector(t01, t01, 1, 1), pm, __builtin_shufflevector(t23, t23, 0, 0));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[0][mt][t] = mfma16(wf[mt].x, v03.x, acc[0][mt][t]);
+      acc[1][mt][t] = mfma16(wf[mt].y, v12.x, acc[1][mt][t]);
+      acc[2][mt][t] = mfma16(wf[mt].z, v12.y, acc[2][mt][t]);
+      acc[3][mt][t] = mfma16(wf[mt].w, v03.y, acc[3][mt][t]);
+    }
+  };
+  f32x4 xs[NITA];
+  auto store_items = [&](int buf, int i0, int i1) {          // window items [i0, i1) of the staged chunk -> buffer `buf`
+#pragma unroll
+    for (int it = i0; it < i1; ++it) {
+      float* dl = (float*)((char*)lds + xlds[it]) + buf * CHUNK;
+      dl[0] = xs[it].x; dl[PLANE] = xs[it].y; dl[2 * PLANE] = xs[it].z; dl[3 * PLANE] = xs[it].w;
+    }
+  };
+  // one k-step (4 input channels): the raw rows of the NEXT tile row (or of the next k-step's first) are requested before the
+  // MFMAs of the current one -- with one wave per SIMD nothing else hides the LDS latency.  FILL: the staged chunk c+1 goes to the
+  // other buffer between the tile rows (LDS stores issue next to the MFMAs), then chunk c+2 is requested.
+  auto kstep = [&](const f32x4 (&wf)[MT], Raw& r, int buf, int ks, bool fill, int next_ch) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      Raw nx;
+      const bool more = t + 1 < NT || ks + 1 < KS;
+      if (more) read_raw(nx, buf, t + 1 < NT ? ks : ks + 1, t + 1 < NT ? t + 1 : 0);
+      __builtin_amdgcn_sched_barrier(0);        // (left alone, the scheduler hoists the next transforms above this tile row's MFMAs
+      tile_row(wf, r, t);                       //  and waits for their LDS reads right after issuing them)
+      if (fill) store_items(buf ^ 1, t * NITA / NT, (t + 1) * NITA / NT);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) r = nx;
+    }
+    if (fill) load_x(xs, next_ch);
+  };
+
+  // Four named fragment sets: k-step ks of a chunk uses set ks, and requests the fragments of three k-steps ahead into the set
+  // freed by the previous k-step (the L2 latency under load is longer than one k-step's 48 MFMAs).  Past the last k-step /
+  // chunk the requests repeat the last one, so that the number of loads in flight -- what the waits count -- does not change.
+  const int last_ks = NC * KS - 1, last_ch = (NC - 1) * KC;
+  f32x4 wf0[MT], wf1[MT], wf2[MT], wf3[MT];
+  f32x4 bias4[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) bias4[mt] = *(const f32x4*)(a.bias + (cg * MT + mt) * 16 + 4 * q);
+  load_x(xs, 0);
+  wait_vmem_all();
+  store_items(0, 0, NITA);
+  load_x(xs, min(KC, last_ch));
+  load_w(wf0, 0);
+  load_w(wf1, min(1, last_ks));
+  load_w(wf2, min(2, last_ks));
+  __syncthreads();
+  static_assert(KS == 4, "four k-steps per chunk, one per fragment set");
+  // chunk c from buffer CUR (a compile-time constant: every LDS address of the loop is a pinned register + an immediate)
+  auto chunk = [&](int c, auto curc) {
+    constexpr int CUR = decltype(curc)::value;
+    // every wave is past chunk c-1 (the barrier that ended it): its buffer takes chunk c+1 during k-step 0
+    Raw r;
+    read_raw(r, CUR, 0, 0);
+    load_w(wf3, min(c * KS + 3, last_ks));
+    kstep(wf0, r, CUR, 0, true, min((c + 2) * KC, last_ch));      // (the last chunk stages a repeat: never read)
+    load_w(wf0, min(c * KS + 4, last_ks));
+    kstep(wf1, r, CUR, 1, false, 0);
+    load_w(wf1, min(c * KS + 5, last_ks));
+    kstep(wf2, r, CUR, 2, false, 0);
+    load_w(wf2, min(c * KS + 6, last_ks));
+    kstep(wf3, r, CUR, 3, false, 0);
+    __syncthreads();
+  };
+  for (int c = 0; c < NC; c += 2) {                          // NC is even for every supported D
+    chunk(c, std::integral_constant<int, 0>{});
+    chunk(c + 1, std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) drain(acc[j][mt][t]);
+
+  // ---- epilogue: rows meet through LDS, one tile row per round; wave (a, b) = output pixel (2 ty + a, 2 tx + b)
+  const int oa = wave >> 1, ob = wave & 1;
+  const float os = oa ? -1.0f : 1.0f;
+  const buf_rsrc ro = make_rsrc((char*)a.out + (long)n * a.h * a.w * (long)D * 4);
+  const buf_rsrc rk = make_rsrc((const char*)(a.skip ? a.skip : a.out) + (long)n * a.h * a.w * (long)D * 4);
+  f32x4* zl = (f32x4*)lds;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t) __syncthreads();                                  // the previous round's readers are done
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      zl[((wave * 2 + 0) * MT + mt) * 64 + lane] = (acc[0][mt][t] + acc[1][mt][t]) + acc[2][mt][t];
+      zl[((wave * 2 + 1) * MT + mt) * 64 + lane] = (acc[1][mt][t] - acc[2][mt][t]) - acc[3][mt][t];
+    }
+    __syncthreads();
+    const int oy = r0 + 2 * t + oa, ox = c0 + 2 * p + ob;
+    const unsigned obase = (oy < a.h && ox < a.w) ? (unsigned)(((oy * a.w + ox) * D + cg * MT * 16 + 4 * q) * 4) : BUF_OOB;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 z0 = zl[(((oa + 0) * 2 + ob) * MT + mt) * 64 + lane];
+      const f32x4 z1 = zl[(((oa + 1) * 2 + ob) * MT + mt) * 64 + lane];
+      const f32x4 z2 = zl[(((oa + 2) * 2 + ob) * MT + mt) * 64 + lane];
+      f32x4 v = z0 + os * (z1 + z2) + bias4[mt];
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (a.skip) v += buf_load4(rk, obase == BUF_OOB ? BUF_OOB : obase + mt * 64);
+      buf_store4(ro, obase == BUF_OOB ? BUF_OOB : obase + mt * 64, v);
+    }
+  }
+}
+
+template <int MT, int NT>
+static int launch_wino_cfg(const WinoArgs& a, int N, hipStream_t st) {
+  const int groups = a.D / (16 * MT);
+  hipLaunchKernelGGL((k_conv_wino<MT, NT>), dim3(groups * cdiv(a.w, 32), cdiv(a.h, 2 * NT), N), dim3(256), 0, st, a, groups);
+  ADAMVS_CHECK_LAUNCH("conv_wino");
+  return 0;
+}
+
+bool wino_depth_supported(int D) { return D == 64 || D == 128 || D == 192 || D == 256; }
+
+int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
+                     int relu, hipStream_t st) {
+  const WinoArgs a{in, wpk, bias, skip, out, D, h, w, relu};
+  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino: D=%d unsupported (64, 128, 192 or 256)", D);
+  return launch_wino_cfg<4, 3>(a, N, st);
+}
+
+}  // namespace adamvs
+
+using namespace adamvs;
+
+extern "C" int adamvs_conv3x3_dd_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N,
+                                      int D, int h, int w, int relu, void* stream) {
+  ADAMVS_CHECK_ARG(in && wpk && bias && out && N > 0 && h > 0 && w > 0, "conv3x3_dd_wino: bad arguments");
+  ADAMVS_CHECK_ARG(N <= 65535, "conv3x3_dd_wino: N=%d exceeds the grid z limit", N);
+  return launch_conv_wino(in, wpk, bias, skip, out, N, D, h, w, relu, (hipStream_t)stream);
+}

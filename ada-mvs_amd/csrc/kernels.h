@@ -67,6 +67,10 @@ int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, 
                           int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st, float* sm_vw = nullptr,
                           float* sm_pd = nullptr, const PlaneSrc* sm_planes = nullptr, int sm_B = 1);
 bool costreg_bf16x3_depth_supported(int D);
+bool wino_depth_supported(int D);
+bool cost_reg_winograd(int D, int precision);
+int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
+                     int relu, hipStream_t st);
 
 int launch_pair_similarity(const float* feat, const float* rt, PlaneSrc planes, float* sim, int B, int S, int C, int D, int h,
                            int w, hipStream_t st);

@@ -12,6 +12,8 @@ BN_EPS = 1e-5
 
 REG_LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11", "prob")
 REG_TRANSPOSED = ("conv7", "conv9", "conv11")
+REG_WINOGRAD = ("conv0", "conv2", "conv4", "conv6", "prob")      # stride-1 layers: also packed in the F(2x2, 3x3) form (fp32)
+WINO_WIDTHS = (64, 128, 192, 256)
 
 
 def _as_cout_cin_tap(w, transposed):
@@ -116,6 +118,20 @@ def pack_reg_layer(w, scale, shift, transposed):
     return torch.cat([frag, shift.detach().to(torch.float32).cpu().reshape(-1)])
 
 
+WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def pack_reg_layer_wino(w, scale):
+    """A stride-1 CostRegNet2D layer for the F(2x2, 3x3) kernel: U = G w G^T (formed in double precision, rounded once),
+    as A fragments [D/4][4 = patch row i][D/16][64][4 = patch column j] (include/adamvs_hip.h)."""
+    w = (w.detach().to(torch.float64).cpu() * scale.detach().to(torch.float64).cpu().reshape(-1, 1, 1, 1))   # [co][ci][3][3]
+    d = w.shape[0]
+    assert w.shape[1] == d and d % 16 == 0
+    u = torch.einsum("ik,ockl,jl->ijoc", WINO_G, w, WINO_G).to(torch.float32)                               # [i][j][co][ci]
+    # (i, j, tile, co16, kc, k4) -> (kc, i, tile, k4, co16, j): lane = k4*16 + co16
+    return u.reshape(4, 4, d // 16, 16, d // 4, 4).permute(4, 0, 2, 5, 3, 1).contiguous().reshape(-1)
+
+
 def pack_reg_layer_bf16x3(w, scale, shift, transposed):
     """One CostRegNet2D layer for the split-bf16 kernels: 9*D*D floats worth of bf16 fragments
     [hi|lo][tap][cin/32][cout/16][lane][8] (include/adamvs_hip.h) + [D] fp32 bias; same size as the fp32 packing."""
@@ -132,9 +148,10 @@ def pack_reg_layer_bf16x3(w, scale, shift, transposed):
 
 
 def pack_cost_reg_net_2d(sd, pre, precision="fp32"):
-    """All 11 layers of `pre` (e.g. 'DepthNet.0.reg.') from a reference-keyed state dict."""
+    """All 11 layers of `pre` (e.g. 'DepthNet.0.reg.') from a reference-keyed state dict; fp32 at the widths the F(2x2, 3x3)
+    kernel supports: followed by the five stride-1 layers in that form (16*D*D floats each, include/adamvs_hip.h)."""
     pack_layer = pack_reg_layer if precision == "fp32" else pack_reg_layer_bf16x3
-    chunks = []
+    chunks, wino = [], []
     for name in REG_LAYERS:
         if name == "prob":
             w = sd[pre + "prob.weight"]
@@ -153,7 +170,9 @@ def pack_cost_reg_net_2d(sd, pre, precision="fp32"):
             scale = g / torch.sqrt(var + BN_EPS)
             shift = b - mu * scale
         chunks.append(pack_layer(w, scale, shift, transposed))
-    return torch.cat(chunks)
+        if precision == "fp32" and name in REG_WINOGRAD and w.shape[0] in WINO_WIDTHS:
+            wino.append(pack_reg_layer_wino(w, scale))
+    return torch.cat(chunks + wino)
 
 
 FUSE_FIELDS = ("conv1", "gates1", "gates1_b", "cand1", "cand1_b", "conv2", "gates2", "gates2_b",

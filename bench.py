@@ -68,6 +68,8 @@ def algorithmic_work(cfg, B):
             # transposed layers touch 2.25 taps on average instead of 9
             macs -= (hw + hw // 4 + hw // 16) * D * D * 9 * (1 - 2.25 / 9)
             st["costreg_flops"] = B * S * 2 * macs
+            # the stride-1 layers conv0, conv2, conv4, conv6, prob (what the F(2x2, 3x3) kernel executes 16/36 of)
+            st["costreg_stride1_flops"] = B * S * 2 * (2 * hw + hw // 4 + hw // 16 + hw // 64) * D * D * 9
         out.append(st)
     return out
 
@@ -150,6 +152,15 @@ COSTREG_PLAN = (  # (layer, mode 0 s1 / 1 s2 / 2 transposed, relu, input, skip),
     ("prob", 0, 0, "conv11", None))
 
 
+WINO_SLOT = {"conv0": 0, "conv2": 1, "conv4": 2, "conv6": 3, "prob": 4}
+
+
+def winograd_active(D, precision):
+    """csrc/costreg2d.hip::cost_reg_winograd: fp32, a supported width, not switched off."""
+    from ada_mvs_amd import packing
+    return precision in (0, "fp32") and D in packing.WINO_WIDTHS and os.environ.get("ADAMVS_WINOGRAD", "1") != "0"
+
+
 def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=None):
     """CostRegNet2D through the one-layer C-ABI op, one timing mark per launch.  softmax = (planes, S, B): the last layer runs
     with the softmax / max / regression epilogue and (view_weight, pair_depth) is returned instead of the scores."""
@@ -158,6 +169,7 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=
     # fp32: conv7's and conv9's skip additions run in the CONSUMING transposed layer (in2), as adamvs_cost_reg_net_2d issues
     # them (csrc/costreg2d.hip); conv11's, and all of them in bf16x3, in the producing layer's epilogue (skip)
     defer = precision == 0 and os.environ.get("ADAMVS_COSTREG_DEFER_SKIPS", "1") != "0"
+    wino = winograd_active(D, precision)
     pending = None                       # the addend the next layer has to add to its input
     for i, (name, mode, relu, src, skip) in enumerate(COSTREG_PLAN):
         xin, hi, wi = acts[src]
@@ -165,6 +177,15 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=
         sk = acts[skip][0] if skip else None
         give = defer and i + 1 < len(COSTREG_PLAN) and COSTREG_PLAN[i + 1][1] == 2      # only a transposed consumer takes the addend
         in2, pending = pending, (sk if give else None)
+        if mode == 0 and wino:          # the stride-1 layers in the F(2x2, 3x3) form, as adamvs_cost_reg_net_2d issues them
+            ww = wpk[len(COSTREG_PLAN) * LW:][WINO_SLOT[name] * 16 * D * D:(WINO_SLOT[name] + 1) * 16 * D * D]
+            if name == "prob" and softmax is not None:
+                planes_t, S, B = softmax
+                return mark("s%d.costreg.prob+softmax.mode0" % stage, lambda: hip_ops.softmax_max_regress(
+                    hip_ops.conv3x3_dd_wino(xin, ww, wl[9 * D * D:], None, N, D, hi, wi, relu), planes_t, S, B, D, hi, wi))
+            acts[name] = (mark("s%d.costreg.%s.mode0" % (stage, name),
+                               lambda: hip_ops.conv3x3_dd_wino(xin, ww, wl[9 * D * D:], None, N, D, hi, wi, relu)), hi, wi)
+            continue
         if name == "prob" and softmax is not None:
             planes_t, S, B = softmax
             return mark("s%d.costreg.prob+softmax.mode0" % stage,
@@ -377,9 +398,17 @@ class Workload:
         tot_bytes = sum(sum(v for k_, v in w_.items() if k_.endswith("_bytes")) for w_ in work)
         f_mfma = (tot_flops * 3 / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS if split else tot_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS)
         f_hbm = tot_bytes / step_s / 1e9 / HBM_PEAK_GBS
-        return {"step_frac_mfma": f_mfma, "step_frac_hbm": f_hbm, "step_frac": f_hbm if split else f_mfma,
-                "step_bound": "hbm" if split else "mfma (fp32)",
-                "step_algorithmic": {"conv_gflop_per_tile": tot_flops / self.B / 1e9, "gbytes_per_tile": tot_bytes / self.B / 1e9}}
+        out = {"step_frac_mfma": f_mfma, "step_frac_hbm": f_hbm, "step_frac": f_hbm if split else f_mfma,
+               "step_bound": "hbm" if split else "mfma (fp32)",
+               "step_algorithmic": {"conv_gflop_per_tile": tot_flops / self.B / 1e9, "gbytes_per_tile": tot_bytes / self.B / 1e9}}
+        if winograd_active(work[0]["D"], self.precision):
+            # step_frac prices the convolutions as SURVEY.md 8d defines them (direct form); the stride-1 layers of CostRegNet2D
+            # execute 16/36 of those products: the fraction of the matrix peak the step actually keeps busy is the second figure
+            executed = tot_flops - work[0].get("costreg_stride1_flops", 0) * (20.0 / 36.0)
+            out["step_frac_executed"] = executed / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            out["step_note"] = ("step_frac = direct-form conv flops (SURVEY 8d) / step time / fp32 MFMA peak; CostRegNet2D's stride-1 "
+                                "layers run in the F(2x2,3x3) form (16 of 36 products): step_frac_executed counts what is executed")
+        return out
 
     def close(self):
         """Release the graph, the stage workspaces and the features before the next workload is set up."""
@@ -612,12 +641,14 @@ def roofline_of(wl, args, ms_per_step):
         hw0, Dd, N = st["h"] * st["w"], st["D"], (c0["views"] - 1) * Bg
         res = {"conv0": 1, "conv2": 2, "conv4": 4, "conv6": 8, "prob": 1, "prob+softmax": 1}       # linear down-scale of the layer's maps
 
+        wino = winograd_active(Dd, args.precision)
+
         def on_dominant_kernel(layer):
             # the fp32 path sends stride-1 layers of at most 2048 blocks of 8 x 16 pixels to the 2-row kernel
             # k_conv_dd_rows2 (csrc/costreg2d.hip: small_grid_rows2); those launches are not the dominant kernel's
             if layer == "prob+softmax":          # the last layer's own instantiation (softmax epilogue): timed, not part of this kernel's launches
                 return False
-            if split:
+            if split or wino:
                 return True
             e = os.environ.get("ADAMVS_CONV_ROWS2", "")
             if e:
@@ -626,16 +657,22 @@ def roofline_of(wl, args, ms_per_step):
             return -(-(st["w"] // r) // 16) * -(-(st["h"] // r) // 8) * N > 2048
 
         lay = {k: v for k, v in avg.items() if ".costreg." in k and k.endswith("mode0") and on_dominant_kernel(k.split(".")[2])}
-        flops = sum(2.0 * N * (hw0 // res[k.split(".")[2]] ** 2) * Dd * Dd * 9 for k in lay) * (3 if split else 1)
+        direct = sum(2.0 * N * (hw0 // res[k.split(".")[2]] ** 2) * Dd * Dd * 9 for k in lay)
+        # executed flops: three bf16 products per fp32 product (split-bf16); 16 products per 2x2 outputs instead of 36 (F(2x2, 3x3))
+        flops = direct * (3 if split else (16.0 / 36.0 if wino else 1))
         ms = sum(lay.values())
         ach = flops / (ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        kname = ("k_conv_dd_bx3<MT,WM,CONV_S1>, executed bf16 flops = 3 x fp32 products" if split else
+                 "k_conv_wino<4,3>, fp32 F(2x2,3x3): executed flops = 16/36 of the direct convolution's" if wino else "k_conv_dd<MT,WM,CONV_S1>")
         roof = {"kernel": "%s (CostRegNet2D 3x3 stride-1 layers %s, %d launches per step)" % (
-                    "k_conv_dd_bx3<MT,WM,CONV_S1>, executed bf16 flops = 3 x fp32 products" if split else "k_conv_dd<MT,WM,CONV_S1>",
-                    "+".join(k.split(".")[2] for k in lay), len(lay)),
+                    kname, "+".join(k.split(".")[2] for k in lay), len(lay)),
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "launch_ms": ms / len(lay),
                 "flops_per_launch": flops / len(lay), "traffic": None}
+        if wino:        # the same launches priced as the direct convolution they replace (can exceed the matrix peak)
+            roof["direct_equivalent_tflops"] = direct / (ms * 1e-3) / 1e12
+            roof["direct_flops_per_launch"] = direct / len(lay)
         stamp = source_stamp()
         for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
             tj = json.load(open(tpath))       # HBM bytes per launch from committed PMC passes (tools/profile_round.sh)
@@ -645,7 +682,7 @@ def roofline_of(wl, args, ms_per_step):
                 roof["traffic_note"] = "%s was measured on another build (stamp %s, this build %s): not quoted" % (
                     os.path.basename(tpath), tj.get("source_stamp"), stamp)
                 continue
-            k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_dd<3, 4, 0, 4, false, false>") in k]
+            k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_wino<4, 3>" if wino else "k_conv_dd<3, 4, 0, 4, false, false>") in k]
             if k0:
                 roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
                 roof["traffic_note"] = ("bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), %s, "

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 10
+#define ADAMVS_ABI_VERSION 11
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -80,7 +80,12 @@ int adamvs_pair_similarity(const float* feat, const float* rt, const float* plan
  * (ConvTranspose2d layers: W[cin][cout][tap]) followed by D bias floats (folded BN shift,
  * or the conv bias for `prob`).  D in {16,32,48,64,96,128,192,256}; h, w multiples of 8.
  *
- * precision ADAMVS_PRECISION_FP32 (0): exact fp32 MFMA.  ADAMVS_PRECISION_BF16X3 (1): bf16 MFMA with every
+ * fp32 with D in {64,128,192,256}: the 11 blocks are followed by the five stride-1 layers (conv0, conv2, conv4, conv6, prob)
+ * in the minimal-filtering form F(2x2, 3x3), 16*D*D floats each, laid out as adamvs_conv3x3_dd_wino takes them; those
+ * layers run on that kernel (fp32 throughout, 16 products instead of 36 per 2x2 outputs and channel pair; environment
+ * ADAMVS_WINOGRAD=0: on the direct kernel).  ada-mvs_amd/packing.py::pack_cost_reg_net_2d produces exactly this.
+ *
+ * precision ADAMVS_PRECISION_FP32 (0): fp32 MFMA.  ADAMVS_PRECISION_BF16X3 (1): bf16 MFMA with every
  * operand split into two bf16 halves, a.b ~ a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulation (maps agree
  * with the fp32 path to ~1e-5); D must then be a multiple of 32 and each layer's 9*D*D-float block of wpk holds
  * bf16 fragments instead: [hi|lo][tap][cin/32][cout/16][lane][8] with element j of lane l =
@@ -102,6 +107,15 @@ int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N
  * adamvs_cost_reg_net_2d uses in2 in fp32 and skip in bf16x3; the result is the same fp32 sum either way. */
 int adamvs_conv3x3_dd(const float* in, const float* in2, const float* wpk, const float* bias, const float* skip, float* out,
                       int N, int D, int hi, int wi, int mode, int relu, int precision, void* stream);
+
+/* A stride-1 layer of CostRegNet2D (conv0, conv2, conv4, conv6, prob: models/adamvs.py:205-227, ConvBnReLU.forward
+ * models/module.py:254-261) in the minimal-filtering form F(2x2, 3x3): 16 products per 2x2 output tile and channel pair
+ * instead of 36, fp32 throughout (results agree with adamvs_conv3x3_dd mode 0 to a few ulp of the accumulated sums).
+ * wpk [D/4][4][D/16][64][4] = the transformed filters U = G w G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], BN scale folded
+ * in) as MFMA A fragments: element j of lane l of fragment (k-step kc, patch row i, channel tile) =
+ * U[i][j][cout = 16*tile + (l&15)][cin = 4*kc + (l>>4)].  D in {64, 128, 192, 256}.  in, out, skip, bias, relu as above. */
+int adamvs_conv3x3_dd_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
+                           int h, int w, int relu, void* stream);
 
 /* models/adamvs.py:481-486 + module.py:617-625: softmax over D, its maximum (view
  * weight) and the expectation of the hypothesis planes (pair depth).

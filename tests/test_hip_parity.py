@@ -221,6 +221,32 @@ def test_cost_reg_net_2d_widths(hip, O, D, h, w):
     assert rel_l1(out, ref) < OP_TOL
 
 
+@pytest.mark.parametrize("N,D,h,w,relu,skip", [(1, 192, 6, 32, 1, False), (2, 192, 13, 45, 0, False), (2, 192, 7, 70, 1, True),
+                                               (1, 192, 1, 1, 1, False), (1, 64, 8, 40, 1, False), (1, 128, 13, 33, 0, True),
+                                               (1, 256, 6, 32, 0, False), (3, 192, 24, 48, 1, False)])
+def test_conv3x3_dd_winograd(hip, N, D, h, w, relu, skip):
+    """A stride-1 CostRegNet2D layer in the F(2x2, 3x3) form (csrc/costreg2d_wino.hip) against a float64 convolution
+    (ConvBnReLU.forward, reference models/module.py:254-261, BN folded) and against the direct kernel: full and ragged
+    blocks of 6 x 32 pixels, maps smaller than one block, every supported width."""
+    from ada_mvs_amd import packing
+    g = torch.Generator().manual_seed(N * 1000 + D + h + w)
+    x = torch.randn(N, D, h, w, generator=g)
+    wt = torch.randn(D, D, 3, 3, generator=g) / (3 * D ** 0.5)
+    scale, shift = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    sk = torch.randn(N, h * w, D, generator=g) if skip else None
+    ref = torch.nn.functional.conv2d(x.double(), (wt * scale.reshape(-1, 1, 1, 1)).double(), shift.double(), padding=1)
+    ref = torch.relu(ref) if relu else ref
+    if skip:
+        ref = ref + sk.double().reshape(N, h, w, D).permute(0, 3, 1, 2)
+    x_cl = dev(x.permute(0, 2, 3, 1).reshape(N, h * w, D).contiguous())
+    pk = dev(packing.pack_reg_layer(wt, scale, shift, False))
+    out = hip.conv3x3_dd_wino(x_cl, dev(packing.pack_reg_layer_wino(wt, scale)), dev(shift), dev(sk) if skip else None, N, D, h, w, relu)
+    direct = hip.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], dev(sk) if skip else None, N, D, h, w, 0, relu)
+    back = lambda y: y.cpu().double().reshape(N, h, w, D).permute(0, 3, 1, 2)
+    assert rel_l1(back(out), ref) < 2e-6                    # measured 2e-7 ... 5e-7 (the direct kernel: 2e-7 ... 7e-7)
+    assert rel_l1(back(out), back(direct)) < 2e-6
+
+
 @pytest.mark.parametrize("D,h,w", [(32, 16, 24), (64, 8, 16), (192, 8, 16), (256, 8, 8)])
 def test_cost_reg_net_2d_bf16x3(hip, O, D, h, w):
     """Split-bf16 MFMA path (three bf16 MFMAs per product, fp32 accumulate) against the fp32 oracle."""

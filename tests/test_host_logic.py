@@ -110,6 +110,40 @@ def test_split_bf16_packing_layout():
     assert float((hi.float() + lo.float() - ws).abs().max() / ws.abs().max()) < 2 ** -15
 
 
+def test_winograd_packing_evaluates_the_convolution():
+    """pack_reg_layer_wino: U = G w G^T in the fragment order of include/adamvs_hip.h; evaluating Y = At[(U . V)]A with
+    V = Bt d B from the PACKED array reproduces the 3x3 convolution (the arithmetic of csrc/costreg2d_wino.hip, on the CPU)."""
+    D, h, w = 64, 6, 8
+    g = torch.Generator().manual_seed(5)
+    wt = torch.randn(D, D, 3, 3, generator=g, dtype=torch.float64)
+    scale = torch.rand(D, generator=g, dtype=torch.float64) + 0.5
+    x = torch.randn(1, D, h, w, generator=g, dtype=torch.float64)
+    pk = packing.pack_reg_layer_wino(wt.float(), scale.float())
+    assert pk.numel() == 16 * D * D
+    frag = pk.reshape(D // 4, 4, D // 16, 64, 4).double()                 # [kc][i][tile][lane][j]
+    u = torch.zeros(4, 4, D, D, dtype=torch.float64)                        # [i][j][co][ci]
+    for lane in range(64):
+        co16, k4 = lane & 15, lane >> 4
+        u[:, :, co16::16, k4::4] = frag[:, :, :, lane, :].permute(1, 3, 2, 0)   # [i][j][tile][kc]
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    xp = torch.nn.functional.pad(x[0], (1, 1, 1, 1))
+    out = torch.zeros(D, h, w, dtype=torch.float64)
+    for ty in range(h // 2):
+        for tx in range(w // 2):
+            d = xp[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]                 # [ci][4][4]
+            v = torch.einsum("ik,ckl,jl->ijc", Bt, d, Bt)
+            m = torch.einsum("ijoc,ijc->ijo", u, v)
+            out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = torch.einsum("ai,ijo,bj->oab", At, m, At)
+    ref = torch.nn.functional.conv2d(x, wt * scale.reshape(-1, 1, 1, 1), padding=1)[0]
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-6         # U is rounded to fp32 once
+    # a network blob carries the five stride-1 layers in this form behind the 11 direct blocks (fp32, supported widths only)
+    from ada_mvs_amd.models.adamvs import CostRegNet2D
+    sd = synth.seeded_state_dict(CostRegNet2D(64), 0)
+    assert packing.pack_cost_reg_net_2d(sd, "").numel() == 11 * (9 * 64 * 64 + 64) + 5 * 16 * 64 * 64
+    assert packing.pack_cost_reg_net_2d(sd, "", "bf16x3").numel() == 11 * (9 * 64 * 64 + 64)
+
+
 def test_packed_network_sizes_match_the_header():
     m = Infer_AdaMVSNet(48, [48, 32, 8], [4, 2, 1], False, [8, 8, 8])
     sd = synth.seeded_state_dict(m, 0)
