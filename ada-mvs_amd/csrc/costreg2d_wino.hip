@@ -25,6 +25,13 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "persistent.h"
+
+// Timing builds only (tools/build_variant.py <name> -DWINO_EXP=<bits>; results are wrong): 1 no epilogue, 2 no weight loads
+// in the loop, 4 no input transform, 8 no window fill / barrier, 16 the chunk loop twice.  DESIGN.md section 4 quotes what each part costs.
+#ifndef WINO_EXP
+#define WINO_EXP 0
+#endif
 
 namespace adamvs {
 
@@ -51,8 +58,18 @@ struct WinoGeom {
   static_assert(PLANE >= NPIX, "plane pitch");
 };
 
+// vmcnt(n) with the other counters left alone (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8])
+template <int N> __device__ __forceinline__ void wait_vmem_but() {
+  static_assert(N >= 0 && N < 64, "vmcnt is six bits");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// Persistent: the grid is the resident capacity (one workgroup per CU) and workgroup i walks tiles i, i + grid, ...;
+// tile = ((image * tiles_y + ty) * tiles_x + tx) * groups + channel group.  The first window chunk and the first three
+// fragment sets of the NEXT tile are requested before the epilogue of the current one, so what a tile start exposes is
+// one LDS fill and one barrier instead of a round trip to memory behind the per-lane address arithmetic.
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, int groups) {
+__global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int groups, unsigned mgroups) {
   using G = WinoGeom<MT, NT>;
   constexpr int KC = G::KC, KS = G::KS, LC = G::LC, NPIX = G::NPIX, PLANE = G::PLANE, GP = G::GP, CHUNK = G::CHUNK;
   constexpr int NITEMS = NPIX * (KC / 4), NITA = (NITEMS + 255) / 256;
@@ -60,21 +77,18 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, int groups) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = patch row i
   const int p = lane & 15, q = lane >> 4;
   const int D = a.D, NTILES = D / 16, NC = D / KC;
-  const int cg = blockIdx.x % groups, bx = blockIdx.x / groups, by = blockIdx.y, n = blockIdx.z;
-  const int r0 = by * 2 * NT, c0 = bx * 32;                  // block origin (output pixels); the window starts one pixel up / left
 
-  // ---- per-lane constants
-  // window fill: item = (pixel of the window, group of 4 channels of the chunk); out-of-image pixels read as zero
-  const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.h + (r0 - 1)) * a.w + (c0 - 1)) * (long)D * 4);
-  unsigned xoff[NITA], xlds[NITA];
+  // ---- per-lane constants (tile-independent)
+  // window fill: item = (pixel of the window, group of 4 channels of the chunk)
+  unsigned goff[NITA], xlds[NITA], wrc[NITA];                // wrc = window row | window column << 16
 #pragma unroll
   for (int it = 0; it < NITA; ++it) {
     const int i = min(tid + it * 256, NITEMS - 1);           // surplus lanes repeat the last item
     const int g = i % (KC / 4), pp = i / (KC / 4), r = pp / LC, c = pp % LC;
-    const bool ok = (unsigned)(r0 - 1 + r) < (unsigned)a.h && (unsigned)(c0 - 1 + c) < (unsigned)a.w;
-    xoff[it] = ok ? (unsigned)(((r * a.w + c) * D + 4 * g) * 4) : BUF_OOB;
+    goff[it] = (unsigned)(((r * a.w + c) * D + 4 * g) * 4);
     xlds[it] = (unsigned)((g * GP + pp) * 4);
-    pin(xoff[it]); pin(xlds[it]);
+    wrc[it] = (unsigned)(r | (c << 16));
+    pin(goff[it]); pin(xlds[it]); pin(wrc[it]);
   }
   // raw patch rows of the wave: T = rowA + sgn * rowB  (i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
   const int rowA = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
@@ -88,26 +102,60 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, int groups) {
   const buf_rsrc rw = make_rsrc(a.wpk);
   unsigned woff = (unsigned)(lane * 16);
   pin(woff);
+  // epilogue: wave (oa, ob) stores output pixel (2 ty + oa, 2 tx + ob) of every 2 x 2 tile
+  const int oa = wave >> 1, ob = wave & 1;
+  const float os = oa ? -1.0f : 1.0f;
+  unsigned ooff = (unsigned)(((oa * a.w + 2 * p + ob) * D + 4 * q) * 4);        // + the tile's origin and the tile row
+  pin(ooff);
+
+  // ---- the tile in flight (scalars) and its window offsets
+  struct Tile { int n, r0, c0, cg; };
+  auto decode = [&](int t) {
+    int n, tx, ty;
+    tile_coords(tg, t, n, tx, ty);                           // tx runs over (block column, channel group)
+    const int bx = groups == 1 ? tx : (int)__umulhi((unsigned)tx, mgroups);
+    return Tile{n, ty * 2 * NT, bx * 32, tx - bx * groups};
+  };
+  buf_rsrc rx;
+  unsigned xoff[NITA];
+  auto window_of = [&](const Tile& t) {                      // out-of-image pixels read as zero (BUF_OOB)
+    rx = make_rsrc((const char*)a.in + (((long)t.n * a.h + (t.r0 - 1)) * a.w + (t.c0 - 1)) * (long)D * 4);
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+      const bool ok = (unsigned)(t.r0 - 1 + (int)(wrc[it] & 0xffff)) < (unsigned)a.h && (unsigned)(t.c0 - 1 + (int)(wrc[it] >> 16)) < (unsigned)a.w;
+      xoff[it] = ok ? goff[it] : BUF_OOB;
+    }
+  };
 
   f32x4 acc[4][MT][NT];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[j][mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 xs[NITA];
+  f32x4 wf0[MT], wf1[MT], wf2[MT], wf3[MT];                  // four named fragment sets (below)
+  f32x4 bias4[MT];
+  int cg = 0;                                                // channel group of the fragments being requested
 
   auto load_w = [&](f32x4 (&wf)[MT], int ks) {               // ks: global k-step
+    if ((WINO_EXP & 2) && ks > 3) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const unsigned frag = (unsigned)(((ks * 4 + wave) * NTILES + cg * MT + mt) * 1024);                 // uniform
       wf[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, frag, 0));
     }
   };
-  auto load_x = [&](f32x4 (&st)[NITA], int ch) {
+  auto load_x = [&](int ch) {
 #pragma unroll
     for (int it = 0; it < NITA; ++it)
-      st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+      xs[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+  };
+  auto load_bias = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bias4[mt] = *(const f32x4*)(a.bias + (cg * MT + mt) * 16 + 4 * q);
+  };
+  auto store_items = [&](int buf, int i0, int i1) {          // window items [i0, i1) of the staged chunk -> buffer `buf`
+#pragma unroll
+    for (int it = i0; it < i1; ++it) {
+      float* dl = (float*)((char*)lds + xlds[it]) + buf * CHUNK;
+      dl[0] = xs[it].x; dl[PLANE] = xs[it].y; dl[2 * PLANE] = xs[it].z; dl[3 * PLANE] = xs[it].w;
+    }
   };
   // The raw patch rows of tile row t, k-step ks of the chunk in buffer `buf`: four ds_read_b64 at pinned base + immediate
   // (the halves of a row go through two separately pinned bases: merged into one ds_read2_b64, whose offset field is 8 bits,
@@ -118,124 +166,163 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, int groups) {
     r.a01 = *(const f32x2*)((const char*)lds + pa + off); r.a23 = *(const f32x2*)((const char*)lds + pa2 + off);
     r.b01 = *(const f32x2*)((const char*)lds + pb + off); r.b23 = *(const f32x2*)((const char*)lds + pb2 + off);
   };
-  // one tile row of one k-step: 4 packed vector instructions, 4 MT MFMAs
-  auto tile_row = [&](const f32x4 (&wf)[MT], const Raw& r, int t) {
+  // one tile row of one k-step: 4 packed vector instructions, 4 MT MFMAs.  FIRST: the first k-step of a tile starts the sums
+  // (C = 0 as an inline constant: no pass over the 192 accumulator registers to clear them)
+  auto tile_row = [&](const f32x4 (&wf)[MT], const Raw& r, int t, auto firstc) {
+    constexpr bool FIRST = decltype(firstc)::value;
     // T = A + sgn B; (v0, v3) = (t0 - t2, t1 - t3); (v1, v2) = (t2 + t1, t2 - t1)
-    const f32x2 t01 = __builtin_elementwise_fma(sgn2, r.b01, r.a01), t23 = __builtin_elementwise_fma(sgn2, r.b23, r.a23);
-    const f32x2 v03 = t01 - t23;
-    const f32x2 v12 = __builtin_elementwise_fma(__builtin_shufflevector(t01, t01, 1, 1), pm, __builtin_shufflevector(t23, t23, 0, 0));
+    f32x2 t01 = __builtin_elementwise_fma(sgn2, r.b01, r.a01), t23 = __builtin_elementwise_fma(sgn2, r.b23, r.a23);
+    f32x2 v03 = t01 - t23;
+    f32x2 v12 = __builtin_elementwise_fma(__builtin_shufflevector(t01, t01, 1, 1), pm, __builtin_shufflevector(t23, t23, 0, 0));
+    if (WINO_EXP & 4) { v03 = r.a01; v12 = r.b23; }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      acc[0][mt][t] = mfma16(wf[mt].x, v03.x, acc[0][mt][t]);
-      acc[1][mt][t] = mfma16(wf[mt].y, v12.x, acc[1][mt][t]);
-      acc[2][mt][t] = mfma16(wf[mt].z, v12.y, acc[2][mt][t]);
-      acc[3][mt][t] = mfma16(wf[mt].w, v03.y, acc[3][mt][t]);
-    }
-  };
-  f32x4 xs[NITA];
-  auto store_items = [&](int buf, int i0, int i1) {          // window items [i0, i1) of the staged chunk -> buffer `buf`
-#pragma unroll
-    for (int it = i0; it < i1; ++it) {
-      float* dl = (float*)((char*)lds + xlds[it]) + buf * CHUNK;
-      dl[0] = xs[it].x; dl[PLANE] = xs[it].y; dl[2 * PLANE] = xs[it].z; dl[3 * PLANE] = xs[it].w;
+      acc[0][mt][t] = mfma16(wf[mt].x, v03.x, FIRST ? zero : acc[0][mt][t]);
+      acc[1][mt][t] = mfma16(wf[mt].y, v12.x, FIRST ? zero : acc[1][mt][t]);
+      acc[2][mt][t] = mfma16(wf[mt].z, v12.y, FIRST ? zero : acc[2][mt][t]);
+      acc[3][mt][t] = mfma16(wf[mt].w, v03.y, FIRST ? zero : acc[3][mt][t]);
     }
   };
   // one k-step (4 input channels): the raw rows of the NEXT tile row (or of the next k-step's first) are requested before the
   // MFMAs of the current one -- with one wave per SIMD nothing else hides the LDS latency.  FILL: the staged chunk c+1 goes to the
   // other buffer between the tile rows (LDS stores issue next to the MFMAs), then chunk c+2 is requested.
-  auto kstep = [&](const f32x4 (&wf)[MT], Raw& r, int buf, int ks, bool fill, int next_ch) {
+  auto kstep = [&](const f32x4 (&wf)[MT], Raw& r, int buf, int ks, bool fill, int next_ch, auto firstc) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       Raw nx;
       const bool more = t + 1 < NT || ks + 1 < KS;
       if (more) read_raw(nx, buf, t + 1 < NT ? ks : ks + 1, t + 1 < NT ? t + 1 : 0);
       __builtin_amdgcn_sched_barrier(0);        // (left alone, the scheduler hoists the next transforms above this tile row's MFMAs
-      tile_row(wf, r, t);                       //  and waits for their LDS reads right after issuing them)
-      if (fill) store_items(buf ^ 1, t * NITA / NT, (t + 1) * NITA / NT);
+      tile_row(wf, r, t, firstc);               //  and waits for their LDS reads right after issuing them)
+      if (fill && !(WINO_EXP & 8)) store_items(buf ^ 1, t * NITA / NT, (t + 1) * NITA / NT);
       __builtin_amdgcn_sched_barrier(0);
       if (more) r = nx;
     }
-    if (fill) load_x(xs, next_ch);
+    if (fill && !(WINO_EXP & 8)) load_x(next_ch);
   };
-
   // Four named fragment sets: k-step ks of a chunk uses set ks, and requests the fragments of three k-steps ahead into the set
-  // freed by the previous k-step (the L2 latency under load is longer than one k-step's 48 MFMAs).  Past the last k-step /
-  // chunk the requests repeat the last one, so that the number of loads in flight -- what the waits count -- does not change.
-  const int last_ks = NC * KS - 1, last_ch = (NC - 1) * KC;
-  f32x4 wf0[MT], wf1[MT], wf2[MT], wf3[MT];
-  f32x4 bias4[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) bias4[mt] = *(const f32x4*)(a.bias + (cg * MT + mt) * 16 + 4 * q);
-  load_x(xs, 0);
-  wait_vmem_all();
-  store_items(0, 0, NITA);
-  load_x(xs, min(KC, last_ch));
-  load_w(wf0, 0);
-  load_w(wf1, min(1, last_ks));
-  load_w(wf2, min(2, last_ks));
-  __syncthreads();
+  // freed by the previous k-step (the L2 latency under load is longer than one k-step's 48 MFMAs).  Past the last chunk the
+  // window requests repeat the last one, so that the number of loads in flight -- what the waits count -- does not change.
+  const int last_ks = NC * KS - 1;
   static_assert(KS == 4, "four k-steps per chunk, one per fragment set");
   // chunk c from buffer CUR (a compile-time constant: every LDS address of the loop is a pinned register + an immediate)
-  auto chunk = [&](int c, auto curc) {
+  auto chunk = [&](int c, auto curc, auto firstc, bool fill, int next_ch) {
     constexpr int CUR = decltype(curc)::value;
     // every wave is past chunk c-1 (the barrier that ended it): its buffer takes chunk c+1 during k-step 0
     Raw r;
     read_raw(r, CUR, 0, 0);
     load_w(wf3, min(c * KS + 3, last_ks));
-    kstep(wf0, r, CUR, 0, true, min((c + 2) * KC, last_ch));      // (the last chunk stages a repeat: never read)
-    load_w(wf0, min(c * KS + 4, last_ks));
-    kstep(wf1, r, CUR, 1, false, 0);
+    kstep(wf0, r, CUR, 0, fill, next_ch, firstc);
+    load_w(wf0, min(c * KS + 4, last_ks));                   // (the next tile's first sets are requested below)
+    kstep(wf1, r, CUR, 1, false, 0, std::false_type{});
     load_w(wf1, min(c * KS + 5, last_ks));
-    kstep(wf2, r, CUR, 2, false, 0);
+    kstep(wf2, r, CUR, 2, false, 0, std::false_type{});
     load_w(wf2, min(c * KS + 6, last_ks));
-    kstep(wf3, r, CUR, 3, false, 0);
-    __syncthreads();
+    kstep(wf3, r, CUR, 3, false, 0, std::false_type{});
+    if (!(WINO_EXP & 8)) __syncthreads();
   };
-  for (int c = 0; c < NC; c += 2) {                          // NC is even for every supported D
-    chunk(c, std::integral_constant<int, 0>{});
-    chunk(c + 1, std::integral_constant<int, 1>{});
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) drain(acc[j][mt][t]);
 
-  // ---- epilogue: rows meet through LDS, one tile row per round; wave (a, b) = output pixel (2 ty + a, 2 tx + b)
-  const int oa = wave >> 1, ob = wave & 1;
-  const float os = oa ? -1.0f : 1.0f;
-  const buf_rsrc ro = make_rsrc((char*)a.out + (long)n * a.h * a.w * (long)D * 4);
-  const buf_rsrc rk = make_rsrc((const char*)(a.skip ? a.skip : a.out) + (long)n * a.h * a.w * (long)D * 4);
-  f32x4* zl = (f32x4*)lds;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t) __syncthreads();                                  // the previous round's readers are done
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      zl[((wave * 2 + 0) * MT + mt) * 64 + lane] = (acc[0][mt][t] + acc[1][mt][t]) + acc[2][mt][t];
-      zl[((wave * 2 + 1) * MT + mt) * 64 + lane] = (acc[1][mt][t] - acc[2][mt][t]) - acc[3][mt][t];
-    }
+  // ---- tile loop
+  int tile = blockIdx.x;
+  Tile cur = decode(tile);
+  window_of(cur);
+  cg = cur.cg;
+  load_x(0);
+  load_w(wf0, 0);
+  load_w(wf1, min(1, last_ks));
+  load_w(wf2, min(2, last_ks));
+  wait_vmem_all();
+  while (true) {
+    const int next = tile + (int)gridDim.x;
+    const bool more = next < tg.ntiles;
+    // here: chunk 0 of `cur` has arrived in xs, nothing reads LDS
+    store_items(0, 0, NITA);
+    load_x(KC);
     __syncthreads();
-    const int oy = r0 + 2 * t + oa, ox = c0 + 2 * p + ob;
-    const unsigned obase = (oy < a.h && ox < a.w) ? (unsigned)(((oy * a.w + ox) * D + cg * MT * 16 + 4 * q) * 4) : BUF_OOB;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 z0 = zl[(((oa + 0) * 2 + ob) * MT + mt) * 64 + lane];
-      const f32x4 z1 = zl[(((oa + 1) * 2 + ob) * MT + mt) * 64 + lane];
-      const f32x4 z2 = zl[(((oa + 2) * 2 + ob) * MT + mt) * 64 + lane];
-      f32x4 v = z0 + os * (z1 + z2) + bias4[mt];
-      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (a.skip) v += buf_load4(rk, obase == BUF_OOB ? BUF_OOB : obase + mt * 64);
-      buf_store4(ro, obase == BUF_OOB ? BUF_OOB : obase + mt * 64, v);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[j][mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rep = 0; rep < ((WINO_EXP & 16) ? 2 : 1); ++rep)  // (timing build 16: the chunk loop twice)
+    for (int c = 0; c < NC - 2; c += 2) {                    // NC is even (>= 4) for every supported D
+      chunk(c, std::integral_constant<int, 0>{}, std::false_type{}, true, (c + 2) * KC);
+      chunk(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, true, (c + 3) * KC);
     }
+    // the last two chunks: the window request of chunk NC-2 is the NEXT tile's first chunk (a chunk and the epilogue ahead of
+    // its use; it stays in registers: the buffers are the epilogue's), chunk NC-1 stages and requests nothing
+    const Tile done = cur;
+    if (more) {
+      cur = decode(next);
+      window_of(cur);
+    }
+    chunk(NC - 2, std::integral_constant<int, 0>{}, std::false_type{}, true, 0);
+    chunk(NC - 1, std::integral_constant<int, 1>{}, std::false_type{}, false, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) drain(acc[j][mt][0]);   // (tile row 0 is read first; tools/mfma_hazard_lint.py checks the rest)
+
+    // the next tile's first fragment sets fly during the epilogue
+    if (more) {
+      cg = cur.cg;
+      load_w(wf0, 0);
+      load_w(wf1, min(1, last_ks));
+      load_w(wf2, min(2, last_ks));
+    }
+    cg = done.cg;
+    load_bias();
+    cg = cur.cg;
+    // ---- epilogue of `done`: the four rows meet through LDS, one tile row per round
+    if (!((WINO_EXP & 1) && a.relu != 12345)) {
+      const long img = (long)done.n * a.h * a.w * (long)D * 4;
+      const buf_rsrc ro = make_rsrc((char*)a.out + img);
+      const buf_rsrc rk = make_rsrc((const char*)(a.skip ? a.skip : a.out) + img);
+      f32x4* zl = (f32x4*)lds;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t) __syncthreads();                                // the previous round's readers are done
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          zl[((wave * 2 + 0) * MT + mt) * 64 + lane] = (acc[0][mt][t] + acc[1][mt][t]) + acc[2][mt][t];
+          zl[((wave * 2 + 1) * MT + mt) * 64 + lane] = (acc[1][mt][t] - acc[2][mt][t]) - acc[3][mt][t];
+        }
+        __syncthreads();
+        const int oy = done.r0 + 2 * t + oa, ox = done.c0 + 2 * p + ob;
+        const unsigned obase = (oy < a.h && ox < a.w)
+            ? ooff + (unsigned)((((done.r0 + 2 * t) * a.w + done.c0) * D + done.cg * MT * 16) * 4) : BUF_OOB;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 z0 = zl[(((oa + 0) * 2 + ob) * MT + mt) * 64 + lane];
+          const f32x4 z1 = zl[(((oa + 1) * 2 + ob) * MT + mt) * 64 + lane];
+          const f32x4 z2 = zl[(((oa + 2) * 2 + ob) * MT + mt) * 64 + lane];
+          f32x4 v = z0 + os * (z1 + z2) + bias4[mt];
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (a.skip) v += buf_load4(rk, obase == BUF_OOB ? BUF_OOB : obase + mt * 64);
+          buf_store4(ro, obase == BUF_OOB ? BUF_OOB : obase + mt * 64, v);
+        }
+      }
+    }
+    if (!more) break;
+    tile = next;
+    // the window chunk and the fragments were requested BEFORE the epilogue's NT * MT stores (vmcnt retires in order):
+    // wait for them, not for the stores.  With a skip operand its loads were waited for already.
+    wait_vmem_but<NT * MT>();                                // (the bias loads, younger still, were consumed by the epilogue)
+    __syncthreads();                                         // the epilogue's LDS readers are done: the buffers are free
   }
 }
 
 template <int MT, int NT>
 static int launch_wino_cfg(const WinoArgs& a, int N, hipStream_t st) {
   const int groups = a.D / (16 * MT);
-  hipLaunchKernelGGL((k_conv_wino<MT, NT>), dim3(groups * cdiv(a.w, 32), cdiv(a.h, 2 * NT), N), dim3(256), 0, st, a, groups);
+  auto kern = k_conv_wino<MT, NT>;
+  static const int capacity = resident_blocks(kern, 256, 0);       // once per instantiation, thread-safely (magic static)
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, groups * cdiv(a.w, 32), cdiv(a.h, 2 * NT), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a, tg, groups, (unsigned)(((1ull << 32) + groups - 1) / groups));
   ADAMVS_CHECK_LAUNCH("conv_wino");
   return 0;
 }
