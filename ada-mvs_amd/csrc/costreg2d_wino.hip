@@ -240,14 +240,11 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
     store_items(0, 0, NITA);
     load_x(KC);
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[j][mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the first k-step of a tile starts the sums (C = 0 as an inline constant: no pass over the 192 accumulator registers)
+    chunk(0, std::integral_constant<int, 0>{}, std::true_type{}, true, 2 * KC);
+    chunk(1, std::integral_constant<int, 1>{}, std::false_type{}, true, 3 * KC);
     for (int rep = 0; rep < ((WINO_EXP & 16) ? 2 : 1); ++rep)  // (timing build 16: the chunk loop twice)
-    for (int c = 0; c < NC - 2; c += 2) {                    // NC is even (>= 4) for every supported D
+    for (int c = 2; c < NC - 2; c += 2) {                    // NC is even (>= 4) for every supported D
       chunk(c, std::integral_constant<int, 0>{}, std::false_type{}, true, (c + 2) * KC);
       chunk(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, true, (c + 3) * KC);
     }
