@@ -295,7 +295,7 @@ class Infer_AdaMVSNet(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def set_precision(self, precision):
-        """"fp32": exact fp32 MFMA everywhere (default).  "bf16x3": CostRegNet2D, conv1 and the ConvGRU convolutions
+        """"fp32": fp32 MFMA everywhere (default; CostRegNet2D's stride-1 layers in the F(2x2, 3x3) form at D in {64,128,192,256}).  "bf16x3": CostRegNet2D, conv1 and the ConvGRU convolutions
         on the bf16 matrix cores with split operands (hi + lo bf16, three MFMAs per product), fp32 accumulation --
         agrees with fp32 to ~1e-5."""
         assert precision in _PRECISIONS

@@ -179,12 +179,12 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=
         in2, pending = pending, (sk if give else None)
         if mode == 0 and wino:          # the stride-1 layers in the F(2x2, 3x3) form, as adamvs_cost_reg_net_2d issues them
             ww = wpk[len(COSTREG_PLAN) * LW:][WINO_SLOT[name] * 16 * D * D:(WINO_SLOT[name] + 1) * 16 * D * D]
-            if name == "prob" and softmax is not None:
-                planes_t, S, B = softmax
-                return mark("s%d.costreg.prob+softmax.mode0" % stage, lambda: hip_ops.softmax_max_regress(
-                    hip_ops.conv3x3_dd_wino(xin, ww, wl[9 * D * D:], None, N, D, hi, wi, relu), planes_t, S, B, D, hi, wi))
             acts[name] = (mark("s%d.costreg.%s.mode0" % (stage, name),
                                lambda: hip_ops.conv3x3_dd_wino(xin, ww, wl[9 * D * D:], None, N, D, hi, wi, relu)), hi, wi)
+            if name == "prob" and softmax is not None:          # the scores go through k_softmax_regress (its own launch)
+                planes_t, S, B = softmax
+                return mark("s%d.costreg.softmax.launch" % stage,
+                            lambda: hip_ops.softmax_max_regress(acts["prob"][0], planes_t, S, B, D, hi, wi))
             continue
         if name == "prob" and softmax is not None:
             planes_t, S, B = softmax
@@ -481,7 +481,7 @@ def main():
                          "per hypothesis plane and out-of-bounds warps)")
     ap.add_argument("--groups", type=int, default=1, help="independent tile groups run concurrently on separate HIP streams")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
-                    help="fp32: exact fp32 MFMA (the cfg2 headline); bf16x3: split-bf16 MFMA for the convolutions (~1e-5 of fp32)")
+                    help="fp32: fp32 MFMA, stride-1 CostRegNet2D layers in the F(2x2,3x3) form (the cfg2 headline); bf16x3: split-bf16 MFMA for the convolutions (~1e-5 of fp32)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
