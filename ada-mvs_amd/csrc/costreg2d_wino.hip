@@ -28,7 +28,7 @@
 #include "persistent.h"
 
 // Timing builds only (tools/build_variant.py <name> -DWINO_EXP=<bits>; results are wrong): 1 no epilogue, 2 no weight loads
-// in the loop, 4 no input transform, 8 no window fill / barrier, 16 the chunk loop twice.  DESIGN.md section 4 quotes what each part costs.
+// in the loop, 4 no input transform, 8 no window fill / barrier (32 barrier only, 64 LDS stores only, 128 window loads only), 16 the chunk loop twice.  DESIGN.md section 4 quotes what each part costs.
 #ifndef WINO_EXP
 #define WINO_EXP 0
 #endif
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
       if (more) read_raw(nx, buf, t + 1 < NT ? ks : ks + 1, t + 1 < NT ? t + 1 : 0);
       __builtin_amdgcn_sched_barrier(0);        // (left alone, the scheduler hoists the next transforms above this tile row's MFMAs
       tile_row(wf, r, t, firstc);               //  and waits for their LDS reads right after issuing them)
-      if (fill && !(WINO_EXP & 8)) store_items(buf ^ 1, t * NITA / NT, (t + 1) * NITA / NT);
+      if (fill && !(WINO_EXP & (8 | 64))) store_items(buf ^ 1, t * NITA / NT, (t + 1) * NITA / NT);
       __builtin_amdgcn_sched_barrier(0);
       if (more) r = nx;
     }
-    if (fill && !(WINO_EXP & 8)) load_x(next_ch);
+    if (fill && !(WINO_EXP & (8 | 128))) load_x(next_ch);
   };
   // Four named fragment sets: k-step ks of a chunk uses set ks, and requests the fragments of three k-steps ahead into the set
   // freed by the previous k-step (the L2 latency under load is longer than one k-step's 48 MFMAs).  Past the last chunk the
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
     kstep(wf2, r, CUR, 2, false, 0, std::false_type{});
     load_w(wf2, min(c * KS + 6, last_ks));
     kstep(wf3, r, CUR, 3, false, 0, std::false_type{});
-    if (!(WINO_EXP & 8)) __syncthreads();
+    if (!(WINO_EXP & (8 | 32))) __syncthreads();
   };
 
   // ---- tile loop
