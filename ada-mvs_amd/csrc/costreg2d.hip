@@ -37,6 +37,11 @@ struct ConvDDArgs {
   const float* in2;    // [N][hi*wi][D] or null: the layer convolves in + in2, summed when the window enters LDS.  The
                        // hourglass's skip additions (x = conv4 + conv7(x), adamvs.py:234-236) run HERE, in the consumer of x:
                        // in the producer's epilogue a skip operand is a second round of loads that nothing overlaps
+  // k_conv_dd_resident only (MS-REDNet's deep GRU levels): GroupNorm(1 group) partial sums of the output's channels [0, gn_n)
+  // in the epilogue -- wave w of workgroup (x, y) writes (sum, sum of squares) in double to
+  // gn_part[((n * gn_ngroups + gn_group) * parts + (y * gridDim.x + x) * 4 + w) * 2], parts = 4 * workgroups per map
+  double* gn_part;
+  int gn_n, gn_group, gn_ngroups;
 };
 
 enum { CONV_S1 = 0, CONV_S2 = 1, CONV_T2 = 2 };
@@ -635,13 +640,19 @@ bool costreg_depth_supported(int D) {
 // A fragments in registers (9 * D/4 <= 144 VGPRs), the (TR+2) x 18 window of all D input channels goes to LDS in one
 // round of loads, and what follows is MFMAs fed from LDS.  Same fragment layout, planar LDS layout and epilogue as
 // k_conv_dd.  D = 32: two waves per channel tile (NTR rows each, TR = 2 NTR); D = 64: one (TR = NTR).
-template <int D, int NTR>
-__global__ __launch_bounds__(256) void k_conv_dd_resident(ConvDDArgs a) {
+// DUAL: two layers on the same input in one launch (the reset- and the update-gate convolution of a ConvGRUCell2,
+// reference models/module.py:72-92): 8 waves, waves 4-7 take the second layer's weights / bias / skip / output (`b`) over
+// the window the first four staged with them; their GroupNorm partials go to group 1.
+template <int D, int NTR, bool DUAL>
+__global__ __launch_bounds__(DUAL ? 512 : 256) void k_conv_dd_resident(ConvDDArgs a0, ConvDDArgs a1) {
   constexpr int WM = D / 16, WN = 4 / WM, TR = NTR * WN, KCT = D / 4, NTILES = D / 16;
   constexpr int LR = TR + 2, LC = 18, PLANE = plane_pitch16(LR * LC);
-  constexpr int NITEMS = LR * LC * KCT, NIT = (NITEMS + 255) / 256;
+  constexpr int NTHR = DUAL ? 512 : 256;
+  constexpr int NITEMS = LR * LC * KCT, NIT = (NITEMS + NTHR - 1) / NTHR;
   __shared__ float lds[D * PLANE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = DUAL ? wave8 >> 2 : 0, wave = wave8 & 3;
+  const ConvDDArgs& a = half ? a1 : a0;
   const int wm = wave % WM, wn = wave / WM;
   const int p = lane & 15, q = lane >> 4;
   const int n = blockIdx.z, r0 = blockIdx.y * TR, c0 = blockIdx.x * 16;
@@ -656,20 +667,20 @@ __global__ __launch_bounds__(256) void k_conv_dd_resident(ConvDDArgs a) {
     for (int kc = 0; kc < KCT; ++kc)
       wf[t][kc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
           rw, (unsigned)(lane * 4), (unsigned)(((t * KCT + kc) * NTILES + wm) * 256), 0));
-  const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
+  const buf_rsrc rx = make_rsrc((const char*)a0.in + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
   f32x4 xs[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int i = min(tid + it * 256, NITEMS - 1);
+    const int i = min(tid + it * NTHR, NITEMS - 1);
     const int g = i % KCT, pp = i / KCT, r = pp / LC, c = pp % LC;
     const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi;
     xs[it] = buf_load4(rx, ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB);
   }
-  if (a.in2) {                                               // uniform: the layer convolves in + in2
-    const buf_rsrc rx2 = make_rsrc((const char*)a.in2 + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
+  if (a0.in2) {                                              // uniform: the layer convolves in + in2
+    const buf_rsrc rx2 = make_rsrc((const char*)a0.in2 + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = min(tid + it * 256, NITEMS - 1);
+      const int i = min(tid + it * NTHR, NITEMS - 1);
       const int g = i % KCT, pp = i / KCT, r = pp / LC, c = pp % LC;
       const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi;
       xs[it] += buf_load4(rx2, ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB);
@@ -677,7 +688,7 @@ __global__ __launch_bounds__(256) void k_conv_dd_resident(ConvDDArgs a) {
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int i = min(tid + it * 256, NITEMS - 1);
+    const int i = min(tid + it * NTHR, NITEMS - 1);
     const int g = i % KCT, pp = i / KCT;
     float* d = lds + 4 * g * PLANE + pp;
     d[0] = xs[it].x; d[PLANE] = xs[it].y; d[2 * PLANE] = xs[it].z; d[3 * PLANE] = xs[it].w;
@@ -708,6 +719,26 @@ __global__ __launch_bounds__(256) void k_conv_dd_resident(ConvDDArgs a) {
     if (a.skip) v += *(const f32x4*)(a.skip + opix * D + co4);
     *(f32x4*)(a.out + opix * D + co4) = v;
   }
+  if (a.gn_part) {                                           // uniform
+    double gs = 0.0, gq = 0.0;
+#pragma unroll
+    for (int r = 0; r < NTR; ++r) {
+      const int oy = r0 + wn * NTR + r, ox = c0 + p;
+      if (oy < a.ho && ox < a.wo && co4 < a.gn_n) {
+        f32x4 v = acc[r] + bias;
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.skip) v += *(const f32x4*)(a.skip + (((size_t)n * a.ho + oy) * a.wo + ox) * D + co4);
+        gs += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        gq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { gs += __shfl_down(gs, o); gq += __shfl_down(gq, o); }             // fixed tree: deterministic
+    if (lane == 0) {
+      const int parts = gridDim.x * gridDim.y * 4;
+      double* o = a.gn_part + (((size_t)n * a.gn_ngroups + (DUAL ? half : a.gn_group)) * parts + (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 2;
+      o[0] = gs; o[1] = gq;
+    }
+  }
 }
 
 static int small_grid_limit() {          // workgroups up to which the resident form is used (0 disables it)
@@ -718,19 +749,34 @@ static int small_grid_limit() {          // workgroups up to which the resident 
 template <int D, int NTR>
 static int launch_conv_dd_resident_rows(const ConvDDArgs& a, int N, hipStream_t st) {
   constexpr int TR = NTR * (4 / (D / 16));
-  hipLaunchKernelGGL((k_conv_dd_resident<D, NTR>), dim3(cdiv(a.wo, 16), cdiv(a.ho, TR), N), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((k_conv_dd_resident<D, NTR, false>), dim3(cdiv(a.wo, 16), cdiv(a.ho, TR), N), dim3(256), 0, st, a, a);
   ADAMVS_CHECK_LAUNCH("conv_dd (resident)");
   return 0;
 }
+template <int D, int NTR>
+static int launch_conv_dd_resident_dual(const ConvDDArgs& a, const ConvDDArgs& b, int N, hipStream_t st) {
+  constexpr int TR = NTR * (4 / (D / 16));
+  hipLaunchKernelGGL((k_conv_dd_resident<D, NTR, true>), dim3(cdiv(a.wo, 16), cdiv(a.ho, TR), N), dim3(512), 0, st, a, b);
+  ADAMVS_CHECK_LAUNCH("conv_dd (resident, two layers)");
+  return 0;
+}
 
-// the fewest rows per workgroup (most workgroups) that stays within the limit; -1: grid too large for this form
+// the fewest rows per workgroup (most workgroups) that stays within the limit; 0: grid too large for this form
 template <int D>
-static int launch_conv_dd_resident(const ConvDDArgs& a, int N, hipStream_t st) {
+static int resident_rows(const ConvDDArgs& a, int N) {
   constexpr int WN = 4 / (D / 16);
   const long cols = (long)cdiv(a.wo, 16) * N, limit = small_grid_limit();
-  if (cols * cdiv(a.ho, 1 * WN) <= limit) return launch_conv_dd_resident_rows<D, 1>(a, N, st);
-  if (cols * cdiv(a.ho, 2 * WN) <= limit) return launch_conv_dd_resident_rows<D, 2>(a, N, st);
-  if (cols * cdiv(a.ho, 4 * WN) <= limit) return launch_conv_dd_resident_rows<D, 4>(a, N, st);
+  for (int ntr = 1; ntr <= 4; ntr *= 2)
+    if (cols * cdiv(a.ho, ntr * WN) <= limit) return ntr;
+  return 0;
+}
+template <int D>
+static int launch_conv_dd_resident(const ConvDDArgs& a, int N, hipStream_t st) {
+  switch (resident_rows<D>(a, N)) {
+    case 1: return launch_conv_dd_resident_rows<D, 1>(a, N, st);
+    case 2: return launch_conv_dd_resident_rows<D, 2>(a, N, st);
+    case 4: return launch_conv_dd_resident_rows<D, 4>(a, N, st);
+  }
   return -1;
 }
 
@@ -773,6 +819,50 @@ static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) 
       return launch_conv_dd_cfg<4, 4>(a, N, mode, st);
   }
   return set_error(-1, "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", a.D);
+}
+
+int launch_conv_dd_gn(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
+                      hipStream_t st, double* gn_part, int gn_n, int gn_group, int gn_ngroups, int* gn_parts) {
+  ConvDDArgs a{in, wpk, bias, skip, out, D, h, w, h, w, 0, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, nullptr};
+  *gn_parts = 0;
+  if (gn_part && (D == 32 || D == 64)) {
+    const int ntr = D == 32 ? resident_rows<32>(a, N) : resident_rows<64>(a, N);
+    const long parts = ntr ? (long)cdiv(w, 16) * cdiv(h, ntr * (4 / (D / 16))) * 4 : 0;
+    if (gn_epilogue_partials(parts, N)) {
+      a.gn_part = gn_part; a.gn_n = gn_n; a.gn_group = gn_group; a.gn_ngroups = gn_ngroups;
+      *gn_parts = (int)parts;
+    }
+  }
+  return launch_conv_dd(a, N, CONV_S1, st);
+}
+
+// Two stride-1 layers on the same input (the gate convolutions of a ConvGRUCell2) with their GroupNorm partial sums (groups
+// 0 and 1 of 2): ONE launch when the small-grid kernel takes the map (*gn_parts > 0), otherwise two plain launches (*gn_parts = 0).
+int launch_conv_dd_gates_gn(const float* in, const float* wpk_r, const float* bias_r, const float* skip_r, float* out_r,
+                            const float* wpk_u, const float* bias_u, const float* skip_u, float* out_u, int N, int D, int h, int w,
+                            hipStream_t st, double* gn_part, int gn_n, int* gn_parts) {
+  ConvDDArgs a{in, wpk_r, bias_r, skip_r, out_r, D, h, w, h, w, 0, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, nullptr};
+  ConvDDArgs b = a;
+  b.wpk = wpk_u; b.bias = bias_u; b.skip = skip_u; b.out = out_u;
+  *gn_parts = 0;
+  if (gn_part && (D == 32 || D == 64)) {
+    const int ntr = D == 32 ? resident_rows<32>(a, N) : resident_rows<64>(a, N);
+    const long parts = ntr ? (long)cdiv(w, 16) * cdiv(h, ntr * (4 / (D / 16))) * 4 : 0;
+    if (gn_epilogue_partials(parts, N)) {
+      a.gn_part = b.gn_part = gn_part; a.gn_n = b.gn_n = gn_n; a.gn_ngroups = b.gn_ngroups = 2;
+      *gn_parts = (int)parts;
+      if (D == 32) {
+        switch (ntr) { case 1: return launch_conv_dd_resident_dual<32, 1>(a, b, N, st);
+                       case 2: return launch_conv_dd_resident_dual<32, 2>(a, b, N, st);
+                       default: return launch_conv_dd_resident_dual<32, 4>(a, b, N, st); }
+      }
+      switch (ntr) { case 1: return launch_conv_dd_resident_dual<64, 1>(a, b, N, st);
+                     case 2: return launch_conv_dd_resident_dual<64, 2>(a, b, N, st);
+                     default: return launch_conv_dd_resident_dual<64, 4>(a, b, N, st); }
+    }
+  }
+  if (int rc = launch_conv_dd(a, N, CONV_S1, st)) return rc;
+  return launch_conv_dd(b, N, CONV_S1, st);
 }
 
 // ---------------------------------------------------------------------------

@@ -49,8 +49,21 @@ int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBu
 // sb.rh1 / sb.rh2 after an even step of the split-bf16 path, whose fused GRU kernels alternate the two)
 int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers& sb, float* vol, int B, int h, int w, int D,
                       int d, int in_up, int precision, hipStream_t st, float** h1_now = nullptr, float** h2_now = nullptr);
+constexpr int GN_PARTS_LIMIT = 2048;     // partial sums per (sample, group) the GroupNorm buffers of msred.hip hold
+// A convolution writes its GroupNorm partials itself (one dependent launch fewer) while the stage is launch-bound: every block
+// of the consumer finishes the reduction on its own, which is free for 64 partials and not for 1152 x 16 samples (measured at
+// 16 tiles per step: 136 -> 147 ms with epilogue partials everywhere).
+inline bool gn_epilogue_partials(long parts, int samples) { return parts > 0 && parts <= GN_PARTS_LIMIT && parts * samples <= 4096; }
 int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias, float* out,
-                     int cout, int B, int h, int w, hipStream_t st);
+                     int cout, int B, int h, int w, hipStream_t st, double* gn_part = nullptr, int gn_hc = 0, int gn_groups = 0,
+                     int* gn_parts = nullptr);
+// one stride-1 layer with the GroupNorm partial sums of its output in the epilogue when the small-grid kernel takes it
+// (*gn_parts > 0), plain otherwise (*gn_parts = 0): MS-REDNet's deep levels
+int launch_conv_dd_gates_gn(const float* in, const float* wpk_r, const float* bias_r, const float* skip_r, float* out_r,
+                            const float* wpk_u, const float* bias_u, const float* skip_u, float* out_u, int N, int D, int h, int w,
+                            hipStream_t st, double* gn_part, int gn_n, int* gn_parts);
+int launch_conv_dd_gn(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
+                      hipStream_t st, double* gn_part, int gn_n, int gn_group, int gn_ngroups, int* gn_parts);
 int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,
                        int in_up, hipStream_t st);
 int launch_sweep_conv1(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,

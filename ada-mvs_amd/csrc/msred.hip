@@ -70,7 +70,7 @@ __global__ void k_channel_copy(const float* __restrict__ src, float* __restrict_
 // pixel ranges per (sample, group): 64 for the small maps of the deep levels, up to 1024 so that a full-resolution
 // map (5 M pixels at the reference's predict size) is not reduced by 64 workgroups.  The consumers (the two epilogue
 // kernels below) finish the reduction themselves: one fewer dependent launch per normalisation.
-constexpr int GN_PARTS_MAX = 1024;
+constexpr int GN_PARTS_MAX = GN_PARTS_LIMIT;
 __host__ __device__ inline int gn_parts(int npix) {
   const int want = (npix + 2047) / 2048;
   return want < 64 ? 64 : (want > GN_PARTS_MAX ? GN_PARTS_MAX : want);
@@ -103,23 +103,29 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x0
   }
 }
 
-// mean and 1/sqrt(biased var + eps) of the groups of sample b from the partial sums, into shared memory.  Wave 0 does
-// it: lane l sums partials l, l + 64, ... in order, then a fixed shuffle tree -- the same association every time.
+// mean and 1/sqrt(biased var + eps) of the groups of sample b from the partial sums, into shared memory.  Every thread of
+// the block sums partials tid, tid + blockDim, ... in order, a fixed shuffle tree joins the lanes of a wave and thread 0 the
+// waves in order -- the same association every time.  (A convolution epilogue writes up to 2048 partials per group: summed by
+// one wave alone they cost every block of the consumer 18 dependent trips to L2.)
 __device__ __forceinline__ void gn_finish(const double* __restrict__ part, int b, int ngroups, int parts, int count, float eps,
                                           float (*st)[2]) {
-  if (threadIdx.x < 64) {
-    for (int g = 0; g < ngroups; ++g) {
-      const double* p = part + ((size_t)b * ngroups + g) * parts * 2;
-      double s = 0.0, q = 0.0;
-      for (int k = threadIdx.x; k < parts; k += 64) { s += p[2 * k]; q += p[2 * k + 1]; }
-      for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); q += __shfl_down(q, o); }
-      if (threadIdx.x == 0) {
-        const double mean = s / count;
-        const double var = fmax(q / count - mean * mean, 0.0);    // biased, as torch.nn.GroupNorm
-        st[g][0] = (float)mean;
-        st[g][1] = (float)(1.0 / sqrt(var + (double)eps));
-      }
-    }
+  __shared__ double wsum[2][4][2];
+  const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
+  for (int g = 0; g < ngroups; ++g) {
+    const double* p = part + ((size_t)b * ngroups + g) * parts * 2;
+    double s = 0.0, q = 0.0;
+    for (int k = tid; k < parts; k += blockDim.x) { s += p[2 * k]; q += p[2 * k + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); q += __shfl_down(q, o); }
+    if ((tid & 63) == 0) { wsum[g][tid >> 6][0] = s; wsum[g][tid >> 6][1] = q; }
+  }
+  __syncthreads();
+  if (tid < ngroups) {
+    double s = 0.0, q = 0.0;
+    for (int w = 0; w < nw; ++w) { s += wsum[tid][w][0]; q += wsum[tid][w][1]; }
+    const double mean = s / count;
+    const double var = fmax(q / count - mean * mean, 0.0);    // biased, as torch.nn.GroupNorm
+    st[tid][0] = (float)mean;
+    st[tid][1] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
 }
@@ -140,10 +146,10 @@ __global__ void k_gn_final(const double* __restrict__ part, float* __restrict__ 
 // grid (blocks over npix * HC/4, N).
 __global__ void k_gru2_gates_apply(const float* __restrict__ fr, const float* __restrict__ fu, const double* __restrict__ part,
                                    const float* __restrict__ gn, const float* __restrict__ h, float* __restrict__ rh,
-                                   float* __restrict__ u, int npix, int Wf, int W, int HC, float eps) {
+                                   float* __restrict__ u, int npix, int Wf, int W, int HC, float eps, int parts) {
   __shared__ float st[2][2];
   const int b = blockIdx.y;
-  gn_finish(part, b, 2, gn_parts(npix), npix * HC, eps, st);
+  gn_finish(part, b, 2, parts, npix * HC, eps, st);
   const int G = HC >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix * G) return;
@@ -163,10 +169,10 @@ __global__ void k_gru2_gates_apply(const float* __restrict__ fr, const float* __
 // into channels [0, HC) of out [N][npix][Wo] (the decoder's input).  grid (blocks over npix * HC/4, N).
 __global__ void k_gru2_out_apply(const float* __restrict__ o, const double* __restrict__ part, const float* __restrict__ gn,
                                  const float* __restrict__ u, float* __restrict__ h, float* __restrict__ out, int npix, int W,
-                                 int HC, int Wo, float eps) {
+                                 int HC, int Wo, float eps, int parts) {
   __shared__ float st[2][2];
   const int b = blockIdx.y;
-  gn_finish(part, b, 1, gn_parts(npix), npix * HC, eps, st);
+  gn_finish(part, b, 1, parts, npix * HC, eps, st);
   const int G = HC >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix * G) return;
@@ -181,6 +187,22 @@ __global__ void k_gru2_out_apply(const float* __restrict__ o, const double* __re
   const f32x4 hn = u4 * *(const f32x4*)hp + (1.0f - u4) * y;
   *(f32x4*)hp = hn;
   if (out) *(f32x4*)(out + bp * Wo + c) = hn;
+}
+
+// `parts` partial sums per (sample, group): gn_parts(npix) from k_gn_partial, or what the producing convolution's epilogue wrote
+static int launch_gates_apply(const float* fr, const float* fu, int Wf, const double* partials, int parts, const float* gn,
+                              const float* h, float* rh, float* u, int N, int npix, int W, int HC, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(k_gru2_gates_apply, dim3(cdiv(npix * (HC / 4), 256), N), dim3(256), 0, st, fr, fu, partials, gn, h, rh, u, npix,
+                     Wf, W, HC, eps, parts);
+  ADAMVS_CHECK_LAUNCH("gru2_gates_apply");
+  return 0;
+}
+static int launch_out_apply(const float* o, const double* partials, int parts, const float* gn, const float* u, float* h, float* out,
+                            int Wo, int N, int npix, int W, int HC, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(k_gru2_out_apply, dim3(cdiv(npix * (HC / 4), 256), N), dim3(256), 0, st, o, partials, gn, u, h, out, npix, W, HC,
+                     Wo, eps, parts);
+  ADAMVS_CHECK_LAUNCH("gru2_out_apply");
+  return 0;
 }
 
 }  // namespace adamvs
@@ -256,20 +278,14 @@ extern "C" int adamvs_gru2_gates_apply(const float* fr, const float* fu, int Wf,
                                        void* stream) {
   ADAMVS_CHECK_ARG(fr && fu && partials && gn && h && rh && u && N > 0 && npix > 0 && (HC % 4) == 0 && (W % 4) == 0 && HC <= W &&
                    (Wf % 4) == 0 && HC <= Wf, "gru2_gates_apply: bad arguments (Wf=%d W=%d HC=%d)", Wf, W, HC);
-  hipLaunchKernelGGL(k_gru2_gates_apply, dim3(cdiv(npix * (HC / 4), 256), N), dim3(256), 0, (hipStream_t)stream, fr, fu,
-                     (const double*)partials, gn, h, rh, u, npix, Wf, W, HC, eps);
-  ADAMVS_CHECK_LAUNCH("gru2_gates_apply");
-  return 0;
+  return launch_gates_apply(fr, fu, Wf, (const double*)partials, gn_parts(npix), gn, h, rh, u, N, npix, W, HC, eps, (hipStream_t)stream);
 }
 
 extern "C" int adamvs_gru2_out_apply(const float* o, const void* partials, const float* gn, const float* u, float* h, float* out,
                                      int Wo, int N, int npix, int W, int HC, float eps, void* stream) {
   ADAMVS_CHECK_ARG(o && partials && gn && u && h && N > 0 && npix > 0 && (HC % 4) == 0 && (W % 4) == 0 && HC <= W &&
                    (!out || ((Wo % 4) == 0 && HC <= Wo)), "gru2_out_apply: bad arguments (W=%d HC=%d Wo=%d)", W, HC, Wo);
-  hipLaunchKernelGGL(k_gru2_out_apply, dim3(cdiv(npix * (HC / 4), 256), N), dim3(256), 0, (hipStream_t)stream, o,
-                     (const double*)partials, gn, u, h, out, npix, W, HC, Wo, eps);
-  ADAMVS_CHECK_LAUNCH("gru2_out_apply");
-  return 0;
+  return launch_out_apply(o, (const double*)partials, gn_parts(npix), gn, u, h, out, Wo, N, npix, W, HC, eps, (hipStream_t)stream);
 }
 
 extern "C" int adamvs_conv3x3_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias,
@@ -326,13 +342,21 @@ extern "C" int adamvs_red_recur_pair(const float* x, int Cx, const float* wg, co
   for (int d = 0; d < D; ++d) {
     const float* xd = x + (size_t)d * B * npix * Cx;
     int rc;
-    if ((rc = adamvs_conv3x3_pair(xd, Cx, r.state, HC, wg, bg, r.f, 2 * HC, B, h, w, stream))) return rc;
-    if ((rc = adamvs_group_stats_partial(r.f, r.f + HC, B, npix, 2 * HC, HC, r.part, pbytes, stream))) return rc;
-    if ((rc = adamvs_gru2_gates_apply(r.f, r.f + HC, 2 * HC, r.part, gn, r.state, r.rh, r.u, B, npix, HC, HC, eps, stream))) return rc;
-    if ((rc = adamvs_conv3x3_pair(xd, Cx, r.rh, HC, wc, bc, r.o, HC, B, h, w, stream))) return rc;
-    if ((rc = adamvs_group_stats_partial(r.o, nullptr, B, npix, HC, HC, r.part, pbytes, stream))) return rc;
-    if ((rc = adamvs_gru2_out_apply(r.o, r.part, gn + 4 * HC, r.u, r.state, R + (size_t)d * B * npix * RW, RW, B, npix, HC, HC, eps,
-                                    stream)))
+    // the GroupNorm statistics of a convolution's output come out of its epilogue as partial sums (one dependent launch fewer
+    // per normalisation); maps with more tiles than the partial buffer holds are reduced by k_gn_partial as before
+    int parts = 0;
+    if ((rc = launch_conv_pair(xd, Cx, r.state, HC, wg, bg, r.f, 2 * HC, B, h, w, st, r.part, HC, 2, &parts))) return rc;
+    if (!parts) {
+      if ((rc = adamvs_group_stats_partial(r.f, r.f + HC, B, npix, 2 * HC, HC, r.part, pbytes, stream))) return rc;
+      parts = gn_parts(npix);
+    }
+    if ((rc = launch_gates_apply(r.f, r.f + HC, 2 * HC, r.part, parts, gn, r.state, r.rh, r.u, B, npix, HC, HC, eps, st))) return rc;
+    if ((rc = launch_conv_pair(xd, Cx, r.rh, HC, wc, bc, r.o, HC, B, h, w, st, r.part, HC, 1, &parts))) return rc;
+    if (!parts) {
+      if ((rc = adamvs_group_stats_partial(r.o, nullptr, B, npix, HC, HC, r.part, pbytes, stream))) return rc;
+      parts = gn_parts(npix);
+    }
+    if ((rc = launch_out_apply(r.o, r.part, parts, gn + 4 * HC, r.u, r.state, R + (size_t)d * B * npix * RW, RW, B, npix, HC, HC, eps, st)))
       return rc;
   }
   return 0;
@@ -353,14 +377,22 @@ extern "C" int adamvs_red_recur_split(const float* gxr, const float* gxu, const 
   for (int d = 0; d < D; ++d) {
     int rc;
     // Wh.h + (Wx.x + b): the x halves of all planes were computed before the recurrence and enter as `skip`
-    if ((rc = adamvs_conv3x3_dd(r.state, nullptr, w_ghr, w_ghr + wsz, gxr + d * plane, r.f, B, W, h, w, 0, 0, 0, stream))) return rc;
-    if ((rc = adamvs_conv3x3_dd(r.state, nullptr, w_ghu, w_ghu + wsz, gxu + d * plane, r.fu, B, W, h, w, 0, 0, 0, stream))) return rc;
-    if ((rc = adamvs_group_stats_partial(r.f, r.fu, B, npix, W, HC, r.part, pbytes, stream))) return rc;
-    if ((rc = adamvs_gru2_gates_apply(r.f, r.fu, W, r.part, gn, r.state, r.rh, r.u, B, npix, W, HC, eps, stream))) return rc;
-    if ((rc = adamvs_conv3x3_dd(r.rh, nullptr, w_ch, w_ch + wsz, cx + d * plane, r.o, B, W, h, w, 0, 0, 0, stream))) return rc;
-    if ((rc = adamvs_group_stats_partial(r.o, nullptr, B, npix, W, HC, r.part, pbytes, stream))) return rc;
-    if ((rc = adamvs_gru2_out_apply(r.o, r.part, gn + 4 * HC, r.u, r.state, R + (size_t)d * B * npix * RW, RW, B, npix, W, HC, eps,
-                                    stream)))
+    int pr = 0, po = 0;
+    // the reset- and the update-gate convolution read the same state: one launch (8 waves) on the small maps
+    if ((rc = launch_conv_dd_gates_gn(r.state, w_ghr, w_ghr + wsz, gxr + d * plane, r.f, w_ghu, w_ghu + wsz, gxu + d * plane, r.fu, B, W,
+                                      h, w, st, r.part, HC, &pr)))
+      return rc;
+    if (!pr) {
+      if ((rc = adamvs_group_stats_partial(r.f, r.fu, B, npix, W, HC, r.part, pbytes, stream))) return rc;
+      pr = gn_parts(npix);
+    }
+    if ((rc = launch_gates_apply(r.f, r.fu, W, r.part, pr, gn, r.state, r.rh, r.u, B, npix, W, HC, eps, st))) return rc;
+    if ((rc = launch_conv_dd_gn(r.rh, w_ch, w_ch + wsz, cx + d * plane, r.o, B, W, h, w, st, r.part, HC, 0, 1, &po))) return rc;
+    if (!po) {
+      if ((rc = adamvs_group_stats_partial(r.o, nullptr, B, npix, W, HC, r.part, pbytes, stream))) return rc;
+      po = gn_parts(npix);
+    }
+    if ((rc = launch_out_apply(r.o, r.part, po, gn + 4 * HC, r.u, r.state, R + (size_t)d * B * npix * RW, RW, B, npix, W, HC, eps, st)))
       return rc;
   }
   return 0;

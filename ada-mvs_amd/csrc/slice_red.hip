@@ -394,9 +394,18 @@ static int launch_conv1_c(const float* cost, const float* w, float* c1, int N, i
 
 // out = conv3x3(cat(srcA, srcB)) + bias on compact channel-last maps (the ConvGRUCell2 convolutions of MS-REDNet's two
 // shallow levels: gate_conv / output_conv of reference models/module.py:62-67 before their GroupNorm)
+// gn_part != null: GroupNorm partial sums of the output in the epilogue (SmallConvArgs); *gn_parts receives the number of
+// partials per (sample, group), or 0 when the map has more tiles than the partial buffer holds (the caller then reduces the
+// map with k_gn_partial as before).
 int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias, float* out,
-                     int cout, int B, int h, int w, hipStream_t st) {
+                     int cout, int B, int h, int w, hipStream_t st, double* gn_part, int gn_hc, int gn_groups, int* gn_parts) {
   SmallConvArgs a{srcA, srcB, wpk, bias, out, nullptr, h, w, h, w, cout};
+  if (gn_parts) *gn_parts = 0;
+  const long parts = (long)cdiv(w, 16) * cdiv(h, 4) * 4;            // launch_small: tiles of 4 rows x 16 columns, one run per wave
+  if (gn_part && gn_parts && gn_epilogue_partials(parts, B)) {
+    a.gn_part = gn_part; a.gn_hc = gn_hc; a.gn_groups = gn_groups;
+    *gn_parts = (int)parts;
+  }
   if (CB == 8 && cout <= 16) {
     if (CA == 32) return launch_small<32, 8, 1, 1, EPI_LINEAR>(a, B, st, "conv_pair");
     if (CA == 16) return launch_small<16, 8, 1, 1, EPI_LINEAR>(a, B, st, "conv_pair");

@@ -25,6 +25,12 @@ struct SmallConvArgs {
   float* dst1;         // GATES: u out [B][..][HC];    CAND: u in
   int hi, wi, ho, wo, cout;
   const float* hin;    // CAND: the state that is blended (h of the previous step); null = dst0 (update in place)
+  // LINEAR, MS-REDNet: GroupNorm(1 group) statistics of the output in the epilogue (reference models/module.py:62-67: the
+  // normalisation that follows gate_conv / output_conv): every (tile, wave) writes the sum and the sum of squares (double) of
+  // its real output values of channel group g = channel / gn_hc < gn_groups to
+  // gn_part[((b * gn_groups + g) * parts + (ty * tiles_x + tx) * 4 + wave) * 2], parts = 4 * tiles per map; null: none
+  double* gn_part;
+  int gn_hc, gn_groups;
 };
 
 // Range of tiles a role instance walks: tiles [begin, end) of its TileGrid.
@@ -228,6 +234,27 @@ struct ConvSmallRole {
         f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
         f32x4 u4 = pre_u[nt], h4 = pre_h[nt];
         buf_store4(r0, oo[nt], u4 * h4 + (1.0f - u4) * cnd);
+      }
+    }
+    if (EPI == EPI_LINEAR && a.gn_part) {          // uniform
+      double gs[2] = {0.0, 0.0}, gq[2] = {0.0, 0.0};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co4 = nt * 16 + 4 * q, g = co4 >= a.gn_hc ? 1 : 0;
+        if (oo[nt] != BUF_OOB && co4 < a.gn_groups * a.gn_hc) {
+          const f32x4 v = acc[nt] + bias[nt];
+          gs[g] += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+          gq[g] += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        }
+      }
+      const int parts = tg.tiles_x * tg.tiles_y * 4;
+      for (int g = 0; g < a.gn_groups; ++g) {
+        double s_ = gs[g], q_ = gq[g];
+        for (int o = 32; o > 0; o >>= 1) { s_ += __shfl_down(s_, o); q_ += __shfl_down(q_, o); }      // fixed tree: deterministic
+        if (lane == 0) {
+          double* o = a.gn_part + (((size_t)b * a.gn_groups + g) * parts + (ty * tg.tiles_x + tx) * 4 + wave) * 2;
+          o[0] = s_; o[1] = q_;
+        }
       }
     }
     if (!more) break;
