@@ -340,6 +340,5 @@ using namespace adamvs;
 extern "C" int adamvs_conv3x3_dd_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N,
                                       int D, int h, int w, int relu, void* stream) {
   ADAMVS_CHECK_ARG(in && wpk && bias && out && N > 0 && h > 0 && w > 0, "conv3x3_dd_wino: bad arguments");
-  ADAMVS_CHECK_ARG(N <= 65535, "conv3x3_dd_wino: N=%d exceeds the grid z limit", N);
   return launch_conv_wino(in, wpk, bias, skip, out, N, D, h, w, relu, (hipStream_t)stream);
 }
