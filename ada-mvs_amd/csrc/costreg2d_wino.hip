@@ -12,12 +12,14 @@
 // Mapping.  fp32 MFMA shares the vector lanes (lesson 1), so the input transform must cost few vector
 // instructions per MFMA, and each weight fragment (one per MFMA) must be reused over as many tiles as the accumulators
 // allow.  A workgroup = 4 waves = the 4 ROWS i of the transformed patch: wave i needs two raw patch rows (d0-d2 | d1+d2 |
-// d2-d1 | d1-d3: 4 vector instructions), the column transform of that row (4 more), and owns the accumulators of its
-// four positions (i, 0..3) for MT channel tiles x NT tile rows: 8 vector instructions per 4 MT MFMAs.  One wave per SIMD
-// (up to 512 registers: 4 x MT x NT accumulator tiles = 288 registers at MT 6, NT 3), LDS double-buffered in chunks
-// of 16 input channels with ONE barrier per chunk, weight fragments L2 -> VGPR as one 16-byte load per (k-step, channel
-// tile) carrying the four positions of the wave's row.  A workgroup covers 2 NT x 32 output pixels x 16 MT channels;
-// the channel groups of a pixel block are neighbouring workgroups (they share the input window in L2).
+// d2-d1 | d1-d3) and the column transform of that row -- four PACKED fp32 instructions in all (v_pk_fma / v_pk_add with
+// op_sel / neg modifiers) -- and owns the accumulators of its four positions (i, 0..3) for MT channel tiles x NT tile
+// rows: 4 vector instructions per 4 MT MFMAs.  One wave per SIMD; MT 4 x NT 3 = 48 accumulator tiles = 192 AGPRs (more
+// than ~200 accumulator registers and the compiler wraps every MFMA in AGPR <-> VGPR copies: DESIGN.md lesson 9); LDS
+// double-buffered in chunks of 16 input channels with ONE barrier per chunk, weight fragments L2 -> VGPR as one 16-byte
+// load per (k-step, channel tile) carrying the four positions of the wave's row, four sets, three k-steps ahead.
+// A workgroup covers 2 NT x 32 output pixels x 16 MT channels; the channel groups of a pixel block are neighbouring tiles
+// of the persistent grid (they share the input window in L2).
 // The four rows meet in the epilogue: Z_i[b] = sum_j M[i][j] At[b][j] in registers, then through LDS, wave (a, b) forms
 // Y[a][b] = sum_i At[a][i] Z_i[b], adds bias / ReLU / skip and stores.
 #include <stdlib.h>
