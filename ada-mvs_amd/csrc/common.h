@@ -40,6 +40,11 @@ __device__ __forceinline__ float tanh_fast(float x) {
 // s_waitcnt vmcnt(0) as a real instruction (not inline asm), so the compiler's own wait insertion knows that no
 // vector-memory result is pending after it.  gfx9 encoding: vmcnt [3:0]+[15:14], expcnt [6:4], lgkmcnt [11:8].
 __device__ __forceinline__ void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// vmcnt(N): wait until at most the N youngest vector-memory operations are outstanding (they retire in order)
+template <int N> __device__ __forceinline__ void wait_vmem_but() {
+  static_assert(N >= 0 && N < 64, "vmcnt is six bits");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
 
 // ---- buffer addressing: workgroup-uniform base (128-bit descriptor in SGPRs) + 32-bit lane offset.
 // No per-lane 64-bit address arithmetic, and the range check does the masking: a lane offset >= num_records

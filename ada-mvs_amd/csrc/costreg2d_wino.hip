@@ -60,12 +60,6 @@ struct WinoGeom {
   static_assert(PLANE >= NPIX, "plane pitch");
 };
 
-// vmcnt(n) with the other counters left alone (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8])
-template <int N> __device__ __forceinline__ void wait_vmem_but() {
-  static_assert(N >= 0 && N < 64, "vmcnt is six bits");
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
-}
-
 // Persistent: the grid is the resident capacity (one workgroup per CU) and workgroup i walks tiles i, i + grid, ...;
 // tile = ((image * tiles_y + ty) * tiles_x + tx) * groups + channel group.  The first window chunk and the first three
 // fragment sets of the NEXT tile are requested before the epilogue of the current one, so what a tile start exposes is
