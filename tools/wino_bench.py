@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""One stride-1 CostRegNet2D layer on the direct kernel and in the F(2x2, 3x3) form (GPU box): error of both against a float64
+convolution on small maps, then the time of the five layer shapes of cfg2 at 128 tiles (N = 512 maps, D = 192).
+
+    python tools/wino_bench.py                      -> profiles/r03_wino_layer_bench.txt is the output of this command
+    ADAMVS_LIB_PATH=ada-mvs_amd/libadamvs_hip.<name>.so python tools/wino_bench.py --time-only     (a timing build, tools/build_variant.py)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ada_mvs_amd  # noqa: E402,F401
+from ada_mvs_amd import hip_ops, packing  # noqa: E402
+
+dev = "cuda"
+
+
+def accuracy(N, D, h, w, relu=1, skip=False):
+    g = torch.Generator().manual_seed(N * 1000 + D + h + w)
+    x = torch.randn(N, D, h, w, generator=g)
+    wt = torch.randn(D, D, 3, 3, generator=g) / (3 * D ** 0.5)
+    scale, b = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double(), (wt * scale.reshape(-1, 1, 1, 1)).double(), b.double(), padding=1)
+    ref = torch.relu(ref) if relu else ref
+    x_cl = x.permute(0, 2, 3, 1).reshape(N, h * w, D).contiguous().to(dev)
+    sk = torch.randn(N, h * w, D, generator=g).to(dev) if skip else None
+    if skip:
+        ref = ref + sk.cpu().double().reshape(N, h, w, D).permute(0, 3, 1, 2)
+    pk = packing.pack_reg_layer(wt, scale, b, False).to(dev)
+    yd = hip_ops.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], sk, N, D, h, w, 0, relu)
+    yw = hip_ops.conv3x3_dd_wino(x_cl, packing.pack_reg_layer_wino(wt, scale).to(dev), b.to(dev), sk, N, D, h, w, relu)
+    torch.cuda.synchronize()
+    back = lambda y: y.cpu().double().reshape(N, h, w, D).permute(0, 3, 1, 2)
+    rel = lambda y: (back(y) - ref).abs().mean().item() / ref.abs().mean().item()
+    print("N=%d D=%d %dx%d relu=%d skip=%d   relative L1 against float64: direct %.2e  F(2x2,3x3) %.2e" % (N, D, h, w, relu, skip, rel(yd), rel(yw)),
+          flush=True)
+
+
+def timing(N, D, h, w, reps=5):
+    x_cl = torch.randn(N, h * w, D, device=dev)
+    wt = torch.randn(D, D, 3, 3) / (3 * D ** 0.5)
+    b = torch.randn(D) * 0.1
+    pk = packing.pack_reg_layer(wt, torch.ones(D), b, False).to(dev)
+    pw, bias = packing.pack_reg_layer_wino(wt, torch.ones(D)).to(dev), b.to(dev)
+    out = torch.empty(N, h * w, D, device=dev)
+    flops = 2.0 * 9 * D * D * h * w * N
+    for name, fn, executed in (("direct", lambda: hip_ops.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], None, N, D, h, w, 0, 1, out=out), 1.0),
+                               ("F(2x2,3x3)", lambda: hip_ops.conv3x3_dd_wino(x_cl, pw, bias, None, N, D, h, w, 1, out=out), 16.0 / 36.0)):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print("N=%d D=%d %dx%d %-11s %7.3f ms   executed %.1f TFLOP/s (%.1f %% of 157.3)   direct-form %.1f TFLOP/s" % (
+            N, D, h, w, name, ms, flops * executed / ms / 1e9, flops * executed / ms / 1e9 / 157.3 * 100, flops / ms / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    if "--time-only" not in sys.argv:
+        for case in ((1, 192, 6, 32), (2, 192, 13, 45, 0), (2, 192, 7, 70, 1, True), (1, 64, 8, 40), (1, 128, 13, 33), (1, 256, 6, 32, 0)):
+            accuracy(*case)
+    for shape in ((512, 192, 96, 192), (512, 192, 48, 96), (512, 192, 24, 48), (512, 192, 12, 24), (16, 192, 96, 192)):
+        timing(*shape)
