@@ -640,11 +640,39 @@ bool costreg_depth_supported(int D) {
 // A fragments in registers (9 * D/4 <= 144 VGPRs), the (TR+2) x 18 window of all D input channels goes to LDS in one
 // round of loads, and what follows is MFMAs fed from LDS.  Same fragment layout, planar LDS layout and epilogue as
 // k_conv_dd.  D = 32: two waves per channel tile (NTR rows each, TR = 2 NTR); D = 64: one (TR = NTR).
+// What the elementwise kernels between the convolutions of a ConvGRUCell2 did (reference models/module.py:72-106), folded
+// into the window fill of the convolution that FOLLOWS them (MS-REDNet's deep levels at one or a few tiles are bound by the
+// number of dependent launches per plane: four -> two).  Every workgroup finishes the GroupNorm reductions it needs from the
+// partial sums the producing convolutions' epilogues wrote, then forms its input window on the fly:
+//   GRU_PRO_GATES (the candidate convolution):  in = sigmoid(GN_r(f)) * h                       f = gate_conv's reset half
+//   GRU_PRO_OUT   (the NEXT plane's gate convolutions):  in = h' = u * h + (1 - u) * tanh(GN_o(o)),   u = sigmoid(GN_u(f)),
+//                 f = the previous plane's update half, o = its output_conv; the workgroup also stores h' of its own pixels
+//                 (the new state, a second buffer: neighbours still read the old one) and its channels [0, hc) into R
+// (halo pixels are recomputed by the neighbours: the same operands in the same order, the same bits).
+// mean and 1 / sqrt(biased variance + eps) from `parts` partial sums (doubles), by the whole block, deterministic
+template <int NTHR>
+__device__ __forceinline__ void gru_pro_stats(const double* __restrict__ p, int parts, int count, float eps, double (*wsum)[2], float* st) {
+  const int tid = threadIdx.x;
+  double s_ = 0.0, q_ = 0.0;
+  for (int k = tid; k < parts; k += NTHR) { s_ += p[2 * k]; q_ += p[2 * k + 1]; }
+  for (int o = 32; o > 0; o >>= 1) { s_ += __shfl_down(s_, o); q_ += __shfl_down(q_, o); }
+  if ((tid & 63) == 0) { wsum[tid >> 6][0] = s_; wsum[tid >> 6][1] = q_; }
+  __syncthreads();
+  if (tid == 0) {
+    double s2 = 0.0, q2 = 0.0;
+    for (int w = 0; w < NTHR / 64; ++w) { s2 += wsum[w][0]; q2 += wsum[w][1]; }
+    const double mean = s2 / count, var = fmax(q2 / count - mean * mean, 0.0);
+    st[0] = (float)mean;
+    st[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+}
+
 // DUAL: two layers on the same input in one launch (the reset- and the update-gate convolution of a ConvGRUCell2,
 // reference models/module.py:72-92): 8 waves, waves 4-7 take the second layer's weights / bias / skip / output (`b`) over
 // the window the first four staged with them; their GroupNorm partials go to group 1.
 template <int D, int NTR, bool DUAL>
-__global__ __launch_bounds__(DUAL ? 512 : 256) void k_conv_dd_resident(ConvDDArgs a0, ConvDDArgs a1) {
+__global__ __launch_bounds__(DUAL ? 512 : 256) void k_conv_dd_resident(ConvDDArgs a0, ConvDDArgs a1, GruPro pro) {
   constexpr int WM = D / 16, WN = 4 / WM, TR = NTR * WN, KCT = D / 4, NTILES = D / 16;
   constexpr int LR = TR + 2, LC = 18, PLANE = plane_pitch16(LR * LC);
   constexpr int NTHR = DUAL ? 512 : 256;
@@ -667,7 +695,8 @@ __global__ __launch_bounds__(DUAL ? 512 : 256) void k_conv_dd_resident(ConvDDArg
     for (int kc = 0; kc < KCT; ++kc)
       wf[t][kc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
           rw, (unsigned)(lane * 4), (unsigned)(((t * KCT + kc) * NTILES + wm) * 256), 0));
-  const buf_rsrc rx = make_rsrc((const char*)a0.in + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
+  const long wbase = (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4;
+  const buf_rsrc rx = make_rsrc((const char*)a0.in + wbase);
   f32x4 xs[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -675,6 +704,44 @@ __global__ __launch_bounds__(DUAL ? 512 : 256) void k_conv_dd_resident(ConvDDArg
     const int g = i % KCT, pp = i / KCT, r = pp / LC, c = pp % LC;
     const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi;
     xs[it] = buf_load4(rx, ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB);
+  }
+  if (pro.mode != GRU_PRO_NONE) {                            // uniform: the window is formed from the previous kernels' maps
+    __shared__ double wsum[NTHR / 64][2];
+    __shared__ float st[2][2];
+    gru_pro_stats<NTHR>(pro.part_f + ((size_t)n * 2 + pro.group_f) * pro.parts_f * 2, pro.parts_f, pro.count, pro.eps, wsum, st[0]);
+    if (pro.mode == GRU_PRO_OUT) gru_pro_stats<NTHR>(pro.part_o + (size_t)n * pro.parts_o * 2, pro.parts_o, pro.count, pro.eps, wsum, st[1]);
+    const buf_rsrc rf = make_rsrc((const char*)pro.f + wbase);
+    const buf_rsrc ro_ = make_rsrc((const char*)(pro.mode == GRU_PRO_OUT ? pro.o : pro.f) + wbase);
+    const float mf = st[0][0], rf_ = st[0][1], mo = st[1][0], ro2 = st[1][1];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = min(tid + it * NTHR, NITEMS - 1);
+      const int g = i % KCT, pp = i / KCT, r = pp / LC, c = pp % LC;
+      const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi && 4 * g < pro.hc;
+      const unsigned off = ok ? (unsigned)(((r * a.wi + c) * D + 4 * g) * 4) : BUF_OOB;
+      const int c4 = min(4 * g, pro.hc - 4);
+      const f32x4 fv = buf_load4(rf, off);
+      const f32x4 gw = *(const f32x4*)(pro.gn_f + c4), gb = *(const f32x4*)(pro.gn_f + pro.hc + c4);
+      const f32x4 fn = (fv - mf) * rf_ * gw + gb;
+      const f32x4 sg = {sigmoidf_(fn.x), sigmoidf_(fn.y), sigmoidf_(fn.z), sigmoidf_(fn.w)};
+      f32x4 v;
+      if (pro.mode == GRU_PRO_GATES) {
+        v = sg * xs[it];                                     // r * h
+      } else {
+        const f32x4 ov = buf_load4(ro_, off);
+        const f32x4 ow = *(const f32x4*)(pro.gn_o + c4), ob = *(const f32x4*)(pro.gn_o + pro.hc + c4);
+        const f32x4 on = (ov - mo) * ro2 * ow + ob;
+        const f32x4 y = {tanhf(on.x), tanhf(on.y), tanhf(on.z), tanhf(on.w)};
+        v = sg * xs[it] + (1.0f - sg) * y;                   // h' = u h + (1 - u) y
+      }
+      xs[it] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};           // zero padding / padding channels
+      // the block's own pixels: the new state (and R)
+      if (pro.mode == GRU_PRO_OUT && ok && tid + it * NTHR < NITEMS && r >= 1 && r <= TR && c >= 1 && c <= 16) {
+        const size_t pix = ((size_t)n * a.hi + (iy0 + r)) * a.wi + (ix0 + c);
+        *(f32x4*)(pro.state_out + pix * D + 4 * g) = xs[it];
+        if (pro.R) *(f32x4*)(pro.R + pix * pro.RW + 4 * g) = xs[it];
+      }
+    }
   }
   if (a0.in2) {                                              // uniform: the layer convolves in + in2
     const buf_rsrc rx2 = make_rsrc((const char*)a0.in2 + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
@@ -747,16 +814,16 @@ static int small_grid_limit() {          // workgroups up to which the resident 
 }
 
 template <int D, int NTR>
-static int launch_conv_dd_resident_rows(const ConvDDArgs& a, int N, hipStream_t st) {
+static int launch_conv_dd_resident_rows(const ConvDDArgs& a, int N, hipStream_t st, const GruPro& pro = GruPro{}) {
   constexpr int TR = NTR * (4 / (D / 16));
-  hipLaunchKernelGGL((k_conv_dd_resident<D, NTR, false>), dim3(cdiv(a.wo, 16), cdiv(a.ho, TR), N), dim3(256), 0, st, a, a);
+  hipLaunchKernelGGL((k_conv_dd_resident<D, NTR, false>), dim3(cdiv(a.wo, 16), cdiv(a.ho, TR), N), dim3(256), 0, st, a, a, pro);
   ADAMVS_CHECK_LAUNCH("conv_dd (resident)");
   return 0;
 }
 template <int D, int NTR>
-static int launch_conv_dd_resident_dual(const ConvDDArgs& a, const ConvDDArgs& b, int N, hipStream_t st) {
+static int launch_conv_dd_resident_dual(const ConvDDArgs& a, const ConvDDArgs& b, int N, hipStream_t st, const GruPro& pro = GruPro{}) {
   constexpr int TR = NTR * (4 / (D / 16));
-  hipLaunchKernelGGL((k_conv_dd_resident<D, NTR, true>), dim3(cdiv(a.wo, 16), cdiv(a.ho, TR), N), dim3(512), 0, st, a, b);
+  hipLaunchKernelGGL((k_conv_dd_resident<D, NTR, true>), dim3(cdiv(a.wo, 16), cdiv(a.ho, TR), N), dim3(512), 0, st, a, b, pro);
   ADAMVS_CHECK_LAUNCH("conv_dd (resident, two layers)");
   return 0;
 }
@@ -822,7 +889,7 @@ static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) 
 }
 
 int launch_conv_dd_gn(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
-                      hipStream_t st, double* gn_part, int gn_n, int gn_group, int gn_ngroups, int* gn_parts) {
+                      hipStream_t st, double* gn_part, int gn_n, int gn_group, int gn_ngroups, int* gn_parts, const GruPro* prop) {
   ConvDDArgs a{in, wpk, bias, skip, out, D, h, w, h, w, 0, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, nullptr};
   *gn_parts = 0;
   if (gn_part && (D == 32 || D == 64)) {
@@ -831,16 +898,39 @@ int launch_conv_dd_gn(const float* in, const float* wpk, const float* bias, cons
     if (gn_epilogue_partials(parts, N)) {
       a.gn_part = gn_part; a.gn_n = gn_n; a.gn_group = gn_group; a.gn_ngroups = gn_ngroups;
       *gn_parts = (int)parts;
+      if (prop) {                                            // the caller has asked can_fold_gru_applies(): this branch is taken
+        if (D == 32) {
+          switch (ntr) { case 1: return launch_conv_dd_resident_rows<32, 1>(a, N, st, *prop);
+                         case 2: return launch_conv_dd_resident_rows<32, 2>(a, N, st, *prop);
+                         default: return launch_conv_dd_resident_rows<32, 4>(a, N, st, *prop); }
+        }
+        switch (ntr) { case 1: return launch_conv_dd_resident_rows<64, 1>(a, N, st, *prop);
+                       case 2: return launch_conv_dd_resident_rows<64, 2>(a, N, st, *prop);
+                       default: return launch_conv_dd_resident_rows<64, 4>(a, N, st, *prop); }
+      }
     }
   }
+  if (prop) return set_error(-1, "conv_dd: the folded GRU prologue needs the small-grid kernel (D=%d, %dx%d, N=%d)", D, h, w, N);
   return launch_conv_dd(a, N, CONV_S1, st);
+}
+
+// true when launch_conv_dd_gn / _gates_gn run a level's convolutions on the small-grid kernel with epilogue partials: the
+// condition for folding the elementwise kernels of a ConvGRUCell2 into the convolutions' window fills (msred.hip)
+bool can_fold_gru_applies(int N, int D, int h, int w) {
+  if (D != 32 && D != 64) return false;
+  ConvDDArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, D, h, w, h, w, 0, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, nullptr};
+  const int ntr = D == 32 ? resident_rows<32>(a, N) : resident_rows<64>(a, N);
+  const long parts = ntr ? (long)cdiv(w, 16) * cdiv(h, ntr * (4 / (D / 16))) * 4 : 0;
+  static const bool on = [] { const char* e = getenv("ADAMVS_RED_FOLD_APPLIES"); return !(e && *e == '0'); }();
+  return on && gn_epilogue_partials(parts, N);
 }
 
 // Two stride-1 layers on the same input (the gate convolutions of a ConvGRUCell2) with their GroupNorm partial sums (groups
 // 0 and 1 of 2): ONE launch when the small-grid kernel takes the map (*gn_parts > 0), otherwise two plain launches (*gn_parts = 0).
 int launch_conv_dd_gates_gn(const float* in, const float* wpk_r, const float* bias_r, const float* skip_r, float* out_r,
                             const float* wpk_u, const float* bias_u, const float* skip_u, float* out_u, int N, int D, int h, int w,
-                            hipStream_t st, double* gn_part, int gn_n, int* gn_parts) {
+                            hipStream_t st, double* gn_part, int gn_n, int* gn_parts, const GruPro* prop) {
+  const GruPro pro = prop ? *prop : GruPro{};
   ConvDDArgs a{in, wpk_r, bias_r, skip_r, out_r, D, h, w, h, w, 0, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, nullptr};
   ConvDDArgs b = a;
   b.wpk = wpk_u; b.bias = bias_u; b.skip = skip_u; b.out = out_u;
@@ -852,15 +942,16 @@ int launch_conv_dd_gates_gn(const float* in, const float* wpk_r, const float* bi
       a.gn_part = b.gn_part = gn_part; a.gn_n = b.gn_n = gn_n; a.gn_ngroups = b.gn_ngroups = 2;
       *gn_parts = (int)parts;
       if (D == 32) {
-        switch (ntr) { case 1: return launch_conv_dd_resident_dual<32, 1>(a, b, N, st);
-                       case 2: return launch_conv_dd_resident_dual<32, 2>(a, b, N, st);
-                       default: return launch_conv_dd_resident_dual<32, 4>(a, b, N, st); }
+        switch (ntr) { case 1: return launch_conv_dd_resident_dual<32, 1>(a, b, N, st, pro);
+                       case 2: return launch_conv_dd_resident_dual<32, 2>(a, b, N, st, pro);
+                       default: return launch_conv_dd_resident_dual<32, 4>(a, b, N, st, pro); }
       }
-      switch (ntr) { case 1: return launch_conv_dd_resident_dual<64, 1>(a, b, N, st);
-                     case 2: return launch_conv_dd_resident_dual<64, 2>(a, b, N, st);
-                     default: return launch_conv_dd_resident_dual<64, 4>(a, b, N, st); }
+      switch (ntr) { case 1: return launch_conv_dd_resident_dual<64, 1>(a, b, N, st, pro);
+                     case 2: return launch_conv_dd_resident_dual<64, 2>(a, b, N, st, pro);
+                     default: return launch_conv_dd_resident_dual<64, 4>(a, b, N, st, pro); }
     }
   }
+  if (prop) return set_error(-1, "conv_dd: the folded GRU prologue needs the small-grid kernel (D=%d, %dx%d, N=%d)", D, h, w, N);
   if (int rc = launch_conv_dd(a, N, CONV_S1, st)) return rc;
   return launch_conv_dd(b, N, CONV_S1, st);
 }

@@ -59,11 +59,29 @@ int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const
                      int* gn_parts = nullptr);
 // one stride-1 layer with the GroupNorm partial sums of its output in the epilogue when the small-grid kernel takes it
 // (*gn_parts > 0), plain otherwise (*gn_parts = 0): MS-REDNet's deep levels
+// (csrc/costreg2d.hip, k_conv_dd_resident)
+enum { GRU_PRO_NONE = 0, GRU_PRO_GATES = 1, GRU_PRO_OUT = 2 };
+struct GruPro {
+  int mode;
+  const float* f;            // [N][npix][D]
+  const float* o;            // [N][npix][D] (GRU_PRO_OUT)
+  const double* part_f;      // partial sums of f's group: [(n * 2 + group_f) * parts_f + k][2]
+  const double* part_o;      // [(n * parts_o + k)][2]
+  int parts_f, group_f, parts_o;
+  const float* gn_f;         // [2][hc]: weight, bias of f's norm
+  const float* gn_o;         // [2][hc]: output_norm
+  float* state_out;          // [N][npix][D]
+  float* R; int RW;          // [N][npix][RW] or null
+  int hc, count;             // real channels; pixels x real channels of a sample (the norm's population)
+  float eps;
+};
+
+bool can_fold_gru_applies(int N, int D, int h, int w);
 int launch_conv_dd_gates_gn(const float* in, const float* wpk_r, const float* bias_r, const float* skip_r, float* out_r,
                             const float* wpk_u, const float* bias_u, const float* skip_u, float* out_u, int N, int D, int h, int w,
-                            hipStream_t st, double* gn_part, int gn_n, int* gn_parts);
+                            hipStream_t st, double* gn_part, int gn_n, int* gn_parts, const GruPro* pro = nullptr);
 int launch_conv_dd_gn(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
-                      hipStream_t st, double* gn_part, int gn_n, int gn_group, int gn_ngroups, int* gn_parts);
+                      hipStream_t st, double* gn_part, int gn_n, int gn_group, int gn_ngroups, int* gn_parts, const GruPro* pro = nullptr);
 int launch_soft_argmin(const float* vol, const float* planes, float* depth, float* conf, int B, int D, int h, int w,
                        int in_up, hipStream_t st);
 int launch_sweep_conv1(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,

@@ -189,6 +189,30 @@ __global__ void k_gru2_out_apply(const float* __restrict__ o, const double* __re
   if (out) *(f32x4*)(out + bp * Wo + c) = hn;
 }
 
+// The last plane of a level whose elementwise kernels are folded into the convolutions (adamvs_red_recur_split below): there
+// is no next gate convolution to form h' in its window fill.  u = sigmoid(GN_u(fu)), y = tanh(GN_o(o)), h' = u h + (1 - u) y
+// -> channels [0, HC) of out.  gn [6][HC] as adamvs_red_recur_*.  grid (blocks over npix * HC/4, N).
+__global__ void k_gru2_last_apply(const float* __restrict__ o, const float* __restrict__ fu, const double* __restrict__ part_o, int parts_o,
+                                  const double* __restrict__ part_f, int parts_f, const float* __restrict__ gn,
+                                  const float* __restrict__ h, float* __restrict__ out, int npix, int W, int HC, int Wo, float eps) {
+  __shared__ float sf[2][2], so[2][2];
+  const int b = blockIdx.y;
+  gn_finish(part_f, b, 2, parts_f, npix * HC, eps, sf);
+  gn_finish(part_o, b, 1, parts_o, npix * HC, eps, so);
+  const int G = HC >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * G) return;
+  const int c = 4 * (i % G);
+  const size_t bp = (size_t)b * npix + i / G;
+  const f32x4 fv = *(const f32x4*)(fu + bp * W + c), ov = *(const f32x4*)(o + bp * W + c);
+  const f32x4 gu = *(const f32x4*)(gn + 2 * HC + c), bu = *(const f32x4*)(gn + 3 * HC + c);
+  const f32x4 ga = *(const f32x4*)(gn + 4 * HC + c), be = *(const f32x4*)(gn + 5 * HC + c);
+  const f32x4 un = (fv - sf[1][0]) * sf[1][1] * gu + bu, on = (ov - so[0][0]) * so[0][1] * ga + be;
+  const f32x4 u4 = {sigmoidf_(un.x), sigmoidf_(un.y), sigmoidf_(un.z), sigmoidf_(un.w)};
+  const f32x4 y = {tanhf(on.x), tanhf(on.y), tanhf(on.z), tanhf(on.w)};
+  *(f32x4*)(out + bp * Wo + c) = u4 * *(const f32x4*)(h + bp * W + c) + (1.0f - u4) * y;
+}
+
 // `parts` partial sums per (sample, group): gn_parts(npix) from k_gn_partial, or what the producing convolution's epilogue wrote
 static int launch_gates_apply(const float* fr, const float* fu, int Wf, const double* partials, int parts, const float* gn,
                               const float* h, float* rh, float* u, int N, int npix, int W, int HC, float eps, hipStream_t st) {
@@ -298,16 +322,18 @@ extern "C" int adamvs_conv3x3_pair(const float* srcA, int CA, const float* srcB,
 // ---- one level's recurrence over the planes of a stage, launched from native code (a Python loop of 6-7 ctypes calls
 // per plane and level costs more than the kernels it launches)
 namespace {
-struct RecurBuffers { float *state, *rh, *f, *fu, *o, *u; double* part; };
+struct RecurBuffers { float *state, *rh, *f, *fu, *f2, *fu2, *o, *u; double* part; };
 
-size_t recur_floats(int B, int npix, int W, int Wf, int HC) {      // state, rh, o: W wide; f (and fu): Wf wide; u: HC
+// state, rh, o: W wide; f, fu and their second buffers (the folded path of _split keeps two planes of them): Wf wide; u: HC
+size_t recur_floats(int B, int npix, int W, int Wf, int HC) {
   auto al = [](size_t n) { return (n + 63) / 64 * 64; };
-  return 3 * al((size_t)B * npix * W) + 2 * al((size_t)B * npix * Wf) + al((size_t)B * npix * HC);
+  return 3 * al((size_t)B * npix * W) + 4 * al((size_t)B * npix * Wf) + al((size_t)B * npix * HC);
 }
+size_t recur_partial_bytes(int B) { return 3 * adamvs_group_stats_workspace_bytes(B, 2); }     // f of two planes, o
 
 int carve_recur(RecurBuffers& r, void* workspace, size_t bytes, int B, int npix, int W, int Wf, int HC, hipStream_t st) {
   auto al = [](size_t n) { return (n + 63) / 64 * 64; };
-  const size_t need = recur_floats(B, npix, W, Wf, HC) * sizeof(float) + adamvs_group_stats_workspace_bytes(B, 2);
+  const size_t need = recur_floats(B, npix, W, Wf, HC) * sizeof(float) + recur_partial_bytes(B);
   if (!workspace || bytes < need) return set_error(-1, "red_recur: workspace too small (%zu < %zu bytes)", bytes, need);
   float* p = (float*)workspace;
   r.state = p; p += al((size_t)B * npix * W);
@@ -315,6 +341,8 @@ int carve_recur(RecurBuffers& r, void* workspace, size_t bytes, int B, int npix,
   r.o = p;     p += al((size_t)B * npix * W);
   r.f = p;     p += al((size_t)B * npix * Wf);
   r.fu = p;    p += al((size_t)B * npix * Wf);
+  r.f2 = p;    p += al((size_t)B * npix * Wf);
+  r.fu2 = p;   p += al((size_t)B * npix * Wf);
   r.u = p;     p += al((size_t)B * npix * HC);
   r.part = (double*)p;
   // the state starts at zero; rh keeps zeros in its padding channels (only HC channels are ever written)
@@ -326,7 +354,7 @@ int carve_recur(RecurBuffers& r, void* workspace, size_t bytes, int B, int npix,
 
 extern "C" size_t adamvs_red_recur_workspace_bytes(int B, int h, int w, int W, int Wf, int HC) {
   if (B <= 0 || h <= 0 || w <= 0 || W <= 0 || Wf <= 0 || HC <= 0) return 0;
-  return recur_floats(B, h * w, W, Wf, HC) * sizeof(float) + adamvs_group_stats_workspace_bytes(B, 2);
+  return recur_floats(B, h * w, W, Wf, HC) * sizeof(float) + recur_partial_bytes(B);
 }
 
 extern "C" int adamvs_red_recur_pair(const float* x, int Cx, const float* wg, const float* bg, const float* wc, const float* bc,
@@ -374,6 +402,34 @@ extern "C" int adamvs_red_recur_split(const float* gxr, const float* gxu, const 
   if (int rc = carve_recur(r, workspace, workspace_bytes, B, npix, W, W, HC, st)) return rc;
   const size_t pbytes = adamvs_group_stats_workspace_bytes(B, 2);
   const size_t wsz = (size_t)9 * W * W, plane = (size_t)B * npix * W;
+  if (can_fold_gru_applies(B, W, h, w)) {
+    // Two dependent launches per plane: the gate convolutions of plane d form h(d-1) = u h(d-2) + (1 - u) tanh(GN(o)) in their
+    // window fill (GRU_PRO_OUT) and store it; the candidate convolution forms r * h(d-1) in its own (GRU_PRO_GATES).  The maps a
+    // launch reads while it writes their successors are double-buffered: states S[k & 1] = h(k), f(d) in F[d & 1], and the
+    // partial sums with them (rh's space of the unfolded path is the second state).
+    float* S[2] = {r.state, r.rh};                           // both zeroed by carve_recur: h(-1) = h(-2) = 0
+    float* FR[2] = {r.f, r.f2};
+    float* FU[2] = {r.fu, r.fu2};
+    double* PF[2] = {r.part, r.part + pbytes / sizeof(double)};
+    double* PO = r.part + 2 * (pbytes / sizeof(double));
+    int pf_parts[2] = {0, 0}, po_parts = 0;
+    for (int d = 0; d < D; ++d) {
+      int rc;
+      GruPro out{GRU_PRO_OUT, FU[(d + 1) & 1], r.o, PF[(d + 1) & 1], PO, pf_parts[(d + 1) & 1], 1, po_parts, gn + 2 * HC, gn + 4 * HC,
+                 S[(d + 1) & 1], d > 0 ? R + (size_t)(d - 1) * B * npix * RW : nullptr, RW, HC, npix * HC, eps};
+      if ((rc = launch_conv_dd_gates_gn(S[d & 1], w_ghr, w_ghr + wsz, gxr + d * plane, FR[d & 1], w_ghu, w_ghu + wsz, gxu + d * plane,
+                                        FU[d & 1], B, W, h, w, st, PF[d & 1], HC, &pf_parts[d & 1], d > 0 ? &out : nullptr)))
+        return rc;
+      GruPro gates{GRU_PRO_GATES, FR[d & 1], nullptr, PF[d & 1], nullptr, pf_parts[d & 1], 0, 0, gn, nullptr,
+                   nullptr, nullptr, 0, HC, npix * HC, eps};
+      if ((rc = launch_conv_dd_gn(S[(d + 1) & 1], w_ch, w_ch + wsz, cx + d * plane, r.o, B, W, h, w, st, PO, HC, 0, 1, &po_parts, &gates)))
+        return rc;
+    }
+    hipLaunchKernelGGL(k_gru2_last_apply, dim3(cdiv(npix * (HC / 4), 256), B), dim3(256), 0, st, r.o, FU[(D - 1) & 1], PO, po_parts,
+                       PF[(D - 1) & 1], pf_parts[(D - 1) & 1], gn, S[D & 1], R + (size_t)(D - 1) * B * npix * RW, npix, W, HC, RW, eps);
+    ADAMVS_CHECK_LAUNCH("gru2_last_apply");
+    return 0;
+  }
   for (int d = 0; d < D; ++d) {
     int rc;
     // Wh.h + (Wx.x + b): the x halves of all planes were computed before the recurrence and enter as `skip`
