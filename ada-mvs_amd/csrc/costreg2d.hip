@@ -921,8 +921,7 @@ bool can_fold_gru_applies(int N, int D, int h, int w) {
   ConvDDArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, D, h, w, h, w, 0, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, nullptr};
   const int ntr = D == 32 ? resident_rows<32>(a, N) : resident_rows<64>(a, N);
   const long parts = ntr ? (long)cdiv(w, 16) * cdiv(h, ntr * (4 / (D / 16))) * 4 : 0;
-  static const bool on = [] { const char* e = getenv("ADAMVS_RED_FOLD_APPLIES"); return !(e && *e == '0'); }();
-  return on && gn_epilogue_partials(parts, N);
+  return gru_fold_enabled(N) && gn_epilogue_partials(parts, N);
 }
 
 // Two stride-1 layers on the same input (the gate convolutions of a ConvGRUCell2) with their GroupNorm partial sums (groups

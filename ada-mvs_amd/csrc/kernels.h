@@ -1,5 +1,7 @@
 // Launchers shared between the kernel translation units and the C-ABI glue.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 #include "planes.h"
 
@@ -49,22 +51,12 @@ int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBu
 // sb.rh1 / sb.rh2 after an even step of the split-bf16 path, whose fused GRU kernels alternate the two)
 int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers& sb, float* vol, int B, int h, int w, int D,
                       int d, int in_up, int precision, hipStream_t st, float** h1_now = nullptr, float** h2_now = nullptr);
-constexpr int GN_PARTS_LIMIT = 2048;     // partial sums per (sample, group) the GroupNorm buffers of msred.hip hold
-// A convolution writes its GroupNorm partials itself (one dependent launch fewer) while the stage is launch-bound: every block
-// of the consumer finishes the reduction on its own, which is free for 64 partials and not for 1152 x 16 samples (measured at
-// 16 tiles per step: 136 -> 147 ms with epilogue partials everywhere).
-inline bool gn_epilogue_partials(long parts, int samples) { return parts > 0 && parts <= GN_PARTS_LIMIT && parts * samples <= 4096; }
-int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias, float* out,
-                     int cout, int B, int h, int w, hipStream_t st, double* gn_part = nullptr, int gn_hc = 0, int gn_groups = 0,
-                     int* gn_parts = nullptr);
-// one stride-1 layer with the GroupNorm partial sums of its output in the epilogue when the small-grid kernel takes it
-// (*gn_parts > 0), plain otherwise (*gn_parts = 0): MS-REDNet's deep levels
 // (csrc/costreg2d.hip, k_conv_dd_resident)
 enum { GRU_PRO_NONE = 0, GRU_PRO_GATES = 1, GRU_PRO_OUT = 2 };
 struct GruPro {
   int mode;
-  const float* f;            // [N][npix][D]
-  const float* o;            // [N][npix][D] (GRU_PRO_OUT)
+  const float* f;            // [N][npix][D] (k_conv_dd_resident); k_conv_small: [N][npix][2 hc] + the half's channel offset
+  const float* o;            // [N][npix][D] (GRU_PRO_OUT); k_conv_small: [N][npix][hc]
   const double* part_f;      // partial sums of f's group: [(n * 2 + group_f) * parts_f + k][2]
   const double* part_o;      // [(n * parts_o + k)][2]
   int parts_f, group_f, parts_o;
@@ -76,6 +68,24 @@ struct GruPro {
   float eps;
 };
 
+constexpr int GN_PARTS_LIMIT = 2048;     // partial sums per (sample, group) the GroupNorm buffers of msred.hip hold
+// A convolution writes its GroupNorm partials itself (one dependent launch fewer) while the stage is launch-bound: every block
+// of the consumer finishes the reduction on its own, which is free for 64 partials and not for 1152 x 16 samples (measured at
+// 16 tiles per step: 136 -> 147 ms with epilogue partials everywhere).
+inline bool gn_epilogue_partials(long parts, int samples) { return parts > 0 && parts <= GN_PARTS_LIMIT && parts * samples <= 4096; }
+int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias, float* out,
+                     int cout, int B, int h, int w, hipStream_t st, double* gn_part = nullptr, int gn_hc = 0, int gn_groups = 0,
+                     int* gn_parts = nullptr, const GruPro* pro = nullptr);
+bool conv_pair_epilogue_partials(int B, int h, int w);       // whether launch_conv_pair writes the GroupNorm partials itself
+// one stride-1 layer with the GroupNorm partial sums of its output in the epilogue when the small-grid kernel takes it
+// (*gn_parts > 0), plain otherwise (*gn_parts = 0): MS-REDNet's deep levels
+// Folding pays while a stage is bound by its dependent launches: one or two tiles per step (measured at cfg3's shape: 51.3 ->
+// 53.8 maps/s at one tile; 92.2 -> 88.7 at four and 115.4 -> 111.6 at sixteen, where the window halo's recomputed sigmoid /
+// tanh and the per-workgroup reductions cost more than the launches they replace).  ADAMVS_RED_FOLD_APPLIES=0 / 1 forces.
+inline bool gru_fold_enabled(int samples) {
+  static const int forced = [] { const char* e = getenv("ADAMVS_RED_FOLD_APPLIES"); return e && *e ? atoi(e) : -1; }();
+  return forced >= 0 ? forced != 0 : samples <= 2;
+}
 bool can_fold_gru_applies(int N, int D, int h, int w);
 int launch_conv_dd_gates_gn(const float* in, const float* wpk_r, const float* bias_r, const float* skip_r, float* out_r,
                             const float* wpk_u, const float* bias_u, const float* skip_u, float* out_u, int N, int D, int h, int w,

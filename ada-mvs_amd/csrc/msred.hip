@@ -194,7 +194,8 @@ __global__ void k_gru2_out_apply(const float* __restrict__ o, const double* __re
 // -> channels [0, HC) of out.  gn [6][HC] as adamvs_red_recur_*.  grid (blocks over npix * HC/4, N).
 __global__ void k_gru2_last_apply(const float* __restrict__ o, const float* __restrict__ fu, const double* __restrict__ part_o, int parts_o,
                                   const double* __restrict__ part_f, int parts_f, const float* __restrict__ gn,
-                                  const float* __restrict__ h, float* __restrict__ out, int npix, int W, int HC, int Wo, float eps) {
+                                  const float* __restrict__ h, float* __restrict__ out, int npix, int Wfu, int W, int HC, int Wo,
+                                  float eps) {        // fu: Wfu floats per pixel; o, h: W; out: Wo
   __shared__ float sf[2][2], so[2][2];
   const int b = blockIdx.y;
   gn_finish(part_f, b, 2, parts_f, npix * HC, eps, sf);
@@ -204,7 +205,7 @@ __global__ void k_gru2_last_apply(const float* __restrict__ o, const float* __re
   if (i >= npix * G) return;
   const int c = 4 * (i % G);
   const size_t bp = (size_t)b * npix + i / G;
-  const f32x4 fv = *(const f32x4*)(fu + bp * W + c), ov = *(const f32x4*)(o + bp * W + c);
+  const f32x4 fv = *(const f32x4*)(fu + bp * Wfu + c), ov = *(const f32x4*)(o + bp * W + c);
   const f32x4 gu = *(const f32x4*)(gn + 2 * HC + c), bu = *(const f32x4*)(gn + 3 * HC + c);
   const f32x4 ga = *(const f32x4*)(gn + 4 * HC + c), be = *(const f32x4*)(gn + 5 * HC + c);
   const f32x4 un = (fv - sf[1][0]) * sf[1][1] * gu + bu, on = (ov - so[0][0]) * so[0][1] * ga + be;
@@ -367,6 +368,32 @@ extern "C" int adamvs_red_recur_pair(const float* x, int Cx, const float* wg, co
   RecurBuffers r;
   if (int rc = carve_recur(r, workspace, workspace_bytes, B, npix, HC, 2 * HC, HC, st)) return rc;
   const size_t pbytes = adamvs_group_stats_workspace_bytes(B, 2);
+  if (gru_fold_enabled(B) && conv_pair_epilogue_partials(B, h, w)) {
+    // two dependent launches per plane, as adamvs_red_recur_split below: gate_conv of plane d forms h(d-1) in its window fill
+    // and stores it, output_conv forms r * h(d-1); compact maps (f: 2 HC wide, the reset half first)
+    float* S[2] = {r.state, r.rh};                           // both zeroed by carve_recur
+    float* F[2] = {r.f, r.f2};
+    double* PF[2] = {r.part, r.part + pbytes / sizeof(double)};
+    double* PO = r.part + 2 * (pbytes / sizeof(double));
+    int pf_parts[2] = {0, 0}, po_parts = 0;
+    for (int d = 0; d < D; ++d) {
+      const float* xd = x + (size_t)d * B * npix * Cx;
+      int rc;
+      GruPro out{GRU_PRO_OUT, F[(d + 1) & 1] + HC, r.o, PF[(d + 1) & 1], PO, pf_parts[(d + 1) & 1], 1, po_parts, gn + 2 * HC, gn + 4 * HC,
+                 S[(d + 1) & 1], d > 0 ? R + (size_t)(d - 1) * B * npix * RW : nullptr, RW, HC, npix * HC, eps};
+      if ((rc = launch_conv_pair(xd, Cx, S[d & 1], HC, wg, bg, F[d & 1], 2 * HC, B, h, w, st, PF[d & 1], HC, 2, &pf_parts[d & 1],
+                                 d > 0 ? &out : nullptr)))
+        return rc;
+      GruPro gates{GRU_PRO_GATES, F[d & 1], nullptr, PF[d & 1], nullptr, pf_parts[d & 1], 0, 0, gn, nullptr,
+                   nullptr, nullptr, 0, HC, npix * HC, eps};
+      if ((rc = launch_conv_pair(xd, Cx, S[(d + 1) & 1], HC, wc, bc, r.o, HC, B, h, w, st, PO, HC, 1, &po_parts, &gates))) return rc;
+    }
+    hipLaunchKernelGGL(k_gru2_last_apply, dim3(cdiv(npix * (HC / 4), 256), B), dim3(256), 0, st, r.o, F[(D - 1) & 1] + HC, PO, po_parts,
+                       PF[(D - 1) & 1], pf_parts[(D - 1) & 1], gn, S[D & 1], R + (size_t)(D - 1) * B * npix * RW, npix, 2 * HC, HC, HC, RW,
+                       eps);
+    ADAMVS_CHECK_LAUNCH("gru2_last_apply");
+    return 0;
+  }
   for (int d = 0; d < D; ++d) {
     const float* xd = x + (size_t)d * B * npix * Cx;
     int rc;
@@ -426,7 +453,7 @@ extern "C" int adamvs_red_recur_split(const float* gxr, const float* gxu, const 
         return rc;
     }
     hipLaunchKernelGGL(k_gru2_last_apply, dim3(cdiv(npix * (HC / 4), 256), B), dim3(256), 0, st, r.o, FU[(D - 1) & 1], PO, po_parts,
-                       PF[(D - 1) & 1], pf_parts[(D - 1) & 1], gn, S[D & 1], R + (size_t)(D - 1) * B * npix * RW, npix, W, HC, RW, eps);
+                       PF[(D - 1) & 1], pf_parts[(D - 1) & 1], gn, S[D & 1], R + (size_t)(D - 1) * B * npix * RW, npix, W, W, HC, RW, eps);
     ADAMVS_CHECK_LAUNCH("gru2_last_apply");
     return 0;
   }

@@ -22,6 +22,12 @@ __global__ __launch_bounds__(256) void k_conv_small(SmallConvArgs a, TileGrid tg
   extern __shared__ __attribute__((aligned(16))) float lds[];
   ConvSmallRole<CA, CB, NT, STRIDE, EPI, TR, RW>::run(a, tg, TileRange{0, tg.ntiles}, blockIdx.x, gridDim.x, lds);
 }
+// MS-REDNet's shallow GRU levels with the elementwise kernels folded into the window fill (GruPro, kernels.h)
+template <int CA, int CB, int NT>
+__global__ __launch_bounds__(256) void k_conv_small_pro(SmallConvArgs a, TileGrid tg, GruPro pro) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  ConvSmallRole<CA, CB, NT, 1, EPI_LINEAR, 4, 1>::run(a, tg, TileRange{0, tg.ntiles}, blockIdx.x, gridDim.x, lds, pro);
+}
 
 template <bool IN_UP>
 __global__ __launch_bounds__(256) void k_decoder(DecoderArgs a, TileGrid tg) {
@@ -392,19 +398,43 @@ static int launch_conv1_c(const float* cost, const float* w, float* c1, int N, i
   return 0;
 }
 
+template <int CA, int CB, int NT>
+static int launch_small_pro(const SmallConvArgs& a, const GruPro& pro, int B, hipStream_t st) {
+  typedef ConvSmallRole<CA, CB, NT, 1, EPI_LINEAR, 4, 1> Role;
+  auto kern = k_conv_small_pro<CA, CB, NT>;
+  static const int capacity = resident_blocks(kern, 256, Role::LDS_BYTES);      // once per instantiation, thread-safely
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(a.wo, 16), cdiv(a.ho, 4), B)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Role::LDS_BYTES, st, a, tg, pro);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "conv_pair (folded): %s", hipGetErrorString(e));
+  return 0;
+}
+
 // out = conv3x3(cat(srcA, srcB)) + bias on compact channel-last maps (the ConvGRUCell2 convolutions of MS-REDNet's two
 // shallow levels: gate_conv / output_conv of reference models/module.py:62-67 before their GroupNorm)
 // gn_part != null: GroupNorm partial sums of the output in the epilogue (SmallConvArgs); *gn_parts receives the number of
 // partials per (sample, group), or 0 when the map has more tiles than the partial buffer holds (the caller then reduces the
 // map with k_gn_partial as before).
 int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const float* wpk, const float* bias, float* out,
-                     int cout, int B, int h, int w, hipStream_t st, double* gn_part, int gn_hc, int gn_groups, int* gn_parts) {
+                     int cout, int B, int h, int w, hipStream_t st, double* gn_part, int gn_hc, int gn_groups, int* gn_parts,
+                     const GruPro* pro) {
   SmallConvArgs a{srcA, srcB, wpk, bias, out, nullptr, h, w, h, w, cout};
   if (gn_parts) *gn_parts = 0;
   const long parts = (long)cdiv(w, 16) * cdiv(h, 4) * 4;            // launch_small: tiles of 4 rows x 16 columns, one run per wave
   if (gn_part && gn_parts && gn_epilogue_partials(parts, B)) {
     a.gn_part = gn_part; a.gn_hc = gn_hc; a.gn_groups = gn_groups;
     *gn_parts = (int)parts;
+  }
+  if (pro) {
+    if (CB == 8 && cout <= 16) {
+      if (CA == 32) return launch_small_pro<32, 8, 1>(a, *pro, B, st);
+      if (CA == 16) return launch_small_pro<16, 8, 1>(a, *pro, B, st);
+      if (CA == 8) return launch_small_pro<8, 8, 1>(a, *pro, B, st);
+    }
+    if (CA == 16 && CB == 16 && cout <= 16) return launch_small_pro<16, 16, 1>(a, *pro, B, st);
+    if (CA == 16 && CB == 16 && cout <= 32) return launch_small_pro<16, 16, 2>(a, *pro, B, st);
   }
   if (CB == 8 && cout <= 16) {
     if (CA == 32) return launch_small<32, 8, 1, 1, EPI_LINEAR>(a, B, st, "conv_pair");
@@ -415,6 +445,8 @@ int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const
   if (CA == 16 && CB == 16 && cout <= 32) return launch_small<16, 16, 2, 1, EPI_LINEAR>(a, B, st, "conv_pair");
   return set_error(-1, "conv3x3_pair: (CA=%d, CB=%d, cout=%d) unsupported: (32|16|8, 8, <=16) or (16, 16, <=32)", CA, CB, cout);
 }
+
+bool conv_pair_epilogue_partials(int B, int h, int w) { return gn_epilogue_partials((long)cdiv(w, 16) * cdiv(h, 4) * 4, B); }
 
 int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int precision, hipStream_t st) {
   if (precision == PRECISION_BF16X3) return launch_conv1_bf16x3(cost, w, c1, N, C, h, w_, st);

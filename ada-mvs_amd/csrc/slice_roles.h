@@ -73,7 +73,11 @@ struct ConvSmallRole {
   static int tiles_y(const Args& a) { return cdiv(a.ho, TR); }
 
   // workgroup `wg` of `nwg` walks tiles tr.begin + wg, + nwg, ... < tr.end
-  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds) {
+  // `pro` (LINEAR, MS-REDNet; its own kernel argument: the recurrence's launches do not carry it): srcB formed on the fly from
+  // the previous kernels' maps (kernels.h, GruPro; srcB itself is the state h) -- GRU_PRO_GATES: r * h; GRU_PRO_OUT:
+  // h' = u h + (1 - u) tanh(GN(o)), also stored for the tile's own pixels
+  static __device__ __forceinline__ void run(const Args& a, const TileGrid& tg, TileRange tr, int wg, int nwg, float* lds,
+                                             const GruPro& pro = GruPro{}) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
   const int p = lane & 15, q = lane >> 4;
   const int row = wave / RW, col = (wave % RW) * 16;      // the wave's run inside a tile
@@ -129,11 +133,73 @@ struct ConvSmallRole {
     pin(ooff[nt]); pin(ooff1[nt]);
   }
 
+  // MS-REDNet (LINEAR): srcB formed on the fly (GruPro); the f map is 2 CB wide, the o map CB wide like srcB = h
+  constexpr int NBP = (EPI == EPI_LINEAR && NB > 0) ? NB : 1;
+  constexpr int GBP = GB > 0 ? GB : 1;
+  const bool pro_on = EPI == EPI_LINEAR && pro.mode != GRU_PRO_NONE;            // uniform
+  unsigned foff[NBP];
+  f32x4 gfw[NBP], gfb[NBP], gow[NBP], gob[NBP];
+  f32x4 stageF[NBP], stageO[NBP];
+  float pst[4] = {0.f, 1.f, 0.f, 1.f};   // mean, 1/sigma of f's group; of o
+  int pst_b = -1;                        // the sample they belong to
+  if (EPI == EPI_LINEAR && pro_on) {
+#pragma unroll
+    for (int k = 0; k < NBP; ++k) {
+      const int j = min(tid + k * 256, NPIX * GB - 1);
+      const int g = j % GBP, pp = j / GBP, r = pp / LC, c = pp % LC;
+      foff[k] = (unsigned)(((r * a.wi + c) * 2 * CB + 4 * g) * 4);
+      pin(foff[k]);
+      gfw[k] = *(const f32x4*)(pro.gn_f + 4 * g); gfb[k] = *(const f32x4*)(pro.gn_f + CB + 4 * g);
+      if (pro.mode == GRU_PRO_OUT) { gow[k] = *(const f32x4*)(pro.gn_o + 4 * g); gob[k] = *(const f32x4*)(pro.gn_o + CB + 4 * g); }
+    }
+  }
+  // the GroupNorm statistics of sample b, finished from the partial sums by the whole workgroup (uniform call)
+  auto pro_stats = [&](int b) {
+    if constexpr (EPI == EPI_LINEAR) {                     // (the scratch exists in the LINEAR instantiations only)
+    __shared__ double pro_wsum[4][2];
+    __shared__ float pro_st[2][2];
+    if (b == pst_b) return;
+    pst_b = b;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      if (which == 1 && pro.mode != GRU_PRO_OUT) break;
+      const int parts = which ? pro.parts_o : pro.parts_f;
+      const double* p = which ? pro.part_o + (size_t)b * parts * 2 : pro.part_f + ((size_t)b * 2 + pro.group_f) * parts * 2;
+      double s_ = 0.0, q_ = 0.0;
+      for (int k = tid; k < parts; k += 256) { s_ += p[2 * k]; q_ += p[2 * k + 1]; }
+      for (int o = 32; o > 0; o >>= 1) { s_ += __shfl_down(s_, o); q_ += __shfl_down(q_, o); }
+      __syncthreads();                                     // (the previous use of the scratch is over)
+      if (lane == 0) { pro_wsum[wave][0] = s_; pro_wsum[wave][1] = q_; }
+      __syncthreads();
+      if (tid == 0) {
+        double s2 = 0.0, q2 = 0.0;
+        for (int w = 0; w < 4; ++w) { s2 += pro_wsum[w][0]; q2 += pro_wsum[w][1]; }
+        const double mean = s2 / pro.count, var = fmax(q2 / pro.count - mean * mean, 0.0);
+        pro_st[which][0] = (float)mean;
+        pro_st[which][1] = (float)(1.0 / sqrt(var + (double)pro.eps));
+      }
+      __syncthreads();
+      pst[2 * which] = pro_st[which][0]; pst[2 * which + 1] = pro_st[which][1];
+    }
+    }
+  };
+
   auto load_tile = [&](f32x4 (&stage)[NL], int b, int tx, int ty) {
     const int ix0 = tx * TC * STRIDE - 1, iy0 = ty * TR * STRIDE - 1;
     const long pix0 = ((long)b * a.hi + iy0) * a.wi + ix0;                 // may point one row/column outside
     const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
     const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    if (EPI == EPI_LINEAR && pro_on) {                     // the operands of the on-the-fly srcB (zero padding is applied when it is formed)
+      const buf_rsrc rf = make_rsrc((const char*)pro.f + pix0 * (2 * CB * 4));
+      const buf_rsrc ro = make_rsrc((const char*)(pro.mode == GRU_PRO_OUT ? pro.o : a.srcB) + pix0 * (CB * 4));
+#pragma unroll
+      for (int k = 0; k < NBP; ++k) {
+        const int iy = iy0 + (rc[NA + k] & 0xffff), ix = ix0 + (rc[NA + k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        stageF[k] = buf_load4(rf, ok ? foff[k] : BUF_OOB);
+        if (pro.mode == GRU_PRO_OUT) stageO[k] = buf_load4(ro, ok ? goff[NA + k] : BUF_OOB);
+      }
+    }
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + LR <= a.hi && ix0 + LC <= a.wi;
     if (interior) {
 #pragma unroll
@@ -147,11 +213,33 @@ struct ConvSmallRole {
       }
     }
   };
-  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+  auto store_tile = [&](const f32x4 (&stage)[NL], int b, int tx, int ty) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       float* dl = (float*)((char*)lds + lbyte[k]);
       f32x4 v = stage[k];
+      if (EPI == EPI_LINEAR && k >= NA && pro_on) {
+        const int kb = k - NA < NBP ? k - NA : 0;
+        const int wr = rc[k] & 0xffff, wc = rc[k] >> 16;
+        const int iy = ty * TR - 1 + wr, ix = tx * TC - 1 + wc;
+        const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        const f32x4 fn = (stageF[kb] - pst[0]) * pst[1] * gfw[kb] + gfb[kb];
+        const f32x4 sg = {sigmoidf_(fn.x), sigmoidf_(fn.y), sigmoidf_(fn.z), sigmoidf_(fn.w)};
+        if (pro.mode == GRU_PRO_GATES) {
+          v = sg * v;                                        // r * h
+        } else {
+          const f32x4 on = (stageO[kb] - pst[2]) * pst[3] * gow[kb] + gob[kb];
+          const f32x4 y = {tanhf(on.x), tanhf(on.y), tanhf(on.z), tanhf(on.w)};
+          v = sg * v + (1.0f - sg) * y;                      // h' = u h + (1 - u) y
+        }
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};              // zero padding
+        if (pro.mode == GRU_PRO_OUT && ok && tid + kb * 256 < NPIX * GB && wr >= 1 && wr <= TR && wc >= 1 && wc <= TC) {
+          const size_t pix = ((size_t)b * a.hi + iy) * a.wi + ix;      // the tile's own pixels: the new state (and R)
+          const int c4 = 4 * ((tid + kb * 256) % GBP);
+          *(f32x4*)(pro.state_out + pix * CB + c4) = v;
+          if (pro.R) *(f32x4*)(pro.R + pix * pro.RW + c4) = v;
+        }
+      }
       dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
     }
   };
@@ -163,7 +251,8 @@ struct ConvSmallRole {
   f32x4 stage[NL];
   load_tile(stage, b, tx, ty);
   wait_vmem_all();                     // fragments, biases and the first tile: nothing is pending inside the loop
-  store_tile(stage);
+  if (EPI == EPI_LINEAR && pro_on) pro_stats(b);
+  store_tile(stage, b, tx, ty);
   __syncthreads();
   for (;;) {
     const int oy0 = ty * TR, ox0 = tx * TC;
@@ -216,7 +305,8 @@ struct ConvSmallRole {
 
     wait_vmem_all();                   // the wait point (explicit, so that no other wait is scheduled elsewhere)
     __syncthreads();                   // every wave is done reading the tile
-    if (more) store_tile(stage);
+    if (EPI == EPI_LINEAR && pro_on && more) pro_stats(bn);
+    if (more) store_tile(stage, bn, txn, tyn);
 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {

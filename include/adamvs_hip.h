@@ -325,8 +325,10 @@ int adamvs_conv3x3_pair(const float* srcA, int CA, const float* srcB, int CB, co
 
 /* One level's whole recurrence over the D planes of a stage (the loop of slice_RED_Regularization.forward restricted to
  * one ConvGRUCell2, msrednet.py:349-366), launched from native code: per plane the convolutions, the two GroupNorm
- * reductions and the two epilogues above (small maps: the partial sums come out of the convolutions' own epilogues and
- * the two gate convolutions of _split are one launch -- four dependent launches per plane); the state starts at zero; h' of plane d goes to channels [0, HC) of
+ * reductions and the two epilogues above (small maps: the partial sums come out of the convolutions' own epilogues, the
+ * two gate convolutions of _split are one launch and, at one or two samples, the elementwise kernels are folded into the
+ * window fill of the convolution that follows them -- two dependent launches per plane; ADAMVS_RED_FOLD_APPLIES=0 / 1
+ * forces); the state starts at zero; h' of plane d goes to channels [0, HC) of
  * R [D][B][h*w][RW] (plane-major).  gn [6][HC] = reset / update / output norm weight, bias.
  * _pair (levels 1, 2): x [D][B][h*w][Cx] compact, wg / wc + bg / bc as for adamvs_conv3x3_pair (gate_conv with 2 HC
  * rows, output_conv).  _split (levels 3, 4): gxr, gxu, cx [D][B][h*w][W] = the x halves (+ bias) of the reset / update /
