@@ -1,6 +1,7 @@
 """MS-REDNet inference: oracle/msrednet_oracle.py against fixtures the reference's own
 models/msrednet.py produced (tools/gen_golden_msred.py), and -- on the GPU -- the HIP path against both."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -288,6 +289,23 @@ def test_end_to_end_batch_of_two_against_oracle():
         out = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
     assert rel_l1(out["depth"].cpu(), want["depth"]) < E2E_TOL
     assert rel_l1(out["photometric_confidence"].cpu(), want["photometric_confidence"]) < E2E_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fold,small_grid", [("0", "1024"), ("0", "0")])
+def test_unfolded_recurrence_paths_in_a_child_process(fold, small_grid):
+    """At one or two samples the GRU levels run with their elementwise kernels folded into the convolutions (two dependent
+    launches per plane, csrc/msred.hip); the four-launch form (epilogue partial sums, one launch for both gate
+    convolutions) serves larger batches, and the seven-launch form (k_gn_partial, plain convolutions) maps whose partial sums
+    would not fit.  The switches are read once per process: a child process runs the end-to-end and slice-step cases with
+    folding off, and with the small-grid kernels off as well (ADAMVS_CONV_SMALL_GRID=0: every convolution on the generic
+    kernel, every reduction a launch of its own)."""
+    import subprocess
+    env = dict(os.environ, ADAMVS_RED_FOLD_APPLIES=fold, ADAMVS_CONV_SMALL_GRID=small_grid)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "end_to_end_against_reference_golden_and_oracle or end_to_end_batch_of_two or slice_red_steps"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_cpu_tensors_raise():
