@@ -5,6 +5,9 @@ Bar (BASELINE.json north_star): depth / probability maps within 1e-3 relative L1
 of the reference CPU path.  The asserts below use tighter, per-op tolerances
 (fp32 kernels agree to ~1e-5) so that a real bug cannot hide under the bar.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +17,7 @@ import ada_mvs_amd  # noqa: F401
 from ada_mvs_amd import synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 NORTH_STAR_TOL = 1e-3      # stated bar
 OP_TOL = 5e-5              # what fp32 kernels should reach per op
@@ -245,6 +249,17 @@ def test_conv3x3_dd_winograd(hip, N, D, h, w, relu, skip):
     back = lambda y: y.cpu().double().reshape(N, h, w, D).permute(0, 3, 1, 2)
     assert rel_l1(back(out), ref) < 2e-6                    # measured 2e-7 ... 5e-7 (the direct kernel: 2e-7 ... 7e-7)
     assert rel_l1(back(out), back(direct)) < 2e-6
+
+
+def test_cost_reg_net_2d_direct_kernels_in_a_child_process(hip):
+    """ADAMVS_WINOGRAD=0 (read once per process): CostRegNet2D with its stride-1 layers on the direct kernel at the widths
+    the F(2x2, 3x3) kernel otherwise takes, the softmax epilogue of the direct `prob` layer included."""
+    import subprocess
+    env = dict(os.environ, ADAMVS_WINOGRAD="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_cost_reg_net_2d_widths or test_prob_softmax_regress_fused or test_generated_planes_equal_materialised_planes"],
+                       env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("D,h,w", [(32, 16, 24), (64, 8, 16), (192, 8, 16), (256, 8, 8)])
