@@ -227,11 +227,14 @@ def test_cost_reg_net_2d_widths(hip, O, D, h, w):
 
 @pytest.mark.parametrize("N,D,h,w,relu,skip", [(1, 192, 6, 32, 1, False), (2, 192, 13, 45, 0, False), (2, 192, 7, 70, 1, True),
                                                (1, 192, 1, 1, 1, False), (1, 64, 8, 40, 1, False), (1, 128, 13, 33, 0, True),
-                                               (1, 256, 6, 32, 0, False), (3, 192, 24, 48, 1, False)])
+                                               (1, 256, 6, 32, 0, False), (3, 192, 24, 48, 1, False),
+                                               (12, 192, 30, 64, 1, False), (40, 64, 24, 64, 0, True)])
 def test_conv3x3_dd_winograd(hip, N, D, h, w, relu, skip):
     """A stride-1 CostRegNet2D layer in the F(2x2, 3x3) form (csrc/costreg2d_wino.hip) against a float64 convolution
     (ConvBnReLU.forward, reference models/module.py:254-261, BN folded) and against the direct kernel: full and ragged
-    blocks of 6 x 32 pixels, maps smaller than one block, every supported width."""
+    blocks of 6 x 32 pixels, maps smaller than one block, every supported width; the last two cases have more tiles (360, 320)
+    than the persistent grid has workgroups (256): a workgroup walks several, with the next tile's requests in flight over the
+    epilogue of the current one."""
     from ada_mvs_amd import packing
     g = torch.Generator().manual_seed(N * 1000 + D + h + w)
     x = torch.randn(N, D, h, w, generator=g)
