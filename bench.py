@@ -20,7 +20,65 @@ import os
 import sys
 import time
 
-import torch
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process becomes the launcher.
+    It has imported nothing that can touch the GPU (the check runs before `import torch`), starts N FRESH child processes
+    of this file -- one rank per GPU, torchrun's environment contract, never an exec -- relays rank 0's JSON line and
+    exits non-zero if any rank does.  Under torchrun (WORLD_SIZE set) this is a no-op."""
+    if os.environ.get("WORLD_SIZE"):
+        return
+    n = 1
+    for i, a in enumerate(sys.argv[1:]):
+        if a == "--gpus" and i + 2 <= len(sys.argv[1:]):
+            n = sys.argv[i + 2]
+        elif a.startswith("--gpus="):
+            n = a.split("=", 1)[1]
+    try:
+        n = int(n)
+    except ValueError:
+        return                                   # argparse reports it
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ADAMVS_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    rc, out0 = 0, []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)    # rank 0 prints the one JSON line
+    reader.start()
+    pending = list(procs)
+    while pending:                               # a rank that dies leaves the others in a collective: end them by PID
+        for p in list(pending):
+            c = p.poll()
+            if c is None:
+                continue
+            pending.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                for q in pending:
+                    q.terminate()
+        time.sleep(0.05)
+    reader.join(10)
+    sys.stdout.write(b"".join(out0).decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -495,14 +553,28 @@ def main():
         _lib.load()
         return bench_msrednet(args)
 
+    one_device = bool(os.environ.get("ADAMVS_BENCH_ONE_DEVICE"))   # dry run of the N > 1 path on a 1-GPU box (with ADAMVS_DIST_BACKEND=gloo)
+    if one_device:
+        os.environ["LOCAL_RANK"] = "0"
     rank, world, local = adist.init_from_env()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-    if os.environ.get("ADAMVS_BENCH_ONE_DEVICE"):     # dry run of the N > 1 path on a 1-GPU box (with ADAMVS_DIST_BACKEND=gloo)
-        local = 0
+    if world != args.gpus:
+        # a line that says n_gpus = 1 under --gpus 8 would be a wrong scaling point, not a slow one: refuse
+        print("bench.py: --gpus %d but %d rank(s) were started (WORLD_SIZE); launch with `python bench.py --gpus N` "
+              "(self-launching) or torch.distributed.run --nproc-per-node N" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()
+    backend = torch.distributed.get_backend() if world > 1 else None
+    props = torch.cuda.get_device_properties(local)
+    me = {"rank": rank, "device": "cuda:%d" % local, "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
+    devices = [me]
+    if world > 1:
+        devices = [None] * world
+        torch.distributed.all_gather_object(devices, me)
+        if not one_device and len({d["uuid"] or d["device"] for d in devices}) != world:
+            print("bench.py: %d ranks share devices %s" % (world, devices), file=sys.stderr)
+            sys.exit(2)
     cfg = args.workload
     c = synth.CONFIGS[cfg]
     strong = args.tiles_total > 0
@@ -554,6 +626,8 @@ def main():
                 "value": n_tiles * args.steps / elapsed, "unit": "depth maps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                 "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+                "rccl_ranks": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend, backend), "devices": devices,
+                "launcher": os.environ.get("ADAMVS_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "none"),
                 "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA, fp32 accumulate) for the convolutions, f32 elsewhere",
                 "data": "synthetic",
                 "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, %s" % (
@@ -570,6 +644,9 @@ def main():
 
         if rank == 0 and world == 1 and not args.no_roofline:
             result.update(roofline_of(wl, args, result["ms_per_step"]))
+        if rank == 0 and world > 1:
+            result["roofline"] = result["cpu_baseline"] = None
+            result["note"] = "roofline, cpu_baseline, parity_rel_l1 and cascade are measured by the N = 1 line only (per-kernel timing and the oracle run on rank 0's GPU / host cores)"
         parity_ok = True
         sd = wl.sd
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -111,3 +111,22 @@ def test_bench_two_ranks_strong_scaling_dry_run(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_tiles_per_step"] == 5
     assert d["value"] > 0 and d["steps"] == 2
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """Plain `python bench.py --gpus 2 ...` with no launcher around it (the way the driver starts the 1-GPU line): the process
+    must start two fresh ranks itself and report n_gpus == 2 -- never measure one GPU under a --gpus 2 label."""
+    import json
+    env = dict(os.environ, ADAMVS_BENCH_ONE_DEVICE="1", ADAMVS_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg1", "--tiles-total", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["launcher"] == "self"
+    assert [x["rank"] for x in d["devices"]] == [0, 1] and len({x["pid"] for x in d["devices"]}) == 2
+    assert d["scaling"] == "strong" and d["config"]["global_tiles_per_step"] == 5 and d["value"] > 0
+    assert d["roofline"] is None and d["cpu_baseline"] is None

@@ -310,3 +310,15 @@ def test_share_cr_and_cr_base_chs_are_accepted_and_ignored():
     b = Infer_AdaMVSNet(48, [48, 32, 8], [4.0, 2.0, 1.0], True, [4, 16, 2]).state_dict()
     assert list(a) == list(b) and len(a) == 339
     assert all(a[k].shape == b[k].shape for k in a)
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """bench.py --gpus 2 inside a 1-rank world (WORLD_SIZE=1 set by some launcher) must exit 2, not print an n_gpus = 1 line;
+    and with a rank that fails (no GPU here) the self-launcher must pass the failure on."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2 but 1 rank" in r.stderr and not r.stdout.strip()
