@@ -70,7 +70,9 @@ SIGNATURES = {
     "adamvs_homo_warp": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_pair_similarity": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_cost_reg_net_2d_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
-    "adamvs_cost_reg_net_2d": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_cost_reg_width": (c_i, [c_i, c_i]),
+    "adamvs_cost_reg_net_2d_weight_floats": (c_sz, [c_i, c_i]),
+    "adamvs_cost_reg_net_2d": (c_i, [c_f, c_f, c_sz, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_conv3x3_dd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_conv3x3_dd_wino": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_softmax_max_regress": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
@@ -81,7 +83,7 @@ SIGNATURES = {
     "adamvs_slice_reg_step": (c_i, [c_f, c_f, c_f, ctypes.POINTER(FuseWeights), c_f, c_i, c_i, c_i, c_i, c_i, c_i,
                                     ctypes.c_void_p, c_sz, c_st]),
     "adamvs_depth_stage_workspace_bytes": (c_sz, [ctypes.POINTER(StageDesc)]),
-    "adamvs_depth_stage_forward": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(FuseWeights),
+    "adamvs_depth_stage_forward": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, c_sz, ctypes.POINTER(FuseWeights),
                                          c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_feature_net0_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "adamvs_feature_net0": (c_i, [c_f, ctypes.POINTER(FeatureWeights), c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
@@ -104,7 +106,7 @@ SIGNATURES = {
     "adamvs_soft_argmin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 PLANES_EXPLICIT, PLANES_UNIFORM, PLANES_WINDOW = 0, 1, 2
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15

@@ -31,6 +31,11 @@ struct StageCarve {
   int dc;
 };
 
+// the width CostRegNet2D runs at for the stage's D hypotheses (kernels.h::costreg_width; 0: none)
+static int stage_reg_width(const adamvs_stage_desc& s) {
+  return s.precision == PRECISION_BF16X3 ? costreg_width_bf16x3(s.D) : costreg_width(s.D);
+}
+
 static StageCarve carve(const adamvs_stage_desc& s) {
   StageCarve c;
   size_t hw = (size_t)s.h * s.w, hw4 = (size_t)(s.h / 2) * (s.w / 2);
@@ -51,7 +56,8 @@ static StageCarve carve(const adamvs_stage_desc& s) {
   c.agg = take(sweep_workspace_floats(s.B, s.C, s.D, s.h, s.w));
   c.sim = c.score = c.creg = o;
   if (s.first_stage) {
-    size_t F = (size_t)s.S * s.B * hw * s.D;
+    // the similarity / score volumes and CostRegNet2D's activations at the width the network runs at (>= D)
+    size_t F = (size_t)s.S * s.B * hw * stage_reg_width(s);
     c.sim = take(F);
     c.score = take(F);
     c.creg = take(3 * F);
@@ -66,16 +72,14 @@ static int check_desc(const adamvs_stage_desc* d) {
                    d->B, d->S, d->D, d->h, d->w);
   ADAMVS_CHECK_ARG(d->C == 8 || d->C == 16 || d->C == 32, "stage: C=%d unsupported (8, 16 or 32)", d->C);
   ADAMVS_CHECK_ARG((d->h % 2) == 0 && (d->w % 2) == 0, "stage: h=%d w=%d must be even", d->h, d->w);
-  ADAMVS_CHECK_ARG((size_t)d->B * d->D <= 65535, "stage: B*D=%d exceeds the grid z limit", d->B * d->D);
+  ADAMVS_CHECK_ARG(d->B <= 65535, "stage: B=%d tiles per call (at most 65535)", d->B);
   ADAMVS_CHECK_ARG(d->precision == PRECISION_FP32 || d->precision == PRECISION_BF16X3, "stage: precision=%d (0 fp32, 1 bf16x3)", d->precision);
   ADAMVS_CHECK_ARG(d->eps_in_numerator == 0 || d->eps_in_numerator == 1, "stage: eps_in_numerator=%d (0 or 1)", d->eps_in_numerator);
   ADAMVS_CHECK_ARG(d->plane_mode >= PLANES_EXPLICIT && d->plane_mode <= PLANES_WINDOW, "stage: plane_mode=%d (0 explicit, 1 uniform, 2 window)", d->plane_mode);
   ADAMVS_CHECK_ARG(d->precision_fuse == PRECISION_FP32 || d->precision_fuse == PRECISION_BF16X3,
                    "stage: precision_fuse=%d (0 fp32, 1 bf16x3)", d->precision_fuse);
   if (d->first_stage) {
-    ADAMVS_CHECK_ARG(d->precision == PRECISION_FP32 || costreg_bf16x3_depth_supported(d->D),
-                     "stage: bf16x3 CostRegNet2D needs D in {32,64,96,128,192,256}, got %d", d->D);
-    ADAMVS_CHECK_ARG(costreg_depth_supported(d->D), "stage: D=%d unsupported by CostRegNet2D (16,32,48,64,96,128,192,256)", d->D);
+    ADAMVS_CHECK_ARG(stage_reg_width(*d) > 0, "stage: D=%d hypotheses: CostRegNet2D runs at widths up to 384", d->D);
     ADAMVS_CHECK_ARG((d->h % 8) == 0 && (d->w % 8) == 0, "stage: first stage needs h=%d w=%d multiples of 8", d->h, d->w);
   } else {
     ADAMVS_CHECK_ARG(d->prev_h > 0 && d->prev_w > 0, "stage: prev_h/prev_w missing");
@@ -132,7 +136,7 @@ extern "C" size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* de
 }
 
 extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt,
-                                          const float* planes, const float* prev_conf, const float* w_reg,
+                                          const float* planes, const float* prev_conf, const float* w_reg, size_t w_reg_floats,
                                           const adamvs_fuse_weights* w_fuse, float* view_weight, float* pair_depth,
                                           float* depth, float* confidence, int phases, void* workspace,
                                           size_t workspace_bytes, void* stream) {
@@ -141,6 +145,9 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   const adamvs_stage_desc& s = *desc;
   ADAMVS_CHECK_ARG(feat && rt && planes && w_fuse && view_weight && depth && confidence && workspace, "stage: null pointer");
   ADAMVS_CHECK_ARG(!s.first_stage || (w_reg && pair_depth), "stage: first stage needs w_reg and pair_depth");
+  ADAMVS_CHECK_ARG(!s.first_stage || w_reg_floats == cost_reg_weight_floats(stage_reg_width(s), s.precision),
+                   "stage: w_reg holds %zu floats; D=%d hypotheses run at width %d, whose layout has %zu (include/adamvs_hip.h)",
+                   w_reg_floats, s.D, stage_reg_width(s), cost_reg_weight_floats(stage_reg_width(s), s.precision));
   ADAMVS_CHECK_ARG(s.first_stage || prev_conf, "stage: later stages need prev_conf");
   StageCarve c = carve(s);
   ADAMVS_CHECK_ARG(workspace_bytes >= c.total * sizeof(float), "stage: workspace too small (%zu < %zu bytes)", workspace_bytes,
@@ -154,14 +161,17 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   // -- view weights: scored by CostRegNet2D (stage 1) or resampled from the previous stage
   if (!(phases & ADAMVS_PHASE_VIEW_WEIGHTS)) {
   } else if (s.first_stage) {
-    if ((rc = launch_pair_similarity(feat, rt, ps, ws + c.sim, s.B, s.S, s.C, s.D, s.h, s.w, st))) return rc;
-    if (cost_reg_softmax_fusable(s.D, s.precision, ps)) {       // softmax / max / regression in the epilogue of the last layer
-      if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, s.precision, st,
-                                       view_weight, pair_depth, &ps, s.B)))
+    // Dr >= D: the width CostRegNet2D runs at (w_reg is packed for it: adamvs_cost_reg_width); the pad channels of the
+    // similarity volume are zeros, their scores -1e30, so the softmax sees D hypotheses
+    const int Dr = stage_reg_width(s);
+    if ((rc = launch_pair_similarity(feat, rt, ps, ws + c.sim, s.B, s.S, s.C, s.D, s.h, s.w, st, Dr))) return rc;
+    if (cost_reg_softmax_fusable(Dr, s.precision, ps)) {       // softmax / max / regression in the epilogue of the last layer
+      if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, Dr, s.h, s.w, s.precision, st,
+                                       view_weight, pair_depth, &ps, s.B, s.D)))
         return rc;
     } else {
-      if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, s.D, s.h, s.w, s.precision, st))) return rc;
-      if ((rc = launch_softmax_regress(ws + c.score, ps, view_weight, pair_depth, s.S, s.B, s.D, s.h, s.w, st))) return rc;
+      if ((rc = launch_cost_reg_net_2d(ws + c.sim, w_reg, ws + c.creg, ws + c.score, s.S * s.B, Dr, s.h, s.w, s.precision, st))) return rc;
+      if ((rc = launch_softmax_regress(ws + c.score, ps, view_weight, pair_depth, s.S, s.B, Dr, s.h, s.w, st, s.D))) return rc;
     }
   } else {
     if ((rc = adamvs_resize_bilinear(prev_conf, view_weight, s.S * s.B, s.prev_h, s.prev_w, s.h, s.w, stream))) return rc;

@@ -42,6 +42,7 @@ struct ConvDDArgs {
   // gn_part[((n * gn_ngroups + gn_group) * parts + (y * gridDim.x + x) * 4 + w) * 2], parts = 4 * workgroups per map
   double* gn_part;
   int gn_n, gn_group, gn_ngroups;
+  int sm_D;            // softmax epilogue: the number of hypothesis planes when the network runs wider (costreg_width); 0 = D
 };
 
 enum { CONV_S1 = 0, CONV_S2 = 1, CONV_T2 = 2 };
@@ -197,7 +198,7 @@ __device__ __forceinline__ void conv_dd_body(const ConvDDArgs& a, float* lds, in
 
   if (SOFTMAX) {
     __syncthreads();                                   // the last chunk's readers are done: the tile space is reused
-    softmax_epilogue<MT, WM, NTR, BR>(acc, a.bias, a.sm_planes, a.sm_B, n, r0, c0, a.ho, a.wo, D, a.sm_vw, a.sm_pd, lds);
+    softmax_epilogue<MT, WM, NTR, BR>(acc, a.bias, a.sm_planes, a.sm_B, n, r0, c0, a.ho, a.wo, a.sm_D ? a.sm_D : D, a.sm_vw, a.sm_pd, lds);
     return;
   }
   // epilogue: lane owns channels co4..co4+3 of the pixel in column p
@@ -628,7 +629,25 @@ static int launch_conv_dd_cfg(const ConvDDArgs& a_, int N, int mode, hipStream_t
 }
 
 bool costreg_depth_supported(int D) {
-  return D == 16 || D == 32 || D == 48 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256;
+  return D == 16 || D == 32 || D == 48 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384;
+}
+
+// The width CostRegNet2D runs at for D hypotheses: the next supported one.  The reference builds the network for any D
+// (models/adamvs.py:198-228); here the extra channels are zero weights (packing.py::pack_reg pads to this width: a pad
+// channel's activations are ReLU(0) = 0 in every layer and feed nothing), the pair-similarity volume carries zeros in them,
+// and the pad channels of `prob` get a bias of -1e30: exp(-1e30 - max) = 0 exactly, so softmax, its maximum and the depth
+// expectation see D hypotheses.  0 = more than 384.
+int costreg_width(int D) {
+  static const int widths[] = {16, 32, 48, 64, 96, 128, 192, 256, 384};
+  for (int w : widths)
+    if (D <= w) return w;
+  return 0;
+}
+int costreg_width_bf16x3(int D) {
+  static const int widths[] = {32, 64, 96, 128, 192, 256, 384};
+  for (int w : widths)
+    if (D <= w) return w;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -852,7 +871,31 @@ static bool conv256_split() {
   return on;
 }
 
+static int launch_conv_dd_z(const ConvDDArgs& a, int N, int mode, hipStream_t st);
+
+// The kernels below take the image index from blockIdx.z (at most 65535): more images run as several launches over
+// sub-batches, every pointer moved by whole images (the softmax epilogue's tile index is n % sm_B: sub-batches of whole tiles).
 static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
+  constexpr int ZMAX = 65535;
+  if (N <= ZMAX) return launch_conv_dd_z(a, N, mode, st);
+  ADAMVS_CHECK_ARG(!a.gn_part, "conv_dd: GroupNorm partials with N=%d images (at most %d)", N, ZMAX);
+  const int unit = a.sm_vw ? a.sm_B : 1;
+  ADAMVS_CHECK_ARG(unit <= ZMAX, "conv_dd: softmax epilogue with %d tiles per view (at most %d)", unit, ZMAX);
+  const int step = ZMAX / unit * unit;
+  const size_t in_img = (size_t)a.hi * a.wi * a.D, out_img = (size_t)a.ho * a.wo * a.D, map = (size_t)a.ho * a.wo;
+  for (int n0 = 0; n0 < N; n0 += step) {
+    ConvDDArgs b = a;
+    b.in = a.in + n0 * in_img;
+    if (a.in2) b.in2 = a.in2 + n0 * in_img;
+    if (a.out) b.out = a.out + n0 * out_img;
+    if (a.skip) b.skip = a.skip + n0 * out_img;
+    if (a.sm_vw) { b.sm_vw = a.sm_vw + n0 * map; b.sm_pd = a.sm_pd + n0 * map; }
+    if (int rc = launch_conv_dd_z(b, N - n0 < step ? N - n0 : step, mode, st)) return rc;
+  }
+  return 0;
+}
+
+static int launch_conv_dd_z(const ConvDDArgs& a, int N, int mode, hipStream_t st) {
   if (mode == CONV_S1 && (a.D == 32 || a.D == 64) && !a.sm_vw) {
     const int rc = a.D == 32 ? launch_conv_dd_resident<32>(a, N, st) : launch_conv_dd_resident<64>(a, N, st);
     if (rc >= 0) return rc;
@@ -884,8 +927,23 @@ static int launch_conv_dd(const ConvDDArgs& a, int N, int mode, hipStream_t st) 
         return 0;
       }
       return launch_conv_dd_cfg<4, 4>(a, N, mode, st);
+    case 384: {
+      // the 192-channel tiling twice (as 256 = 2 x 128 above): each launch contracts over all 384 input channels into its half
+      // of the output channels.  No softmax epilogue at this width (it needs a pixel's channels in one workgroup): the scores
+      // go through the score volume to k_softmax_regress.
+      ADAMVS_CHECK_ARG(!a.sm_vw, "conv_dd: no softmax epilogue at D=384");
+      ConvDDArgs h = a;
+      for (int half = 0; half < 2; ++half) {
+        h.wpk = a.wpk + (size_t)half * 12 * 64;
+        h.bias = a.bias + half * 192;
+        h.out = a.out + half * 192;
+        h.skip = a.skip ? a.skip + half * 192 : nullptr;
+        if (int rc = launch_conv_dd_cfg<3, 4>(h, N, mode, st)) return rc;
+      }
+      return 0;
+    }
   }
-  return set_error(-1, "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", a.D);
+  return set_error(-1, "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256 or 384)", a.D);
 }
 
 int launch_conv_dd_gn(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
@@ -960,10 +1018,11 @@ int launch_conv_dd_gates_gn(const float* in, const float* wpk_r, const float* bi
 // score [N=S*B][hw][D] (n = s*B + b), planes [B][D][hw] -> vw, pd [S*B][hw].
 // NQ = D/64 rounded up: the lane's scores stay in registers between the max pass and the exp pass, so the
 // score volume is read once (NQ = 0: any D, two passes over global memory).
+// Dp = hypothesis planes (<= D, the channels of `score`: pad channels carry -1e30 and weigh exactly 0).
 template <int NQ>
 __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict__ score, PlaneSrc planes,
                                                          float* __restrict__ vw, float* __restrict__ pd, int B, int D, int hw,
-                                                         size_t npix) {
+                                                         size_t npix, int Dp) {
   size_t gp = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
   const bool live = gp < npix;
@@ -971,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
   size_t n = pix / hw, pp = pix % hw;
   size_t b = n % B;
   const float* sc = score + pix * D;
-  const PlaneLine pl = plane_line(planes, b, pp, D, hw);
+  const PlaneLine pl = plane_line(planes, b, pp, Dp, hw);
   // The 16 pixels of a block are consecutive; read per lane, a plane value costs a whole 64-byte sector for 16 bytes
   // (lanes of a wave hold 16 different planes of 4 pixels: 4x the plane volume through L2).  When the block lies inside
   // one map the [D][16] patch is staged through LDS with full sectors instead (row pitch 17: 2-way at worst).
@@ -981,8 +1040,8 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
   // (generated planes need no staging: a plane value is one multiply and one add)
   const bool staged = NQ > 0 && planes.mode == PLANES_EXPLICIT && gp0 + 16 <= npix && (gp0 % hw) + 16 <= (size_t)hw;     // uniform
   if (staged) {
-    const float* src = planes.p + ((gp0 / hw) % B) * D * hw + gp0 % hw;
-    for (int i = threadIdx.x; i < D * 16; i += 256) lp[(i >> 4) * 17 + (i & 15)] = src[(size_t)(i >> 4) * hw + (i & 15)];
+    const float* src = planes.p + ((gp0 / hw) % B) * Dp * hw + gp0 % hw;
+    for (int i = threadIdx.x; i < D * 16; i += 256) lp[(i >> 4) * 17 + (i & 15)] = src[(size_t)min(i >> 4, Dp - 1) * hw + (i & 15)];
     __syncthreads();
   }
   const float* lpp = lp + (threadIdx.x >> 4);
@@ -1011,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
     se += (e0 + e1) + (e2 + e3);
     float p0, p1, p2, p3;
     if (staged) { p0 = lpp[d * 17]; p1 = lpp[(d + 1) * 17]; p2 = lpp[(d + 2) * 17]; p3 = lpp[(d + 3) * 17]; }
-    else { p0 = plane_at(planes, pl, d, hw); p1 = plane_at(planes, pl, d + 1, hw); p2 = plane_at(planes, pl, d + 2, hw); p3 = plane_at(planes, pl, d + 3, hw); }
+    else { p0 = plane_at_pad(planes, pl, d, hw); p1 = plane_at_pad(planes, pl, d + 1, hw); p2 = plane_at_pad(planes, pl, d + 2, hw); p3 = plane_at_pad(planes, pl, d + 3, hw); }
     sd = __fmaf_rn(e3, p3, __fmaf_rn(e2, p2, __fmaf_rn(e1, p1, __fmaf_rn(e0, p0, sd))));
   };
   if (NQ > 0) {
@@ -1051,8 +1110,11 @@ bool cost_reg_winograd(int D, int precision) {
 }
 
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
-                           int precision, hipStream_t st, float* sm_vw, float* sm_pd, const PlaneSrc* sm_planes, int sm_B) {
+                           int precision, hipStream_t st, float* sm_vw, float* sm_pd, const PlaneSrc* sm_planes, int sm_B, int n_planes) {
+  // D = the width the network runs at; n_planes <= D hypothesis planes for the softmax (0: D)
   const bool fuse_softmax = sm_vw != nullptr;
+  // the softmax epilogue of the direct kernels needs a pixel's channels in one workgroup: not at D = 384 (two launches)
+  const bool epilogue_sm = fuse_softmax && D <= 256;
   const bool wino = cost_reg_winograd(D, precision);
   const size_t F = (size_t)N * h * w * D;
   const size_t LW = (size_t)9 * D * D + D;
@@ -1093,24 +1155,28 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
     const float* wl = wpk + (size_t)i * LW;
     int rc;
     if (precision == PRECISION_BF16X3) {
-      const bool sm = i == 10 && fuse_softmax;
+      const bool sm = i == 10 && epilogue_sm;
       rc = launch_conv_dd_bf16x3(plan[i].in, wl, wl + (size_t)9 * D * D, plan[i].skip, plan[i].out, N, D, plan[i].hi,
                                  plan[i].wi, plan[i].ho, plan[i].wo, plan[i].mode, plan[i].relu, st, sm ? sm_vw : nullptr,
-                                 sm ? sm_pd : nullptr, sm ? sm_planes : nullptr, sm_B);
+                                 sm ? sm_pd : nullptr, sm ? sm_planes : nullptr, sm_B, n_planes);
+      if (!rc && i == 10 && fuse_softmax && !epilogue_sm)
+        rc = launch_softmax_regress(score, *sm_planes, sm_vw, sm_pd, N / sm_B, sm_B, D, h, w, st, n_planes);
     } else if (wino && plan[i].mode == CONV_S1) {
       // stride-1 layers in the minimal-filtering form (none of them carries a skip or takes a second input); the scores of the
       // last one go through the score volume to k_softmax_regress: its channel groups are different workgroups
       const float* ww = wpk + (size_t)11 * LW + (size_t)(i == 10 ? 4 : i / 2) * 16 * D * D;
       rc = launch_conv_wino(plan[i].in, ww, wl + (size_t)9 * D * D, nullptr, plan[i].out, N, D, plan[i].hi, plan[i].wi, plan[i].relu, st);
-      if (!rc && i == 10 && fuse_softmax) rc = launch_softmax_regress(score, *sm_planes, sm_vw, sm_pd, N / sm_B, sm_B, D, h, w, st);
+      if (!rc && i == 10 && fuse_softmax) rc = launch_softmax_regress(score, *sm_planes, sm_vw, sm_pd, N / sm_B, sm_B, D, h, w, st, n_planes);
     } else {
       const bool give = defer && i + 1 < 11 && plan[i + 1].mode == CONV_T2;        // layer i + 1 adds this layer's skip to its input
       const bool take = defer && i > 0 && plan[i].mode == CONV_T2 && plan[i - 1].skip;
       ConvDDArgs a{plan[i].in, wl, wl + (size_t)9 * D * D, give ? nullptr : plan[i].skip, plan[i].out, D,
                    plan[i].hi, plan[i].wi, plan[i].ho, plan[i].wo, plan[i].relu, nullptr, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1,
                    take ? plan[i - 1].skip : nullptr};
-      if (i == 10 && fuse_softmax) { a.sm_vw = sm_vw; a.sm_pd = sm_pd; a.sm_planes = *sm_planes; a.sm_B = sm_B; }
+      if (i == 10 && epilogue_sm) { a.sm_vw = sm_vw; a.sm_pd = sm_pd; a.sm_planes = *sm_planes; a.sm_B = sm_B; a.sm_D = n_planes; }
       rc = launch_conv_dd(a, N, plan[i].mode, st);
+      if (!rc && i == 10 && fuse_softmax && !epilogue_sm)
+        rc = launch_softmax_regress(score, *sm_planes, sm_vw, sm_pd, N / sm_B, sm_B, D, h, w, st, n_planes);
     }
     if (rc) return rc;
   }
@@ -1118,15 +1184,18 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
 }
 
 int launch_softmax_regress(const float* score, PlaneSrc planes, float* vw, float* pd, int S, int B, int D, int h, int w,
-                           hipStream_t st) {
+                           hipStream_t st, int n_planes) {
   size_t npix = (size_t)S * B * h * w;
+  const int Dp = n_planes > 0 ? n_planes : D;
+  ADAMVS_CHECK_ARG(Dp <= D, "softmax_regress: %d planes for %d score channels", Dp, D);
   const dim3 grid((unsigned)((npix + 15) / 16));
   switch ((D + 63) / 64) {
-    case 1: hipLaunchKernelGGL(k_softmax_regress<1>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
-    case 2: hipLaunchKernelGGL(k_softmax_regress<2>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
-    case 3: hipLaunchKernelGGL(k_softmax_regress<3>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
-    case 4: hipLaunchKernelGGL(k_softmax_regress<4>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
-    default: hipLaunchKernelGGL(k_softmax_regress<0>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix); break;
+    case 1: hipLaunchKernelGGL(k_softmax_regress<1>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
+    case 2: hipLaunchKernelGGL(k_softmax_regress<2>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
+    case 3: hipLaunchKernelGGL(k_softmax_regress<3>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
+    case 4: hipLaunchKernelGGL(k_softmax_regress<4>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
+    case 6: hipLaunchKernelGGL(k_softmax_regress<6>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
+    default: hipLaunchKernelGGL(k_softmax_regress<0>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
   }
   ADAMVS_CHECK_LAUNCH("softmax_regress");
   return 0;
@@ -1143,20 +1212,32 @@ extern "C" size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, in
 static int check_precision(int precision, int D, const char* who) {
   ADAMVS_CHECK_ARG(precision == PRECISION_FP32 || precision == PRECISION_BF16X3, "%s: precision=%d (0 fp32, 1 bf16x3)", who, precision);
   ADAMVS_CHECK_ARG(precision == PRECISION_FP32 || costreg_bf16x3_depth_supported(D),
-                   "%s: bf16x3 needs D in {32,64,96,128,192,256}, got %d", who, D);
+                   "%s: bf16x3 needs D in {32,64,96,128,192,256,384}, got %d", who, D);
   return 0;
 }
 
-extern "C" int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N, int D, int h, int w,
+extern "C" int adamvs_cost_reg_width(int D, int precision) {
+  return D < 1 ? 0 : (precision == PRECISION_BF16X3 ? costreg_width_bf16x3(D) : costreg_width(D));
+}
+
+size_t adamvs::cost_reg_weight_floats(int D, int precision) {
+  if (!(precision == PRECISION_BF16X3 ? costreg_bf16x3_depth_supported(D) : costreg_depth_supported(D))) return 0;
+  return (size_t)11 * ((size_t)9 * D * D + D) + (precision == PRECISION_FP32 && wino_depth_supported(D) ? (size_t)5 * 16 * D * D : 0);
+}
+extern "C" size_t adamvs_cost_reg_net_2d_weight_floats(int D, int precision) { return cost_reg_weight_floats(D, precision); }
+
+extern "C" int adamvs_cost_reg_net_2d(const float* x, const float* wpk, size_t wpk_floats, float* score, int N, int D, int h, int w,
                                       int precision, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_precision(precision, D, "cost_reg_net_2d")) return rc;
   ADAMVS_CHECK_ARG(x && wpk && score && workspace && N > 0 && h > 0 && w > 0, "cost_reg_net_2d: bad arguments");
-  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
+  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256 or 384)", D);
+  ADAMVS_CHECK_ARG(wpk_floats == cost_reg_weight_floats(D, precision),
+                   "cost_reg_net_2d: wpk holds %zu floats, the layout for D=%d precision=%d has %zu (include/adamvs_hip.h)", wpk_floats, D,
+                   precision, cost_reg_weight_floats(D, precision));
   ADAMVS_CHECK_ARG((h % 8) == 0 && (w % 8) == 0, "cost_reg_net_2d: h=%d w=%d must be multiples of 8 (three stride-2 levels)", h, w);
   ADAMVS_CHECK_ARG(workspace_bytes >= adamvs_cost_reg_net_2d_workspace_bytes(N, D, h, w),
                    "cost_reg_net_2d: workspace too small (%zu < %zu bytes)", workspace_bytes,
                    adamvs_cost_reg_net_2d_workspace_bytes(N, D, h, w));
-  ADAMVS_CHECK_ARG((size_t)N * 4 <= 65535, "cost_reg_net_2d: N=%d exceeds the grid z limit", N);
   return launch_cost_reg_net_2d(x, wpk, (float*)workspace, score, N, D, h, w, precision, (hipStream_t)stream);
 }
 
@@ -1164,10 +1245,9 @@ extern "C" int adamvs_conv3x3_dd(const float* in, const float* in2, const float*
                                  float* out, int N, int D, int hi, int wi, int mode, int relu, int precision, void* stream) {
   if (int rc = check_precision(precision, D, "conv3x3_dd")) return rc;
   ADAMVS_CHECK_ARG(in && wpk && bias && out && N > 0 && hi > 0 && wi > 0, "conv3x3_dd: bad arguments");
-  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "conv3x3_dd: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
+  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "conv3x3_dd: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256 or 384)", D);
   ADAMVS_CHECK_ARG(mode >= 0 && mode <= 2, "conv3x3_dd: mode=%d (0 stride 1, 1 stride 2, 2 transposed stride 2)", mode);
   ADAMVS_CHECK_ARG(mode != CONV_S2 || ((hi % 2) == 0 && (wi % 2) == 0), "conv3x3_dd: stride 2 needs even hi, wi");
-  ADAMVS_CHECK_ARG((size_t)N * 4 <= 65535, "conv3x3_dd: N=%d exceeds the grid z limit", N);
   int ho = mode == CONV_S2 ? hi / 2 : (mode == CONV_T2 ? 2 * hi : hi);
   int wo = mode == CONV_S2 ? wi / 2 : (mode == CONV_T2 ? 2 * wi : wi);
   ADAMVS_CHECK_ARG(!(in2 && (precision == PRECISION_BF16X3 || mode == CONV_S2)),
@@ -1184,8 +1264,7 @@ extern "C" int adamvs_prob_softmax_regress(const float* in, const float* wpk, co
   if (int rc = check_precision(precision, D, "prob_softmax_regress")) return rc;
   ADAMVS_CHECK_ARG(in && wpk && bias && planes && view_weight && pair_depth && S > 0 && B > 0 && h > 0 && w > 0,
                    "prob_softmax_regress: bad arguments");
-  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "prob_softmax_regress: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
-  ADAMVS_CHECK_ARG((size_t)S * B <= 65535, "prob_softmax_regress: S*B=%d exceeds the grid z limit", S * B);
+  ADAMVS_CHECK_ARG(costreg_depth_supported(D) && D <= 256, "prob_softmax_regress: D=%d unsupported (16, 32, 48, 64, 96, 128, 192 or 256)", D);
   const PlaneSrc ps = explicit_planes(planes);
   if (precision == PRECISION_BF16X3)
     return launch_conv_dd_bf16x3(in, wpk, bias, nullptr, nullptr, S * B, D, h, w, h, w, CONV_S1, 0, (hipStream_t)stream, view_weight,

@@ -29,6 +29,7 @@ struct ConvDDArgs16 {
   float* sm_vw; float* sm_pd;   // softmax epilogue (stride-1 `prob` layer): see costreg_softmax.h; null = store the scores
   PlaneSrc sm_planes;
   int sm_B;
+  int sm_D;               // hypothesis planes of the softmax epilogue when the network runs wider (costreg_width); 0 = D
 };
 
 enum { BX_S1 = 0, BX_S2 = 1, BX_T2 = 2 };
@@ -180,7 +181,7 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
 
   if (SOFTMAX) {                         // the last layer inside a stage: scores reduced over D here, never stored
     __syncthreads();                     // the last chunk's readers are done: the tile space is reused for the partials
-    softmax_epilogue<MT, WM, NTR, BR>(acc, a.bias, a.sm_planes, a.sm_B, n, r0, c0, a.ho, a.wo, D, a.sm_vw, a.sm_pd, (float*)lds);
+    softmax_epilogue<MT, WM, NTR, BR>(acc, a.bias, a.sm_planes, a.sm_B, n, r0, c0, a.ho, a.wo, a.sm_D ? a.sm_D : D, a.sm_vw, a.sm_pd, (float*)lds);
     return;
   }
   // epilogue (C/D layout of the 16x16 MFMA family is shape-independent: lane owns channels co4..co4+3 of pixel p)
@@ -246,15 +247,40 @@ static int launch_bx3_cfg(const ConvDDArgs16& a, int N, int mode, hipStream_t st
   return launch_bx3_mode<MT, WM, BX_T2>(a, dim3(cdiv(a.wi, 16), cdiv(a.hi, BxGeom<BX_T2>::BR), N * 4), st);
 }
 
-bool costreg_bf16x3_depth_supported(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256; }
+bool costreg_bf16x3_depth_supported(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384; }
 
 // `wpk` is the layer's packed block reinterpreted: 9*D*D floats worth of bf16 fragments (hi half, then lo half)
 int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
                           int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st, float* sm_vw, float* sm_pd,
-                          const PlaneSrc* sm_planes, int sm_B) {
+                          const PlaneSrc* sm_planes, int sm_B, int n_planes) {
   ConvDDArgs16 a{in, (const bf16x8*)wpk, bias, skip, out, D, hi, wi, ho, wo, relu, sm_vw, sm_pd,
-                 sm_planes ? *sm_planes : PlaneSrc{nullptr, 0, 0.f}, sm_B};
+                 sm_planes ? *sm_planes : PlaneSrc{nullptr, 0, 0.f}, sm_B, n_planes};
+  constexpr int ZMAX = 65535 / 4;            // blockIdx.z = image (x 4 parity classes in the transposed layers)
+  if (N > ZMAX) {                            // sub-batches of whole images (of whole tiles under the softmax epilogue: n % sm_B)
+    const int unit = sm_vw ? sm_B : 1;
+    ADAMVS_CHECK_ARG(unit <= ZMAX, "conv_dd_bf16x3: softmax epilogue with %d tiles per view (at most %d)", unit, ZMAX);
+    const int step = ZMAX / unit * unit;
+    const size_t in_img = (size_t)hi * wi * D, out_img = (size_t)ho * wo * D, map = (size_t)ho * wo;
+    for (int n0 = 0; n0 < N; n0 += step)
+      if (int rc = launch_conv_dd_bf16x3(in + n0 * in_img, wpk, bias, skip ? skip + n0 * out_img : nullptr, out ? out + n0 * out_img : nullptr,
+                                         N - n0 < step ? N - n0 : step, D, hi, wi, ho, wo, mode, relu, st, sm_vw ? sm_vw + n0 * map : nullptr,
+                                         sm_pd ? sm_pd + n0 * map : nullptr, sm_planes, sm_B, n_planes))
+        return rc;
+    return 0;
+  }
   switch (D) {
+    case 384: {                              // the 192-channel tiling twice: each launch contracts all 384 input channels into its
+      ADAMVS_CHECK_ARG(!sm_vw, "conv_dd_bf16x3: no softmax epilogue at D=384");      // half of the output channels (fp32 twin: costreg2d.hip)
+      for (int half = 0; half < 2; ++half) {
+        ConvDDArgs16 h = a;
+        h.wpk = a.wpk + (size_t)half * 12 * 64;        // fragment = 64 lanes x 8 bf16; index (... * D/16 + tile)
+        h.bias = bias + half * 192;
+        h.out = out + half * 192;
+        h.skip = skip ? skip + half * 192 : nullptr;
+        if (int rc = launch_bx3_cfg<3, 4>(h, N, mode, st)) return rc;
+      }
+      return 0;
+    }
     case 32: return launch_bx3_cfg<2, 1>(a, N, mode, st);
     case 64: return launch_bx3_cfg<4, 1>(a, N, mode, st);
     case 96: return launch_bx3_cfg<3, 2>(a, N, mode, st);
@@ -262,7 +288,7 @@ int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, 
     case 192: return launch_bx3_cfg<3, 4>(a, N, mode, st);
     case 256: return launch_bx3_cfg<4, 4>(a, N, mode, st);      // (the two-launch 128-channel form of the fp32 path does not pay here: 155.0 -> 156.0 ms at cfg5)
   }
-  return set_error(-1, "cost_reg_net_2d (bf16x3): D=%d unsupported (32, 64, 96, 128, 192 or 256)", D);
+  return set_error(-1, "cost_reg_net_2d (bf16x3): D=%d unsupported (32, 64, 96, 128, 192, 256 or 384)", D);
 }
 
 }  // namespace adamvs

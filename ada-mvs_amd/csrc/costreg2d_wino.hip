@@ -258,16 +258,17 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) drain(acc[j][mt][0]);   // (tile row 0 is read first; tools/mfma_hazard_lint.py checks the rest)
 
+    // the bias BEFORE the next tile's fragment sets: vmcnt retires in order, and the epilogue consumes the bias first -- requested
+    // after them, its wait would drain the very loads that are meant to fly during the epilogue (advisor, round 3)
+    cg = done.cg;
+    load_bias();
+    cg = cur.cg;
     // the next tile's first fragment sets fly during the epilogue
     if (more) {
-      cg = cur.cg;
       load_w(wf0, 0);
       load_w(wf1, min(1, last_ks));
       load_w(wf2, min(2, last_ks));
     }
-    cg = done.cg;
-    load_bias();
-    cg = cur.cg;
     // ---- epilogue of `done`: the four rows meet through LDS, one tile row per round
     if (!((WINO_EXP & 1) && a.relu != 12345)) {
       const long img = (long)done.n * a.h * a.w * (long)D * 4;
@@ -320,12 +321,14 @@ static int launch_wino_cfg(const WinoArgs& a, int N, hipStream_t st) {
   return 0;
 }
 
-bool wino_depth_supported(int D) { return D == 64 || D == 128 || D == 192 || D == 256; }
+bool wino_depth_supported(int D) { return D >= 64 && D <= 384 && D % 64 == 0; }       // channel groups of 64; 16-channel LDS chunks
 
 int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
                      int relu, hipStream_t st) {
   const WinoArgs a{in, wpk, bias, skip, out, D, h, w, relu};
-  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino: D=%d unsupported (64, 128, 192 or 256)", D);
+  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino: D=%d unsupported (a multiple of 64 up to 384)", D);
+  // 32-bit byte offsets inside one image through a buffer descriptor (advisor, round 3): larger maps would read zeros
+  ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
   return launch_wino_cfg<4, 3>(a, N, st);
 }
 

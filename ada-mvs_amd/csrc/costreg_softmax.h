@@ -15,6 +15,7 @@ template <int MT, int WM, int NTR, int BR>
 __device__ __forceinline__ void softmax_epilogue(const f32x4 (&acc)[MT][NTR], const float* __restrict__ bias, const PlaneSrc& planes,
                                                  int B, int n, int r0, int c0, int ho, int wo, int D, float* __restrict__ vw,
                                                  float* __restrict__ pd, float* part) {
+  // D = the number of hypothesis planes (<= the channels the lanes hold: pad channels carry a score of -1e30)
   constexpr int NPART = 4 * WM, WN = 4 / WM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
@@ -41,8 +42,8 @@ __device__ __forceinline__ void softmax_epilogue(const f32x4 (&acc)[MT][NTR], co
       const float e0 = __expf(v[mt].x - m), e1 = __expf(v[mt].y - m), e2 = __expf(v[mt].z - m), e3 = __expf(v[mt].w - m);
       se += (e0 + e1) + (e2 + e3);
       // explicit planes: four loads; generated: a multiply and an add each
-      sd = __fmaf_rn(e3, plane_at(planes, pl, d + 3, hw), __fmaf_rn(e2, plane_at(planes, pl, d + 2, hw),
-           __fmaf_rn(e1, plane_at(planes, pl, d + 1, hw), __fmaf_rn(e0, plane_at(planes, pl, d, hw), sd))));
+      sd = __fmaf_rn(e3, plane_at_pad(planes, pl, d + 3, hw), __fmaf_rn(e2, plane_at_pad(planes, pl, d + 2, hw),
+           __fmaf_rn(e1, plane_at_pad(planes, pl, d + 1, hw), __fmaf_rn(e0, plane_at_pad(planes, pl, d, hw), sd))));
     }
     float* o = part + ((row * 16 + p) * NPART + wm * 4 + q) * 3;
     o[0] = m; o[1] = se; o[2] = sd;

@@ -102,21 +102,26 @@ int launch_sweep_variance(const float* feat, const float* rt, const float* plane
 size_t sweep_workspace_floats(int B, int C, int D, int h, int w);
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,
                            int precision, hipStream_t st, float* sm_vw = nullptr, float* sm_pd = nullptr,
-                           const PlaneSrc* sm_planes = nullptr, int sm_B = 1);
+                           const PlaneSrc* sm_planes = nullptr, int sm_B = 1, int n_planes = 0);
+size_t cost_reg_weight_floats(int D, int precision);        // floats of the packed weight blob at width D (0: unsupported)
+int costreg_width(int D);            // the width CostRegNet2D runs at for D hypotheses (next supported; 0: none)
+int costreg_width_bf16x3(int D);
 bool cost_reg_softmax_fusable(int D, int precision, const PlaneSrc& planes);
 int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
                           int hi, int wi, int ho, int wo, int mode, int relu, hipStream_t st, float* sm_vw = nullptr,
-                          float* sm_pd = nullptr, const PlaneSrc* sm_planes = nullptr, int sm_B = 1);
+                          float* sm_pd = nullptr, const PlaneSrc* sm_planes = nullptr, int sm_B = 1, int n_planes = 0);
 bool costreg_bf16x3_depth_supported(int D);
 bool wino_depth_supported(int D);
 bool cost_reg_winograd(int D, int precision);
 int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
                      int relu, hipStream_t st);
 
+// Dw >= D: channels per pixel of sim (the width CostRegNet2D runs at); channels [D, Dw) are written as zeros
 int launch_pair_similarity(const float* feat, const float* rt, PlaneSrc planes, float* sim, int B, int S, int C, int D, int h,
-                           int w, hipStream_t st);
+                           int w, hipStream_t st, int Dw = 0);
+// n_planes <= D hypothesis planes for D score channels (0: D)
 int launch_softmax_regress(const float* score, PlaneSrc planes, float* vw, float* pd, int S, int B, int D, int h, int w,
-                           hipStream_t st);
+                           hipStream_t st, int n_planes = 0);
 bool costreg_depth_supported(int D);
 
 }  // namespace adamvs

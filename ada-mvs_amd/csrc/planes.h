@@ -27,6 +27,7 @@ static inline PlaneSrc explicit_planes(const float* planes) { return PlaneSrc{pl
 struct PlaneLine {
   const float* q;
   float lo, step;
+  int last;          // D - 1
 };
 
 // HIP's __fmul_rn / __fadd_rn are plain operators and hipcc contracts a * b + c into one fused multiply-add by default
@@ -39,7 +40,7 @@ __device__ __forceinline__ float plane_value(float lo, float step, int d) {
 }
 
 __device__ __forceinline__ PlaneLine plane_line(const PlaneSrc& s, size_t b, size_t pix, int D, size_t hw) {
-  PlaneLine l{nullptr, 0.f, 0.f};
+  PlaneLine l{nullptr, 0.f, 0.f, D - 1};
   if (s.mode == PLANES_EXPLICIT) {
     l.q = s.p + b * D * hw + pix;
   } else {
@@ -60,6 +61,11 @@ __device__ __forceinline__ PlaneLine plane_line(const PlaneSrc& s, size_t b, siz
 
 __device__ __forceinline__ float plane_at(const PlaneSrc& s, const PlaneLine& l, int d, size_t hw) {
   return s.mode == PLANES_EXPLICIT ? l.q[(size_t)d * hw] : plane_value(l.lo, l.step, d);
+}
+// For the softmax over CostRegNet2D's channels when the network runs wider than the D hypotheses (costreg_width, pad
+// channels score -1e30 and weigh exactly 0): d may run past the last plane; any finite value will do there.
+__device__ __forceinline__ float plane_at_pad(const PlaneSrc& s, const PlaneLine& l, int d, size_t hw) {
+  return plane_at(s, l, min(d, l.last), hw);
 }
 
 }  // namespace adamvs

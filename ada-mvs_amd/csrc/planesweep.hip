@@ -37,11 +37,12 @@ __device__ __forceinline__ int group_last(int v) {
 }
 
 // ---------------------------------------------------------------------------
-// grid: (pixel groups, S, B); block 256.  sim [S][B][hw][D] (channel-last in d).
+// grid: (pixel groups, S, B); block 256.  sim [S][B][hw][Dw] (channel-last in d; Dw >= D: channels [D, Dw) are zeros -- the
+// width CostRegNet2D runs at when D is not one its kernels are built for, kernels.h::costreg_width).
 template <int C>
 __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict__ feat, const float* __restrict__ rt,
                                                          PlaneSrc planes, float* __restrict__ sim,
-                                                         int B, int S, int D, int h, int w) {
+                                                         int B, int S, int D, int h, int w, int Dw) {
   constexpr int G = C / 4;          // lanes per pixel
   constexpr int PPB = 256 / G;      // pixels per block
   const int hw = h * w;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
   const float ax = r[0] * fx + r[1] * fy + r[2], ay = r[3] * fx + r[4] * fy + r[5], az = r[6] * fx + r[7] * fy + r[8];
   const float tx = r[9], ty = r[10], tz = r[11];
   const PlaneLine pl = plane_line(planes, b, pc, D, hw);
-  float* out = sim + (((size_t)s * B + b) * hw + pc) * D;
+  float* out = sim + (((size_t)s * B + b) * hw + pc) * Dw;
   // sim = mean_c ref[c] * sum_t w_t tap_t[c] = (1/C) sum_t w_t * dot(ref, tap_t): while consecutive planes fall into
   // the same source cell (192 planes span ~1.5 px at stage 1) the four tap . ref dot products do not change, so they
   // are what stays in registers -- reduced over the G lanes of the pixel once per cell -- and a plane costs its own
@@ -112,6 +113,8 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
     }
     if (live && d0 + g < D) out[d0 + g] = keep;       // G lanes x 4 B contiguous per pixel
   }
+  if (live)
+    for (int d = D + g; d < Dw; d += G) out[d] = 0.f;
 }
 
 }  // namespace adamvs
@@ -119,17 +122,19 @@ __global__ __launch_bounds__(256) void k_pair_similarity(const float* __restrict
 using namespace adamvs;
 
 int adamvs::launch_pair_similarity(const float* feat, const float* rt, PlaneSrc planes, float* sim, int B, int S, int C, int D, int h,
-                                   int w, hipStream_t st) {
+                                   int w, hipStream_t st, int Dw) {
+  if (Dw <= 0) Dw = D;
+  ADAMVS_CHECK_ARG(Dw >= D && S <= 65535 && B <= 65535, "pair_similarity: Dw=%d < D=%d, or S=%d / B=%d above 65535", Dw, D, S, B);
   ADAMVS_CHECK_ARG(feat && rt && planes.p && sim && B > 0 && S > 0 && D > 0 && h > 1 && w > 1,
                    "pair_similarity: bad arguments (B=%d S=%d D=%d h=%d w=%d)", B, S, D, h, w);
   ADAMVS_CHECK_ARG(C == 8 || C == 16 || C == 32, "pair_similarity: C=%d unsupported (8, 16 or 32)", C);
   int hw = h * w;
   if (C == 32)
-    hipLaunchKernelGGL((k_pair_similarity<32>), dim3(cdiv(hw, 32), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w);
+    hipLaunchKernelGGL((k_pair_similarity<32>), dim3(cdiv(hw, 32), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w, Dw);
   else if (C == 16)
-    hipLaunchKernelGGL((k_pair_similarity<16>), dim3(cdiv(hw, 64), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w);
+    hipLaunchKernelGGL((k_pair_similarity<16>), dim3(cdiv(hw, 64), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w, Dw);
   else
-    hipLaunchKernelGGL((k_pair_similarity<8>), dim3(cdiv(hw, 128), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w);
+    hipLaunchKernelGGL((k_pair_similarity<8>), dim3(cdiv(hw, 128), S, B), dim3(256), 0, st, feat, rt, planes, sim, B, S, D, h, w, Dw);
   ADAMVS_CHECK_LAUNCH("pair_similarity");
   return 0;
 }

@@ -187,10 +187,12 @@ template <int G> __device__ __forceinline__ float quad_bcast_f(float v, int q) {
 // views 0-3 and waves 2, 3 views 4-7 of the SAME 128 / G pixels; each half parks its partial sum of a group of 8 planes in
 // LDS and the halves meet at the flush (one barrier pair per 8 planes).  Eight views in one lane need 128 registers of taps
 // (208 in all: two waves per SIMD); split, a lane keeps the 122 of the four-view kernel and four waves cover the reloads.
+// More than 8 source views (the reference loops over any number, adamvs.py:501): one launch per group of 8 views, views
+// [vbase, vbase + 8) each; the first writes its share of the sum (plus the eps term), the others add theirs to what is there.
 template <int C, int HALVES, bool GEN>
 __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ feat, const float* __restrict__ rt, PlaneSrc planes,
                                                      const float* __restrict__ vw, float* __restrict__ sim, int B, int S, int D,
-                                                     int d0, int d1, int h, int w, int eps_num) {
+                                                     int d0, int d1, int h, int w, int eps_num, int vbase) {
   constexpr int SV = 4, G = C / 4, NT = 256 / HALVES, PPB = NT / G, NQ = G < 4 ? G : 4, VPL = (SV + NQ - 1) / NQ, PK = 8, NM = PK / G;
   const int hw = h * w;
   const int tid = threadIdx.x, half = __builtin_amdgcn_readfirstlane(tid / NT), ltid = tid % NT;      // half: wave-uniform
@@ -201,8 +203,9 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
   const int pc = live ? pix : hw - 1;
   const float x = (float)(pc % w), y = (float)(pc / w);
   const f32x4 ref4 = *(const f32x4*)(feat + ((size_t)b * hw + pc) * C + 4 * g);
-  const int v0 = SV * half;                              // first view of this half
-  const int Sm = min(S - v0, SV);                        // views of this half (>= 1: HALVES = 2 only when S > 4)
+  const int v0 = vbase + SV * half;                      // first view of this half
+  const int Sm = min(S - v0, SV);                        // views of this half (>= 1: HALVES = 2 only when the group has > 4 views)
+  const bool accum = vbase > 0;                          // uniform: a later view group adds to the first one's result
 
   // normalisation of the view weights (adamvs.py:497-512), per pixel: all lanes, all S views
   float winv, eps_term;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
     float wsum = eps_num ? 0.f : 1e-5f;
     for (int s = 0; s < S; ++s) wsum += vw[((size_t)s * B + b) * hw + pc];
     winv = 1.0f / wsum;
-    eps_term = eps_num ? 1e-5f * winv : 0.f;       // train/test twin (adamvs.py:262-300): (1e-5 + sum) / sum_v w_v
+    eps_term = (eps_num && !accum) ? 1e-5f * winv : 0.f;       // train/test twin (adamvs.py:262-300): (1e-5 + sum) / sum_v w_v
   }
   // the views this lane projects: v0 + gq, v0 + gq + NQ, ... (views past S-1 repeat the last one; never consumed)
   float ax[VPL], ay[VPL], az[VPL], tx[VPL], ty[VPL], tz[VPL], wn[VPL];
@@ -322,13 +325,21 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
     const int nd_ = min(PK, d1 - dg);
     if (HALVES == 1) {
 #pragma unroll 1
-      for (int j = 0; j < nd_; ++j)
-        buf_store4(make_rsrc(sim + (size_t)(dg + j - d0) * ostride), ooff, park[j][tid]);
+      for (int j = 0; j < nd_; ++j) {
+        const buf_rsrc ro = make_rsrc(sim + (size_t)(dg + j - d0) * ostride);
+        f32x4 v = park[j][tid];
+        if (accum) v += buf_load4(ro, ooff);
+        buf_store4(ro, ooff, v);
+      }
     } else {
       __syncthreads();                              // both halves have parked the group
 #pragma unroll 1
-      for (int j = half; j < nd_; j += 2)           // half h finishes planes h, h + 2, ...: views 0-3 first, then 4-7 (fixed order)
-        buf_store4(make_rsrc(sim + (size_t)(dg + j - d0) * ostride), ooff, ref4 * (park[j][ltid] + park[j][NT + ltid]) + eps_term);
+      for (int j = half; j < nd_; j += 2) {         // half h finishes planes h, h + 2, ...: views 0-3 first, then 4-7 (fixed order)
+        const buf_rsrc ro = make_rsrc(sim + (size_t)(dg + j - d0) * ostride);
+        f32x4 v = ref4 * (park[j][ltid] + park[j][NT + ltid]) + eps_term;
+        if (accum) v += buf_load4(ro, ooff);
+        buf_store4(ro, ooff, v);
+      }
       __syncthreads();                              // before the next group overwrites the parked sums
     }
   }
@@ -371,17 +382,20 @@ static int launch_sweep_c(const float* feat, const float* rt, PlaneSrc planes, c
   dim3 grid(cdiv(h * w, 256 / (C / 4)), 1, B);
   if (sweep_blend_enabled() && (size_t)B * h * w * C * 4 < 0x7fffffffu) {      // 32-bit lane offsets inside one view / one plane
     const bool gen = planes.mode != PLANES_EXPLICIT;
-    if (S <= 4) {
-      if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 1, true>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
-      else hipLaunchKernelGGL((k_sweep_blend<C, 1, false>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
-    } else {                    // 5 ... 8 views: two halves of the workgroup share 128 / G pixels
-      const dim3 grid2(cdiv(h * w, 128 / (C / 4)), 1, B);
-      if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 2, true>), grid2, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
-      else hipLaunchKernelGGL((k_sweep_blend<C, 2, false>), grid2, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
+    for (int vbase = 0; vbase < S; vbase += 8) {        // groups of 8 views; the later ones accumulate
+      if (S - vbase <= 4) {
+        if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 1, true>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num, vbase);
+        else hipLaunchKernelGGL((k_sweep_blend<C, 1, false>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num, vbase);
+      } else {                    // 5 ... 8 views: two halves of the workgroup share 128 / G pixels
+        const dim3 grid2(cdiv(h * w, 128 / (C / 4)), 1, B);
+        if (gen) hipLaunchKernelGGL((k_sweep_blend<C, 2, true>), grid2, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num, vbase);
+        else hipLaunchKernelGGL((k_sweep_blend<C, 2, false>), grid2, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num, vbase);
+      }
+      ADAMVS_CHECK_LAUNCH("sweep_blend");
     }
-    ADAMVS_CHECK_LAUNCH("sweep_blend");
     return 0;
   }
+  if (S > 8) return set_error(-1, "aggregate_conv1: S=%d source views need the blend sweep (ADAMVS_SWEEP=0 and maps of 2 GiB per view take at most 8)", S);
   if (S <= 4)
     hipLaunchKernelGGL((k_sweep_aggregate<C, 4>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
   else
@@ -402,7 +416,7 @@ size_t sweep_workspace_floats(int B, int C, int D, int h, int w) {
 int launch_sweep_conv1_chunk(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,
                              float* c1_chunk, float* sim_ws, int B, int S, int C, int D, int d0, int d1, int h, int w, int precision,
                              int eps_num, hipStream_t st) {
-  if (S > 8 || S < 1) return set_error(-1, "aggregate_conv1: S=%d source views unsupported (at most 8)", S);
+  if (S < 1) return set_error(-1, "aggregate_conv1: S=%d source views", S);
   int rc;
   if (C == 32) rc = launch_sweep_c<32>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
   else if (C == 16) rc = launch_sweep_c<16>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);

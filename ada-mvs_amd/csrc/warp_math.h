@@ -5,10 +5,19 @@
 //   sample at pixel coordinates (u,v): grid_sample(bilinear, padding zeros,
 //   align_corners=True) applied to the reference's normalised grid lands on
 //   exactly these pixel coordinates.  Taps outside [0,w-1]x[0,h-1] add 0.
+//
+// The reference has no guard for X2 <= 0 (module.py:553).  X2 < 0 (a plane behind the source camera) gives finite,
+// mirrored coordinates, sampled like any others -- here too.  X2 == 0 gives inf (0/0: NaN) coordinates, and ATen's
+// grid_sample then returns NaN in EVERY channel of that pixel: floor(inf) - inf = NaN bilinear weights times the zero it
+// substitutes for a masked tap (pinned by tests/golden/op_warp_behind.npz, a run of the reference).  The tap sets below
+// reproduce that: a non-finite coordinate poisons all four weights with NaN; finite coordinates outside the image keep 0.
 #pragma once
 #include "common.h"
 
 namespace adamvs {
+
+// 0 when u and v are finite, NaN when either is inf or NaN (0 * inf = NaN); two instructions
+__device__ __forceinline__ float nonfinite_poison(float u, float v) { return fmaf(0.f, u, 0.f * v); }
 
 struct WarpTaps {
   float w00, w01, w10, w11;   // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1); 0 when the tap is out of range
@@ -26,9 +35,9 @@ __device__ __forceinline__ WarpTaps warp_taps(const float* __restrict__ rt, floa
   float u = X0 / X2;
   float v = X1 / X2;
   WarpTaps t;
-  t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+  t.w00 = t.w01 = t.w10 = t.w11 = nonfinite_poison(u, v);
   t.o00 = t.o01 = t.o10 = t.o11 = 0;
-  // fully outside (or NaN/inf from X2 ~ 0): every tap is padding
+  // fully outside: every tap is padding (weight 0; NaN for inf / NaN coordinates, as grid_sample returns them)
   if (!(u > -1.0f && u < (float)w && v > -1.0f && v < (float)h)) return t;
   float fx0 = floorf(u), fy0 = floorf(v);
   int x0 = (int)fx0, y0 = (int)fy0;
@@ -65,7 +74,7 @@ __device__ __forceinline__ PlaneTaps plane_taps(float ax, float ay, float az, fl
   float u = X0 * rz, v = X1 * rz;                                              // module.py:553
   PlaneTaps t;
   t.cell = -1;
-  t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+  t.w00 = t.w01 = t.w10 = t.w11 = nonfinite_poison(u, v);          // 0; NaN on the source camera's focal plane (X2 == 0)
   if (u > -1.0f && u < (float)w && v > -1.0f && v < (float)h) {
     float fx0 = floorf(u), fy0 = floorf(v);
     int ix = (int)fx0, iy = (int)fy0;
@@ -93,7 +102,10 @@ __device__ __forceinline__ PlaneTaps plane_taps_scaled(float ax, float ay, float
   const float fx0 = floorf(u), fy0 = floorf(v);
   const int ix = (int)fx0, iy = (int)fy0;
   const float lx = u - fx0, ly = v - fy0;
-  const float wx0 = (inside && ix >= 0) ? 1.f - lx : 0.f, wx1 = (inside && ix < w - 1) ? lx : 0.f;
+  // outside the image: x weights 0 (finite y weights times 0); inf / NaN coordinates: NaN in all four products, whatever
+  // the y weights came out as (see the header of this file)
+  const float pz = nonfinite_poison(u, v);
+  const float wx0 = (inside && ix >= 0) ? 1.f - lx : pz, wx1 = (inside && ix < w - 1) ? lx : pz;
   const float wy0 = (iy >= 0 ? 1.f - ly : 0.f) * scale, wy1 = (iy < h - 1 ? ly : 0.f) * scale;
   PlaneTaps t;
   t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;

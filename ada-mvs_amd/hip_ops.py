@@ -126,7 +126,7 @@ def cost_reg_net_2d(x_cl, wpk, h, w, precision=0):
     nbytes = lib.adamvs_cost_reg_net_2d_workspace_bytes(N, D, h, w)
     ws = torch.empty(nbytes // 4, device=x_cl.device, dtype=torch.float32)
     score = torch.empty_like(x_cl)
-    check(lib.adamvs_cost_reg_net_2d(_p(x_cl), _p(wpk), _p(score), N, D, h, w, int(precision), _p(ws), nbytes, _stream()),
+    check(lib.adamvs_cost_reg_net_2d(_p(x_cl), _p(wpk), wpk.numel(), _p(score), N, D, h, w, int(precision), _p(ws), nbytes, _stream()),
           "cost_reg_net_2d")
     return score
 
@@ -149,7 +149,9 @@ def prob_softmax_regress(x_cl, wpk_layer, bias, planes, S, B, D, h, w, precision
     return vw, pd
 
 
-def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w, precision=0):
+def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w, precision=0, return_similarity=False):
+    """-> c1 [D,B,hw,8]; return_similarity (D <= 32, one chunk): also the aggregated similarity [D,B,hw,C] the call left in
+    its workspace (include/adamvs_hip.h: the workspace holds the last chunk's similarity on return)."""
     c1 = torch.empty(D, B, h * w, 8, device=feat.device, dtype=torch.float32)
     lib = _lib.load()
     nbytes = lib.adamvs_aggregate_conv1_workspace_bytes(B, C, D, h, w)
@@ -157,6 +159,10 @@ def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w, preci
     check(_lib.load().adamvs_aggregate_conv1(_p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")),
                                              _p(_dev(view_weight, "view_weight")), _p(w1pk), _p(c1), B, S, C, D, h, w, int(precision),
                                              _p(ws), nbytes, _stream()), "aggregate_conv1")
+    if return_similarity:
+        if D > 32:
+            raise _lib.AdaMVSHipError("aggregate_conv1: return_similarity needs D <= 32 (one chunk of planes in the workspace)")
+        return c1, ws[:D * B * h * w * C].reshape(D, B, h * w, C)
     return c1
 
 
@@ -358,7 +364,7 @@ def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspac
     check(_lib.load().adamvs_depth_stage_forward(
         ctypes.byref(desc), _p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")),
         _p(_dev(prev_conf, "prev_conf")) if prev_conf is not None else null,
-        _p(w_reg) if w_reg is not None else null, fuse.ptr(),
+        _p(w_reg) if w_reg is not None else null, w_reg.numel() if w_reg is not None else 0, fuse.ptr(),
         _p(vw), _p(pd) if pd is not None else null, _p(depth), _p(conf), int(phases), _p(workspace), nbytes, _stream()),
         "depth_stage_forward")
     return vw, pd, depth, conf

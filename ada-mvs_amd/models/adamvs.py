@@ -147,8 +147,14 @@ class CostRegNet2D(PackedCache, nn.Module):
 
     def forward(self, x):
         N, D, h, w = x.shape
-        score = hip_ops.cost_reg_net_2d(hip_ops.pack_features(x), self.packed(x.device), h, w,
-                                        _PRECISIONS[self.effective_precision()])
+        prec = self.effective_precision()
+        x_cl = hip_ops.pack_features(x)
+        dr = packing.reg_width(D, prec)          # the kernels' width for D hypotheses: zero channels in, pad scores dropped
+        if dr != D:
+            x_cl = torch.nn.functional.pad(x_cl, (0, dr - D))
+        score = hip_ops.cost_reg_net_2d(x_cl, self.packed(x.device), h, w, _PRECISIONS[prec])
+        if dr != D:
+            score = score[..., :D].contiguous()
         return hip_ops.unpack_features(score, h, w)
 
 

@@ -13,7 +13,20 @@ BN_EPS = 1e-5
 REG_LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11", "prob")
 REG_TRANSPOSED = ("conv7", "conv9", "conv11")
 REG_WINOGRAD = ("conv0", "conv2", "conv4", "conv6", "prob")      # stride-1 layers: also packed in the F(2x2, 3x3) form (fp32)
-WINO_WIDTHS = (64, 128, 192, 256)
+WINO_WIDTHS = (64, 128, 192, 256, 384)              # the widths of REG_WIDTHS that csrc/costreg2d_wino.hip takes (multiples of 64)
+# The widths CostRegNet2D's kernels are built for (csrc/costreg2d.hip::costreg_width, costreg_width_bf16x3; held equal to the
+# library's table by tests/test_host_logic.py).  The reference builds the network for any number of hypotheses
+# (models/adamvs.py:198-228): other D run at the next width, see pack_cost_reg_net_2d.
+REG_WIDTHS = {"fp32": (16, 32, 48, 64, 96, 128, 192, 256, 384), "bf16x3": (32, 64, 96, 128, 192, 256, 384)}
+PAD_SCORE = -1e30          # bias of `prob`'s pad channels: exp(PAD_SCORE - max) = 0 exactly, and finite (no inf - inf in the merges)
+
+
+def reg_width(d, precision="fp32"):
+    """The width CostRegNet2D runs at for d hypotheses."""
+    for w in REG_WIDTHS[precision]:
+        if d <= w:
+            return w
+    raise ValueError("CostRegNet2D: %d hypotheses (at most %d)" % (d, REG_WIDTHS[precision][-1]))
 
 
 def _as_cout_cin_tap(w, transposed):
@@ -147,10 +160,30 @@ def pack_reg_layer_bf16x3(w, scale, shift, transposed):
     return torch.cat([frag, shift.detach().to(torch.float32).cpu().reshape(-1)])
 
 
+def _pad_square(w, transposed, dr):
+    """[D][D][3][3] conv weights (ConvTranspose2d: [in][out]) zero-padded to [dr][dr][3][3]."""
+    d = w.shape[0]
+    if d == dr:
+        return w
+    out = torch.zeros(dr, dr, 3, 3, dtype=w.dtype)
+    out[:d, :d] = w.detach().cpu()
+    return out
+
+
 def pack_cost_reg_net_2d(sd, pre, precision="fp32"):
     """All 11 layers of `pre` (e.g. 'DepthNet.0.reg.') from a reference-keyed state dict; fp32 at the widths the F(2x2, 3x3)
-    kernel supports: followed by the five stride-1 layers in that form (16*D*D floats each, include/adamvs_hip.h)."""
+    kernel supports: followed by the five stride-1 layers in that form (16*D*D floats each, include/adamvs_hip.h).
+    A network of D hypotheses is packed at Dr = reg_width(D) channels: zero filters for the pad channels (their activations are
+    ReLU(0 + 0) = 0 in every layer and no real channel reads them), PAD_SCORE as the bias of `prob`'s pad channels."""
     pack_layer = pack_reg_layer if precision == "fp32" else pack_reg_layer_bf16x3
+    d = sd[pre + "prob.weight"].shape[0]
+    dr = reg_width(d, precision)
+
+    def pad_vec(v, fill):
+        out = torch.full((dr,), float(fill))
+        out[:d] = v.detach().float().cpu()
+        return out
+
     chunks, wino = [], []
     for name in REG_LAYERS:
         if name == "prob":
@@ -169,8 +202,10 @@ def pack_cost_reg_net_2d(sd, pre, precision="fp32"):
             var = sd[bnpre + "running_var"].detach().float().cpu()
             scale = g / torch.sqrt(var + BN_EPS)
             shift = b - mu * scale
+        w = _pad_square(w, transposed, dr)
+        scale, shift = pad_vec(scale, 1.0), pad_vec(shift, PAD_SCORE if (name == "prob" and dr > d) else 0.0)
         chunks.append(pack_layer(w, scale, shift, transposed))
-        if precision == "fp32" and name in REG_WINOGRAD and w.shape[0] in WINO_WIDTHS:
+        if precision == "fp32" and name in REG_WINOGRAD and dr in WINO_WIDTHS:
             wino.append(pack_reg_layer_wino(w, scale))
     return torch.cat(chunks + wino)
 

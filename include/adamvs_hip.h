@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 11
+#define ADAMVS_ABI_VERSION 12
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -78,12 +78,20 @@ int adamvs_pair_similarity(const float* feat, const float* rt, const float* plan
  * A-fragment order [tap][cin/4][cout/16][lane] with value
  * W[cout = 16*tile + (lane&15)][cin = 4*kc + (lane>>4)][tap] * bn_scale[cout]
  * (ConvTranspose2d layers: W[cin][cout][tap]) followed by D bias floats (folded BN shift,
- * or the conv bias for `prob`).  D in {16,32,48,64,96,128,192,256}; h, w multiples of 8.
+ * or the conv bias for `prob`).  D in {16,32,48,64,96,128,192,256,384}; h, w multiples of 8.
  *
- * fp32 with D in {64,128,192,256}: the 11 blocks are followed by the five stride-1 layers (conv0, conv2, conv4, conv6, prob)
+ * The reference builds the network for any number of hypotheses (adamvs.py:198-228); here a network of D hypotheses runs at
+ * the next width of that list, adamvs_cost_reg_width(D, precision), with zero filters for the extra channels and -1e30 as
+ * the bias of `prob`'s extra channels (ada-mvs_amd/packing.py::pack_cost_reg_net_2d): the extra channels stay 0 through the
+ * hourglass and weigh exactly 0 in the softmax.  The op-level entry points below take the WIDTH as D (x and score carry
+ * that many channels); adamvs_depth_stage_forward takes the number of hypotheses and handles the rest.
+ *
+ * fp32 with D in {64,128,192,256,384}: the 11 blocks are followed by the five stride-1 layers (conv0, conv2, conv4, conv6, prob)
  * in the minimal-filtering form F(2x2, 3x3), 16*D*D floats each, laid out as adamvs_conv3x3_dd_wino takes them; those
  * layers run on that kernel (fp32 throughout, 16 products instead of 36 per 2x2 outputs and channel pair; environment
  * ADAMVS_WINOGRAD=0: on the direct kernel).  ada-mvs_amd/packing.py::pack_cost_reg_net_2d produces exactly this.
+ * wpk_floats = the length of the blob, adamvs_cost_reg_net_2d_weight_floats(D, precision): a blob of another layout
+ * (e.g. the 11-block blob of ABI <= 10 at a width that now carries the F(2x2, 3x3) blocks) is refused, not read past its end.
  *
  * precision ADAMVS_PRECISION_FP32 (0): fp32 MFMA.  ADAMVS_PRECISION_BF16X3 (1): bf16 MFMA with every
  * operand split into two bf16 halves, a.b ~ a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulation (maps agree
@@ -93,7 +101,9 @@ int adamvs_pair_similarity(const float* feat, const float* rt, const float* plan
 #define ADAMVS_PRECISION_FP32 0
 #define ADAMVS_PRECISION_BF16X3 1
 size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, int w);
-int adamvs_cost_reg_net_2d(const float* x, const float* wpk, float* score, int N, int D, int h, int w,
+int adamvs_cost_reg_width(int D, int precision);                       /* the width the network runs at for D hypotheses; 0: none (D > 384) */
+size_t adamvs_cost_reg_net_2d_weight_floats(int D, int precision);     /* floats of wpk at width D; 0: not a supported width */
+int adamvs_cost_reg_net_2d(const float* x, const float* wpk, size_t wpk_floats, float* score, int N, int D, int h, int w,
                            int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One layer of CostRegNet2D: ConvBnReLU.forward (models/module.py:254-261) or the
@@ -113,7 +123,8 @@ int adamvs_conv3x3_dd(const float* in, const float* in2, const float* wpk, const
  * instead of 36, fp32 throughout (results agree with adamvs_conv3x3_dd mode 0 to a few ulp of the accumulated sums).
  * wpk [D/4][4][D/16][64][4] = the transformed filters U = G w G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], BN scale folded
  * in) as MFMA A fragments: element j of lane l of fragment (k-step kc, patch row i, channel tile) =
- * U[i][j][cout = 16*tile + (l&15)][cin = 4*kc + (l>>4)].  D in {64, 128, 192, 256}.  in, out, skip, bias, relu as above. */
+ * U[i][j][cout = 16*tile + (l&15)][cin = 4*kc + (l>>4)].  D a multiple of 64 up to 384; a map at most 2 GiB.  in, out, skip,
+ * bias, relu as above. */
 int adamvs_conv3x3_dd_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
                            int h, int w, int relu, void* stream);
 
@@ -207,8 +218,9 @@ int adamvs_feature_net_fpn(const float* imgs, const adamvs_feature_fpn_weights* 
 /* models/adamvs.py:495-512 fused with conv1 of SliceCostRegNetRED (adamvs.py:416), for all
  * D hypotheses at once: c1[d][b][pix][8] = ReLU(conv1(sum_v w_v warp_v ref / (1e-5 + sum_v w_v))).
  * view_weight [S][B][h*w].  Hypothesis loop inside the thread, bilinear taps cached in registers
- * across planes; the similarity of a chunk of planes goes through the workspace and conv1 runs
- * over it as a tiled MFMA convolution.  S <= 8. */
+ * across planes; the similarity of a chunk of planes (at most 32) goes through the workspace and conv1 runs
+ * over it as a tiled MFMA convolution.  On return the workspace holds the aggregated similarity of the LAST
+ * chunk, [planes of the chunk][B][h*w][C] (with D <= 32: of all planes; the parity tests read it there). */
 size_t adamvs_aggregate_conv1_workspace_bytes(int B, int C, int D, int h, int w);
 int adamvs_aggregate_conv1(const float* feat, const float* rt, const float* planes, const float* view_weight,
                            const float* w1pk, float* c1, int B, int S, int C, int D, int h, int w, int precision,
@@ -225,7 +237,8 @@ int adamvs_slice_reg_step(const float* cost, float* state1, float* state2, const
 
 /* ---- whole stage: InferDepthNet0.forward, models/adamvs.py:433-533 -------- */
 typedef struct adamvs_stage_desc {
-  int B, S, C, h, w, D;   /* batch, source views, feature channels, feature rows/cols, hypotheses */
+  int B, S, C, h, w, D;   /* batch, source views (any number), feature channels, feature rows/cols, hypotheses (first stage:
+                             at most 384; CostRegNet2D runs at adamvs_cost_reg_width(D, precision) channels) */
   int in_up;              /* 1: maps come out at 2h x 2w (stages 1, 2); 0: h x w (stage 3) */
   int first_stage;        /* 1: confidence_map is None -> pass A scores the views (stage 1) */
   int prev_h, prev_w;     /* size of prev_conf maps when !first_stage */
@@ -263,12 +276,13 @@ size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);
 
 /* feat [V=S+1][B][h*w][C]; rt [B][S][12]; planes: see adamvs_stage_desc.plane_mode;
  * prev_conf [S][B][prev_h*prev_w] (previous stage's view weights; ignored when first_stage);
- * w_reg: packed CostRegNet2D weights (first_stage only);
+ * w_reg: packed CostRegNet2D weights at width adamvs_cost_reg_width(D, precision), w_reg_floats of them
+ *        (= adamvs_cost_reg_net_2d_weight_floats(width, precision); first_stage only);
  * outputs: view_weight [S][B][h*w] (what the next stage consumes as prev_conf),
  *          pair_depth [S][B][h*w] (first_stage only), depth / confidence [B][Ho*Wo].
  * phases: ADAMVS_PHASE_ALL, or VIEW_WEIGHTS alone followed by the other three together (see above). */
 int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt, const float* planes,
-                               const float* prev_conf, const float* w_reg, const adamvs_fuse_weights* w_fuse,
+                               const float* prev_conf, const float* w_reg, size_t w_reg_floats, const adamvs_fuse_weights* w_fuse,
                                float* view_weight, float* pair_depth, float* depth, float* confidence,
                                int phases, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -322,3 +322,31 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "--gpus 2 but 1 rank" in r.stderr and not r.stdout.strip()
+
+
+def test_cost_reg_width_table_and_padded_packing():
+    """packing.REG_WIDTHS is the library's table (csrc/costreg2d.hip::costreg_width); a network of D hypotheses is packed at the
+    next width with zero filters and PAD_SCORE on `prob`'s pad channels, and the blob has the length the library expects."""
+    from ada_mvs_amd.models.adamvs import CostRegNet2D
+    lib = _lib.load()
+    for prec, code in (("fp32", 0), ("bf16x3", 1)):
+        for d in list(range(1, 400, 7)) + [16, 32, 48, 64, 96, 128, 192, 256, 384]:
+            want = lib.adamvs_cost_reg_width(d, code)
+            if d <= 384:
+                assert packing.reg_width(d, prec) == want and want >= d, (d, prec)
+            else:
+                assert want == 0
+                with pytest.raises(ValueError):
+                    packing.reg_width(d, prec)
+    for d, prec, code in ((40, "fp32", 0), (80, "fp32", 0), (64, "fp32", 0), (160, "bf16x3", 1)):
+        net = CostRegNet2D(d)
+        sd = synth.seeded_state_dict(net, seed=1)
+        blob = packing.pack_cost_reg_net_2d(sd, "", prec)
+        dr = packing.reg_width(d, prec)
+        assert blob.numel() == lib.adamvs_cost_reg_net_2d_weight_floats(dr, code) > 0, (d, prec)
+        lw = 9 * dr * dr + dr
+        prob_bias = blob[10 * lw + 9 * dr * dr:11 * lw]
+        assert torch.equal(prob_bias[:d], sd["prob.bias"]) and bool((prob_bias[d:] == packing.PAD_SCORE).all())
+        conv0_bias = blob[9 * dr * dr:lw]
+        assert bool((conv0_bias[d:] == 0).all())
+    assert lib.adamvs_cost_reg_net_2d_weight_floats(40, 0) == 0      # not a width

@@ -131,3 +131,44 @@ def test_batch_items_with_different_depth_ranges():
         assert rel_l1(out[key], g[key]) < 5e-5, key
     assert rel_l1(out["stage1"]["depth"], g["s1_depth"]) < 5e-5 and rel_l1(out["stage2"]["depth"], g["s2_depth"]) < 5e-5
     assert not torch.equal(g["depth_values"][0], g["depth_values"][1])
+
+
+def nan_aware_rel_l1(x, ref):
+    """NaNs must sit at the same places; relative L1 over the rest."""
+    x, ref = x.detach().double(), ref.detach().double()
+    assert torch.equal(torch.isnan(x), torch.isnan(ref)), "NaN pattern differs: %d vs %d" % (int(torch.isnan(x).sum()), int(torch.isnan(ref).sum()))
+    ok = ~torch.isnan(ref)
+    return float((x[ok] - ref[ok]).abs().mean() / ref[ok].abs().mean().clamp_min(1e-30))
+
+
+def test_warp_behind_the_source_camera():
+    """module.py:549-553 has no guard for X2 <= 0: planes behind the source camera sample mirrored coordinates, and a pixel ON
+    its focal plane (X2 == 0: coordinates inf / NaN) comes out of grid_sample as NaN in every channel (0-weight taps times
+    NaN weights).  The fixture is a run of the reference; both forms of the oracle's warp must reproduce it, NaNs included."""
+    g = load_golden("op_warp_behind")
+    y0 = int(g["y0"])
+    assert bool(torch.isnan(g["out"][0, :, 0, y0]).all()) and int(torch.isnan(g["out"]).sum()) == g["out"].shape[1] * g["out"].shape[-1]
+    R, t = O.relative_transform(g["src_proj"], g["ref_proj"])
+    assert torch.equal(R, g["src_proj"][:, :3, :3]) and torch.equal(t, g["src_proj"][:, :3, 3])        # ref = I: exact
+    for d in range(g["depth"].shape[1]):
+        for fn in (O.warp_plane, O.warp_plane_grid_sample):
+            assert nan_aware_rel_l1(fn(g["src"], R, t, g["depth"][:, d]), g["out"][:, :, d]) < TOL, (d, fn.__name__)
+    behind = (torch.arange(16) < y0)
+    assert float(g["out"][0, :, 0, behind].abs().sum()) > 0, "the mirrored zone must land inside the image"
+
+
+def test_end_to_end_with_a_view_behind_the_planes():
+    """The whole cascade on a rig whose second source camera has every hypothesis plane crossing its focal plane inside the
+    image (tools/gen_golden.py::behind_rig): finite everywhere, mirrored samples on one side."""
+    g = load_golden("e2e_tiny_behind")
+    c = synth.CONFIGS["tiny"]
+    assert [round(float(v), 2) for v in g["behind_fraction"]] == [1.0, 0.5, 0.0]
+    imgs, _, dv = synth.tile_inputs("tiny", batch=1, seed=0)
+    proj = {k[5:]: v for k, v in g.items() if k.startswith("proj_")}
+    out = O.infer_adamvs_forward(imgs, proj, dv, _tiny_sd(), c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    for s in (1, 2, 3):
+        assert rel_l1(out["stage%d" % s]["depth"], g["s%d_depth" % s]) < 5e-5
+        assert rel_l1(out["stage%d" % s]["photometric_confidence"], g["s%d_conf" % s]) < 5e-5
+    for i in range(2):
+        assert rel_l1(out["stage1"]["pair_confidence"][i], g["s1_pairconf%d" % i]) < 5e-5
+        assert rel_l1(out["stage1"]["pair_result"][i], g["s1_pairdepth%d" % i]) < 5e-5

@@ -64,6 +64,22 @@ def op_level():
         depth = 400 + 200 * torch.rand(B, 3, h, w, generator=g)
         out = ref_module.homo_warping_float(src, proj[:, 2], proj[:, 0], depth)
         save("op_" + tag, src=src, src_proj=proj[:, 2], ref_proj=proj[:, 0], depth=depth, out=out)
+    # ---- a3 without its missing guard (module.py:549-553 divides by X2 whatever its sign): planes that pass BEHIND the
+    # source camera for part of the image (X2 < 0: finite, mirrored coordinates) and a row on the camera's focal plane
+    # (X2 == 0 exactly: inf, and 0/0 = NaN where X0 == 0 too).  ref_proj = I, so T = src_proj exactly; with
+    # T[2] = (0, 1/64, 1, -(Y0 + 64)) and d = 64, X2 = y - Y0 in exact arithmetic at every row.
+    B, C, h, w, Y0 = 1, 8, 16, 24, 6
+    gb = torch.Generator().manual_seed(11)                   # its own generator: the fixtures below keep their draws
+    src = synth.smooth_features(B, C, h, w, seed=5)
+    sp = torch.eye(4)[None].clone()
+    sp[0, 0, 0], sp[0, 0, 3] = 1.0 / 64, -12.0               # X0 = x - 12 at d = 64: zero at x = 12
+    sp[0, 1, 1], sp[0, 1, 3] = 1.0 / 64, -8.0                # X1 = y - 8
+    sp[0, 2, 1], sp[0, 2, 3] = 1.0 / 64, -(Y0 + 64.0)
+    depth = torch.stack([torch.full((h, w), 64.0), 60 + 8 * torch.rand(h, w, generator=gb), torch.full((h, w), 128.0)])[None]
+    depth[0, 1, 3] = 64.0                                    # plane 1: one more exact row of its own (X2 = 3 - 6 = -3: behind)
+    out = ref_module.homo_warping_float(src, sp, torch.eye(4)[None], depth)
+    assert bool(torch.isnan(out[0, :, 0, Y0]).all()) and bool(torch.isfinite(out[0, :, 0, :Y0]).all())
+    save("op_warp_behind", src=src, src_proj=sp, ref_proj=torch.eye(4)[None], depth=depth, out=out, y0=Y0)
     # ---- a2 both branches
     dv = torch.tensor([[400.0, 600.0], [380.0, 640.0]])
     s1 = ref_module.get_depth_range_samples(dv, 12, 4 * 200 / 48, "cpu", torch.float32, [2, 6, 10])
@@ -151,13 +167,61 @@ def two_ranges():
          s1_depth=r["stage1"]["depth"], s2_depth=r["stage2"]["depth"])
 
 
+def behind_rig(cfg, batch=1):
+    """synth's rig with source view 2 turned by 0.3 rad and moved 480 forward: X2 = a2 . d - 480 with a2 in [0.83, 1.08] over
+    the image, so for d in [400, 600] every hypothesis plane crosses that camera's focal plane somewhere in the image --
+    behind it on one side (mirrored coordinates), in front on the other (module.py:549-553 has no guard)."""
+    import math
+    c = synth.CONFIGS[cfg]
+    proj = synth.rig_projections(c["views"], c["H"], c["W"], batch=batch)
+    H, W = c["H"], c["W"]
+    K = np.array([[1.2 * W, 0, W / 2.0], [0, 1.2 * W, H / 2.0], [0, 0, 1.0]])
+    a = 0.3
+    R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    P = np.eye(4)
+    P[:3, :3], P[:3, 3] = K @ R, K @ np.array([-16.0, 0.0, -480.0])
+    for name, s in (("stage1", 4.0), ("stage2", 2.0), ("stage3", 1.0)):
+        m = P.copy()
+        m[:2] /= s
+        proj[name][:, 2] = torch.from_numpy(m.astype(np.float32))
+    return proj
+
+
+@torch.no_grad()
+def end_to_end_behind():
+    """The whole cascade of the reference on the rig above (inputs: synth.tile_inputs("tiny", 1, seed=0) images, behind_rig)."""
+    m = build_ref_model("tiny")
+    imgs, _, dv = synth.tile_inputs("tiny", batch=1, seed=0)
+    proj = behind_rig("tiny")
+    r = m(imgs, proj, dv)
+    arrays = {"proj_" + k: v for k, v in proj.items()}
+    for s in (1, 2, 3):
+        arrays["s%d_depth" % s] = r["stage%d" % s]["depth"]
+        arrays["s%d_conf" % s] = r["stage%d" % s]["photometric_confidence"]
+    for i in range(2):
+        arrays["s1_pairconf%d" % i] = r["stage1"]["pair_confidence"][i]
+        arrays["s1_pairdepth%d" % i] = r["stage1"]["pair_result"][i]
+    # how much of the image the near / far plane puts behind view 2 at stage 1 (recorded for the test's own sanity check)
+    T = torch.matmul(proj["stage1"][0, 2], torch.inverse(proj["stage1"][0, 0]))
+    h, w = 16, 24
+    y, x = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    a2 = T[2, 0] * x + T[2, 1] * y + T[2, 2]
+    arrays["behind_fraction"] = torch.tensor([float((a2 * d + T[2, 3] < 0).float().mean()) for d in (400.0, 500.0, 600.0)])
+    assert all(bool(torch.isfinite(v).all()) for v in arrays.values())
+    save("e2e_tiny_behind", **arrays)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if "--only-two-ranges" in sys.argv:
         two_ranges()
+        sys.exit(0)
+    if "--only-behind" in sys.argv:
+        end_to_end_behind()
         sys.exit(0)
     op_level()
     net_level()
     end_to_end("tiny", with_inputs=True)
     end_to_end("cfg1", with_inputs=False)
     two_ranges()
+    end_to_end_behind()
