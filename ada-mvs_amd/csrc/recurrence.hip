@@ -27,6 +27,7 @@
 #include "persistent.h"
 #include "slice_roles.h"
 #include "slice_roles_bx3.h"
+#include "slice_roles_fused.h"
 
 namespace adamvs {
 
@@ -53,6 +54,8 @@ struct SlotArgs {
 template <class R> struct min_blocks { static constexpr int value = 1; };
 template <> struct min_blocks<Gru1FusedBx3Role> { static constexpr int value = 2; };
 template <> struct min_blocks<Gru2FusedBx3Role> { static constexpr int value = 2; };
+// (Gru1FusedRole<8, 2> held to three workgroups per CU -- 168 registers, 18 of its 194 spilled -- is slower than at two:
+//  stage 2 of cfg3 at 32 tiles 28.3 against 27.8 ms, the separate kernels 26.5)
 constexpr int imax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 template <class R0, class R1, class R2>
@@ -208,6 +211,9 @@ typedef Cand1TwoRowRole Cand1;
 typedef ConvSmallRole<8, 0, 1, 2, EPI_RELU> Conv2;
 typedef ConvSmallRole<16, 16, 2, 1, EPI_GATES> Gates2;
 typedef ConvSmallRole<16, 16, 1, 1, EPI_CAND> Cand2;
+typedef Gru1FusedRole<4, 2> Gru1S;      // fp32, both levels fused: 4 x 30 / 4 x 14 tiles for stages with few tiles per CU
+typedef Gru2FusedRole<4> Gru2S;
+typedef Gru1FusedRole<8, 2> Gru1L;      // 8 x 30: the large-batch tile
 typedef Gru1FusedBx3Role Gru1Bx;
 typedef ConvSmallBx3Role<8, 0, 1, 2, BXE_RELU> Conv2Bx;
 typedef Gru2FusedBx3Role Gru2Bx;
@@ -217,6 +223,21 @@ typedef Gru2FusedBx3Role Gru2Bx;
 // fa, fb: the fused bf16x3 level-1 kernel runs tiles [0,fa) in slot A, [fa,fb) in B, [fb,1) in C; fd: the decoder of the
 // bf16x3 schedule runs [0,fd) in slot B and the rest in C.
 struct RoleCosts { float g1, c1, v2, g2, c2, dec, k1bx, v2bx, g2bx, c2bx, fa, fb, fd; };
+// the fused fp32 roles (slice_roles_fused.h), same unit: per tile, from their MFMA counts at the rate of the roles above
+// (4 x 30 level 1: 624 MFMAs; 8 x 30: 1104; 4 x 14 level 2: 1152).  ADAMVS_RECUR_COSTS_FUSED="k1s,k1l,k2s" overrides.
+struct FusedCosts { float k1s, k1l, k2s; };
+static const FusedCosts& fused_costs() {
+  static const FusedCosts c = [] {
+    FusedCosts v = {13.0f, 23.0f, 20.0f};
+    if (const char* e = getenv("ADAMVS_RECUR_COSTS_FUSED")) {
+      float a, b, d;
+      if (sscanf(e, "%f,%f,%f", &a, &b, &d) == 3 && a > 0.f && b > 0.f && d > 0.f && a < 1e6f && b < 1e6f && d < 1e6f) v = FusedCosts{a, b, d};
+      else fprintf(stderr, "adamvs: ADAMVS_RECUR_COSTS_FUSED ignored (three positive values)\n");
+    }
+    return v;
+  }();
+  return c;
+}
 static RoleCosts parse_role_costs() {
   RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 4.46f, 13.8f, 3.2f, 12.0f, 5.0f, 0.6f, 0.8f, 0.42f};
   if (const char* e = getenv("ADAMVS_RECUR_COSTS")) {
@@ -250,7 +271,12 @@ int recurrence_mode(int precision, long pixels) {
   // (cfg4's share at stage 1: 5.27 / 3.75 / 3.49 ms with four / two / one; at 295k 9.95 / 9.40 / 8.99), two up to ~1M (at
   // 590k 15.6 / 15.1 / 15.5; at 1.18M a tie), four beyond (at 2.36M 51.3 against 55.2).
   if (precision != PRECISION_FP32) return pixels <= 300000 ? 5 : (pixels <= 1000000 ? 3 : 0);
-  return pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0);
+  // round 4, fp32 with both ConvGRU levels one kernel each (slice_roles_fused.h): ONE launch per hypothesis pays on the
+  // smallest stages only -- cfg4's share at stage 1 (74k pixels) 5.01 -> 4.79 ms; at 295k 4.44 -> 5.28, at 1.18M 1.72 -> 2.50:
+  // the fused tiles execute 36 % more MFMAs and the stage is not latency- but throughput-bound as soon as every CU has a few tiles.
+  // Schedule 6 (level 1 fused on 8 x 30 tiles, a launch per role) loses at every size: cfg3 at 32 tiles 23.4 / 26.5 / 13.2 ms
+  // per stage -> 25.4 / 27.8 / 13.4; cfg2 at 128 tiles 79.6 -> 86.5.  Kept behind ADAMVS_RECUR_MODE=6 as the measurement.
+  return pixels <= 100000 ? 5 : (pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0));
 }
 
 template <class R> static RoleUse<R> use(const typename R::Args* a, float cost, float f0 = 0.f, float f1 = 1.f) {
@@ -267,9 +293,11 @@ template <class R> static RoleUse<R> none() { return RoleUse<R>{nullptr, 0.f, 0.
 // Schedule 2 keeps the one role that needs 234 registers (gates2: two 16-row output tiles of 32 input channels, 144
 // registers of weights) in a launch of its own, so that the roles sharing a launch all run at three to five waves per
 // SIMD; in schedule 1 cand1 runs at gates2's two.
+//   schedule 5 (both levels one kernel each)   gru1(t) | conv2(t-1) | gru2(t-2) | decoder(t-3): ONE launch per hypothesis
+//   schedule 6 (fp32, level 1 fused)           gru1(t); conv2(t-1); gates2(t-1); cand2(t-1); decoder(t-2): one role per launch
 RecurLags recurrence_lags(int schedule, int precision) {
   if (schedule == 2 && precision == PRECISION_FP32) return RecurLags{2, 3};
-  if (schedule == 5 && precision == PRECISION_BF16X3) return RecurLags{2, 3};       // one launch: gru2 two, the decoder three behind
+  if (schedule == 5) return RecurLags{2, 3};       // one launch: gru2 two, the decoder three behind
   return RecurLags{1, 2};
 }
 
@@ -330,11 +358,41 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
                                                            "recurrence slot B (bf16x3)");
   }
 
+  if (schedule == 5) {
+    // fp32 with both ConvGRU levels one kernel each (slice_roles_fused.h): one launch per hypothesis, as in bf16x3 above
+    const FusedCosts& fk = fused_costs();
+    Gru1F32Args f1{c1_t, H1(t - 1), H1(t), fw.gates1, fw.gates1_b, fw.cand1, fw.cand1_b, h, w};
+    SmallConvArgs v2s{H1(s2), nullptr, fw.conv2, nullptr, C2(s2), nullptr, h, w, h2, w2, 16, nullptr};
+    Gru2F32Args f2{C2(sc), H2(sc - 1), H2(sc), fw.gates2, fw.gates2_b, fw.cand2, fw.cand2_b, h2, w2};
+    if (in_up)
+      return launch_slot4<Gru1S, Conv2, Gru2S, DecoderRole<true>>(
+          l1 ? use<Gru1S>(&f1, fk.k1s) : none<Gru1S>(), l2 ? use<Conv2>(&v2s, k.v2) : none<Conv2>(), lc ? use<Gru2S>(&f2, fk.k2s) : none<Gru2S>(),
+          dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(), B, st, "recurrence, one launch (fp32)");
+    return launch_slot4<Gru1S, Conv2, Gru2S, DecoderRole<false>>(
+        l1 ? use<Gru1S>(&f1, fk.k1s) : none<Gru1S>(), l2 ? use<Conv2>(&v2s, k.v2) : none<Conv2>(), lc ? use<Gru2S>(&f2, fk.k2s) : none<Gru2S>(),
+        dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st, "recurrence, one launch (fp32)");
+  }
   SmallConvArgs g1{c1_t, H1(t - 1), fw.gates1, fw.gates1_b, rb.rh1, rb.u1, h, w, h, w, 16, nullptr};
   SmallConvArgs c1{c1_t, rb.rh1, fw.cand1, fw.cand1_b, H1(t), rb.u1, h, w, h, w, 8, H1(t - 1)};
   SmallConvArgs v2{H1(s2), nullptr, fw.conv2, nullptr, C2(s2), nullptr, h, w, h2, w2, 16, nullptr};
   SmallConvArgs g2{C2(s2), H2(s2 - 1), fw.gates2, fw.gates2_b, rb.rh2, rb.u2, h2, w2, h2, w2, 32, nullptr};
   SmallConvArgs c2{C2(sc), rb.rh2, fw.cand2, fw.cand2_b, H2(sc), rb.u2, h2, w2, h2, w2, 16, H2(sc - 1)};
+  if (schedule == 6) {
+    // level 1 as one kernel on the large tile, every role a launch of its own (large stages: sharing launches buys nothing)
+    Gru1F32Args f1{c1_t, H1(t - 1), H1(t), fw.gates1, fw.gates1_b, fw.cand1, fw.cand1_b, h, w};
+    if (l1 && (rc = launch_slot<Gru1L, NopRole, NopRole>(use<Gru1L>(&f1, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: gru1 (fp32, fused)"))) return rc;
+    if (l2) {
+      if ((rc = launch_slot<Conv2, NopRole, NopRole>(use<Conv2>(&v2, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: conv2"))) return rc;
+      if ((rc = launch_slot<Gates2, NopRole, NopRole>(use<Gates2>(&g2, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: gates2"))) return rc;
+    }
+    if (lc && (rc = launch_slot<Cand2, NopRole, NopRole>(use<Cand2>(&c2, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: cand2"))) return rc;
+    if (dec) {
+      if (in_up) rc = launch_slot<DecoderRole<true>, NopRole, NopRole>(use<DecoderRole<true>>(&da, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: decoder");
+      else rc = launch_slot<DecoderRole<false>, NopRole, NopRole>(use<DecoderRole<false>>(&da, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: decoder");
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (schedule == 3) {
     Conv2Gates2Args vg{H1(s2), H2(s2 - 1), fw.conv2, fw.gates2, fw.gates2_b, C2(s2), rb.rh2, rb.u2, h, w, h2, w2};
     if (l1 || l2)

@@ -608,12 +608,12 @@ def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, monkeypatch, c
     imgs, proj, dv = synth.tile_inputs(cfg, batch=batch, seed=21)
     args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
     outs = {}
-    for mode in ("0", "1", "2", "3", "5"):      # 5: bf16x3 with one launch per hypothesis
+    for mode in ("0", "1", "2", "3", "5", "6"):      # 5: one launch per hypothesis (both levels fused); 6: fp32, level 1 fused, a launch per role
         monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
         with torch.no_grad():
             outs[mode] = m(*args)
         torch.cuda.synchronize()
-    for mode in ("1", "2", "3", "5"):
+    for mode in ("1", "2", "3", "5", "6"):
         for s in ("stage1", "stage2", "stage3"):
             for key in ("depth", "photometric_confidence"):
                 assert torch.equal(outs["0"][s][key], outs[mode][s][key]), (mode, s, key)
@@ -641,12 +641,12 @@ def test_pipelined_recurrence_on_ragged_stage_sizes(hip, O, monkeypatch, precisi
     planes = (near + 4.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).contiguous()
     prev = [torch.rand(B, 1, h // 2, w // 2, generator=g) for _ in range(V - 1)]
     outs = {}
-    for mode in ("0", "1", "2", "3", "5"):      # 5: bf16x3 with one launch per hypothesis
+    for mode in ("0", "1", "2", "3", "5", "6"):      # 5: one launch per hypothesis (both levels fused); 6: fp32, level 1 fused
         monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
         with torch.no_grad():
             outs[mode] = net([dev(f) for f in feats], dev(proj), dev(planes), D, [dev(c) for c in prev])
         torch.cuda.synchronize()
-    for mode in ("1", "2", "3", "5"):
+    for mode in ("1", "2", "3", "5", "6"):
         for key in ("depth", "photometric_confidence"):
             assert torch.equal(outs["0"][key], outs[mode][key]), (mode, key)
     with torch.no_grad():
