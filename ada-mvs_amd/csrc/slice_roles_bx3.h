@@ -22,6 +22,18 @@ __device__ __forceinline__ void split_store(__bf16* hi, __bf16* lo, f32x4 v) {
   *(bf16x4*)lo = l;
 }
 
+// The fused GRU kernels of this mode take their gate / candidate weights and biases PRE-SCALED on the host
+// (packing.pack_slice_reg_net, bf16x3): gates by -log2(e), candidates by 2 log2(e), so that the argument of v_exp_f32 is the
+// accumulator itself -- sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1) -- and the blend
+// u h + (1 - u) c runs as c + u (h - c): one multiply per transcendental and one instruction per blend fewer, of a kernel
+// that spends its time on the vector units (3.4 vector instructions per MFMA before, profiles/r04_asm_mix_gru1_bx3.txt).
+__device__ __forceinline__ float sigmoid_pre(float xs) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
+__device__ __forceinline__ float tanh_pre(float xs) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f); }
+__device__ __forceinline__ f32x4 gru_blend(f32x4 u, f32x4 h, f32x4 c) { return c + u * (h - c); }
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2b __attribute__((ext_vector_type(2)));
+
 enum { BXE_RELU = 0, BXE_GATES = 1, BXE_CAND = 2, BXE_TWO_ROW = 3 };
 
 // bf16 per pixel of the LDS tile.  ds_read_b128 is serviced in four NON-contiguous 16-lane groups (lanes {0-3, 12-15,
@@ -324,9 +336,14 @@ struct Gru1FusedBx3Role {
     xoff[kb] = (unsigned)((((rr0 + pos / 3) * WC + c0w + p + pos % 3) * PB) + ch0 * 2);
     pin(xoff[kb]);
   }
-  // gate epilogue: lanes q < 2 turn h into r*h in the window tile, lanes q >= 2 keep u
-  const unsigned hbyte = (unsigned)(((rr0 + 1) * WC + c0w + p + 1) * PB + (8 + 4 * (q & 1)) * 2);
-  const unsigned ubyte_w = (unsigned)(U0 + ((rr0 * 32 + c0w + p) * 8 + 4 * (q & 1)) * 4);
+  // gate epilogue.  The rows of the gate convolution are PERMUTED on the host (packing.pack_slice_reg_net, bf16x3): MFMA row
+  // 4q + e is reset-gate channel 2q + e (e = 0, 1) or update-gate channel 2q + e - 2 (e = 2, 3), so every lane holds two reset
+  // and two update values of its pixel -- channels 2q, 2q + 1 -- and does a quarter of the r*h work and a quarter of the u work.
+  // (In the reference's order, r = rows 0-7, u = rows 8-15, lanes q < 2 did all of the r*h work -- state halves read back,
+  // product, split, store -- while lanes q >= 2 waited behind the exec mask: 33 vector instructions per run and lane, now 24;
+  // the gate epilogue was the largest share of the kernel's 3.4 vector instructions per MFMA.)
+  const unsigned hbyte = (unsigned)(((rr0 + 1) * WC + c0w + p + 1) * PB + (8 + 2 * q) * 2);
+  const unsigned ubyte_w = (unsigned)(U0 + ((rr0 * 32 + c0w + p) * 8 + 2 * q) * 4);
   // candidate epilogue: lanes q < 2, inner pixel (rr0 + 2j, c0w + p): u of region (ir+1, ic+1)
   const unsigned ubyte_r = (unsigned)(U0 + (((rr0 + 1) * 32 + c0w + p + 1) * 8 + 4 * (q & 1)) * 4);
   const bool lane_out = q < 2 && c0w + p < TC;
@@ -414,16 +431,16 @@ struct Gru1FusedBx3Role {
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const f32x4 v = ag[j];
-      const f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
-      if (q < 2) {
-        __bf16* hi = (__bf16*)(lds + hbyte + j * (2 * WC * PB));
-        __bf16* lo = (__bf16*)((char*)hi + LO);
-        const bf16x4 h4 = *(const bf16x4*)hi, l4 = *(const bf16x4*)lo;
-        const f32x4 hv = {(float)h4.x + (float)l4.x, (float)h4.y + (float)l4.y, (float)h4.z + (float)l4.z, (float)h4.w + (float)l4.w};
-        split_store(hi, lo, sg * hv);
-      } else {
-        *(f32x4*)(lds + ubyte_w + j * (2 * 32 * 32)) = sg;
-      }
+      const f32x4 sg = {sigmoid_pre(v.x), sigmoid_pre(v.y), sigmoid_pre(v.z), sigmoid_pre(v.w)};      // r(2q), r(2q+1), u(2q), u(2q+1)
+      __bf16* hi = (__bf16*)(lds + hbyte + j * (2 * WC * PB));
+      __bf16* lo = (__bf16*)((char*)hi + LO);
+      const bf16x2 h2 = *(const bf16x2*)hi, l2 = *(const bf16x2*)lo;
+      const float r0 = sg.x * ((float)h2.x + (float)l2.x), r1 = sg.y * ((float)h2.y + (float)l2.y);
+      const bf16x2 nh = {(__bf16)r0, (__bf16)r1};
+      const bf16x2 nl = {(__bf16)(r0 - (float)nh.x), (__bf16)(r1 - (float)nh.y)};
+      *(bf16x2*)hi = nh;
+      *(bf16x2*)lo = nl;
+      *(f32x2b*)(lds + ubyte_w + j * (2 * 32 * 32)) = f32x2b{sg.z, sg.w};
     }
     __syncthreads();                   // r*h and u visible
 
@@ -454,8 +471,8 @@ struct Gru1FusedBx3Role {
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const f32x4 v = ac[j];
-      const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
-      buf_store4(rout, oo[j], u4[j] * pre_h[j] + (1.0f - u4[j]) * cnd);
+      const f32x4 cnd = {tanh_pre(v.x), tanh_pre(v.y), tanh_pre(v.z), tanh_pre(v.w)};
+      buf_store4(rout, oo[j], gru_blend(u4[j], pre_h[j], cnd));
     }
     if (!more) break;
     __syncthreads();                   // next tile visible
@@ -608,7 +625,7 @@ struct Gru2FusedBx3Role {
         ag = mfma_bx(gl[kb], bh, ag);
       }
       drain(ag);
-      const f32x4 sg = {sigmoidf_(ag.x), sigmoidf_(ag.y), sigmoidf_(ag.z), sigmoidf_(ag.w)};
+      const f32x4 sg = {sigmoid_pre(ag.x), sigmoid_pre(ag.y), sigmoid_pre(ag.z), sigmoid_pre(ag.w)};
       if (half == 0) {
         const __bf16* hi = (const __bf16*)(lds + hbyte + j * (2 * WC * PB));
         const bf16x4 h4 = *(const bf16x4*)hi, l4 = *(const bf16x4*)((const char*)hi + LO);
@@ -660,8 +677,8 @@ struct Gru2FusedBx3Role {
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const f32x4 v = ac[j];
-      const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
-      buf_store4(rout, oo[j], u4[j] * pre_h[j] + (1.0f - u4[j]) * cnd);
+      const f32x4 cnd = {tanh_pre(v.x), tanh_pre(v.y), tanh_pre(v.z), tanh_pre(v.w)};
+      buf_store4(rout, oo[j], gru_blend(u4[j], pre_h[j], cnd));
     }
     if (!more) break;
     __syncthreads();                   // every wave is done with the tile

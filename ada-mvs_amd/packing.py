@@ -219,18 +219,30 @@ def pack_slice_reg_net(sd, pre, precision="fp32"):
     precision "bf16x3": conv1 / gates / cand / conv2 as split-bf16 fragments (upconv1, final layer, biases stay fp32)."""
     pack_small, pack_c1 = (pack_small_conv, pack_conv1_two_row) if precision == "fp32" else \
                           (pack_small_conv_bf16x3, pack_conv1_two_row_bf16x3)
+    wg1, bg1 = sd[pre + "conv_gru1.conv_gates.0.weight"], sd[pre + "conv_gru1.conv_gates.0.bias"]
+    LOG2E = 1.4426950408889634
+    # bf16x3: gate convolutions scaled by -log2(e), candidate convolutions by 2 log2(e): the fused GRU kernels feed their
+    # accumulators to v_exp_f32 (2^x) directly (csrc/slice_roles_bx3.h: sigmoid_pre, tanh_pre)
+    gs, cs = (1.0, 1.0) if precision == "fp32" else (-LOG2E, 2.0 * LOG2E)
+    scaled = lambda key, s: sd[pre + key].detach().cpu().double().mul(s).float()       # noqa: E731
+    if precision != "fp32":
+        wg1, bg1 = scaled("conv_gru1.conv_gates.0.weight", gs), scaled("conv_gru1.conv_gates.0.bias", gs)
+        # the fused level-1 kernel of the split-bf16 mode (csrc/slice_roles_bx3.h, Gru1FusedBx3Role) wants the gate rows
+        # interleaved: MFMA row 4q + e = reset-gate channel 2q + e (e = 0, 1) | update-gate channel 2q + e - 2 (e = 2, 3)
+        perm = torch.tensor([2 * (m // 4) + (m % 4) if m % 4 < 2 else 8 + 2 * (m // 4) + (m % 4 - 2) for m in range(16)])
+        wg1, bg1 = wg1.detach().cpu()[perm], bg1.detach().cpu()[perm]
     parts = {
         "conv1": pack_c1(sd[pre + "conv1.conv.weight"]),
-        "gates1": pack_small(sd[pre + "conv_gru1.conv_gates.0.weight"]),
-        "gates1_b": pad_bias(sd[pre + "conv_gru1.conv_gates.0.bias"], 16),
+        "gates1": pack_small(wg1),
+        "gates1_b": pad_bias(bg1, 16),
         # fp32: 8 outputs fill half an MFMA tile, so the kernel takes them in the two-row form of conv1
-        "cand1": (pack_conv1_two_row if precision == "fp32" else pack_small)(sd[pre + "conv_gru1.convc.0.weight"]),
-        "cand1_b": pad_bias(sd[pre + "conv_gru1.convc.0.bias"], 16),
+        "cand1": (pack_conv1_two_row if precision == "fp32" else pack_small)(scaled("conv_gru1.convc.0.weight", cs)),
+        "cand1_b": pad_bias(scaled("conv_gru1.convc.0.bias", cs), 16),
         "conv2": pack_small(sd[pre + "conv2.conv.weight"]),
-        "gates2": pack_small(sd[pre + "conv_gru2.conv_gates.0.weight"]),
-        "gates2_b": pad_bias(sd[pre + "conv_gru2.conv_gates.0.bias"], 32),
-        "cand2": pack_small(sd[pre + "conv_gru2.convc.0.weight"]),
-        "cand2_b": pad_bias(sd[pre + "conv_gru2.convc.0.bias"], 16),
+        "gates2": pack_small(scaled("conv_gru2.conv_gates.0.weight", gs)),
+        "gates2_b": pad_bias(scaled("conv_gru2.conv_gates.0.bias", gs), 32),
+        "cand2": pack_small(scaled("conv_gru2.convc.0.weight", cs)),
+        "cand2_b": pad_bias(scaled("conv_gru2.convc.0.bias", cs), 16),
         "upconv1": pack_small_conv(sd[pre + "upconv1.weight"], transposed=True),
         "upconv1_b": pad_bias(sd[pre + "upconv1.bias"], 16),
         # [8][1][3][3] (transposed, stages 1-2) and [1][8][3][3] (stage 3) both flatten to c*9 + tap; stored

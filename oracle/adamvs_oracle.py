@@ -48,11 +48,11 @@ def warp_plane(src_fea, R, t, depth):
     """
     B, C, h, w = src_fea.shape
     dev = src_fea.device
-    y, x = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev),
-                          torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
-    xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(h * w, device=dev)))  # [3,hw]
-    rot_xyz = torch.matmul(R, xyz.unsqueeze(0).expand(B, 3, h * w))                  # [B,3,hw]
-    p = rot_xyz * depth.reshape(B, 1, h * w) + t.reshape(B, 3, 1)
+    dt = src_fea.dtype        # fp32 as the reference; float64 when a test asks for the exact-arithmetic version of a path
+    y, x = torch.meshgrid(torch.arange(h, dtype=dt, device=dev), torch.arange(w, dtype=dt, device=dev), indexing="ij")
+    xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(h * w, dtype=dt, device=dev)))  # [3,hw]
+    rot_xyz = torch.matmul(R.to(dt), xyz.unsqueeze(0).expand(B, 3, h * w))           # [B,3,hw]
+    p = rot_xyz * depth.reshape(B, 1, h * w).to(dt) + t.to(dt).reshape(B, 3, 1)
     u = p[:, 0] / p[:, 2]
     v = p[:, 1] / p[:, 2]
     gx = u / ((w - 1) / 2) - 1
@@ -83,10 +83,10 @@ def warp_plane_grid_sample(src_fea, R, t, depth):
     CPU baseline (ATen's vectorised sampler instead of the explicit gather above); tests hold the two equal."""
     B, C, h, w = src_fea.shape
     dev = src_fea.device
-    y, x = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev),
-                          torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
-    xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(h * w, device=dev)))
-    p = torch.matmul(R, xyz.unsqueeze(0).expand(B, 3, h * w)) * depth.reshape(B, 1, h * w) + t.reshape(B, 3, 1)
+    dt = src_fea.dtype
+    y, x = torch.meshgrid(torch.arange(h, dtype=dt, device=dev), torch.arange(w, dtype=dt, device=dev), indexing="ij")
+    xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(h * w, dtype=dt, device=dev)))
+    p = torch.matmul(R.to(dt), xyz.unsqueeze(0).expand(B, 3, h * w)) * depth.reshape(B, 1, h * w).to(dt) + t.to(dt).reshape(B, 3, 1)
     gx = (p[:, 0] / p[:, 2]) / ((w - 1) / 2) - 1
     gy = (p[:, 1] / p[:, 2]) / ((h - 1) / 2) - 1
     grid = torch.stack((gx, gy), dim=2).view(B, h, w, 2)

@@ -438,3 +438,53 @@ def test_regulariser_packing_layout():
     assert float(flat[o + 9 * D * D]) == float(sd["upconv2d.bias"][0])
     gn_o, hc = off["gn2"]
     assert hc == 16 and torch.equal(flat[gn_o + 4 * hc:gn_o + 5 * hc], sd["conv_gru2.output_norm.weight"])
+
+
+@pytest.mark.gpu
+def test_end_to_end_at_the_benchmark_shape_against_oracle():
+    """One tile at the shape bench.py --model msrednet is quoted on (5 views, 768 x 384, hypotheses 192/64/8: 264 recurrent
+    planes through four GRU levels, 96 x 192 ... 12 x 24 maps at stage 1) against oracle/msrednet_oracle.py (itself pinned by
+    the reference-run fixtures above), evaluated twice: in the reference's fp32 and in float64.
+
+    What the first run of this case showed (round 4): at this size the fp32 CPU path -- the reference's own arithmetic -- is
+    itself 3.5e-3 away from the float64 evaluation on the final confidence map (2.6e-4 / 8.6e-4 at stages 1 / 2; depth maps
+    2-5e-5), whatever the thread count or the form of the warp (those move it by 8e-5 ... 2e-4), and the HIP path differs from
+    the fp32 run by exactly those amounts: it sits next to the float64 result.  So the bar (1e-3 relative L1, BASELINE.json)
+    is asserted where it is meaningful -- every depth map against the fp32 oracle, every map against the float64 oracle --
+    and the confidence maps must be no farther from the fp32 oracle than the fp32 oracle is from float64 (plus the bar)."""
+    from ada_mvs_amd.models.msrednet import Infer_CascadeREDNet
+    c = synth.CONFIGS["cfg3"]
+    m = Infer_CascadeREDNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs("cfg3", batch=1, seed=0)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+    def oracle(dt):
+        sd_ = {k: (v.cpu().to(dt) if v.is_floating_point() else v.cpu()) for k, v in sd.items()}
+        with torch.no_grad(), mo.ao.use_grid_sample():
+            return mo.infer_cascade_rednet_forward(imgs.to(dt), {k: v.to(dt) for k, v in proj.items()}, dv.to(dt), sd_, c["num_depth"],
+                                                   c["ndepths"], synth.DEPTH_INTERVALS_RATIO)
+    want32, want64 = oracle(torch.float32), oracle(torch.float64)
+    with torch.no_grad():
+        out = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+    rows = {}
+    for s in ("stage1", "stage2", "stage3"):
+        for key in ("depth", "photometric_confidence"):
+            assert out[s][key].shape == want32[s][key].shape
+            rows[s + "." + key] = (rel_l1(out[s][key].cpu(), want32[s][key]), rel_l1(out[s][key].cpu().double(), want64[s][key]),
+                                   rel_l1(want32[s][key].double(), want64[s][key]))
+    print("msrednet cfg3-shape parity (hip vs fp32 oracle, hip vs float64 oracle, fp32 oracle vs float64):",
+          {k: "%.2e %.2e %.2e" % v for k, v in rows.items()})
+    try:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_msrednet_full_size.json"), "w") as f:
+            import json
+            json.dump({k: {"hip_vs_fp32_oracle": v[0], "hip_vs_float64_oracle": v[1], "fp32_oracle_vs_float64": v[2]} for k, v in rows.items()}, f, indent=1)
+    except OSError:
+        pass
+    for k, (e32, e64, o) in rows.items():
+        assert e64 < 1e-3, (k, e64)                          # against exact arithmetic: the bar
+        if k.endswith("depth"):
+            assert e32 < 1e-3, (k, e32)                      # against the reference's fp32: the bar
+        assert e32 < o + 1e-3, (k, e32, o)                   # never farther from the reference than the reference is from exact, + the bar
