@@ -22,7 +22,7 @@ class FuseWeights(ctypes.Structure):
     """adamvs_fuse_weights"""
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "conv1", "gates1", "gates1_b", "cand1", "cand1_b", "conv2", "gates2", "gates2_b",
-        "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w")]
+        "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w", "gates1_w", "gates2_w", "cand2_w", "cand1_w")]
 
 
 class FConvWeights(ctypes.Structure):
@@ -83,6 +83,8 @@ SIGNATURES = {
     "adamvs_slice_reg_step": (c_i, [c_f, c_f, c_f, ctypes.POINTER(FuseWeights), c_f, c_i, c_i, c_i, c_i, c_i, c_i,
                                     ctypes.c_void_p, c_sz, c_st]),
     "adamvs_depth_stage_workspace_bytes": (c_sz, [ctypes.POINTER(StageDesc)]),
+    "adamvs_recurrence_schedule": (c_i, [c_i, ctypes.c_longlong]),
+    "adamvs_gru_wino_mask": (c_i, []),
     "adamvs_depth_stage_forward": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, c_sz, ctypes.POINTER(FuseWeights),
                                          c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_feature_net0_workspace_bytes": (c_sz, [c_i, c_i, c_i]),

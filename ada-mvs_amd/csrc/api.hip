@@ -130,6 +130,9 @@ extern "C" int adamvs_slice_reg_step(const float* cost, float* state1, float* st
   return 0;
 }
 
+extern "C" int adamvs_recurrence_schedule(int precision_fuse, long long pixels) { return recurrence_mode(precision_fuse, (long)pixels); }
+extern "C" int adamvs_gru_wino_mask(void) { return gru_wino_mask(); }
+
 extern "C" size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc) {
   if (check_desc(desc)) return 0;
   return carve(*desc).total * sizeof(float);

@@ -18,7 +18,10 @@ struct FuseWeights {          // mirrors adamvs_fuse_weights in include/adamvs_h
   const float* cand2;  const float* cand2_b;    // [1][9][8][64], [16]
   const float* upconv1; const float* upconv1_b; // [1][9][4][64], [16]
   const float* final_w;                         // [73]
+  // fp32 only: the GRU convolutions in the F(2x2, 3x3) form (slice_roles_wino.h), U = G g Gt as fragments [NT][4][4][cin/4][64]
+  const float* gates1_w; const float* gates2_w; const float* cand2_w; const float* cand1_w;
 };
+int gru_wino_mask();          // which GRU convolutions run in the F(2x2, 3x3) form in one-role launches (slice_red.hip)
 
 struct StepBuffers {          // all channel-last
   float* h1; float* rh1; float* u1;              // [B][hw][8]

@@ -28,6 +28,7 @@
 #include "slice_roles.h"
 #include "slice_roles_bx3.h"
 #include "slice_roles_fused.h"
+#include "slice_roles_wino.h"
 
 namespace adamvs {
 
@@ -109,9 +110,12 @@ static void split_grid(int total, const long (&tiles)[NR], const double (&work)[
 template <class R0, class R1, class R2>
 static int launch_slot(const RoleUse<R0>& u0, const RoleUse<R1>& u1, const RoleUse<R2>& u2, int B, hipStream_t st, const char* name) {
   constexpr size_t lds = max3(R0::LDS_BYTES, R1::LDS_BYTES, R2::LDS_BYTES);
-  static_assert(lds <= 64 * 1024, "slot exceeds the default dynamic LDS limit");
+  static_assert(lds <= 160 * 1024, "slot exceeds the LDS of a CU");
   auto kern = k_slot<R0, R1, R2>;
-  static const int capacity = resident_blocks(kern, 256, lds);      // per instantiation; once, thread-safely (magic static)
+  static const int capacity = [&] {                                  // per instantiation; once, thread-safely (magic static)
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return resident_blocks(kern, 256, lds);
+  }();
   SlotArgs<R0, R1, R2> s;
   memset(&s, 0, sizeof(s));
   long tiles[3] = {0, 0, 0};
@@ -211,6 +215,9 @@ typedef Cand1TwoRowRole Cand1;
 typedef ConvSmallRole<8, 0, 1, 2, EPI_RELU> Conv2;
 typedef ConvSmallRole<16, 16, 2, 1, EPI_GATES> Gates2;
 typedef ConvSmallRole<16, 16, 1, 1, EPI_CAND> Cand2;
+typedef ConvWinoRole<8, 8, 1, EPI_GATES> Gates1W;      // the same convolutions in the F(2x2, 3x3) form (slice_roles_wino.h), 8 x 32 tiles
+typedef ConvWinoRole<16, 16, 2, EPI_GATES> Gates2W;
+typedef ConvWinoRole<16, 16, 1, EPI_CAND> Cand2W;
 typedef Gru1FusedRole<4, 2> Gru1S;      // fp32, both levels fused: 4 x 30 / 4 x 14 tiles for stages with few tiles per CU
 typedef Gru2FusedRole<4> Gru2S;
 typedef Gru1FusedRole<8, 2> Gru1L;      // 8 x 30: the large-batch tile
@@ -276,7 +283,9 @@ int recurrence_mode(int precision, long pixels) {
   // the fused tiles execute 36 % more MFMAs and the stage is not latency- but throughput-bound as soon as every CU has a few tiles.
   // Schedule 6 (level 1 fused on 8 x 30 tiles, a launch per role) loses at every size: cfg3 at 32 tiles 23.4 / 26.5 / 13.2 ms
   // per stage -> 25.4 / 27.8 / 13.4; cfg2 at 128 tiles 79.6 -> 86.5.  Kept behind ADAMVS_RECUR_MODE=6 as the measurement.
-  return pixels <= 100000 ? 5 : (pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0));
+  // One role per launch (0) from 550k pixels up since its gate convolutions run in the F(2x2, 3x3) form (slice_roles_wino.h;
+  // until then 800k): cfg3 at 32 tiles, stage 1 (590k) 23.3 ms with three launches per hypothesis, 22.7 with six.
+  return pixels <= 100000 ? 5 : (pixels <= 200000 ? 3 : (pixels <= 550000 ? 1 : 0));
 }
 
 template <class R> static RoleUse<R> use(const typename R::Args* a, float cost, float f0 = 0.f, float f1 = 1.f) {
@@ -408,6 +417,33 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
     return launch_slot<Cand1, Cand2, DecoderRole<false>>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
                                                          dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st,
                                                          "recurrence slot B (schedule 3)");
+  }
+  if (schedule == 1 && (gru_wino_mask() & 7) == 7 && fw.gates1_w && fw.gates2_w && fw.cand2_w) {
+    // schedule 1 with the gate convolutions of both levels and the level-2 candidate in the F(2x2, 3x3) form (8 x 32 tiles; cost
+    // per tile = four 4 x 16 tiles of the direct role times the measured ratio of the one-role launches: 0.76 / 0.69 / 0.89)
+    SmallConvArgs g1w = g1, g2w = g2, c2w = c2;
+    g1w.wpk = fw.gates1_w; g2w.wpk = fw.gates2_w; c2w.wpk = fw.cand2_w;
+    const float kg1 = 4.f * 0.76f * k.g1, kg2 = 4.f * 0.69f * k.g2, kc2 = 4.f * 0.89f * k.c2;
+    if (l1 || l2)
+      if ((rc = launch_slot<Gates1W, Conv2, NopRole>(l1 ? use<Gates1W>(&g1w, kg1) : none<Gates1W>(), l2 ? use<Conv2>(&v2, k.v2) : none<Conv2>(),
+                                                     none<NopRole>(), B, st, "recurrence slot A (F(2x2,3x3))")))
+        return rc;
+    if (l1 || l2)
+      if ((rc = launch_slot<Cand1, Gates2W, NopRole>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), l2 ? use<Gates2W>(&g2w, kg2) : none<Gates2W>(),
+                                                     none<NopRole>(), B, st, "recurrence slot B (F(2x2,3x3))")))
+        return rc;
+    if (lc || dec) {
+      if (in_up)
+        rc = launch_slot<Cand2W, DecoderRole<true>, NopRole>(lc ? use<Cand2W>(&c2w, kc2) : none<Cand2W>(),
+                                                             dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(),
+                                                             none<NopRole>(), B, st, "recurrence slot C (F(2x2,3x3))");
+      else
+        rc = launch_slot<Cand2W, DecoderRole<false>, NopRole>(lc ? use<Cand2W>(&c2w, kc2) : none<Cand2W>(),
+                                                              dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(),
+                                                              none<NopRole>(), B, st, "recurrence slot C (F(2x2,3x3))");
+      if (rc) return rc;
+    }
+    return 0;
   }
   if (l1 || l2)
     if ((rc = launch_slot<Gates1, Conv2, NopRole>(l1 ? use<Gates1>(&g1, k.g1) : none<Gates1>(), l2 ? use<Conv2>(&v2, k.v2) : none<Conv2>(),

@@ -12,8 +12,16 @@
 #include "kernels.h"
 #include "persistent.h"
 #include "slice_roles.h"
+#include "slice_roles_wino.h"
 
 namespace adamvs {
+
+// A GRU convolution in the F(2x2, 3x3) form (slice_roles_wino.h), one role per launch
+template <int CA, int CB, int NT, int EPI>
+__global__ __launch_bounds__(256, 2) void k_conv_small_wino(SmallConvArgs a, TileGrid tg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  ConvWinoRole<CA, CB, NT, EPI>::run(a, tg, TileRange{0, tg.ntiles}, blockIdx.x, gridDim.x, lds);
+}
 
 // One role per launch (the one-step op adamvs_slice_reg_step, conv3x3_pair of MS-REDNet); the software-pipelined
 // recurrence of a whole stage runs the same roles several per launch (recurrence.hip).
@@ -105,6 +113,33 @@ static int launch_small_shape(const SmallConvArgs& a, int B, hipStream_t st, con
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
   return 0;
+}
+
+template <int CA, int CB, int NT, int EPI>
+static int launch_small_wino(const SmallConvArgs& a, int B, hipStream_t st, const char* name) {
+  typedef ConvWinoRole<CA, CB, NT, EPI> Role;
+  constexpr size_t lds = Role::LDS_BYTES;
+  auto kern = k_conv_small_wino<CA, CB, NT, EPI>;
+  static const int capacity = [&] {                      // once per instantiation, thread-safely (magic static)
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return resident_blocks(kern, 256, lds);
+  }();
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, Role::tiles_x(a), Role::tiles_y(a), B)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tg);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "%s: %s", name, hipGetErrorString(e));
+  return 0;
+}
+
+// ADAMVS_GRU_WINO: bit mask of the GRU convolutions that run in the F(2x2, 3x3) form when a role has a launch of its own
+// (1 gates1, 2 gates2, 4 cand2, 8 cand1; default 7; 0 = the direct kernels, which the pipelined schedules use: their maps
+// equal the direct kernels' bit for bit, the F(2x2, 3x3) ones to ~1e-7).  Read per call: the tests switch it.
+// Measured at cfg2, 128 tiles (recurrence per step, ms): none 79.8; gates1 74.9; gates2 74.2; cand2 78.6; all three 68.3.
+int gru_wino_mask() {
+  const char* e = getenv("ADAMVS_GRU_WINO");
+  return e && *e ? atoi(e) : 7;
 }
 
 // Tile = 4 rows x 16 columns: the smallest halo (6 x 18 input pixels for 64 outputs) of the one-run-per-wave shapes.
@@ -467,9 +502,15 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   } else {
   {  // GRU level 1: gates on cat(c1, h1), candidate on cat(c1, r*h1)
     SmallConvArgs g{c1, sb.h1, fw.gates1, fw.gates1_b, sb.rh1, sb.u1, h, w, h, w, 16};
-    if ((rc = launch_small<8, 8, 1, 1, EPI_GATES>(g, B, st, "gates1"))) return rc;
+    if ((gru_wino_mask() & 1) && fw.gates1_w) {
+      g.wpk = fw.gates1_w;
+      if ((rc = launch_small_wino<8, 8, 1, EPI_GATES>(g, B, st, "gates1 (F(2x2,3x3))"))) return rc;
+    } else if ((rc = launch_small<8, 8, 1, 1, EPI_GATES>(g, B, st, "gates1"))) return rc;
     SmallConvArgs c{c1, sb.rh1, fw.cand1, fw.cand1_b, sb.h1, sb.u1, h, w, h, w, 8};     // cand1: two-row fragments
-    if ((rc = launch_cand1_two_row(c, B, st))) return rc;
+    if ((gru_wino_mask() & 8) && fw.cand1_w) {
+      c.wpk = fw.cand1_w;
+      if ((rc = launch_small_wino<8, 8, 1, EPI_CAND>(c, B, st, "cand1 (F(2x2,3x3))"))) return rc;
+    } else if ((rc = launch_cand1_two_row(c, B, st))) return rc;
   }
   {  // conv2: 8 -> 16, stride 2, ReLU
     SmallConvArgs a{sb.h1, nullptr, fw.conv2, nullptr, sb.c2, nullptr, h, w, h2, w2, 16};
@@ -477,9 +518,15 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   }
   {  // GRU level 2
     SmallConvArgs g{sb.c2, sb.h2, fw.gates2, fw.gates2_b, sb.rh2, sb.u2, h2, w2, h2, w2, 32};
-    if ((rc = launch_small<16, 16, 2, 1, EPI_GATES>(g, B, st, "gates2"))) return rc;
+    if ((gru_wino_mask() & 2) && fw.gates2_w) {
+      g.wpk = fw.gates2_w;
+      if ((rc = launch_small_wino<16, 16, 2, EPI_GATES>(g, B, st, "gates2 (F(2x2,3x3))"))) return rc;
+    } else if ((rc = launch_small<16, 16, 2, 1, EPI_GATES>(g, B, st, "gates2"))) return rc;
     SmallConvArgs c{sb.c2, sb.rh2, fw.cand2, fw.cand2_b, sb.h2, sb.u2, h2, w2, h2, w2, 16};
-    if ((rc = launch_small<16, 16, 1, 1, EPI_CAND>(c, B, st, "cand2"))) return rc;
+    if ((gru_wino_mask() & 4) && fw.cand2_w) {
+      c.wpk = fw.cand2_w;
+      if ((rc = launch_small_wino<16, 16, 1, EPI_CAND>(c, B, st, "cand2 (F(2x2,3x3))"))) return rc;
+    } else if ((rc = launch_small<16, 16, 1, 1, EPI_CAND>(c, B, st, "cand2"))) return rc;
   }
   }
   if (h1_now) *h1_now = h1;

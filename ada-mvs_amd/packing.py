@@ -211,7 +211,20 @@ def pack_cost_reg_net_2d(sd, pre, precision="fp32"):
 
 
 FUSE_FIELDS = ("conv1", "gates1", "gates1_b", "cand1", "cand1_b", "conv2", "gates2", "gates2_b",
-               "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w")
+               "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w", "gates1_w", "gates2_w", "cand2_w", "cand1_w")
+
+
+def pack_small_conv_wino(w):
+    """[cout][cin][3][3] -> the transformed filters U = G w G^T (double precision, rounded once) of the F(2x2, 3x3) form as A
+    fragments [NT][4 = patch row i][4 = patch column j][cin/4][64], cout zero-padded to 16*NT (csrc/slice_roles_wino.h)."""
+    w = w.detach().to(torch.float64).cpu()
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % 4 == 0
+    nt = (cout + 15) // 16
+    u = torch.zeros(4, 4, nt * 16, cin, dtype=torch.float32)
+    u[:, :, :cout] = torch.einsum("ik,ockl,jl->ijoc", WINO_G, w, WINO_G).to(torch.float32)
+    # (i, j, nt, co16, kc, k4) -> (nt, i, j, kc, k4, co16): lane = k4*16 + co16
+    return u.reshape(4, 4, nt, 16, cin // 4, 4).permute(2, 0, 1, 4, 5, 3).contiguous().reshape(-1)
 
 
 def pack_slice_reg_net(sd, pre, precision="fp32"):
@@ -250,8 +263,15 @@ def pack_slice_reg_net(sd, pre, precision="fp32"):
         "final_w": pad_bias(torch.cat([sd[pre + "upconv2d.weight"].detach().float().cpu().reshape(8, 9).t().reshape(-1),
                                        sd[pre + "upconv2d.bias"].detach().float().cpu().reshape(-1)]), 76),
     }
+    if precision == "fp32":
+        parts["gates1_w"] = pack_small_conv_wino(sd[pre + "conv_gru1.conv_gates.0.weight"])
+        parts["gates2_w"] = pack_small_conv_wino(sd[pre + "conv_gru2.conv_gates.0.weight"])
+        parts["cand2_w"] = pack_small_conv_wino(sd[pre + "conv_gru2.convc.0.weight"])
+        parts["cand1_w"] = pack_small_conv_wino(sd[pre + "conv_gru1.convc.0.weight"])
     offsets, chunks, o = {}, [], 0
     for f in FUSE_FIELDS:
+        if f not in parts:               # the F(2x2, 3x3) blocks exist in fp32 only: the field stays NULL
+            continue
         t = parts[f]
         pad = (-t.numel()) % 64          # keep every field 256-byte aligned
         offsets[f] = o

@@ -115,6 +115,9 @@ def algorithmic_work(cfg, B):
         st["recurrence_bytes"] = B * D * (96 * hw)
         st["softargmin_bytes"] = B * D * (24 * HoWo)
         st["recurrence_flops"] = B * D * hw * 2 * 7560
+        # the GRU convolutions that may run in the F(2x2, 3x3) form (csrc/slice_roles_wino.h), MACs per level-1 pixel of their
+        # direct form: gates1 16->16, gates2 32->32 and cand2 32->16 at quarter resolution, cand1 16->8
+        st["gru_conv_macs"] = {1: 2304, 2: 2304, 4: 1152, 8: 1152}
         st["conv1_flops"] = B * D * hw * 2 * 72 * C
         if s == 0:
             st["pair_similarity_bytes"] = B * (S * D * C * hw * e + S * C * hw * e + S * D * hw * 4)
@@ -458,6 +461,15 @@ class Workload:
         # direct form counts; the split-bf16 mode issues three bf16 products per fp32 product
         wino = winograd_active(work[0]["D"], self.precision)
         executed = tot_flops - (work[0].get("costreg_stride1_flops", 0) * (20.0 / 36.0) if wino else 0.0)
+        gru_wino = 0.0
+        if not split:           # fp32: stages whose recurrence runs one role per launch take their GRU convolutions in the F(2x2, 3x3) form
+            lib = _lib.load()
+            mask = lib.adamvs_gru_wino_mask()
+            for w_ in work:
+                sched = lib.adamvs_recurrence_schedule(0, self.B * w_["h"] * w_["w"])
+                if sched == 0 or (sched == 1 and (mask & 7) == 7):
+                    gru_wino += self.B * w_["D"] * w_["h"] * w_["w"] * 2.0 * sum(m for b_, m in w_["gru_conv_macs"].items() if mask & b_)
+        executed -= gru_wino * (20.0 / 36.0)
         f_mfma = (tot_flops * 3 / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS if split else executed / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS)
         f_hbm = tot_bytes / step_s / 1e9 / HBM_PEAK_GBS
         out = {"step_frac_mfma": f_mfma, "step_frac_hbm": f_hbm, "step_frac": f_hbm if split else f_mfma,
@@ -466,7 +478,7 @@ class Workload:
                             "(bf16x3), EXECUTED conv flops / step / fp32 MFMA peak (fp32)",
                "step_algorithmic": {"conv_gflop_per_tile": tot_flops / self.B / 1e9, "executed_conv_gflop_per_tile": executed / self.B / 1e9,
                                     "gbytes_per_tile": tot_bytes / self.B / 1e9}}
-        if wino:
+        if wino or gru_wino:
             # the same step priced in SURVEY 8d's direct-form flops: an algorithmic saving, NOT a hardware fraction (can pass 1)
             out["step_frac_direct_equivalent"] = tot_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
         return out
@@ -784,8 +796,16 @@ def roofline_of(wl, args, ms_per_step):
                                         "same source stamp %s" % (os.path.basename(tpath), stamp))
                 break
     elif kind == "recurrence":
-        # executed flops: the split-bf16 mode issues three bf16 products per fp32 product
-        ach = st["recurrence_flops"] * (3 if split else 1) / (avg[dom] * 1e-3) / 1e12
+        # executed flops: the split-bf16 mode issues three bf16 products per fp32 product; fp32 stages that run one role per
+        # launch (or the three-launch schedule) take their gate / level-2 candidate convolutions in the F(2x2, 3x3) form: 16 of 36
+        rec_flops = st["recurrence_flops"] * (3 if split else 1)
+        if not split:
+            lib = _lib.load()
+            mask = lib.adamvs_gru_wino_mask()
+            sched = lib.adamvs_recurrence_schedule(0, Bg * st["h"] * st["w"])
+            if sched == 0 or (sched == 1 and (mask & 7) == 7):
+                rec_flops -= Bg * st["D"] * st["h"] * st["w"] * 2.0 * sum(m for b_, m in st["gru_conv_macs"].items() if mask & b_) * (20.0 / 36.0)
+        ach = rec_flops / (avg[dom] * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         # launches per hypothesis depend on the stage size (csrc/recurrence.hip: 6 / 3 / 2 in fp32, 4 / 2 in bf16x3):
         # the figure priced here is one hypothesis = one recurrent step of all tiles

@@ -165,6 +165,13 @@ typedef struct adamvs_fuse_weights {
   const float* cand2;  const float* cand2_b;    /* [1][9][8][64], [16]      conv_gru2.convc.0 */
   const float* upconv1; const float* upconv1_b; /* [1][9][4][64], [16]      upconv1 (transposed: W[cin][cout][tap]) */
   const float* final_w;                         /* [73]: w[tap*8+c], bias   upconv2d */
+  /* fp32 (NULL in bf16x3): the same gate / candidate convolutions as transformed filters U = G g G^T of the minimal-filtering
+   * form F(2x2, 3x3) (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]), fragments [cout tile][patch row i][patch column j][cin/4][64]:
+   * lane l = U[i][j][cout = 16*tile + (l&15)][cin = 4*kc + (l>>4)] */
+  const float* gates1_w;                        /* [1][4][4][4][64]         conv_gru1.conv_gates.0 */
+  const float* gates2_w;                        /* [2][4][4][8][64]         conv_gru2.conv_gates.0 */
+  const float* cand2_w;                         /* [1][4][4][8][64]         conv_gru2.convc.0 */
+  const float* cand1_w;                         /* [1][4][4][4][64]         conv_gru1.convc.0 (8 of 16 rows) */
 } adamvs_fuse_weights;
 
 /* ---- FeatureNet0.forward, reference models/adamvs.py:49-152 (blocks models/module.py:164-251,
@@ -259,6 +266,13 @@ typedef struct adamvs_stage_desc {
 #define ADAMVS_PLANES_WINDOW   2
 
 size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);
+
+/* How a stage of B*h*w pixels runs its recurrence (for accounting: bench.py prices executed flops): the schedule
+ * (0: one role per launch, sequential; 1, 2, 3, 5, 6: software-pipelined, see ADAMVS_RECUR_MODE in INTEGRATION.md) and, for
+ * schedule 0 in fp32, the bit mask of the GRU convolutions that run in the minimal-filtering form F(2x2, 3x3)
+ * (1 gates1, 2 gates2, 4 cand2, 8 cand1: 16 of the 36 products of the direct form; ADAMVS_GRU_WINO overrides, default 7). */
+int adamvs_recurrence_schedule(int precision_fuse, long long pixels);
+int adamvs_gru_wino_mask(void);
 
 /* phases of a stage.  VIEW_WEIGHTS may run in a call of its own: its results are the view_weight / pair_depth OUTPUT
  * tensors, which a later call reads back.  AGGREGATE, RECURRENCE and SOFT_ARGMIN form one chain over chunks of 32

@@ -124,13 +124,28 @@ def test_cfg4_rank_share_against_oracle(precision):
     out, sd = _run("cfg3", precision, tiles)
     for b in (0, 3):
         _compare(out, _oracle("cfg3", tiles[b], b, 4, sd), b, 3, 4, "cfg4-share/%s/tile%d" % (precision, tiles[b]))
-    # batch invariance at full size: slot 2 alone must reproduce slot 2 of the batch bit for bit
+    # batch invariance at full size: slot 2 alone must reproduce slot 2 of the batch.  bf16x3: bit for bit (one set of kernels
+    # whatever the schedule).  fp32: stages of 550k pixels x tiles and more run their GRU gate convolutions in the F(2x2, 3x3)
+    # form (round 4, csrc/slice_roles_wino.h) -- stage 3 of the four-tile batch does, of the single tile does not -- so the two
+    # agree to rounding, and bit for bit again with the form switched off.
     m, _ = _model("cfg3", precision)
     imgs, proj, dv = _bench_inputs("cfg3", tiles)
     with torch.no_grad():
         one = m(imgs[2:3].cuda(), {k: v[2:3].cuda() for k, v in proj.items()}, dv[2:3].cuda())
-    assert torch.equal(one["depth"][0], out["depth"][2])
-    assert torch.equal(one["photometric_confidence"][0], out["photometric_confidence"][2])
+    if precision == "bf16x3":
+        assert torch.equal(one["depth"][0], out["depth"][2])
+        assert torch.equal(one["photometric_confidence"][0], out["photometric_confidence"][2])
+    else:
+        assert rel_l1(one["depth"][0], out["depth"][2]) < 1e-6 and rel_l1(one["photometric_confidence"][0], out["photometric_confidence"][2]) < 2e-5
+        os.environ["ADAMVS_GRU_WINO"] = "0"
+        try:
+            with torch.no_grad():
+                batch = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+                one = m(imgs[2:3].cuda(), {k: v[2:3].cuda() for k, v in proj.items()}, dv[2:3].cuda())
+        finally:
+            del os.environ["ADAMVS_GRU_WINO"]
+        assert torch.equal(one["depth"][0], batch["depth"][2])
+        assert torch.equal(one["photometric_confidence"][0], batch["photometric_confidence"][2])
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])

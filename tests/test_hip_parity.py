@@ -607,6 +607,7 @@ def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, monkeypatch, c
     m = m.cuda().eval()
     imgs, proj, dv = synth.tile_inputs(cfg, batch=batch, seed=21)
     args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+    monkeypatch.setenv("ADAMVS_GRU_WINO", "0")       # mode 0 on the direct kernels too (its F(2x2, 3x3) form: the test below)
     outs = {}
     for mode in ("0", "1", "2", "3", "5", "6"):      # 5: one launch per hypothesis (both levels fused); 6: fp32, level 1 fused, a launch per role
         monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
@@ -640,6 +641,7 @@ def test_pipelined_recurrence_on_ragged_stage_sizes(hip, O, monkeypatch, precisi
     near = 420.0 + 20.0 * torch.rand(B, 1, h, w, generator=g)
     planes = (near + 4.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).contiguous()
     prev = [torch.rand(B, 1, h // 2, w // 2, generator=g) for _ in range(V - 1)]
+    monkeypatch.setenv("ADAMVS_GRU_WINO", "0")       # mode 0 on the direct kernels too
     outs = {}
     for mode in ("0", "1", "2", "3", "5", "6"):      # 5: one launch per hypothesis (both levels fused); 6: fp32, level 1 fused
         monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
@@ -1109,3 +1111,47 @@ def test_conv_layers_on_more_images_than_one_grid_takes(hip, precision):
         idx = torch.tensor([0, 1, 16382, 16383, 16384, 65534, 65535, 65536, N - 1], device="cuda")
         part = hip.conv3x3_dd(x[idx].contiguous(), layer[:9 * D * D], layer[9 * D * D:], None, idx.numel(), D, hi, wi, mode, 1, precision=precision)
         assert torch.allclose(out[idx], part, rtol=1e-4, atol=1e-5), mode      # (small batches may take another tiling: not bit for bit)
+
+
+@pytest.mark.parametrize("recur,mask", [("0", "1"), ("0", "2"), ("0", "4"), ("0", "8"), ("0", "15"), ("1", "7")])
+@pytest.mark.parametrize("cfg,batch", [("tiny", 3), ("cfg1", 2)])
+def test_gru_convolutions_in_the_minimal_filtering_form(hip, monkeypatch, cfg, batch, recur, mask):
+    """With one role per launch (ADAMVS_RECUR_MODE=0: what large stages run) the gate convolutions of both ConvGRU levels and
+    the level-2 candidate run in the form F(2x2, 3x3) (csrc/slice_roles_wino.h; ADAMVS_GRU_WINO selects which, default 7):
+    16 instead of 36 products, fp32 throughout, so the maps agree with the direct kernels' to rounding (asserted: 2e-5 through
+    the whole cascade; measured ~1e-6) and with the reference's fixture where there is one.  Image sizes that are no multiple
+    of the 8 x 32 tile (tiny: 16 x 24 at stage 1) exercise the edge paths."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    c = synth.CONFIGS[cfg]
+    m = Infer_AdaMVSNet(c["num_depth"], c["ndepths"], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=batch, seed=21)
+    args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+    monkeypatch.setenv("ADAMVS_RECUR_MODE", recur)      # 1: three launches per hypothesis, the same roles sharing launches (mask 7 only)
+    outs = {}
+    for mk in ("0", mask):
+        monkeypatch.setenv("ADAMVS_GRU_WINO", mk)
+        with torch.no_grad():
+            outs[mk] = m(*args)
+        torch.cuda.synchronize()
+    differs = False
+    for s in ("stage1", "stage2", "stage3"):
+        for key in ("depth", "photometric_confidence"):
+            assert rel_l1(outs[mask][s][key], outs["0"][s][key]) < 2e-5, (s, key)
+            differs = differs or not torch.equal(outs[mask][s][key], outs["0"][s][key])
+    assert differs, "the switch did not select another kernel"
+
+
+def test_drop_in_forward_with_one_role_per_launch(hip, monkeypatch):
+    """The reference's fixtures through the schedule large stages run (one role per launch, GRU convolutions in the F(2x2, 3x3)
+    form): the small shapes of the fixtures would otherwise only meet the pipelined schedules."""
+    monkeypatch.setenv("ADAMVS_RECUR_MODE", "0")
+    monkeypatch.setenv("ADAMVS_GRU_WINO", "15")
+    for cfg in ("tiny", "cfg1"):
+        g = load_golden("e2e_" + cfg)
+        m, _ = _model(cfg)
+        imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0)
+        with torch.no_grad():
+            out = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+        _check_against_golden(cfg, g, out, E2E_TOL)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.adamvs_version() == _lib.ABI_VERSION
-    assert ctypes.sizeof(_lib.FuseWeights) == 13 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.FuseWeights) == 17 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_lib.StageDesc) == 14 * ctypes.sizeof(ctypes.c_int) + ctypes.sizeof(ctypes.c_float)      # 14 ints + half_span
 
 
