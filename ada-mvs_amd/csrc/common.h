@@ -37,6 +37,13 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// The same with the argument of v_exp_f32 (2^x) prepared by the producer: xs = -x log2(e) for the sigmoid, 2 x log2(e) for tanh
+// (the host folds the factor into the weights and the bias of the convolution whose output this is: one multiply per value less),
+// and the GRU blend u h + (1 - u) c as c + u (h - c).  Used by the kernels whose weights are packed that way (packing.py).
+__device__ __forceinline__ float sigmoid_pre(float xs) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
+__device__ __forceinline__ float tanh_pre(float xs) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f); }
+__device__ __forceinline__ f32x4 gru_blend(f32x4 u, f32x4 h, f32x4 c) { return c + u * (h - c); }
+
 // s_waitcnt vmcnt(0) as a real instruction (not inline asm), so the compiler's own wait insertion knows that no
 // vector-memory result is pending after it.  gfx9 encoding: vmcnt [3:0]+[15:14], expcnt [6:4], lgkmcnt [11:8].
 __device__ __forceinline__ void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }

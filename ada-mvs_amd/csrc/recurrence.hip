@@ -283,9 +283,9 @@ int recurrence_mode(int precision, long pixels) {
   // the fused tiles execute 36 % more MFMAs and the stage is not latency- but throughput-bound as soon as every CU has a few tiles.
   // Schedule 6 (level 1 fused on 8 x 30 tiles, a launch per role) loses at every size: cfg3 at 32 tiles 23.4 / 26.5 / 13.2 ms
   // per stage -> 25.4 / 27.8 / 13.4; cfg2 at 128 tiles 79.6 -> 86.5.  Kept behind ADAMVS_RECUR_MODE=6 as the measurement.
-  // One role per launch (0) from 550k pixels up since its gate convolutions run in the F(2x2, 3x3) form (slice_roles_wino.h;
-  // until then 800k): cfg3 at 32 tiles, stage 1 (590k) 23.3 ms with three launches per hypothesis, 22.7 with six.
-  return pixels <= 100000 ? 5 : (pixels <= 200000 ? 3 : (pixels <= 550000 ? 1 : 0));
+  // With the gate convolutions in the F(2x2, 3x3) form (slice_roles_wino.h) in both: cfg3 at 32 tiles, stage 1 (590k pixels)
+  // 22.2 ms with three launches per hypothesis, 22.7 with six (direct kernels: 23.3 / 23.9); at 2.36M 27.3 against 22.4.
+  return pixels <= 100000 ? 5 : (pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0));
 }
 
 template <class R> static RoleUse<R> use(const typename R::Args* a, float cost, float f0 = 0.f, float f1 = 1.f) {

@@ -27,9 +27,7 @@ __device__ __forceinline__ void split_store(__bf16* hi, __bf16* lo, f32x4 v) {
 // accumulator itself -- sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1) -- and the blend
 // u h + (1 - u) c runs as c + u (h - c): one multiply per transcendental and one instruction per blend fewer, of a kernel
 // that spends its time on the vector units (3.4 vector instructions per MFMA before, profiles/r04_asm_mix_gru1_bx3.txt).
-__device__ __forceinline__ float sigmoid_pre(float xs) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
-__device__ __forceinline__ float tanh_pre(float xs) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f); }
-__device__ __forceinline__ f32x4 gru_blend(f32x4 u, f32x4 h, f32x4 c) { return c + u * (h - c); }
+// (sigmoid_pre, tanh_pre, gru_blend: common.h)
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2b __attribute__((ext_vector_type(2)));

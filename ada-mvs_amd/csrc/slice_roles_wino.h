@@ -52,9 +52,12 @@ struct ConvWinoRole {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) uf[nt][j][kc] = a.wpk[((((nt * 4 + wave) * 4 + j) * KC) + kc) * 64 + lane];
+  // The transformed filters carry the factor that makes the accumulator v_exp_f32's argument (-log2 e for the gates, 2 log2 e for the
+  // candidate: packing.pack_small_conv_wino); the bias, shared with the direct kernels, is scaled here, once per launch.
+  constexpr float PRE = EPI == EPI_GATES ? -1.4426950408889634f : 2.8853900817779268f;
   f32x4 bias[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bias[nt] = *(const f32x4*)(a.bias + nt * 16 + 4 * q);
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = *(const f32x4*)(a.bias + nt * 16 + 4 * q) * PRE;
 
   // ---- window fill: as ConvSmallRole (two sources, planar groups)
   unsigned goff[NL], lbyte[NL];
@@ -197,7 +200,7 @@ struct ConvWinoRole {
         const f32x4 v = (z0 + os * (z1 + z2)) + bias[nt];
         const int co4 = nt * 16 + 4 * q;
         if (EPI == EPI_GATES) {
-          const f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+          const f32x4 sg = {sigmoid_pre(v.x), sigmoid_pre(v.y), sigmoid_pre(v.z), sigmoid_pre(v.w)};
           if (co4 < HC) {                                              // reset-gate rows -> r * h (module.py:35-41)
             const float* hl = (const float*)((const char*)lds + hbyte + 2 * tr4 * LC * 4);
             const f32x4 hc = {hl[0], hl[PLANE], hl[2 * PLANE], hl[3 * PLANE]};
@@ -206,9 +209,9 @@ struct ConvWinoRole {
             buf_store4(r1, oo == BUF_OOB ? BUF_OOB : oo + (unsigned)((co4 - HC - 4 * q) * 4), sg);
           }
         } else if (co4 < HC) {                                         // EPI_CAND (module.py:44-50)
-          const f32x4 cnd = {tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w)};
+          const f32x4 cnd = {tanh_pre(v.x), tanh_pre(v.y), tanh_pre(v.z), tanh_pre(v.w)};
           const f32x4 u4 = pre_u[EPI == EPI_CAND ? tr4 : 0][nt], h4 = pre_h[EPI == EPI_CAND ? tr4 : 0][nt];
-          buf_store4(r0, oo == BUF_OOB ? BUF_OOB : oo + nt * 64, u4 * h4 + (1.0f - u4) * cnd);
+          buf_store4(r0, oo == BUF_OOB ? BUF_OOB : oo + nt * 64, gru_blend(u4, h4, cnd));
         }
       }
     }

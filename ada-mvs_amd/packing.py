@@ -214,10 +214,11 @@ FUSE_FIELDS = ("conv1", "gates1", "gates1_b", "cand1", "cand1_b", "conv2", "gate
                "cand2", "cand2_b", "upconv1", "upconv1_b", "final_w", "gates1_w", "gates2_w", "cand2_w", "cand1_w")
 
 
-def pack_small_conv_wino(w):
-    """[cout][cin][3][3] -> the transformed filters U = G w G^T (double precision, rounded once) of the F(2x2, 3x3) form as A
-    fragments [NT][4 = patch row i][4 = patch column j][cin/4][64], cout zero-padded to 16*NT (csrc/slice_roles_wino.h)."""
-    w = w.detach().to(torch.float64).cpu()
+def pack_small_conv_wino(w, scale=1.0):
+    """[cout][cin][3][3] -> the transformed filters U = G (scale w) G^T (double precision, rounded once) of the F(2x2, 3x3) form
+    as A fragments [NT][4 = patch row i][4 = patch column j][cin/4][64], cout zero-padded to 16*NT (csrc/slice_roles_wino.h).
+    scale: -log2(e) for the gate convolutions, 2 log2(e) for the candidates -- the kernels feed the result to v_exp_f32."""
+    w = w.detach().to(torch.float64).cpu() * scale
     cout, cin = w.shape[0], w.shape[1]
     assert cin % 4 == 0
     nt = (cout + 15) // 16
@@ -264,10 +265,10 @@ def pack_slice_reg_net(sd, pre, precision="fp32"):
                                        sd[pre + "upconv2d.bias"].detach().float().cpu().reshape(-1)]), 76),
     }
     if precision == "fp32":
-        parts["gates1_w"] = pack_small_conv_wino(sd[pre + "conv_gru1.conv_gates.0.weight"])
-        parts["gates2_w"] = pack_small_conv_wino(sd[pre + "conv_gru2.conv_gates.0.weight"])
-        parts["cand2_w"] = pack_small_conv_wino(sd[pre + "conv_gru2.convc.0.weight"])
-        parts["cand1_w"] = pack_small_conv_wino(sd[pre + "conv_gru1.convc.0.weight"])
+        parts["gates1_w"] = pack_small_conv_wino(sd[pre + "conv_gru1.conv_gates.0.weight"], -LOG2E)
+        parts["gates2_w"] = pack_small_conv_wino(sd[pre + "conv_gru2.conv_gates.0.weight"], -LOG2E)
+        parts["cand2_w"] = pack_small_conv_wino(sd[pre + "conv_gru2.convc.0.weight"], 2.0 * LOG2E)
+        parts["cand1_w"] = pack_small_conv_wino(sd[pre + "conv_gru1.convc.0.weight"], 2.0 * LOG2E)
     offsets, chunks, o = {}, [], 0
     for f in FUSE_FIELDS:
         if f not in parts:               # the F(2x2, 3x3) blocks exist in fp32 only: the field stays NULL
