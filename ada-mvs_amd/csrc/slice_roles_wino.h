@@ -19,6 +19,12 @@
 #pragma once
 #include "slice_roles.h"
 
+// Timing builds only (tools/build_variant.py <name> -DWINO_GRU_EXP=<bits>; results are wrong): 1 no barrier per exchange round,
+// 2 no transcendentals in the epilogue, 4 no input transform, 8 no exchange at all (every wave combines its own Z).
+#ifndef WINO_GRU_EXP
+#define WINO_GRU_EXP 0
+#endif
+
 namespace adamvs {
 
 typedef float f32x2w __attribute__((ext_vector_type(2)));
@@ -76,6 +82,7 @@ struct ConvWinoRole {
   const int rowA = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
   const int rowB = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
   const float sgn = wave == 1 ? 1.0f : -1.0f;
+  const f32x2w sgn2 = {sgn, sgn};
   unsigned pa = (unsigned)((q * PLANE + rowA * LC + 2 * p) * 4), pb = (unsigned)((q * PLANE + rowB * LC + 2 * p) * 4);
   pin(pa); pin(pb);
   // epilogue: wave (oa, ob) owns output pixel (2 t + oa, 2 p + ob) of every 2x2 tile of tile row t
@@ -170,8 +177,12 @@ struct ConvWinoRole {
         const int off = (kc * GP + 2 * tr4 * LC) * 4;
         const f32x2w a01 = *(const f32x2w*)((const char*)lds + pa + off), a23 = *(const f32x2w*)((const char*)lds + pa + off + 8);
         const f32x2w b01 = *(const f32x2w*)((const char*)lds + pb + off), b23 = *(const f32x2w*)((const char*)lds + pb + off + 8);
-        const float t0 = fmaf(sgn, b01.x, a01.x), t1 = fmaf(sgn, b01.y, a01.y), t2 = fmaf(sgn, b23.x, a23.x), t3 = fmaf(sgn, b23.y, a23.y);
-        const float v0 = t0 - t2, v1 = t1 + t2, v2 = t2 - t1, v3 = t1 - t3;
+        // T = A + sgn B as two packed FMAs on the pairs the LDS reads deliver; (v0, v3) = T01 - T23 as one packed subtraction
+        // (written on the vector types: as scalars the compiler packs half of them and pays for it in register moves)
+        const f32x2w t01 = __builtin_elementwise_fma(sgn2, b01, a01), t23 = __builtin_elementwise_fma(sgn2, b23, a23);
+        const f32x2w v03 = t01 - t23;
+        float v0 = v03.x, v3 = v03.y, v1 = t01.y + t23.x, v2 = t23.x - t01.y;
+        if (WINO_GRU_EXP & 4) { v0 = a01.x; v1 = a01.y; v2 = b23.x; v3 = b23.y; }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           m[nt][0] = mfma16(uf[nt][0][kc], v0, m[nt][0]);
@@ -188,19 +199,21 @@ struct ConvWinoRole {
       f32x4* zb = (f32x4*)(zl + (tr4 & 1) * ZBUF);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        if (WINO_GRU_EXP & 8) break;
         zb[((wave * 2 + 0) * NT + nt) * 64 + lane] = (m[nt][0] + m[nt][1]) + m[nt][2];
         zb[((wave * 2 + 1) * NT + nt) * 64 + lane] = (m[nt][1] - m[nt][2]) - m[nt][3];
       }
-      __syncthreads();                                                 // one barrier per round: the buffers alternate
+      if (!(WINO_GRU_EXP & (1 | 8))) __syncthreads();                  // one barrier per round: the buffers alternate
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 z0 = zb[(((oa + 0) * 2 + ob) * NT + nt) * 64 + lane];
-        const f32x4 z1 = zb[(((oa + 1) * 2 + ob) * NT + nt) * 64 + lane];
-        const f32x4 z2 = zb[(((oa + 2) * 2 + ob) * NT + nt) * 64 + lane];
+        f32x4 z0 = zb[(((oa + 0) * 2 + ob) * NT + nt) * 64 + lane];
+        f32x4 z1 = zb[(((oa + 1) * 2 + ob) * NT + nt) * 64 + lane];
+        f32x4 z2 = zb[(((oa + 2) * 2 + ob) * NT + nt) * 64 + lane];
+        if (WINO_GRU_EXP & 8) { z0 = (m[nt][0] + m[nt][1]) + m[nt][2]; z1 = z0; z2 = (m[nt][1] - m[nt][2]) - m[nt][3]; }
         const f32x4 v = (z0 + os * (z1 + z2)) + bias[nt];
         const int co4 = nt * 16 + 4 * q;
         if (EPI == EPI_GATES) {
-          const f32x4 sg = {sigmoid_pre(v.x), sigmoid_pre(v.y), sigmoid_pre(v.z), sigmoid_pre(v.w)};
+          const f32x4 sg = (WINO_GRU_EXP & 2) ? v : f32x4{sigmoid_pre(v.x), sigmoid_pre(v.y), sigmoid_pre(v.z), sigmoid_pre(v.w)};
           if (co4 < HC) {                                              // reset-gate rows -> r * h (module.py:35-41)
             const float* hl = (const float*)((const char*)lds + hbyte + 2 * tr4 * LC * 4);
             const f32x4 hc = {hl[0], hl[PLANE], hl[2 * PLANE], hl[3 * PLANE]};
