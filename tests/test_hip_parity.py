@@ -1155,3 +1155,33 @@ def test_drop_in_forward_with_one_role_per_launch(hip, monkeypatch):
         with torch.no_grad():
             out = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
         _check_against_golden(cfg, g, out, E2E_TOL)
+
+
+@pytest.mark.parametrize("recur", ["0", "1"])
+@pytest.mark.parametrize("stage,h,w", [(1, 22, 38), (2, 26, 50), (0, 8, 40), (1, 4, 6), (2, 70, 34)])
+def test_minimal_filtering_roles_on_ragged_stage_sizes(hip, O, monkeypatch, recur, stage, h, w):
+    """The F(2x2, 3x3) roles (8 x 32 tiles of 2 x 2 output tiles) on maps no tile divides -- level-2 maps of 11 x 19, 13 x 25, 2 x 3,
+    35 x 17 pixels: odd sizes cut through the 2 x 2 tiles --, as their own launches and sharing launches, against the CPU oracle."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    B, V, D = 2, 3, 34
+    m = Infer_AdaMVSNet(48, [48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    net = m.DepthNet[stage]
+    C = (32, 16, 8)[stage]
+    feats = [synth.smooth_features(B, C, h, w, seed=60 + v) for v in range(V)]
+    proj = synth.rig_projections(V, 4 * h, 4 * w, batch=B)["stage1"]
+    g = torch.Generator().manual_seed(9)
+    near = 420.0 + 20.0 * torch.rand(B, 1, h, w, generator=g)
+    D_ = 48 if stage == 0 else D
+    planes = (near + 4.0 * torch.arange(D_, dtype=torch.float32).view(1, D_, 1, 1)).contiguous()
+    prev = None if stage == 0 else [torch.rand(B, 1, h // 2, w // 2, generator=g) for _ in range(V - 1)]
+    monkeypatch.setenv("ADAMVS_RECUR_MODE", recur)
+    monkeypatch.setenv("ADAMVS_GRU_WINO", "7")
+    with torch.no_grad():
+        got = net([dev(f) for f in feats], dev(proj), dev(planes), D_, None if prev is None else [dev(c) for c in prev])
+        ref = O.infer_depth_stage(feats, proj, planes, sd, "DepthNet.%d." % stage, net.in_up, prev)
+    for key in ("depth", "photometric_confidence"):
+        assert got[key].shape == ref[key].shape
+        assert rel_l1(got[key], ref[key]) < E2E_TOL, (key, stage, h, w, recur)
