@@ -55,6 +55,11 @@ struct SlotArgs {
 template <class R> struct min_blocks { static constexpr int value = 1; };
 template <> struct min_blocks<Gru1FusedBx3Role> { static constexpr int value = 2; };
 template <> struct min_blocks<Gru2FusedBx3Role> { static constexpr int value = 2; };
+// the same for the fp32 roles that sit at the edge of two workgroups per CU: a launch that contains them is held to 256 registers
+// (accumulator registers included: the decoder's five accumulators pushed the one-launch schedule to 260 and one workgroup per CU,
+// stage 1 of cfg4's share 4.8 -> 6.4 ms, before this bound)
+template <> struct min_blocks<Gru2FusedRole<4>> { static constexpr int value = 2; };
+template <> struct min_blocks<ConvWinoRole<16, 16, 2, EPI_GATES>> { static constexpr int value = 2; };
 // (Gru1FusedRole<8, 2> held to three workgroups per CU -- 168 registers, 18 of its 194 spilled -- is slower than at two:
 //  stage 2 of cfg3 at 32 tiles 28.3 against 27.8 ms, the separate kernels 26.5)
 constexpr int imax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -246,7 +251,7 @@ static const FusedCosts& fused_costs() {
   return c;
 }
 static RoleCosts parse_role_costs() {
-  RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 4.46f, 13.8f, 3.2f, 12.0f, 5.0f, 0.6f, 0.8f, 0.42f};
+  RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 5.0f, 13.8f, 3.2f, 12.0f, 5.0f, 0.6f, 0.8f, 0.42f};       // (dec: 8 x 30 tiles since round 4)
   if (const char* e = getenv("ADAMVS_RECUR_COSTS")) {
     float v[13];
     bool ok = sscanf(e, "%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9, v + 10,
@@ -346,8 +351,8 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
           dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st, "recurrence, one launch (bf16x3)");
     }
     Gru2Args g2{C2(s2), H2(s2 - 1), H2(s2), (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2};
-    // per level-1 tile (8 x 30 pixels): 0.94 conv2 tiles (4 x 16 at half resolution), 0.54 gru2 tiles (8 x 14), 1.33 decoder tiles (6 x 30)
-    float f = 0.5f + ((0.54f * k.g2bx + 1.33f * k.dec) - 0.94f * k.v2bx) / (2.f * k.k1bx);
+    // per level-1 tile (8 x 30 pixels): 0.94 conv2 tiles (4 x 16 at half resolution), 0.54 gru2 tiles (8 x 14), 1 decoder tile (8 x 30)
+    float f = 0.5f + ((0.54f * k.g2bx + 1.0f * k.dec) - 0.94f * k.v2bx) / (2.f * k.k1bx);
     f = !l2 ? 1.0f : (f < 0.1f ? 0.1f : (f > 1.f ? 1.f : f));
     if (l1 || l2)
       if ((rc = launch_slot<Gru1Bx, Conv2Bx, NopRole>(l1 ? use<Gru1Bx>(&g1, k.k1bx, 0.f, f) : none<Gru1Bx>(),

@@ -533,7 +533,7 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   if (h2_now) *h2_now = h2s;
   DecoderArgs da{h2s, h1, fw.upconv1, fw.upconv1_b, fw.final_w, vol, h, w, D, d};
   TileGrid tg;
-  if ((rc = make_tile_grid(tg, cdiv(w, 30), cdiv(h, 6), B))) return rc;
+  if ((rc = make_tile_grid(tg, cdiv(w, DecoderRole<true>::TCI), cdiv(h, DecoderRole<true>::TRI), B))) return rc;
   constexpr size_t dlds = DecoderRole<true>::LDS_BYTES;
   if (in_up) {
     static const int cap_up = resident_blocks(k_decoder<true>, 256, dlds);      // once, thread-safely (magic static)

@@ -600,20 +600,24 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Persistent, software-pipelined like k_conv_small (same reasoning: uniform descriptors + pinned lane offsets,
-// no bounds checks on interior tiles, one wait per tile).  A tile is 6 x 30 pixels of s (full resolution h x w);
-// its s region is 8 x 32 (one pixel of halo each side), fed by a 5 x 17 region of h2.
-//   phase 1  upconv1 on the matrix cores: 16 runs = 4 parity classes x 4 rows; wave k takes row k of every
-//            class (equal MFMA counts).  + bias + h1 (requested during the previous tile) -> ReLU -> s in LDS.
+// no bounds checks on interior tiles, one wait per tile).  A tile is 8 x 30 pixels of s (full resolution h x w; round 4: 6 x 30
+// until then -- phase 2, the larger half of the kernel's vector work, ran 180 of 256 lanes, now 240);
+// its s region is 10 x 32 (one pixel of halo each side), fed by a 6 x 17 region of h2.
+//   phase 1  upconv1 on the matrix cores: 20 runs = 4 parity classes x 5 rows; wave k takes row k of every
+//            class and class k of the fifth row (equal MFMA counts: 9 taps in all for the four classes of its row, and one class of
+//            the last row -- 1, 2, 2 or 4 taps).  + bias + h1 (requested during the previous tile) -> ReLU -> s in LDS.
 //   phase 2  last layer on the vector units.  Transposed (IN_UP): one thread per s pixel produces its 2 x 2
 //            output quad from s[i..i+1][j..j+1] (72 FMAs, weights as scalar operands), two 8-byte stores.
 //            Flat: one thread per pixel, 3 x 3 x 8 FMAs.
 template <bool IN_UP>
 struct DecoderRole {
   typedef DecoderArgs Args;
-  static constexpr int TRI = 6, TCI = 30;                                   // inner tile of s
-  static constexpr int SR = 8, SC = 32, SPX = 12; // s region, channel-last, 8 channels + 4 floats of padding per
+  static constexpr int TRI = 8, TCI = 30;                                   // inner tile of s
+  static constexpr int SR = TRI + 2, SC = 32, SPX = 12; // s region, channel-last, 8 channels + 4 floats of padding per
                                                   // pixel: 16-byte lane accesses at a 48-byte stride are conflict-free
-  static constexpr int HR = 5, HCOLS = 17, HPLANE = plane_pitch16(HR * HCOLS);     // h2 region, 16 planes in 4 groups
+  static constexpr int HR = TRI / 2 + 2, HCOLS = 17, HPLANE = plane_pitch16(HR * HCOLS);     // h2 region, 16 planes in 4 groups
+  static constexpr int NRUN = 5;                                            // runs per wave: (class j, row wave) j = 0..3; (class wave, row 4)
+  static_assert(TRI == 8 && TRI * TCI <= 256, "five s-row pairs, one thread per inner pixel in phase 2");
   static constexpr int HGP = group_pitch(HPLANE, 4);
   static constexpr int NH = (HR * HCOLS * 4 + 255) / 256;                   // h2 load instructions per tile
   static constexpr size_t LDS_BYTES = (size_t)(4 * HGP + SR * SC * SPX) * sizeof(float);
@@ -643,12 +647,12 @@ struct DecoderRole {
     h2rc[k] = r | (c << 16);
     pin(h2off[k]); pin(h2lds[k]); pin(h2rc[k]);
   }
-  // run j of this wave = parity class j (py = j >> 1, px = j & 1), row k = wave of that class
-  unsigned xbyte[4], h1off[4], sbyte[4];
-  int src[4];          // s-region row | column << 16 of the lane's pixel
+  // run j < 4 of this wave = parity class j (py = j >> 1, px = j & 1), row k = wave of that class; run 4 = class `wave`, row 4
+  unsigned xbyte[NRUN], h1off[NRUN], sbyte[NRUN];
+  int src[NRUN];       // s-region row | column << 16 of the lane's pixel
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int py = j >> 1, px = j & 1, k = wave;
+  for (int j = 0; j < NRUN; ++j) {
+    const int cls = j < 4 ? j : wave, py = cls >> 1, px = cls & 1, k = j < 4 ? wave : 4;
     const int r = py ? 2 * k : 2 * k + 1, c = px ? 2 * p : 2 * p + 1;
     const int li = py ? k : k + 1, lj = px ? p : p + 1;
     xbyte[j] = (unsigned)((q * HPLANE + li * HCOLS + lj) * 4);
@@ -682,17 +686,18 @@ struct DecoderRole {
   };
   // skip operand h1 of the lane's four pixels; returns which of them lie inside the image (bit j; 15 for every
   // lane of an interior tile, which the caller tests with a uniform branch)
-  auto load_h1 = [&](f32x4 (&hreg)[4], int b, int tx, int ty) -> unsigned {
+  constexpr unsigned ALL_IN = (1u << NRUN) - 1u;
+  auto load_h1 = [&](f32x4 (&hreg)[NRUN], int b, int tx, int ty) -> unsigned {
     const int ys0 = ty * TRI - 1, xs0 = tx * TCI - 1;
     const buf_rsrc r1 = make_rsrc((const char*)a.h1 + (((long)b * h + ys0) * w + xs0) * 32);
     if (ys0 >= 0 && xs0 >= 0 && ys0 + SR <= h && xs0 + SC <= w) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) hreg[j] = buf_load4(r1, h1off[j]);
-      return 15u;
+      for (int j = 0; j < NRUN; ++j) hreg[j] = buf_load4(r1, h1off[j]);
+      return ALL_IN;
     }
     unsigned in = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NRUN; ++j) {
       const int ys = ys0 + (src[j] & 0xffff), xs = xs0 + (src[j] >> 16);
       const bool ok = (unsigned)ys < (unsigned)h && (unsigned)xs < (unsigned)w;
       hreg[j] = buf_load4(r1, ok ? h1off[j] : BUF_OOB);
@@ -713,7 +718,7 @@ struct DecoderRole {
   if (t >= tr.end) return;
   int b, tx, ty;
   tile_coords(tg, t, b, tx, ty);
-  f32x4 stage[NH], hreg[4];
+  f32x4 stage[NH], hreg[NRUN];
   load_h2(stage, b, tx, ty);
   unsigned inside = load_h1(hreg, b, tx, ty);
   wait_vmem_all();
@@ -729,30 +734,36 @@ struct DecoderRole {
     }
 
     // ---- phase 1
-    f32x4 sv[4];
+    f32x4 sv[NRUN];
     sv[0] = upconv1_class<0, 0, HGP, HCOLS>(wf, lh2, xbyte[0]);
     sv[1] = upconv1_class<0, 1, HGP, HCOLS>(wf, lh2, xbyte[1]);
     sv[2] = upconv1_class<1, 0, HGP, HCOLS>(wf, lh2, xbyte[2]);
     sv[3] = upconv1_class<1, 1, HGP, HCOLS>(wf, lh2, xbyte[3]);
+    switch (wave) {                                                       // uniform: the wave's class of the fifth row
+      case 0: sv[4] = upconv1_class<0, 0, HGP, HCOLS>(wf, lh2, xbyte[4]); break;
+      case 1: sv[4] = upconv1_class<0, 1, HGP, HCOLS>(wf, lh2, xbyte[4]); break;
+      case 2: sv[4] = upconv1_class<1, 0, HGP, HCOLS>(wf, lh2, xbyte[4]); break;
+      default: sv[4] = upconv1_class<1, 1, HGP, HCOLS>(wf, lh2, xbyte[4]); break;
+    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) drain(sv[j]);
-    const bool all_in = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(inside != 15u) == 0) != 0;
+    for (int j = 0; j < NRUN; ++j) drain(sv[j]);
+    const bool all_in = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(inside != ALL_IN) == 0) != 0;
     if (q < 2) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NRUN; ++j) {
         f32x4 v = sv[j] + bup + hreg[j];                                  // adamvs.py:420-421
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         sv[j] = v;
       }
       if (!all_in) {                                                      // s is zero outside the image
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NRUN; ++j)
           if (!((inside >> j) & 1u)) sv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x4*)((char*)ls + sbyte[j]) = sv[j];
+      for (int j = 0; j < NRUN; ++j) *(f32x4*)((char*)ls + sbyte[j]) = sv[j];
     }
-    unsigned inside_n = 15u;
+    unsigned inside_n = ALL_IN;
     if (more) inside_n = load_h1(hreg, bn, txn, tyn);                     // hreg is free again
     __syncthreads();                                                      // s complete
 
