@@ -64,8 +64,14 @@ struct WinoGeom {
 // tile = ((image * tiles_y + ty) * tiles_x + tx) * groups + channel group.  The first window chunk and the first three
 // fragment sets of the NEXT tile are requested before the epilogue of the current one, so what a tile start exposes is
 // one LDS fill and one barrier instead of a round trip to memory behind the per-lane address arithmetic.
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int groups, unsigned mgroups) {
+// WPS = waves per SIMD the kernel is built for.  1: the whole register file (192 accumulator registers, four fragment sets three
+// k-steps ahead).  2: two workgroups per CU, each wave at most 256 registers -- NT 2 tile rows (128 accumulator registers), two
+// fragment sets one k-step ahead.  The second wave was built to fill the matrix-pipe cycles a lone wave loses to its other
+// instructions (27 % of them); it fills almost none -- 74.3 against 73.6 % of the matrix rate at 512 maps: what the loads,
+// LDS stores and transforms cost the matrix pipe is not issue slots but the register file they share with it -- and earns its
+// keep on small launches (16 maps: 0.79 against 0.93 ms, twice the workgroups).
+template <int MT, int NT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg, int groups, unsigned mgroups) {
   using G = WinoGeom<MT, NT>;
   constexpr int KC = G::KC, KS = G::KS, LC = G::LC, NPIX = G::NPIX, PLANE = G::PLANE, GP = G::GP, CHUNK = G::CHUNK;
   constexpr int NITEMS = NPIX * (KC / 4), NITA = (NITEMS + 255) / 256;
@@ -75,17 +81,15 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
   const int D = a.D, NTILES = D / 16, NC = D / KC;
 
   // ---- per-lane constants (tile-independent)
-  // window fill: item = (pixel of the window, group of 4 channels of the chunk)
-  unsigned goff[NITA], xlds[NITA], wrc[NITA];                // wrc = window row | window column << 16
-#pragma unroll
-  for (int it = 0; it < NITA; ++it) {
-    const int i = min(tid + it * 256, NITEMS - 1);           // surplus lanes repeat the last item
-    const int g = i % (KC / 4), pp = i / (KC / 4), r = pp / LC, c = pp % LC;
-    goff[it] = (unsigned)(((r * a.w + c) * D + 4 * g) * 4);
-    xlds[it] = (unsigned)((g * GP + pp) * 4);
-    wrc[it] = (unsigned)(r | (c << 16));
-    pin(goff[it]); pin(xlds[it]); pin(wrc[it]);
-  }
+  // window fill: item = (pixel of the window, group of 4 channels of the chunk); lane tid holds the items tid + 256 it: one channel
+  // group for all of them, pixels pp0 + 64 it -- LDS addresses one pinned base + immediates, global offsets formed per tile
+  // (window_of) from (row, column) = pp / LC, pp % LC.  The last round's surplus lanes repeat the last item.
+  constexpr int LAST = NITEMS - 1 - 256 * (NITA - 1);        // last item of the last round
+  const int fg = tid & 3, pp0 = tid >> 2;
+  const int ppl = tid <= LAST ? pp0 + 64 * (NITA - 1) : NPIX - 1;
+  unsigned xlds0 = (unsigned)((fg * GP + pp0) * 4), xldsl = (unsigned)(((tid <= LAST ? fg : KC / 4 - 1) * GP + ppl) * 4);
+  const unsigned gch = (unsigned)((tid <= LAST ? fg : KC / 4 - 1) * 16);   // the last round's channel-group byte offset
+  pin(xlds0); pin(xldsl);
   // raw patch rows of the wave: T = rowA + sgn * rowB  (i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3)
   const int rowA = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
   const int rowB = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
@@ -118,8 +122,9 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
     rx = make_rsrc((const char*)a.in + (((long)t.n * a.h + (t.r0 - 1)) * a.w + (t.c0 - 1)) * (long)D * 4);
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
-      const bool ok = (unsigned)(t.r0 - 1 + (int)(wrc[it] & 0xffff)) < (unsigned)a.h && (unsigned)(t.c0 - 1 + (int)(wrc[it] >> 16)) < (unsigned)a.w;
-      xoff[it] = ok ? goff[it] : BUF_OOB;
+      const int pp = it + 1 < NITA ? pp0 + 64 * it : ppl, r = pp / LC, c = pp - r * LC;
+      const bool ok = (unsigned)(t.r0 - 1 + r) < (unsigned)a.h && (unsigned)(t.c0 - 1 + c) < (unsigned)a.w;
+      xoff[it] = ok ? (unsigned)((r * a.w + c) * D * 4) + (it + 1 < NITA ? (unsigned)(fg * 16) : gch) : BUF_OOB;
     }
   };
 
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
   auto store_items = [&](int buf, int i0, int i1) {          // window items [i0, i1) of the staged chunk -> buffer `buf`
 #pragma unroll
     for (int it = i0; it < i1; ++it) {
-      float* dl = (float*)((char*)lds + xlds[it]) + buf * CHUNK;
+      float* dl = (float*)((char*)lds + (it + 1 < NITA ? xlds0 : xldsl)) + buf * CHUNK + (it + 1 < NITA ? 64 * it : 0);
       dl[0] = xs[it].x; dl[PLANE] = xs[it].y; dl[2 * PLANE] = xs[it].z; dl[3 * PLANE] = xs[it].w;
     }
   };
@@ -208,6 +213,18 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
     // every wave is past chunk c-1 (the barrier that ended it): its buffer takes chunk c+1 during k-step 0
     Raw r;
     read_raw(r, CUR, 0, 0);
+    if constexpr (WPS == 2) {                                // two sets, one k-step ahead
+      kstep(wf0, r, CUR, 0, fill, next_ch, firstc);
+      load_w(wf0, min(c * KS + 2, last_ks));
+      kstep(wf1, r, CUR, 1, false, 0, std::false_type{});
+      load_w(wf1, min(c * KS + 3, last_ks));
+      kstep(wf0, r, CUR, 2, false, 0, std::false_type{});
+      load_w(wf0, min(c * KS + 4, last_ks));
+      kstep(wf1, r, CUR, 3, false, 0, std::false_type{});
+      load_w(wf1, min(c * KS + 5, last_ks));
+      if (!(WINO_EXP & (8 | 32))) __syncthreads();
+      return;
+    }
     load_w(wf3, min(c * KS + 3, last_ks));
     kstep(wf0, r, CUR, 0, fill, next_ch, firstc);
     load_w(wf0, min(c * KS + 4, last_ks));                   // (the next tile's first sets are requested below)
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
   load_x(0);
   load_w(wf0, 0);
   load_w(wf1, min(1, last_ks));
-  load_w(wf2, min(2, last_ks));
+  if (WPS == 1) load_w(wf2, min(2, last_ks));
   wait_vmem_all();
   while (true) {
     const int next = tile + (int)gridDim.x;
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
     if (more) {
       load_w(wf0, 0);
       load_w(wf1, min(1, last_ks));
-      load_w(wf2, min(2, last_ks));
+      if (WPS == 1) load_w(wf2, min(2, last_ks));
     }
     // ---- epilogue of `done`: the four rows meet through LDS, one tile row per round
     if (!((WINO_EXP & 1) && a.relu != 12345)) {
@@ -308,10 +325,10 @@ __global__ __launch_bounds__(256) void k_conv_wino(WinoArgs a, TileGrid tg, int 
   }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int WPS>
 static int launch_wino_cfg(const WinoArgs& a, int N, hipStream_t st) {
   const int groups = a.D / (16 * MT);
-  auto kern = k_conv_wino<MT, NT>;
+  auto kern = k_conv_wino<MT, NT, WPS>;
   static const int capacity = resident_blocks(kern, 256, 0);       // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, groups * cdiv(a.w, 32), cdiv(a.h, 2 * NT), N)) return rc;
@@ -329,7 +346,13 @@ int launch_conv_wino(const float* in, const float* wpk, const float* bias, const
   ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino: D=%d unsupported (a multiple of 64 up to 384)", D);
   // 32-bit byte offsets inside one image through a buffer descriptor (advisor, round 3): larger maps would read zeros
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
-  return launch_wino_cfg<4, 3>(a, N, st);
+  // Two workgroups per CU (4 x 32-pixel tiles) except on the smallest maps of the hourglass, where the 6 x 32 tiles of the
+  // one-workgroup form cover a 12-row map without a ragged tile row: 512 maps of 96x192 / 48x96 / 24x48 / 12x24 pixels at D = 192
+  // take 23.8 / 5.91 / 1.92 / 0.58 ms against 24.1 / 6.01 / 1.99 / 0.51, 16 maps of 96x192 (cfg4's share of four tiles) 0.79 against
+  // 0.93 (tools/wino_bench.py).  ADAMVS_WINO_WPS=1 / 2 forces one form (A/B); both give the same bits.
+  static const int forced = [] { const char* e = getenv("ADAMVS_WINO_WPS"); return e ? atoi(e) : 0; }();
+  const bool two = forced ? forced == 2 : h * w >= 1024;
+  return two ? launch_wino_cfg<4, 2, 2>(a, N, st) : launch_wino_cfg<4, 3, 1>(a, N, st);
 }
 
 }  // namespace adamvs

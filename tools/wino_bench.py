@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One stride-1 CostRegNet2D layer on the direct kernel and in the F(2x2, 3x3) form (GPU box): error of both against a float64
+"""One stride-1 CostRegNet2D layer on the direct kernel and in the F(2x2, 3x3) and F(2x4, 3x3) forms (GPU box): error of both against a float64
 convolution on small maps, then the time of the five layer shapes of cfg2 at 128 tiles (N = 512 maps, D = 192).
 
     python tools/wino_bench.py                      -> profiles/r03_wino_layer_bench.txt is the output of this command
@@ -31,10 +31,11 @@ def accuracy(N, D, h, w, relu=1, skip=False):
     pk = packing.pack_reg_layer(wt, scale, b, False).to(dev)
     yd = hip_ops.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], sk, N, D, h, w, 0, relu)
     yw = hip_ops.conv3x3_dd_wino(x_cl, packing.pack_reg_layer_wino(wt, scale).to(dev), b.to(dev), sk, N, D, h, w, relu)
+    y4 = hip_ops.conv3x3_dd_wino24(x_cl, packing.pack_reg_layer_wino24(wt, scale).to(dev), b.to(dev), sk, N, D, h, w, relu)
     torch.cuda.synchronize()
     back = lambda y: y.cpu().double().reshape(N, h, w, D).permute(0, 3, 1, 2)
     rel = lambda y: (back(y) - ref).abs().mean().item() / ref.abs().mean().item()
-    print("N=%d D=%d %dx%d relu=%d skip=%d   relative L1 against float64: direct %.2e  F(2x2,3x3) %.2e" % (N, D, h, w, relu, skip, rel(yd), rel(yw)),
+    print("N=%d D=%d %dx%d relu=%d skip=%d   relative L1 against float64: direct %.2e  F(2x2,3x3) %.2e  F(2x4,3x3) %.2e" % (N, D, h, w, relu, skip, rel(yd), rel(yw), rel(y4)),
           flush=True)
 
 
@@ -44,10 +45,12 @@ def timing(N, D, h, w, reps=5):
     b = torch.randn(D) * 0.1
     pk = packing.pack_reg_layer(wt, torch.ones(D), b, False).to(dev)
     pw, bias = packing.pack_reg_layer_wino(wt, torch.ones(D)).to(dev), b.to(dev)
+    pw4 = packing.pack_reg_layer_wino24(wt, torch.ones(D)).to(dev)
     out = torch.empty(N, h * w, D, device=dev)
     flops = 2.0 * 9 * D * D * h * w * N
     for name, fn, executed in (("direct", lambda: hip_ops.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], None, N, D, h, w, 0, 1, out=out), 1.0),
-                               ("F(2x2,3x3)", lambda: hip_ops.conv3x3_dd_wino(x_cl, pw, bias, None, N, D, h, w, 1, out=out), 16.0 / 36.0)):
+                               ("F(2x2,3x3)", lambda: hip_ops.conv3x3_dd_wino(x_cl, pw, bias, None, N, D, h, w, 1, out=out), 16.0 / 36.0),
+                               ("F(2x4,3x3)", lambda: hip_ops.conv3x3_dd_wino24(x_cl, pw4, bias, None, N, D, h, w, 1, out=out), 24.0 / 72.0)):
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,6 +65,13 @@ def timing(N, D, h, w, reps=5):
 
 
 if __name__ == "__main__":
+    if "--one" in sys.argv:                          # one shape, for timing builds
+        timing(128, 192, 96, 192)
+        sys.exit(0)
+    if "--widths" in sys.argv:                       # efficiency against the width (the transformed filters of a layer against the 4 MB L2 of an XCD)
+        for D, N in ((64, 512), (128, 256), (192, 128), (256, 128), (384, 64)):
+            timing(N, D, 96, 192)
+        sys.exit(0)
     if "--time-only" not in sys.argv:
         for case in ((1, 192, 6, 32), (2, 192, 13, 45, 0), (2, 192, 7, 70, 1, True), (1, 64, 8, 40), (1, 128, 13, 33), (1, 256, 6, 32, 0)):
             accuracy(*case)
