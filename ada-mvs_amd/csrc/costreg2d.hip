@@ -19,6 +19,7 @@
 #include "conv_frag.h"
 #include "costreg_softmax.h"
 #include "kernels.h"
+#include "persistent.h"
 
 namespace adamvs {
 
@@ -1023,8 +1024,14 @@ template <int NQ>
 __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict__ score, PlaneSrc planes,
                                                          float* __restrict__ vw, float* __restrict__ pd, int B, int D, int hw,
                                                          size_t npix, int Dp) {
-  size_t gp = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  // persistent: the grid is the resident capacity and a workgroup walks the 16-pixel groups blk, blk + grid, ... -- as one
+  // workgroup per group (590 000 of them at cfg2) the launch ran at the rate workgroups are dispatched, 2.2 TB/s
+  constexpr int DMAX = NQ > 0 ? 64 * NQ : 1;
+  __shared__ float lp[NQ > 0 ? DMAX * 17 : 1];
   const int l = threadIdx.x & 15;
+  const size_t nblk = (npix + 15) / 16;
+  for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  size_t gp = blk * 16 + (threadIdx.x >> 4);
   const bool live = gp < npix;
   size_t pix = live ? gp : npix - 1;
   size_t n = pix / hw, pp = pix % hw;
@@ -1034,9 +1041,7 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
   // The 16 pixels of a block are consecutive; read per lane, a plane value costs a whole 64-byte sector for 16 bytes
   // (lanes of a wave hold 16 different planes of 4 pixels: 4x the plane volume through L2).  When the block lies inside
   // one map the [D][16] patch is staged through LDS with full sectors instead (row pitch 17: 2-way at worst).
-  constexpr int DMAX = NQ > 0 ? 64 * NQ : 1;
-  __shared__ float lp[NQ > 0 ? DMAX * 17 : 1];
-  const size_t gp0 = (size_t)blockIdx.x * 16;
+  const size_t gp0 = blk * 16;
   // (generated planes need no staging: a plane value is one multiply and one add)
   const bool staged = NQ > 0 && planes.mode == PLANES_EXPLICIT && gp0 + 16 <= npix && (gp0 % hw) + 16 <= (size_t)hw;     // uniform
   if (staged) {
@@ -1087,6 +1092,8 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
   if (live && l == 0) {
     vw[pix] = 1.0f / se;          // max_d softmax = exp(max - max) / sum
     pd[pix] = sd / se;
+  }
+  if (staged) __syncthreads();    // (uniform) the patch is refilled by the next group
   }
 }
 
@@ -1183,19 +1190,27 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
   return 0;
 }
 
+template <int NQ>
+static void launch_softmax_nq(const float* score, const PlaneSrc& planes, float* vw, float* pd, int B, int D, int hw, size_t npix, int Dp,
+                              hipStream_t st) {
+  static const int capacity = resident_blocks(k_softmax_regress<NQ>, 256, 0);     // once per instantiation
+  const size_t nblk = (npix + 15) / 16;
+  hipLaunchKernelGGL(k_softmax_regress<NQ>, dim3((unsigned)(nblk < (size_t)capacity ? nblk : (size_t)capacity)), dim3(256), 0, st, score,
+                     planes, vw, pd, B, D, hw, npix, Dp);
+}
+
 int launch_softmax_regress(const float* score, PlaneSrc planes, float* vw, float* pd, int S, int B, int D, int h, int w,
                            hipStream_t st, int n_planes) {
   size_t npix = (size_t)S * B * h * w;
   const int Dp = n_planes > 0 ? n_planes : D;
   ADAMVS_CHECK_ARG(Dp <= D, "softmax_regress: %d planes for %d score channels", Dp, D);
-  const dim3 grid((unsigned)((npix + 15) / 16));
   switch ((D + 63) / 64) {
-    case 1: hipLaunchKernelGGL(k_softmax_regress<1>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
-    case 2: hipLaunchKernelGGL(k_softmax_regress<2>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
-    case 3: hipLaunchKernelGGL(k_softmax_regress<3>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
-    case 4: hipLaunchKernelGGL(k_softmax_regress<4>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
-    case 6: hipLaunchKernelGGL(k_softmax_regress<6>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
-    default: hipLaunchKernelGGL(k_softmax_regress<0>, grid, dim3(256), 0, st, score, planes, vw, pd, B, D, h * w, npix, Dp); break;
+    case 1: launch_softmax_nq<1>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
+    case 2: launch_softmax_nq<2>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
+    case 3: launch_softmax_nq<3>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
+    case 4: launch_softmax_nq<4>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
+    case 6: launch_softmax_nq<6>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
+    default: launch_softmax_nq<0>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
   }
   ADAMVS_CHECK_LAUNCH("softmax_regress");
   return 0;

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=64)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--same", action="store_true", help="both streams run the WHOLE stage of their tile group (small groups: do latency-bound launches of two groups share the chip?)")
     a = ap.parse_args()
     cfg = "cfg2"
     c = synth.CONFIGS[cfg]
@@ -74,6 +75,22 @@ def main():
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t0) / a.iters
 
+        if a.same:
+            ALL = _lib.PHASE_VIEW_WEIGHTS | REST
+
+            def both(two_streams):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.iters):
+                    for g in range(2):
+                        with torch.cuda.stream((s0, s1)[g] if two_streams else s0):
+                            run(g, ALL)
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t0) / a.iters
+            both(False), both(True)
+            t1, t2 = both(False), both(True)
+            print("whole stage 1 of two groups of %d tiles (%s): one stream %.2f ms, two streams %.2f ms (%.2f x)" % (B, a.precision, t1, t2, t2 / t1))
+            return
         ta, tb = timed(True, False), timed(False, True)
         tab = timed(True, True)
         print("pass A alone %.1f ms, pass B alone %.1f ms, sum %.1f ms; both streams %.1f ms (%.2f x the sum) -- %d tiles per group, %s"
