@@ -78,6 +78,8 @@ SIGNATURES = {
     "adamvs_conv3x3_dd_wino24": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_softmax_max_regress": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_prob_softmax_regress": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "adamvs_prob_softmax_regress_wino_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "adamvs_prob_softmax_regress_wino": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_aggregate_conv1_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "adamvs_aggregate_conv1": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_slice_reg_step_scratch_bytes": (c_sz, [c_i, c_i, c_i]),

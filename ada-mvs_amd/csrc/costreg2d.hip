@@ -1172,8 +1172,13 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
       // stride-1 layers in the minimal-filtering form (none of them carries a skip or takes a second input); the scores of the
       // last one go through the score volume to k_softmax_regress: its channel groups are different workgroups
       const float* ww = wpk + (size_t)11 * LW + (size_t)(i == 10 ? 4 : i / 2) * 16 * D * D;
-      rc = launch_conv_wino(plan[i].in, ww, wl + (size_t)9 * D * D, nullptr, plan[i].out, N, D, plan[i].hi, plan[i].wi, plan[i].relu, st);
-      if (!rc && i == 10 && fuse_softmax) rc = launch_softmax_regress(score, *sm_planes, sm_vw, sm_pd, N / sm_B, sm_B, D, h, w, st, n_planes);
+      if (i == 10 && fuse_softmax && wino_softmax_fused() && sm_planes->mode == PLANES_UNIFORM && (n_planes > 0 ? n_planes : D) > 1) {
+        // every lane's softmax partial instead of the scores (D bytes per pixel instead of 4 D), in the score volume's place
+        rc = launch_conv_wino_softmax(plan[i].in, ww, wl + (size_t)9 * D * D, score, *sm_planes, sm_vw, sm_pd, N, sm_B, D, n_planes, h, w, st);
+      } else {
+        rc = launch_conv_wino(plan[i].in, ww, wl + (size_t)9 * D * D, nullptr, plan[i].out, N, D, plan[i].hi, plan[i].wi, plan[i].relu, st);
+        if (!rc && i == 10 && fuse_softmax) rc = launch_softmax_regress(score, *sm_planes, sm_vw, sm_pd, N / sm_B, sm_B, D, h, w, st, n_planes);
+      }
     } else {
       const bool give = defer && i + 1 < 11 && plan[i + 1].mode == CONV_T2;        // layer i + 1 adds this layer's skip to its input
       const bool take = defer && i > 0 && plan[i].mode == CONV_T2 && plan[i - 1].skip;

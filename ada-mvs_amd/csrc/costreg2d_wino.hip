@@ -28,6 +28,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "persistent.h"
+#include "planes.h"
 
 // Timing builds only (tools/build_variant.py <name> -DWINO_EXP=<bits>; results are wrong): 1 no epilogue, 2 no weight loads
 // in the loop, 4 no input transform, 8 no window fill / barrier (32 barrier only, 64 LDS stores only, 128 window loads only), 16 the chunk loop twice.  DESIGN.md section 4 quotes what each part costs.
@@ -44,6 +45,11 @@ struct WinoArgs {
   const float* skip;   // [N][h*w][D] or null; added after the ReLU
   float* out;          // [N][h*w][D]
   int D, h, w, relu;
+  // SM kernels (the `prob` layer under adamvs_depth_stage_forward): no `out`; every lane reduces the 16 scores it holds of a
+  // pixel to (max, sum of exp, sum of exp * plane) and stores that partial, [N][h*w][D/16][4]; k_softmax_merge finishes
+  float* sm_part;
+  PlaneSrc sm_planes;
+  int sm_B, sm_D;      // image n belongs to tile n % sm_B; sm_D hypothesis planes (<= D: pad channels score -1e30)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -70,12 +76,12 @@ struct WinoGeom {
 // instructions (27 % of them); it fills almost none -- 74.3 against 73.6 % of the matrix rate at 512 maps: what the loads,
 // LDS stores and transforms cost the matrix pipe is not issue slots but the register file they share with it -- and earns its
 // keep on small launches (16 maps: 0.79 against 0.93 ms, twice the workgroups).
-template <int MT, int NT, int WPS>
+template <int MT, int NT, int WPS, bool SM>
 __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg, int groups, unsigned mgroups) {
   using G = WinoGeom<MT, NT>;
   constexpr int KC = G::KC, KS = G::KS, LC = G::LC, NPIX = G::NPIX, PLANE = G::PLANE, GP = G::GP, CHUNK = G::CHUNK;
   constexpr int NITEMS = NPIX * (KC / 4), NITA = (NITEMS + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + 384];   // + the layer's bias vector (D <= 384)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = patch row i
   const int p = lane & 15, q = lane >> 4;
   const int D = a.D, NTILES = D / 16, NC = D / KC;
@@ -131,7 +137,11 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
   f32x4 acc[4][MT][NT];
   f32x4 xs[NITA];
   f32x4 wf0[MT], wf1[MT], wf2[MT], wf3[MT];                  // four named fragment sets (below)
-  f32x4 bias4[MT];
+  // The bias rides in the accumulators: At E A is all ones for E = the unit matrix element (1, 1), so position (1, 1) of every tile
+  // starts from the bias instead of zero (wave 1, first k-step) and the epilogue adds nothing.  It comes from LDS (filled once per
+  // workgroup): a vector-memory load in the epilogue would make its wait drain the next tile's requests, which fly there.
+  f32x4 cb[MT];
+  for (int i = tid; i < D; i += 256) lds[G::LDS_FLOATS + i] = a.bias[i];
   int cg = 0;                                                // channel group of the fragments being requested
 
   auto load_w = [&](f32x4 (&wf)[MT], int ks) {               // ks: global k-step
@@ -147,9 +157,13 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
     for (int it = 0; it < NITA; ++it)
       xs[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
   };
-  auto load_bias = [&]() {
+  auto read_bias = [&]() {                                   // before the first k-step of a tile (cg = its channel group)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) bias4[mt] = *(const f32x4*)(a.bias + (cg * MT + mt) * 16 + 4 * q);
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 b = *(const f32x4*)(lds + G::LDS_FLOATS + (cg * MT + mt) * 16 + 4 * q);
+      cb[mt] = wave == 1 ? b : zero;
+    }
   };
   auto store_items = [&](int buf, int i0, int i1) {          // window items [i0, i1) of the staged chunk -> buffer `buf`
 #pragma unroll
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       acc[0][mt][t] = mfma16(wf[mt].x, v03.x, FIRST ? zero : acc[0][mt][t]);
-      acc[1][mt][t] = mfma16(wf[mt].y, v12.x, FIRST ? zero : acc[1][mt][t]);
+      acc[1][mt][t] = mfma16(wf[mt].y, v12.x, FIRST ? cb[mt] : acc[1][mt][t]);
       acc[2][mt][t] = mfma16(wf[mt].z, v12.y, FIRST ? zero : acc[2][mt][t]);
       acc[3][mt][t] = mfma16(wf[mt].w, v03.y, FIRST ? zero : acc[3][mt][t]);
     }
@@ -253,6 +267,7 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
     store_items(0, 0, NITA);
     load_x(KC);
     __syncthreads();
+    read_bias();
     // the first k-step of a tile starts the sums (C = 0 as an inline constant: no pass over the 192 accumulator registers)
     chunk(0, std::integral_constant<int, 0>{}, std::true_type{}, true, 2 * KC);
     chunk(1, std::integral_constant<int, 1>{}, std::false_type{}, true, 3 * KC);
@@ -275,10 +290,6 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) drain(acc[j][mt][0]);   // (tile row 0 is read first; tools/mfma_hazard_lint.py checks the rest)
 
-    // the bias BEFORE the next tile's fragment sets: vmcnt retires in order, and the epilogue consumes the bias first -- requested
-    // after them, its wait would drain the very loads that are meant to fly during the epilogue (advisor, round 3)
-    cg = done.cg;
-    load_bias();
     cg = cur.cg;
     // the next tile's first fragment sets fly during the epilogue
     if (more) {
@@ -292,6 +303,11 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
       const buf_rsrc ro = make_rsrc((char*)a.out + img);
       const buf_rsrc rk = make_rsrc((const char*)(a.skip ? a.skip : a.out) + img);
       f32x4* zl = (f32x4*)lds;
+      // SM: the tile's plane line (uniform: scalar loads) and the partials' descriptor (D/16 partials x 16 bytes = D bytes per pixel)
+      const int sm_b = SM ? done.n % a.sm_B : 0, sm_last = a.sm_D - 1, dq = 4 * q;
+      const float sm_lo = SM ? a.sm_planes.p[2 * sm_b] : 0.f, sm_hi = SM ? a.sm_planes.p[2 * sm_b + 1] : 0.f;
+      const float sm_step = (sm_hi - sm_lo) / (float)sm_last;   // as planes.h::plane_line
+      const buf_rsrc rp = make_rsrc((char*)a.sm_part + (size_t)done.n * a.h * a.w * (size_t)D);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (t) __syncthreads();                                // the previous round's readers are done
@@ -302,6 +318,33 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
         }
         __syncthreads();
         const int oy = done.r0 + 2 * t + oa, ox = done.c0 + 2 * p + ob;
+        if constexpr (SM) {
+          // The softmax partial of the lane's 16 channels (costreg_softmax.h; the merge over a pixel's D/16 lanes is k_softmax_merge's:
+          // the channel groups of a pixel are different workgroups), accumulated channel tile by channel tile with the running
+          // maximum -- one more exponential per tile instead of sixteen live scores.  Planes: uniform per tile (stage 1,
+          // planes.h PLANES_UNIFORM): (lo, hi) through the scalar cache, nothing that would wait on the vector-memory counter and
+          // with it on the next tile's window and fragments, which are in flight here.
+          float m = -INFINITY, se = 0.f, sd = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 z0 = zl[(((oa + 0) * 2 + ob) * MT + mt) * 64 + lane];
+            const f32x4 z1 = zl[(((oa + 1) * 2 + ob) * MT + mt) * 64 + lane];
+            const f32x4 z2 = zl[(((oa + 2) * 2 + ob) * MT + mt) * 64 + lane];
+            const f32x4 v = z0 + os * (z1 + z2);
+            const float mn = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            const float sc = __expf(m - mn);                   // (first tile: exp(-inf) = 0 times 0)
+            const int d = (done.cg * MT + mt) * 16 + dq;
+            const float e0 = __expf(v.x - mn), e1 = __expf(v.y - mn), e2 = __expf(v.z - mn), e3 = __expf(v.w - mn);
+            se = __fmaf_rn(se, sc, (e0 + e1) + (e2 + e3));
+            sd = sd * sc;
+            sd = __fmaf_rn(e3, plane_value(sm_lo, sm_step, min(d + 3, sm_last)), __fmaf_rn(e2, plane_value(sm_lo, sm_step, min(d + 2, sm_last)),
+                 __fmaf_rn(e1, plane_value(sm_lo, sm_step, min(d + 1, sm_last)), __fmaf_rn(e0, plane_value(sm_lo, sm_step, min(d, sm_last)), sd))));
+            m = mn;
+          }
+          // one 16-byte store per lane and round, always issued (out-of-image pixels: BUF_OOB) so that the wait below counts right
+          const unsigned pbase = (oy < a.h && ox < a.w) ? (unsigned)(((oy * a.w + ox) * (D / 16) + done.cg * 4 + q) * 16) : BUF_OOB;
+          buf_store4(rp, pbase, f32x4{m, se, sd, 0.f});
+        } else {
         const unsigned obase = (oy < a.h && ox < a.w)
             ? ooff + (unsigned)((((done.r0 + 2 * t) * a.w + done.c0) * D + done.cg * MT * 16) * 4) : BUF_OOB;
 #pragma unroll
@@ -309,10 +352,11 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
           const f32x4 z0 = zl[(((oa + 0) * 2 + ob) * MT + mt) * 64 + lane];
           const f32x4 z1 = zl[(((oa + 1) * 2 + ob) * MT + mt) * 64 + lane];
           const f32x4 z2 = zl[(((oa + 2) * 2 + ob) * MT + mt) * 64 + lane];
-          f32x4 v = z0 + os * (z1 + z2) + bias4[mt];
+          f32x4 v = z0 + os * (z1 + z2);
           if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           if (a.skip) v += buf_load4(rk, obase == BUF_OOB ? BUF_OOB : obase + mt * 64);
           buf_store4(ro, obase == BUF_OOB ? BUF_OOB : obase + mt * 64, v);
+        }
         }
       }
     }
@@ -320,15 +364,15 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
     tile = next;
     // the window chunk and the fragments were requested BEFORE the epilogue's NT * MT stores (vmcnt retires in order):
     // wait for them, not for the stores.  With a skip operand its loads were waited for already.
-    wait_vmem_but<NT * MT>();                                // (the bias loads, younger still, were consumed by the epilogue)
+    wait_vmem_but<SM ? NT : NT * MT>();
     __syncthreads();                                         // the epilogue's LDS readers are done: the buffers are free
   }
 }
 
-template <int MT, int NT, int WPS>
+template <int MT, int NT, int WPS, bool SM = false>
 static int launch_wino_cfg(const WinoArgs& a, int N, hipStream_t st) {
   const int groups = a.D / (16 * MT);
-  auto kern = k_conv_wino<MT, NT, WPS>;
+  auto kern = k_conv_wino<MT, NT, WPS, SM>;
   static const int capacity = resident_blocks(kern, 256, 0);       // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, groups * cdiv(a.w, 32), cdiv(a.h, 2 * NT), N)) return rc;
@@ -342,7 +386,7 @@ bool wino_depth_supported(int D) { return D >= 64 && D <= 384 && D % 64 == 0; } 
 
 int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
                      int relu, hipStream_t st) {
-  const WinoArgs a{in, wpk, bias, skip, out, D, h, w, relu};
+  const WinoArgs a{in, wpk, bias, skip, out, D, h, w, relu, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, D};
   ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino: D=%d unsupported (a multiple of 64 up to 384)", D);
   // 32-bit byte offsets inside one image through a buffer descriptor (advisor, round 3): larger maps would read zeros
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
@@ -355,9 +399,83 @@ int launch_conv_wino(const float* in, const float* wpk, const float* bias, const
   return two ? launch_wino_cfg<4, 2, 2>(a, N, st) : launch_wino_cfg<4, 3, 1>(a, N, st);
 }
 
+// The merge of a pixel's D/16 partials (m, sum exp, sum exp * plane): the online-softmax merge of costreg_softmax.h.  Four
+// lanes per pixel, lane l taking partials l, l + 4, ... -- a load instruction then covers whole 64-byte segments (one thread
+// per pixel walked its D bytes 16 at a time, 64 segments per instruction: 0.5 TB/s) -- and a butterfly over the four lanes.
+// view weight = max_d softmax = 1 / sum, pair depth = weighted sum / sum (adamvs.py:481-486).
+__global__ __launch_bounds__(256) void k_softmax_merge(const f32x4* __restrict__ part, float* __restrict__ vw, float* __restrict__ pd,
+                                                       size_t npix, int np) {
+  const size_t gp = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int l = threadIdx.x & 3;
+  const size_t pix = gp < npix ? gp : npix - 1;
+  const f32x4* pp = part + pix * np;
+  float M = -INFINITY, Z = 0.f, P = 0.f;
+  for (int j = l; j < np; j += 4) {                            // np is a multiple of 4
+    const f32x4 t = pp[j];
+    const float mn = fmaxf(M, t.x), so = __expf(M - mn), sn = __expf(t.x - mn);
+    Z = __fmaf_rn(t.y, sn, Z * so);
+    P = __fmaf_rn(t.z, sn, P * so);
+    M = mn;
+  }
+#pragma unroll
+  for (int o = 1; o < 4; o <<= 1) {
+    const float m2 = __shfl_xor(M, o, 64), z2 = __shfl_xor(Z, o, 64), p2 = __shfl_xor(P, o, 64);
+    const float mn = fmaxf(M, m2), s1 = __expf(M - mn), s2 = __expf(m2 - mn);
+    Z = __fmaf_rn(z2, s2, Z * s1);
+    P = __fmaf_rn(p2, s2, P * s1);
+    M = mn;
+  }
+  if (gp < npix && l == 0) {
+    vw[pix] = 1.0f / Z;
+    pd[pix] = P / Z;
+  }
+}
+
+// ADAMVS_WINO_SOFTMAX=0: the scores of `prob` through the score volume to k_softmax_regress, as in rounds 3-4 (A/B)
+bool wino_softmax_fused() {
+  static const bool on = [] { const char* e = getenv("ADAMVS_WINO_SOFTMAX"); return !(e && *e == '0'); }();
+  return on;
+}
+
+size_t wino_softmax_part_floats(int N, int D, int h, int w) { return (size_t)N * h * w * (D / 16) * 4; }
+
+// `prob` in the F(2x2, 3x3) form with softmax / max / depth regression behind it, the score volume never stored:
+// part = wino_softmax_part_floats() floats of scratch; planes: uniform per tile ([B][2] = lo, hi: stage 1's plane source),
+// n_planes <= D hypothesis planes, image n of tile n % B
+int launch_conv_wino_softmax(const float* in, const float* wpk, const float* bias, float* part, const PlaneSrc& planes, float* vw, float* pd,
+                             int N, int B, int D, int n_planes, int h, int w, hipStream_t st) {
+  const WinoArgs a{in, wpk, bias, nullptr, nullptr, D, h, w, 0, part, planes, B, n_planes > 0 ? n_planes : D};
+  ADAMVS_CHECK_ARG(planes.mode == PLANES_UNIFORM && a.sm_D > 1, "conv_wino_softmax: planes uniform per tile, at least two (mode %d, %d planes)", planes.mode, a.sm_D);
+  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino_softmax: D=%d unsupported (a multiple of 64 up to 384)", D);
+  ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino_softmax: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
+  static const int forced = [] { const char* e = getenv("ADAMVS_WINO_WPS"); return e ? atoi(e) : 0; }();
+  const bool two = forced ? forced == 2 : h * w >= 1024;
+  if (int rc = two ? launch_wino_cfg<4, 2, 2, true>(a, N, st) : launch_wino_cfg<4, 3, 1, true>(a, N, st)) return rc;
+  const size_t npix = (size_t)N * h * w;
+  hipLaunchKernelGGL(k_softmax_merge, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, st, (const f32x4*)part, vw, pd, npix, D / 16);
+  ADAMVS_CHECK_LAUNCH("softmax_merge");
+  return 0;
+}
+
 }  // namespace adamvs
 
 using namespace adamvs;
+
+extern "C" size_t adamvs_prob_softmax_regress_wino_workspace_bytes(int S, int B, int D, int h, int w) {
+  return wino_softmax_part_floats(S * B, D, h, w) * sizeof(float);
+}
+
+extern "C" int adamvs_prob_softmax_regress_wino(const float* in, const float* wpk, const float* bias, const float* depth_range, float* view_weight,
+                                                float* pair_depth, int S, int B, int D, int h, int w, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  ADAMVS_CHECK_ARG(in && wpk && bias && depth_range && view_weight && pair_depth && workspace && S > 0 && B > 0 && h > 0 && w > 0,
+                   "prob_softmax_regress_wino: bad arguments");
+  ADAMVS_CHECK_ARG(workspace_bytes >= adamvs_prob_softmax_regress_wino_workspace_bytes(S, B, D, h, w),
+                   "prob_softmax_regress_wino: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                   adamvs_prob_softmax_regress_wino_workspace_bytes(S, B, D, h, w));
+  return launch_conv_wino_softmax(in, wpk, bias, (float*)workspace, PlaneSrc{depth_range, PLANES_UNIFORM, 0.f}, view_weight, pair_depth, S * B, B,
+                                  D, D, h, w, (hipStream_t)stream);
+}
 
 extern "C" int adamvs_conv3x3_dd_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N,
                                       int D, int h, int w, int relu, void* stream) {

@@ -149,6 +149,20 @@ def prob_softmax_regress(x_cl, wpk_layer, bias, planes, S, B, D, h, w, precision
     return vw, pd
 
 
+def prob_softmax_regress_wino(x_cl, wino_layer, bias, depth_range, S, B, D, h, w):
+    """The same with `prob` in the F(2x2, 3x3) form (wino_layer from packing.pack_reg_layer_wino): per-lane softmax partials and a
+    merge kernel instead of the score volume -- what the fp32 stage runs at D a multiple of 64.  depth_range [B, 2]: first and
+    last hypothesis plane of every tile (stage 1's uniform planes)."""
+    vw = torch.empty(S, B, h, w, device=x_cl.device, dtype=torch.float32)
+    pd = torch.empty(S, B, h, w, device=x_cl.device, dtype=torch.float32)
+    lib = _lib.load()
+    nbytes = lib.adamvs_prob_softmax_regress_wino_workspace_bytes(S, B, D, h, w)
+    ws = torch.empty(nbytes // 4, device=x_cl.device, dtype=torch.float32)
+    check(lib.adamvs_prob_softmax_regress_wino(_p(_dev(x_cl, "x")), _p(wino_layer), _p(bias), _p(_dev(depth_range, "depth_range")), _p(vw), _p(pd),
+                                               S, B, D, h, w, ctypes.c_void_p(ws.data_ptr()), nbytes, _stream()), "prob_softmax_regress_wino")
+    return vw, pd
+
+
 def aggregate_conv1(feat, rt, planes, view_weight, w1pk, B, S, C, D, h, w, precision=0, return_similarity=False):
     """-> c1 [D,B,hw,8]; return_similarity (D <= 32, one chunk): also the aggregated similarity [D,B,hw,C] the call left in
     its workspace (include/adamvs_hip.h: the workspace holds the last chunk's similarity on return)."""

@@ -151,6 +151,18 @@ int adamvs_prob_softmax_regress(const float* in, const float* wpk, const float* 
                                 float* view_weight, float* pair_depth, int S, int B, int D, int h, int w, int precision,
                                 void* stream);
 
+/* The same with `prob` in the form F(2x2, 3x3) (what the fp32 stage runs at D a multiple of 64): the channel groups of a pixel
+ * are different workgroups, so every lane stores the softmax partial (max, sum of exp, sum of exp * plane) of the 16 scores it
+ * holds -- D bytes per pixel instead of the 4 D of the scores -- and a second kernel merges a pixel's D/16 partials.
+ * The hypothesis planes are those of stage 1, uniform per tile: depth_range [B][2] = (first, last) plane of tile b, plane d =
+ * first + d * ((last - first) / (D - 1)) (get_depth_range_samples, module.py:628-640); with per-pixel planes the stage takes
+ * the score volume and adamvs_softmax_max_regress.  wpk as adamvs_conv3x3_dd_wino; workspace:
+ * adamvs_prob_softmax_regress_wino_workspace_bytes (S*B*h*w*D bytes). */
+size_t adamvs_prob_softmax_regress_wino_workspace_bytes(int S, int B, int D, int h, int w);
+int adamvs_prob_softmax_regress_wino(const float* in, const float* wpk, const float* bias, const float* depth_range, float* view_weight,
+                                     float* pair_depth, int S, int B, int D, int h, int w, void* workspace, size_t workspace_bytes,
+                                     void* stream);
+
 /* ---- aggregation + recurrent regularisation (pass B) --------------------- */
 
 /* SliceCostRegNetRED weights (models/adamvs.py:400-413), packed by the host:

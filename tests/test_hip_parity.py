@@ -863,6 +863,30 @@ def test_prob_softmax_regress_fused(hip, D, h, w):  # fp32; the bf16x3 twin is h
     assert float((vw1 - vw0).abs().max()) < 1e-5 and float((pd1 - pd0).abs().max() / 500.0) < 1e-5
 
 
+@pytest.mark.parametrize("D,h,w", [(64, 24, 40), (192, 5, 70), (192, 32, 48), (384, 9, 33)])
+def test_prob_softmax_regress_winograd(hip, D, h, w):
+    """adamvs_prob_softmax_regress_wino -- `prob` in the F(2x2, 3x3) form with every lane's softmax partial in its epilogue and a
+    merge kernel behind it, the score volume never stored (what the fp32 stage runs at these widths; reference adamvs.py:238,
+    481-486) -- against the layer and the softmax / regression as two ops: ragged tiles, planes uniform per tile, one to six channel
+    groups per pixel, both tilings of the kernel (32 x 48 pixels take the two-workgroups-per-CU form)."""
+    from ada_mvs_amd import packing
+    S, B = 2, 2
+    g = torch.Generator().manual_seed(D + h)
+    x = dev(torch.randn(S * B, h * w, D, generator=g))
+    wt = torch.randn(D, D, 3, 3, generator=g) * (2.0 / (9 * D)) ** 0.5 * 3.0                 # gain 3 on the logits layer, as in synth
+    bias = dev(torch.randn(D, generator=g) * 0.3)
+    wk = dev(packing.pack_reg_layer_wino(wt, torch.ones(D)))
+    rng = torch.tensor([[400.0, 580.0], [350.0, 610.0]])                                      # first and last plane of the two tiles
+    step = (rng[:, 1] - rng[:, 0]) / (D - 1)
+    planes = dev((rng[:, 0].view(B, 1, 1, 1) + torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) * step.view(B, 1, 1, 1)).expand(B, D, h, w).contiguous())
+    score = hip.conv3x3_dd_wino(x, wk, bias, None, S * B, D, h, w, 0)
+    vw0, pd0 = hip.softmax_max_regress(score, planes, S, B, D, h, w)
+    vw1, pd1 = hip.prob_softmax_regress_wino(x, wk, bias, dev(rng), S, B, D, h, w)
+    torch.cuda.synchronize()
+    assert rel_l1(vw1, vw0) < 2e-6 and rel_l1(pd1, pd0) < 2e-6
+    assert float((vw1 - vw0).abs().max()) < 1e-5 and float((pd1 - pd0).abs().max() / 500.0) < 1e-5
+
+
 @pytest.mark.parametrize("C,S", [(32, 1), (32, 4), (32, 5), (32, 8), (16, 2), (16, 4), (16, 7), (8, 1), (8, 3), (8, 4), (8, 8)])
 def test_sweep_blend_views_and_widths(hip, O, C, S):
     """The aggregation sweep (k_sweep_blend, reference adamvs.py:495-512) for every channel width and 1 ... 8 source views

@@ -64,7 +64,33 @@ def timing(N, D, h, w, reps=5):
             N, D, h, w, name, ms, flops * executed / ms / 1e9, flops * executed / ms / 1e9 / 157.3 * 100, flops / ms / 1e9), flush=True)
 
 
+def softmax_timing(N=512, D=192, h=96, w=192, B=128, reps=5):
+    """`prob` + softmax / regression: two ops through the score volume against the fused partials + merge."""
+    x_cl = torch.randn(N, h * w, D, device=dev)
+    wt = torch.randn(D, D, 3, 3) * (2.0 / (9 * D)) ** 0.5 * 3.0
+    pw, bias = packing.pack_reg_layer_wino(wt, torch.ones(D)).to(dev), (torch.randn(D) * 0.3).to(dev)
+    planes = (400.0 + (180.0 / D) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) + torch.zeros(B, 1, h, w)).contiguous().to(dev)
+    out = torch.empty(N, h * w, D, device=dev)
+
+    def two():
+        hip_ops.conv3x3_dd_wino(x_cl, pw, bias, None, N, D, h, w, 0, out=out)
+        return hip_ops.softmax_max_regress(out, planes, N // B, B, D, h, w)
+    for name, fn in (("two ops", two), ("fused", lambda: hip_ops.prob_softmax_regress_wino(x_cl, pw, bias, torch.tensor([[400.0, 580.0]] * B, device=dev), N // B, B, D, h, w))):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print("prob + softmax, N=%d D=%d %dx%d  %-8s %7.3f ms" % (N, D, h, w, name, e0.elapsed_time(e1) / reps), flush=True)
+
+
 if __name__ == "__main__":
+    if "--softmax" in sys.argv:
+        softmax_timing()
+        sys.exit(0)
     if "--one" in sys.argv:                          # one shape, for timing builds
         timing(128, 192, 96, 192)
         sys.exit(0)
