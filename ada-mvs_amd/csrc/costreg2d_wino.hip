@@ -251,7 +251,11 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
   };
 
   // ---- tile loop
-  int tile = blockIdx.x;
+  // Workgroups i, i + 8, ... share an XCD and its L2 (cdna_hip_programming.md T1): give them NEIGHBOURING tiles of every sweep
+  // -- the channel groups of a pixel block and the blocks above and below it, which read the same window -- instead of every
+  // eighth one.  (Strided, the three groups of a block met in three different L2s: 2 FETCH + WRITE = 9 x the layer's input.)
+  const int nwg = (int)gridDim.x, xq = nwg / 8, xr = nwg % 8, xcd = (int)blockIdx.x % 8;
+  int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)blockIdx.x / 8;
   Tile cur = decode(tile);
   window_of(cur);
   cg = cur.cg;

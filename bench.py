@@ -767,7 +767,7 @@ def roofline_of(wl, args, ms_per_step):
         ach = flops / (ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         kname = ("k_conv_dd_bx3<MT,WM,CONV_S1>, executed bf16 flops = 3 x fp32 products" if split else
-                 "k_conv_wino<4,3>, fp32 F(2x2,3x3): executed flops = 16/36 of the direct convolution's" if wino else "k_conv_dd<MT,WM,CONV_S1>")
+                 "k_conv_wino<4,NT,WPS,SM>, fp32 F(2x2,3x3): executed flops = 16/36 of the direct convolution's" if wino else "k_conv_dd<MT,WM,CONV_S1>")
         roof = {"kernel": "%s (CostRegNet2D 3x3 stride-1 layers %s, %d launches per step)" % (
                     kname, "+".join(k.split(".")[2] for k in lay), len(lay)),
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
@@ -789,9 +789,11 @@ def roofline_of(wl, args, ms_per_step):
                 alg = sum(sum(v for k_, v in w_.items() if k_.endswith("_bytes")) for w_ in work)
                 roof["traffic_bytes_per_step"] = tj["hot_path_bytes_per_pass"]
                 roof["traffic_over_algorithmic_bytes"] = tj["hot_path_bytes_per_pass"] / alg
-            k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_wino<4, 3>" if wino else "k_conv_dd<3, 4, 0, 4, false, false>") in k]
+            # every instantiation of the kernel family the layers run on (F(2x2, 3x3): the one- and two-workgroups-per-CU tilings and
+            # the softmax form of `prob`), averaged over their launches
+            k0 = [v for k, v in tj["kernels"].items() if ("k_conv_dd_bx3<3, 4, 0" if split else "k_conv_wino<" if wino else "k_conv_dd<3, 4, 0, 4, false, false>") in k]
             if k0:
-                roof["traffic"] = (2 * k0[0]["fetch_size_kib"] + k0[0]["write_size_kib"]) * 1024
+                roof["traffic"] = sum((2 * v["fetch_size_kib"] + v["write_size_kib"]) * 1024 * v["launches"] for v in k0) / sum(v["launches"] for v in k0)
                 roof["traffic_note"] = ("bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 float4 correction), %s, "
                                         "same source stamp %s" % (os.path.basename(tpath), stamp))
                 break
