@@ -733,6 +733,10 @@ def roofline_of(wl, args, ms_per_step):
     layers = {k.split(".costreg.")[1]: round(v, 4) for k, v in avg.items() if ".costreg." in k}
     if layers:
         result["cost_reg_layers_ms"] = layers          # one launch each: <layer>.mode<0 s1 | 1 s2 | 2 transposed>
+        if "softmax.launch" in layers and os.environ.get("ADAMVS_WINO_SOFTMAX", "1") != "0":
+            result["cost_reg_layers_note"] = ("prob.mode0 and softmax.launch are the two ops timed one by one; the step runs them as one "
+                                              "(adamvs_prob_softmax_regress_wino: softmax partials in the layer's epilogue + a merge kernel, "
+                                              "no score volume), which the cost_reg_net_2d phase time contains")
     dom = max(phases, key=phases.get)
     st = work[int(dom[1]) - 1]
     kind = dom.split(".", 1)[1]
