@@ -453,6 +453,50 @@ static int launch_fconv(const FConvArgs& a_in, int N, hipStream_t st, const char
 }
 
 // ---------------------------------------------------------------------------
+// The full-resolution output convolution (out3: 1x1, 8 -> 8 channels, + the two upsampled context maps) as a streaming kernel:
+// one thread per pixel.  On k_fconv's 4 x 16-pixel tiles it was a 2-MFMA chain per wave between a window fill, two barriers and
+// 140 vector instructions of bilinear taps (5.4 % MFMA busy, 70 vector instructions per MFMA, 2.9 ms per 160 images: the
+// per-tile latency chain of 64 pixels); as 64 FMAs per pixel on the vector units with the weights in scalar registers it
+// moves its 64 bytes per pixel and nothing else (FeatureNet0 0.335 -> 0.310 ms per tile; the same for out2 -- 16 channels at half
+// resolution, 256 FMAs and 32 tap loads per thread -- was slower than its MFMA kernel: 0.325 -> 0.333).  Same arithmetic as the
+// MFMA chain up to the order of the eight products.
+__global__ __launch_bounds__(256) void k_out8_context(FConvArgs a, size_t npix) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  const int hw = a.ho * a.wo;
+  const int n = (int)(i / hw), pp = (int)(i % hw), y = pp / a.wo, x = pp % a.wo;
+  const f32x4 f0 = *(const f32x4*)(a.srcA + i * 8), f1 = *(const f32x4*)(a.srcA + i * 8 + 4);
+  const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+  f32x4 o[2];                          // all sixteen tap loads are issued here, ahead of the products
+#pragma unroll
+  for (int h4 = 0; h4 < 2; ++h4) {
+    o[h4] = *(const f32x4*)(a.bias + 4 * h4) + up_sample4(a.ctxA, n, a.hA, a.wA, 8, 4 * h4, y, x, a.syA, a.sxA) +
+            up_sample4(a.ctxB, n, a.hB, a.wB, 8, 4 * h4, y, x, a.syB, a.sxB);
+  }
+  float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // A fragments [KC = 2][64]: element lane l of fragment kc = W[cout = l & 15][cin = 4 kc + (l >> 4)] (uniform addresses: scalar loads)
+#pragma unroll
+  for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+    for (int co = 0; co < 8; ++co) r[co] = __fmaf_rn(a.wpk[(ci >> 2) * 64 + (ci & 3) * 16 + co], f[ci], r[co]);
+  o[0] += f32x4{r[0], r[1], r[2], r[3]};
+  o[1] += f32x4{r[4], r[5], r[6], r[7]};
+  *(f32x4*)(a.out + i * 8) = o[0];
+  *(f32x4*)(a.out + i * 8 + 4) = o[1];
+}
+
+static int launch_out8_context(const FConvArgs& a_in, int N, hipStream_t st) {
+  FConvArgs a = a_in;
+  a.syA = (float)a.hA / (float)a.ho; a.sxA = (float)a.wA / (float)a.wo;
+  a.syB = (float)a.hB / (float)a.ho; a.sxB = (float)a.wB / (float)a.wo;
+  const size_t npix = (size_t)N * a.ho * a.wo;
+  hipLaunchKernelGGL(k_out8_context, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, a, npix);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "feature_net0 out3: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // Pooled-context branches of one stage: AvgPool2d(4) and AvgPool2d(8), each -> 1x1 conv (C -> C/2, BN folded) -> ReLU
 // -> 1x1 (C/2 -> C: the branch's columns of the stage's output convolution).  One thread per 8 x 8 block of the
 // feature map: it is read once, the four 4 x 4 means feed branch a and their mean feeds branch b.  The pooled maps
@@ -687,7 +731,7 @@ static int feature_net0_impl(const float* imgs, const adamvs_feature_weights* wt
   if ((rc = launch_context<8>(f2, fw.br3_1, fw.br3_2, x3a, x3b, N, H, W, st))) return rc;
   {
     FConvArgs a{f2, nullptr, fw.out3.w, fw.out3.b, stage3, x3a, x3b, H, W, H, W, 8, 8, 0, H / 4, W / 4, H / 8, W / 8, 0.f, 0.f, 0.f, 0.f};
-    if ((rc = launch_fconv<8, 0, 1, FM_K1, FE_CONTEXT>(a, N, st, "out3"))) return rc;
+    if ((rc = launch_out8_context(a, N, st))) return rc;
   }
   return 0;
 }

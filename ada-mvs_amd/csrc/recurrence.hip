@@ -282,7 +282,9 @@ int recurrence_mode(int precision, long pixels) {
   // bf16x3 (both GRU levels are one kernel each: four launches per hypothesis, two, or one) -- one up to ~300k pixels
   // (cfg4's share at stage 1: 5.27 / 3.75 / 3.49 ms with four / two / one; at 295k 9.95 / 9.40 / 8.99), two up to ~1M (at
   // 590k 15.6 / 15.1 / 15.5; at 1.18M a tie), four beyond (at 2.36M 51.3 against 55.2).
-  if (precision != PRECISION_FP32) return pixels <= 300000 ? 5 : (pixels <= 1000000 ? 3 : 0);
+  // (round 4, after the fused levels' gate rows were interleaved: at 295k -- stage 2 of cfg4's share -- 2.77 ms with one launch per
+  // hypothesis, 2.67 with two; at 74k 3.45 against 3.69)
+  if (precision != PRECISION_FP32) return pixels <= 250000 ? 5 : (pixels <= 1000000 ? 3 : 0);
   // round 4, fp32 with both ConvGRU levels one kernel each (slice_roles_fused.h): ONE launch per hypothesis pays on the
   // smallest stages only -- cfg4's share at stage 1 (74k pixels) 5.01 -> 4.79 ms; at 295k 4.44 -> 5.28, at 1.18M 1.72 -> 2.50:
   // the fused tiles execute 36 % more MFMAs and the stage is not latency- but throughput-bound as soon as every CU has a few tiles.
