@@ -240,7 +240,7 @@ struct RoleCosts { float g1, c1, v2, g2, c2, dec, k1bx, v2bx, g2bx, c2bx, fa, fb
 struct FusedCosts { float k1s, k1l, k2s; };
 static const FusedCosts& fused_costs() {
   static const FusedCosts c = [] {
-    FusedCosts v = {13.0f, 23.0f, 20.0f};
+    FusedCosts v = {10.0f, 23.0f, 15.0f};        // (13, ., 20 by MFMA count; swept at 1 / 2 / 4 tiles: a plateau over 8-11, 12-16, cfg4's share 17.05 -> 16.97 ms)
     if (const char* e = getenv("ADAMVS_RECUR_COSTS_FUSED")) {
       float a, b, d;
       if (sscanf(e, "%f,%f,%f", &a, &b, &d) == 3 && a > 0.f && b > 0.f && d > 0.f && a < 1e6f && b < 1e6f && d < 1e6f) v = FusedCosts{a, b, d};
