@@ -3,6 +3,10 @@
 convolution on small maps, then the time of the five layer shapes of cfg2 at 128 tiles (N = 512 maps, D = 192).
 
     python tools/wino_bench.py                      -> profiles/r03_wino_layer_bench.txt is the output of this command
+    python tools/wino_bench.py --widths             efficiency of the three forms against the network width (D = 64 ... 384, 96x192 maps)
+    python tools/wino_bench.py --softmax            `prob` + softmax / regression: two ops through the score volume against the fused partials + merge
+    python tools/wino_bench.py --one                one shape (128 maps, D = 192, 96x192), for timing builds and counter passes
+                                                    (profiles/r04_wino_forms.txt = the first three of these, one after the other)
     ADAMVS_LIB_PATH=ada-mvs_amd/libadamvs_hip.<name>.so python tools/wino_bench.py --time-only     (a timing build, tools/build_variant.py)
 """
 import os
