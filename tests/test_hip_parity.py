@@ -299,13 +299,17 @@ def test_winograd_one_and_two_workgroups_per_cu_give_the_same_bits(hip, tmp_path
     assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
 
 
-def test_cost_reg_net_2d_direct_kernels_in_a_child_process(hip):
-    """ADAMVS_WINOGRAD=0 (read once per process): CostRegNet2D with its stride-1 layers on the direct kernel at the widths
-    the F(2x2, 3x3) kernel otherwise takes, the softmax epilogue of the direct `prob` layer included."""
+@pytest.mark.parametrize("switch", ["ADAMVS_WINOGRAD", "ADAMVS_WINO_SOFTMAX"])
+def test_cost_reg_net_2d_direct_kernels_in_a_child_process(hip, switch):
+    """The A/B switches of CostRegNet2D (read once per process).  ADAMVS_WINOGRAD=0: its stride-1 layers on the direct kernel at
+    the widths the F(2x2, 3x3) kernel otherwise takes, the softmax epilogue of the direct `prob` layer included.
+    ADAMVS_WINO_SOFTMAX=0: the F(2x2, 3x3) `prob` layer writes its scores and k_softmax_regress reads them, as before round 4's
+    partials + merge (test_piecewise_phase_masks runs stage 1 at D = 192 through it)."""
     import subprocess
-    env = dict(os.environ, ADAMVS_WINOGRAD="0")
+    env = dict(os.environ, **{switch: "0"})
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                        "test_cost_reg_net_2d_widths or test_prob_softmax_regress_fused or test_generated_planes_equal_materialised_planes"],
+                        "test_cost_reg_net_2d_widths or test_prob_softmax_regress_fused or test_generated_planes_equal_materialised_planes "
+                        "or test_piecewise_phase_masks"],
                        env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
