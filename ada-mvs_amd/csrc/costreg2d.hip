@@ -1169,8 +1169,10 @@ int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* s
       if (!rc && i == 10 && fuse_softmax && !epilogue_sm)
         rc = launch_softmax_regress(score, *sm_planes, sm_vw, sm_pd, N / sm_B, sm_B, D, h, w, st, n_planes);
     } else if (wino && plan[i].mode == CONV_S1) {
-      // stride-1 layers in the minimal-filtering form (none of them carries a skip or takes a second input); the scores of the
-      // last one go through the score volume to k_softmax_regress: its channel groups are different workgroups
+      // stride-1 layers in the minimal-filtering form (none of them carries a skip or takes a second input).  The channel groups of
+      // a pixel are different workgroups there, so the softmax behind the last layer is every lane's partial + a merge kernel
+      // (uniform planes: stage 1); with per-pixel planes, or ADAMVS_WINO_SOFTMAX=0, the scores go through the score volume to
+      // k_softmax_regress
       const float* ww = wpk + (size_t)11 * LW + (size_t)(i == 10 ? 4 : i / 2) * 16 * D * D;
       if (i == 10 && fuse_softmax && wino_softmax_fused() && sm_planes->mode == PLANES_UNIFORM && (n_planes > 0 ? n_planes : D) > 1) {
         // every lane's softmax partial instead of the scores (D bytes per pixel instead of 4 D), in the score volume's place

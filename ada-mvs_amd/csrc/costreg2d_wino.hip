@@ -75,7 +75,8 @@ struct WinoGeom {
 // fragment sets one k-step ahead.  The second wave was built to fill the matrix-pipe cycles a lone wave loses to its other
 // instructions (27 % of them); it fills almost none -- 74.3 against 73.6 % of the matrix rate at 512 maps: what the loads,
 // LDS stores and transforms cost the matrix pipe is not issue slots but the register file they share with it -- and earns its
-// keep on small launches (16 maps: 0.79 against 0.93 ms, twice the workgroups).
+// keep through the XCD-aware tile order below: with three channel groups of every pixel block in one L2 it is the form whose
+// extra window traffic (4-row tiles) stops mattering, 76.4 against 73.8 %.
 template <int MT, int NT, int WPS, bool SM>
 __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg, int groups, unsigned mgroups) {
   using G = WinoGeom<MT, NT>;
@@ -395,9 +396,10 @@ int launch_conv_wino(const float* in, const float* wpk, const float* bias, const
   // 32-bit byte offsets inside one image through a buffer descriptor (advisor, round 3): larger maps would read zeros
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
   // Two workgroups per CU (4 x 32-pixel tiles) except on the smallest maps of the hourglass, where the 6 x 32 tiles of the
-  // one-workgroup form cover a 12-row map without a ragged tile row: 512 maps of 96x192 / 48x96 / 24x48 / 12x24 pixels at D = 192
-  // take 23.8 / 5.91 / 1.92 / 0.58 ms against 24.1 / 6.01 / 1.99 / 0.51, 16 maps of 96x192 (cfg4's share of four tiles) 0.79 against
-  // 0.93 (tools/wino_bench.py).  ADAMVS_WINO_WPS=1 / 2 forces one form (A/B); both give the same bits.
+  // one-workgroup form cover a 12-row map without a ragged tile row.  With the XCD-aware tile order, D = 192 (tools/wino_bench.py):
+  // 512 maps of 96x192 / 48x96 / 24x48 / 12x24 pixels 23.2 / 5.79 / 1.90 / 0.57 ms against 24.0 / 5.99 / 2.00 / 0.51 - 0.56;
+  // 64 maps of 96x192 2.87 against 3.01, 16 maps (cfg4's share of four tiles) 0.74 against 0.76.
+  // ADAMVS_WINO_WPS=1 / 2 forces one form (A/B); both give the same bits.
   static const int forced = [] { const char* e = getenv("ADAMVS_WINO_WPS"); return e ? atoi(e) : 0; }();
   const bool two = forced ? forced == 2 : h * w >= 1024;
   return two ? launch_wino_cfg<4, 2, 2>(a, N, st) : launch_wino_cfg<4, 3, 1>(a, N, st);
