@@ -21,58 +21,41 @@ import sys
 import time
 
 
+def _argv_value(name, default):
+    """The value of `--name V` / `--name=V` on the command line, before argparse (and torch) exist."""
+    v, argv = default, sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == name and i + 1 < len(argv):
+            v = argv[i + 1]
+        elif a.startswith(name + "="):
+            v = a.split("=", 1)[1]
+    return v
+
+
 def _self_launch():
     """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process becomes the launcher.
     It has imported nothing that can touch the GPU (the check runs before `import torch`), starts N FRESH child processes
     of this file -- one rank per GPU, torchrun's environment contract, never an exec -- relays rank 0's JSON line and
-    exits non-zero if any rank does.  Under torchrun (WORLD_SIZE set) this is a no-op."""
+    exits non-zero if any rank does.  A rank that hangs (a collective that never completes) trips `--launch-timeout`
+    (default 900 s): every rank is ended by PID, the last stderr lines of every rank are relayed and the exit code is 124
+    (ada-mvs_amd/launch.py).  Under torchrun (WORLD_SIZE set) this is a no-op."""
     if os.environ.get("WORLD_SIZE"):
         return
-    n = 1
-    for i, a in enumerate(sys.argv[1:]):
-        if a == "--gpus" and i + 2 <= len(sys.argv[1:]):
-            n = sys.argv[i + 2]
-        elif a.startswith("--gpus="):
-            n = a.split("=", 1)[1]
     try:
-        n = int(n)
+        n = int(_argv_value("--gpus", 1))
+        timeout = float(_argv_value("--launch-timeout", 900.0))
     except ValueError:
         return                                   # argparse reports it
     if n <= 1:
         return
-    import socket
-    import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ADAMVS_BENCH_LAUNCHER="self")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    import threading
-    rc, out0 = 0, []
-    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)    # rank 0 prints the one JSON line
-    reader.start()
-    pending = list(procs)
-    while pending:                               # a rank that dies leaves the others in a collective: end them by PID
-        for p in list(pending):
-            c = p.poll()
-            if c is None:
-                continue
-            pending.remove(p)
-            if c != 0 and rc == 0:
-                rc = c if c > 0 else 1
-                for q in pending:
-                    q.terminate()
-        time.sleep(0.05)
-    reader.join(10)
-    sys.stdout.write(b"".join(out0).decode())
-    sys.stdout.flush()
-    sys.exit(rc)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "adamvs_launch", os.path.join(os.path.dirname(os.path.abspath(__file__)), "ada-mvs_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)              # imports no torch
+    code, _ = launch.run_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], n, timeout=timeout,
+                               extra_env={"ADAMVS_BENCH_LAUNCHER": "self"})
+    sys.exit(code)
 
 
 if __name__ == "__main__":
@@ -468,7 +451,8 @@ class Workload:
             for w_ in work:
                 sched = lib.adamvs_recurrence_schedule(0, self.B * w_["h"] * w_["w"])
                 if sched == 0 or (sched == 1 and (mask & 7) == 7):
-                    gru_wino += self.B * w_["D"] * w_["h"] * w_["w"] * 2.0 * sum(m for b_, m in w_["gru_conv_macs"].items() if mask & b_)
+                    eff = mask if sched == 0 else 7          # the three-launch schedule never takes cand1 (bit 8) in that form
+                    gru_wino += self.B * w_["D"] * w_["h"] * w_["w"] * 2.0 * sum(m for b_, m in w_["gru_conv_macs"].items() if eff & b_)
         executed -= gru_wino * (20.0 / 36.0)
         f_mfma = (tot_flops * 3 / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS if split else executed / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS)
         f_hbm = tot_bytes / step_s / 1e9 / HBM_PEAK_GBS
@@ -571,6 +555,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cascade", action="store_true",
                     help="skip the cfg3 / cfg4-share measurements that follow the headline (N = 1, default workload only)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="self-launched N > 1 runs: seconds after which every rank is ended by PID and the launcher exits 124 "
+                         "(a rank hanging in a collective); read by the launcher before argparse, listed here for --help")
     ap.add_argument("--red-batch", type=int, default=1, help="--model msrednet: tiles per step")
     ap.add_argument("--model", default="adamvs", choices=["adamvs", "msrednet"],
                     help="adamvs: the headline path; msrednet: the sibling model (SURVEY.md 8f row f3), --red-batch tiles per step, 1 GPU")
@@ -634,13 +621,20 @@ def main():
             step()
         gathered = gatherer.finish()             # the last gather is inside the timed region
         torch.cuda.synchronize()
+        t_own = time.perf_counter()
         if world > 1:
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
+        rank_ms = [1e3 * (t_own - t0) / args.steps]                  # this rank's own replays + gathers, before the closing barrier
         if world > 1:
-            t = torch.tensor([elapsed], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            cdev = dev if torch.distributed.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
+            mine = torch.tensor([rank_ms[0]], device=cdev, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(every, mine)
+            rank_ms = [float(x.item()) for x in every]
 
         result = None
         if rank == 0:
@@ -654,6 +648,8 @@ def main():
                 "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
                 "rccl_ranks": world, "backend": {"nccl": "nccl (RCCL)"}.get(backend, backend), "devices": devices,
                 "launcher": os.environ.get("ADAMVS_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "none"),
+                # every rank's own time per step before the closing barrier: a straggler GPU shows as max >> min
+                "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": [round(x, 4) for x in rank_ms]},
                 "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-bf16 MFMA, fp32 accumulate) for the convolutions, f32 elsewhere",
                 "data": "synthetic",
                 "config": {"workload": "%s: %d views, %dx%d, hypotheses %s, %s" % (
@@ -810,7 +806,8 @@ def roofline_of(wl, args, ms_per_step):
             mask = lib.adamvs_gru_wino_mask()
             sched = lib.adamvs_recurrence_schedule(0, Bg * st["h"] * st["w"])
             if sched == 0 or (sched == 1 and (mask & 7) == 7):
-                rec_flops -= Bg * st["D"] * st["h"] * st["w"] * 2.0 * sum(m for b_, m in st["gru_conv_macs"].items() if mask & b_) * (20.0 / 36.0)
+                eff = mask if sched == 0 else 7
+                rec_flops -= Bg * st["D"] * st["h"] * st["w"] * 2.0 * sum(m for b_, m in st["gru_conv_macs"].items() if eff & b_) * (20.0 / 36.0)
         ach = rec_flops / (avg[dom] * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         # launches per hypothesis depend on the stage size (csrc/recurrence.hip: 6 / 3 / 2 in fp32, 4 / 2 in bf16x3):
