@@ -79,7 +79,7 @@ static int check_desc(const adamvs_stage_desc* d) {
   ADAMVS_CHECK_ARG(d->precision_fuse == PRECISION_FP32 || d->precision_fuse == PRECISION_BF16X3,
                    "stage: precision_fuse=%d (0 fp32, 1 bf16x3)", d->precision_fuse);
   if (d->first_stage) {
-    ADAMVS_CHECK_ARG(stage_reg_width(*d) > 0, "stage: D=%d hypotheses: CostRegNet2D runs at widths up to 384", d->D);
+    ADAMVS_CHECK_ARG(stage_reg_width(*d) > 0, "stage: D=%d hypotheses: CostRegNet2D runs at widths up to 512", d->D);
     ADAMVS_CHECK_ARG((d->h % 8) == 0 && (d->w % 8) == 0, "stage: first stage needs h=%d w=%d multiples of 8", d->h, d->w);
   } else {
     ADAMVS_CHECK_ARG(d->prev_h > 0 && d->prev_w > 0, "stage: prev_h/prev_w missing");

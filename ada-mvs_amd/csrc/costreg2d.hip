@@ -630,22 +630,22 @@ static int launch_conv_dd_cfg(const ConvDDArgs& a_, int N, int mode, hipStream_t
 }
 
 bool costreg_depth_supported(int D) {
-  return D == 16 || D == 32 || D == 48 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384;
+  return D == 16 || D == 32 || D == 48 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384 || D == 512;
 }
 
 // The width CostRegNet2D runs at for D hypotheses: the next supported one.  The reference builds the network for any D
 // (models/adamvs.py:198-228); here the extra channels are zero weights (packing.py::pack_reg pads to this width: a pad
 // channel's activations are ReLU(0) = 0 in every layer and feed nothing), the pair-similarity volume carries zeros in them,
 // and the pad channels of `prob` get a bias of -1e30: exp(-1e30 - max) = 0 exactly, so softmax, its maximum and the depth
-// expectation see D hypotheses.  0 = more than 384.
+// expectation see D hypotheses.  0 = more than 512.
 int costreg_width(int D) {
-  static const int widths[] = {16, 32, 48, 64, 96, 128, 192, 256, 384};
+  static const int widths[] = {16, 32, 48, 64, 96, 128, 192, 256, 384, 512};
   for (int w : widths)
     if (D <= w) return w;
   return 0;
 }
 int costreg_width_bf16x3(int D) {
-  static const int widths[] = {32, 64, 96, 128, 192, 256, 384};
+  static const int widths[] = {32, 64, 96, 128, 192, 256, 384, 512};
   for (int w : widths)
     if (D <= w) return w;
   return 0;
@@ -943,8 +943,22 @@ static int launch_conv_dd_z(const ConvDDArgs& a, int N, int mode, hipStream_t st
       }
       return 0;
     }
+    case 512: {
+      // the 128-channel tiling four times (round 5; the class default of the reference is num_depth = 384, adamvs.py:538, and
+      // ndepths[0] is unconstrained): each launch contracts over all 512 input channels into its quarter of the output channels
+      ADAMVS_CHECK_ARG(!a.sm_vw, "conv_dd: no softmax epilogue at D=512");
+      ConvDDArgs h = a;
+      for (int part = 0; part < 4; ++part) {
+        h.wpk = a.wpk + (size_t)part * 8 * 64;
+        h.bias = a.bias + part * 128;
+        h.out = a.out + part * 128;
+        h.skip = a.skip ? a.skip + part * 128 : nullptr;
+        if (int rc = launch_conv_dd_cfg<4, 2>(h, N, mode, st)) return rc;
+      }
+      return 0;
+    }
   }
-  return set_error(-1, "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256 or 384)", a.D);
+  return set_error(-1, "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256, 384 or 512)", a.D);
 }
 
 int launch_conv_dd_gn(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
@@ -1217,6 +1231,7 @@ int launch_softmax_regress(const float* score, PlaneSrc planes, float* vw, float
     case 3: launch_softmax_nq<3>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
     case 4: launch_softmax_nq<4>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
     case 6: launch_softmax_nq<6>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
+    case 8: launch_softmax_nq<8>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
     default: launch_softmax_nq<0>(score, planes, vw, pd, B, D, h * w, npix, Dp, st); break;
   }
   ADAMVS_CHECK_LAUNCH("softmax_regress");
@@ -1234,7 +1249,7 @@ extern "C" size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, in
 static int check_precision(int precision, int D, const char* who) {
   ADAMVS_CHECK_ARG(precision == PRECISION_FP32 || precision == PRECISION_BF16X3, "%s: precision=%d (0 fp32, 1 bf16x3)", who, precision);
   ADAMVS_CHECK_ARG(precision == PRECISION_FP32 || costreg_bf16x3_depth_supported(D),
-                   "%s: bf16x3 needs D in {32,64,96,128,192,256,384}, got %d", who, D);
+                   "%s: bf16x3 needs D in {32,64,96,128,192,256,384,512}, got %d", who, D);
   return 0;
 }
 
@@ -1252,7 +1267,7 @@ extern "C" int adamvs_cost_reg_net_2d(const float* x, const float* wpk, size_t w
                                       int precision, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_precision(precision, D, "cost_reg_net_2d")) return rc;
   ADAMVS_CHECK_ARG(x && wpk && score && workspace && N > 0 && h > 0 && w > 0, "cost_reg_net_2d: bad arguments");
-  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256 or 384)", D);
+  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "cost_reg_net_2d: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256, 384 or 512)", D);
   ADAMVS_CHECK_ARG(wpk_floats == cost_reg_weight_floats(D, precision),
                    "cost_reg_net_2d: wpk holds %zu floats, the layout for D=%d precision=%d has %zu (include/adamvs_hip.h)", wpk_floats, D,
                    precision, cost_reg_weight_floats(D, precision));
@@ -1267,7 +1282,7 @@ extern "C" int adamvs_conv3x3_dd(const float* in, const float* in2, const float*
                                  float* out, int N, int D, int hi, int wi, int mode, int relu, int precision, void* stream) {
   if (int rc = check_precision(precision, D, "conv3x3_dd")) return rc;
   ADAMVS_CHECK_ARG(in && wpk && bias && out && N > 0 && hi > 0 && wi > 0, "conv3x3_dd: bad arguments");
-  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "conv3x3_dd: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256 or 384)", D);
+  ADAMVS_CHECK_ARG(costreg_depth_supported(D), "conv3x3_dd: D=%d unsupported (16, 32, 48, 64, 96, 128, 192, 256, 384 or 512)", D);
   ADAMVS_CHECK_ARG(mode >= 0 && mode <= 2, "conv3x3_dd: mode=%d (0 stride 1, 1 stride 2, 2 transposed stride 2)", mode);
   ADAMVS_CHECK_ARG(mode != CONV_S2 || ((hi % 2) == 0 && (wi % 2) == 0), "conv3x3_dd: stride 2 needs even hi, wi");
   int ho = mode == CONV_S2 ? hi / 2 : (mode == CONV_T2 ? 2 * hi : hi);

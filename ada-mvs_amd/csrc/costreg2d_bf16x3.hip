@@ -247,7 +247,7 @@ static int launch_bx3_cfg(const ConvDDArgs16& a, int N, int mode, hipStream_t st
   return launch_bx3_mode<MT, WM, BX_T2>(a, dim3(cdiv(a.wi, 16), cdiv(a.hi, BxGeom<BX_T2>::BR), N * 4), st);
 }
 
-bool costreg_bf16x3_depth_supported(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384; }
+bool costreg_bf16x3_depth_supported(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384 || D == 512; }
 
 // `wpk` is the layer's packed block reinterpreted: 9*D*D floats worth of bf16 fragments (hi half, then lo half)
 int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
@@ -281,6 +281,18 @@ int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, 
       }
       return 0;
     }
+    case 512: {                              // the 256-channel tiling twice
+      ADAMVS_CHECK_ARG(!sm_vw, "conv_dd_bf16x3: no softmax epilogue at D=512");
+      for (int half = 0; half < 2; ++half) {
+        ConvDDArgs16 h = a;
+        h.wpk = a.wpk + (size_t)half * 16 * 64;
+        h.bias = bias + half * 256;
+        h.out = out + half * 256;
+        h.skip = skip ? skip + half * 256 : nullptr;
+        if (int rc = launch_bx3_cfg<4, 4>(h, N, mode, st)) return rc;
+      }
+      return 0;
+    }
     case 32: return launch_bx3_cfg<2, 1>(a, N, mode, st);
     case 64: return launch_bx3_cfg<4, 1>(a, N, mode, st);
     case 96: return launch_bx3_cfg<3, 2>(a, N, mode, st);
@@ -288,7 +300,7 @@ int launch_conv_dd_bf16x3(const float* in, const float* wpk, const float* bias, 
     case 192: return launch_bx3_cfg<3, 4>(a, N, mode, st);
     case 256: return launch_bx3_cfg<4, 4>(a, N, mode, st);      // (the two-launch 128-channel form of the fp32 path does not pay here: 155.0 -> 156.0 ms at cfg5)
   }
-  return set_error(-1, "cost_reg_net_2d (bf16x3): D=%d unsupported (32, 64, 96, 128, 192, 256 or 384)", D);
+  return set_error(-1, "cost_reg_net_2d (bf16x3): D=%d unsupported (32, 64, 96, 128, 192, 256, 384 or 512)", D);
 }
 
 }  // namespace adamvs

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
   using G = WinoGeom<MT, NT>;
   constexpr int KC = G::KC, KS = G::KS, LC = G::LC, NPIX = G::NPIX, PLANE = G::PLANE, GP = G::GP, CHUNK = G::CHUNK;
   constexpr int NITEMS = NPIX * (KC / 4), NITA = (NITEMS + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + 384];   // + the layer's bias vector (D <= 384)
+  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + 512];   // + the layer's bias vector (D <= 512)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = patch row i
   const int p = lane & 15, q = lane >> 4;
   const int D = a.D, NTILES = D / 16, NC = D / KC;
@@ -387,12 +387,12 @@ static int launch_wino_cfg(const WinoArgs& a, int N, hipStream_t st) {
   return 0;
 }
 
-bool wino_depth_supported(int D) { return D >= 64 && D <= 384 && D % 64 == 0; }       // channel groups of 64; 16-channel LDS chunks
+bool wino_depth_supported(int D) { return D >= 64 && D <= 512 && D % 64 == 0; }       // channel groups of 64; 16-channel LDS chunks
 
 int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
                      int relu, hipStream_t st) {
   const WinoArgs a{in, wpk, bias, skip, out, D, h, w, relu, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, D};
-  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino: D=%d unsupported (a multiple of 64 up to 384)", D);
+  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino: D=%d unsupported (a multiple of 64 up to 512)", D);
   // 32-bit byte offsets inside one image through a buffer descriptor (advisor, round 3): larger maps would read zeros
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
   // Two workgroups per CU (4 x 32-pixel tiles) except on the smallest maps of the hourglass, where the 6 x 32 tiles of the
@@ -452,7 +452,7 @@ int launch_conv_wino_softmax(const float* in, const float* wpk, const float* bia
                              int N, int B, int D, int n_planes, int h, int w, hipStream_t st) {
   const WinoArgs a{in, wpk, bias, nullptr, nullptr, D, h, w, 0, part, planes, B, n_planes > 0 ? n_planes : D};
   ADAMVS_CHECK_ARG(planes.mode == PLANES_UNIFORM && a.sm_D > 1, "conv_wino_softmax: planes uniform per tile, at least two (mode %d, %d planes)", planes.mode, a.sm_D);
-  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino_softmax: D=%d unsupported (a multiple of 64 up to 384)", D);
+  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino_softmax: D=%d unsupported (a multiple of 64 up to 512)", D);
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino_softmax: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
   static const int forced = [] { const char* e = getenv("ADAMVS_WINO_WPS"); return e ? atoi(e) : 0; }();
   const bool two = forced ? forced == 2 : h * w >= 1024;
@@ -468,6 +468,7 @@ int launch_conv_wino_softmax(const float* in, const float* wpk, const float* bia
 using namespace adamvs;
 
 extern "C" size_t adamvs_prob_softmax_regress_wino_workspace_bytes(int S, int B, int D, int h, int w) {
+  if (!wino_depth_supported(D) || D < 2 || S <= 0 || B <= 0 || h <= 0 || w <= 0) return 0;      // unsupported: no size to satisfy
   return wino_softmax_part_floats(S * B, D, h, w) * sizeof(float);
 }
 
@@ -476,6 +477,8 @@ extern "C" int adamvs_prob_softmax_regress_wino(const float* in, const float* wp
                                                 size_t workspace_bytes, void* stream) {
   ADAMVS_CHECK_ARG(in && wpk && bias && depth_range && view_weight && pair_depth && workspace && S > 0 && B > 0 && h > 0 && w > 0,
                    "prob_softmax_regress_wino: bad arguments");
+  // before any size is derived from D (D / 16 partials per pixel would truncate silently)
+  ADAMVS_CHECK_ARG(wino_depth_supported(D) && D > 1, "prob_softmax_regress_wino: D=%d unsupported (a multiple of 64 up to 512)", D);
   ADAMVS_CHECK_ARG(workspace_bytes >= adamvs_prob_softmax_regress_wino_workspace_bytes(S, B, D, h, w),
                    "prob_softmax_regress_wino: workspace too small (%zu < %zu bytes)", workspace_bytes,
                    adamvs_prob_softmax_regress_wino_workspace_bytes(S, B, D, h, w));

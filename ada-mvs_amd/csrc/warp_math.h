@@ -16,7 +16,18 @@
 
 namespace adamvs {
 
-// 0 when u and v are finite, NaN when either is inf or NaN (0 * inf = NaN); two instructions
+//
+// WHICH backend of the reference is the contract: its CPU path (BASELINE.json: "maps match the reference CPU path"; every
+// fixture is a CPU run).  ATen's CUDA grid_sample differs exactly here -- it skips out-of-bounds taps, so +-inf coordinates give 0
+// and only NaN coordinates give NaN -- i.e. a user comparing against a GPU run of the reference sees 0 where this library (and the
+// reference on CPU) returns NaN, for pixels exactly on a source camera's focal plane.  Either way the tile is garbage downstream.
+
+// 0 when u and v are finite, NaN when either is inf or NaN (0 * inf = NaN); two instructions in the plane loops of the sweeps.
+// The arithmetic form needs IEEE semantics for 0 * x: the library is never built with -ffast-math / -ffinite-math-only
+// (ada-mvs_amd/build.py FLAGS), and a build that tries does not compile.
+#if defined(__FAST_MATH__) || (defined(__FINITE_MATH_ONLY__) && __FINITE_MATH_ONLY__)
+#error "warp_math.h: nonfinite_poison() relies on 0 * inf = NaN; do not build with -ffast-math / -ffinite-math-only"
+#endif
 __device__ __forceinline__ float nonfinite_poison(float u, float v) { return fmaf(0.f, u, 0.f * v); }
 
 struct WarpTaps {

@@ -9,9 +9,10 @@ it calls in models/module.py) running in libadamvs_hip.so.
     out = model(imgs, proj_matrices, depth_values)     # out["depth"], out["photometric_confidence"], ...
 
 FeatureNet0 (upstream of the hot path) runs on hand-written kernels as well
-(adamvs_feature_net0; image sizes that are no multiple of 32 go through the
-same layers in PyTorch on the GPU).  There is no CPU fallback: CPU tensors, a
-missing library, or train mode raise.
+(adamvs_feature_net0).  Image sizes that are no multiple of 32 raise, as they
+break the reference's own size rule (its predict-time loader crops to
+multiples of 32, datasets/preprocess.py:68-83).  There is no CPU fallback and
+no PyTorch fallback on the GPU: CPU tensors, a missing library, or train mode raise.
 """
 import torch
 import torch.nn as nn
@@ -228,6 +229,12 @@ class InferDepthNet0(nn.Module):
             D, mode, half_span = depth_values.shape[1], 0, 0.0
         else:
             (mode, half_span, depth_values), D = planes, num_depth
+        if first and D != self.reg.prob.weight.shape[0]:
+            # CostRegNet2D is D -> D (reference adamvs.py:198-228, built with in_depths = ndepths[0]): the reference's conv0 fails on
+            # any other plane count.  Here the network may run zero-padded to a wider tiling (packing.reg_width), so a count that
+            # happens to equal the PADDED width would pass every size check of the library and weight the surplus planes 0.
+            raise AdaMVSHipError("stage 1 was given %d hypothesis planes but its CostRegNet2D is built for %d (ndepths[0])"
+                                 % (D, self.reg.prob.weight.shape[0]))
         desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()],
                                   _PRECISIONS[self.reg_fuse.precision], eps_in_numerator=int(twin), plane_mode=mode, half_span=half_span)
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4

@@ -13,11 +13,11 @@ BN_EPS = 1e-5
 REG_LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11", "prob")
 REG_TRANSPOSED = ("conv7", "conv9", "conv11")
 REG_WINOGRAD = ("conv0", "conv2", "conv4", "conv6", "prob")      # stride-1 layers: also packed in the F(2x2, 3x3) form (fp32)
-WINO_WIDTHS = (64, 128, 192, 256, 384)              # the widths of REG_WIDTHS that csrc/costreg2d_wino.hip takes (multiples of 64)
+WINO_WIDTHS = (64, 128, 192, 256, 384, 512)              # the widths of REG_WIDTHS that csrc/costreg2d_wino.hip takes (multiples of 64)
 # The widths CostRegNet2D's kernels are built for (csrc/costreg2d.hip::costreg_width, costreg_width_bf16x3; held equal to the
 # library's table by tests/test_host_logic.py).  The reference builds the network for any number of hypotheses
 # (models/adamvs.py:198-228): other D run at the next width, see pack_cost_reg_net_2d.
-REG_WIDTHS = {"fp32": (16, 32, 48, 64, 96, 128, 192, 256, 384), "bf16x3": (32, 64, 96, 128, 192, 256, 384)}
+REG_WIDTHS = {"fp32": (16, 32, 48, 64, 96, 128, 192, 256, 384, 512), "bf16x3": (32, 64, 96, 128, 192, 256, 384, 512)}
 PAD_SCORE = -1e30          # bias of `prob`'s pad channels: exp(PAD_SCORE - max) = 0 exactly, and finite (no inf - inf in the merges)
 
 

@@ -78,7 +78,7 @@ int adamvs_pair_similarity(const float* feat, const float* rt, const float* plan
  * A-fragment order [tap][cin/4][cout/16][lane] with value
  * W[cout = 16*tile + (lane&15)][cin = 4*kc + (lane>>4)][tap] * bn_scale[cout]
  * (ConvTranspose2d layers: W[cin][cout][tap]) followed by D bias floats (folded BN shift,
- * or the conv bias for `prob`).  D in {16,32,48,64,96,128,192,256,384}; h, w multiples of 8.
+ * or the conv bias for `prob`).  D in {16,32,48,64,96,128,192,256,384,512}; h, w multiples of 8.
  *
  * The reference builds the network for any number of hypotheses (adamvs.py:198-228); here a network of D hypotheses runs at
  * the next width of that list, adamvs_cost_reg_width(D, precision), with zero filters for the extra channels and -1e30 as
@@ -86,7 +86,7 @@ int adamvs_pair_similarity(const float* feat, const float* rt, const float* plan
  * hourglass and weigh exactly 0 in the softmax.  The op-level entry points below take the WIDTH as D (x and score carry
  * that many channels); adamvs_depth_stage_forward takes the number of hypotheses and handles the rest.
  *
- * fp32 with D in {64,128,192,256,384}: the 11 blocks are followed by the five stride-1 layers (conv0, conv2, conv4, conv6, prob)
+ * fp32 with D in {64,128,192,256,384,512}: the 11 blocks are followed by the five stride-1 layers (conv0, conv2, conv4, conv6, prob)
  * in the minimal-filtering form F(2x2, 3x3), 16*D*D floats each, laid out as adamvs_conv3x3_dd_wino takes them; those
  * layers run on that kernel (fp32 throughout, 16 products instead of 36 per 2x2 outputs and channel pair; environment
  * ADAMVS_WINOGRAD=0: on the direct kernel).  ada-mvs_amd/packing.py::pack_cost_reg_net_2d produces exactly this.
@@ -101,7 +101,7 @@ int adamvs_pair_similarity(const float* feat, const float* rt, const float* plan
 #define ADAMVS_PRECISION_FP32 0
 #define ADAMVS_PRECISION_BF16X3 1
 size_t adamvs_cost_reg_net_2d_workspace_bytes(int N, int D, int h, int w);
-int adamvs_cost_reg_width(int D, int precision);                       /* the width the network runs at for D hypotheses; 0: none (D > 384) */
+int adamvs_cost_reg_width(int D, int precision);                       /* the width the network runs at for D hypotheses; 0: none (D > 512) */
 size_t adamvs_cost_reg_net_2d_weight_floats(int D, int precision);     /* floats of wpk at width D; 0: not a supported width */
 int adamvs_cost_reg_net_2d(const float* x, const float* wpk, size_t wpk_floats, float* score, int N, int D, int h, int w,
                            int precision, void* workspace, size_t workspace_bytes, void* stream);
@@ -123,7 +123,7 @@ int adamvs_conv3x3_dd(const float* in, const float* in2, const float* wpk, const
  * instead of 36, fp32 throughout (results agree with adamvs_conv3x3_dd mode 0 to a few ulp of the accumulated sums).
  * wpk [D/4][4][D/16][64][4] = the transformed filters U = G w G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], BN scale folded
  * in) as MFMA A fragments: element j of lane l of fragment (k-step kc, patch row i, channel tile) =
- * U[i][j][cout = 16*tile + (l&15)][cin = 4*kc + (l>>4)].  D a multiple of 64 up to 384; a map at most 2 GiB.  in, out, skip,
+ * U[i][j][cout = 16*tile + (l&15)][cin = 4*kc + (l>>4)].  D a multiple of 64 up to 512; a map at most 2 GiB.  in, out, skip,
  * bias, relu as above. */
 int adamvs_conv3x3_dd_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
                            int h, int w, int relu, void* stream);
@@ -176,7 +176,26 @@ int adamvs_prob_softmax_regress_wino(const float* in, const float* wpk, const fl
  * With precision ADAMVS_PRECISION_BF16X3 the conv1 / gates / cand / conv2 fields point to split-bf16 fragments
  * instead: the contraction index is flattened, k = pos*cin_total + cin (pos = tap ky*3+kx, or rr*3+kx for the
  * two-row conv1), zero-padded to a multiple of 32; layout [cout tile][hi|lo][k/32][lane][8 bf16], element j of
- * lane l = W[16*tile + (l&15)][k = 32*kb + 8*(l>>4) + j].  upconv1 / final_w / the biases keep the fp32 form. */
+ * lane l = W[16*tile + (l&15)][k = 32*kb + 8*(l>>4) + j].  upconv1 / final_w / the biases keep the fp32 form.
+ *
+ * PRE-SCALED FIELDS (since ABI 13; nothing in the struct's size or layout shows it, so a caller that packs its own blob must
+ * do this or gets silently wrong GRU states).  The kernels that consume these fields feed the convolution's accumulator to
+ * v_exp_f32 (2^x) directly -- sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1) -- so the factor is
+ * folded into weights AND bias by the host, in double precision, before the fragments are formed (rounded once):
+ *   ADAMVS_PRECISION_BF16X3:  gates1, gates1_b, gates2, gates2_b  = (-log2 e) x the reference tensors;
+ *                             cand1, cand1_b, cand2, cand2_b       = (2 log2 e) x the reference tensors;
+ *                             and the 16 output rows of gates1 / gates1_b are INTERLEAVED so that every lane of the fused
+ *                             level-1 kernel holds two reset- and two update-gate values: MFMA row m = 4 q + e carries
+ *                             reset-gate channel 2 q + e for e = 0, 1 and update-gate channel 2 q + e - 2 for e = 2, 3
+ *                             (q = 0..3), i.e. rows = conv_gates rows [0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15]
+ *                             (conv_gates rows 0-7 = reset gate, 8-15 = update gate, module.py:35-41).
+ *                             gates2 keeps the reference's row order.  conv1, conv2: unscaled.
+ *   ADAMVS_PRECISION_FP32:    gates1 / gates2 / cand1 / cand2 and their biases are the UNSCALED reference tensors (the direct
+ *                             kernels apply exp themselves); the *_w fields below are U = G (s g) G^T with s = -log2 e for
+ *                             gates1_w, gates2_w and s = 2 log2 e for cand1_w, cand2_w, reference row order; the kernels that
+ *                             read a *_w field scale the shared, unscaled bias by the same s once per launch.
+ * ada-mvs_amd/packing.py::pack_slice_reg_net is the reference implementation of this format
+ * (tests/test_host_logic.py::test_gru_prescaled_fields_follow_the_header recomputes it from this text). */
 typedef struct adamvs_fuse_weights {
   const float* conv1;                           /* [12][C/4][64] two-row form reg_fuse.conv1.conv.weight */
   const float* gates1; const float* gates1_b;   /* [1][9][4][64], [16]      conv_gru1.conv_gates.0 */
@@ -186,8 +205,9 @@ typedef struct adamvs_fuse_weights {
   const float* cand2;  const float* cand2_b;    /* [1][9][8][64], [16]      conv_gru2.convc.0 */
   const float* upconv1; const float* upconv1_b; /* [1][9][4][64], [16]      upconv1 (transposed: W[cin][cout][tap]) */
   const float* final_w;                         /* [73]: w[tap*8+c], bias   upconv2d */
-  /* fp32 (NULL in bf16x3): the same gate / candidate convolutions as transformed filters U = G g G^T of the minimal-filtering
-   * form F(2x2, 3x3) (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]), fragments [cout tile][patch row i][patch column j][cin/4][64]:
+  /* fp32 (NULL in bf16x3): the same gate / candidate convolutions as transformed filters U = G (s g) G^T of the minimal-filtering
+   * form F(2x2, 3x3) (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; s = -log2 e for the gates, 2 log2 e for the candidates: "PRE-SCALED
+   * FIELDS" above), fragments [cout tile][patch row i][patch column j][cin/4][64]:
    * lane l = U[i][j][cout = 16*tile + (l&15)][cin = 4*kc + (l>>4)] */
   const float* gates1_w;                        /* [1][4][4][4][64]         conv_gru1.conv_gates.0 */
   const float* gates2_w;                        /* [2][4][4][8][64]         conv_gru2.conv_gates.0 */
@@ -266,7 +286,7 @@ int adamvs_slice_reg_step(const float* cost, float* state1, float* state2, const
 /* ---- whole stage: InferDepthNet0.forward, models/adamvs.py:433-533 -------- */
 typedef struct adamvs_stage_desc {
   int B, S, C, h, w, D;   /* batch, source views (any number), feature channels, feature rows/cols, hypotheses (first stage:
-                             at most 384; CostRegNet2D runs at adamvs_cost_reg_width(D, precision) channels) */
+                             at most 512; CostRegNet2D runs at adamvs_cost_reg_width(D, precision) channels) */
   int in_up;              /* 1: maps come out at 2h x 2w (stages 1, 2); 0: h x w (stage 3) */
   int first_stage;        /* 1: confidence_map is None -> pass A scores the views (stage 1) */
   int prev_h, prev_w;     /* size of prev_conf maps when !first_stage */

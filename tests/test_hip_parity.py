@@ -228,7 +228,8 @@ def test_cost_reg_net_2d_widths(hip, O, D, h, w):
 @pytest.mark.parametrize("N,D,h,w,relu,skip", [(1, 192, 6, 32, 1, False), (2, 192, 13, 45, 0, False), (2, 192, 7, 70, 1, True),
                                                (1, 192, 1, 1, 1, False), (1, 64, 8, 40, 1, False), (1, 128, 13, 33, 0, True),
                                                (1, 256, 6, 32, 0, False), (3, 192, 24, 48, 1, False),
-                                               (12, 192, 30, 64, 1, False), (40, 64, 24, 64, 0, True)])
+                                               (12, 192, 30, 64, 1, False), (40, 64, 24, 64, 0, True),
+                                               (1, 512, 7, 34, 1, True)])
 def test_conv3x3_dd_winograd(hip, N, D, h, w, relu, skip):
     """A stride-1 CostRegNet2D layer in the F(2x2, 3x3) form (csrc/costreg2d_wino.hip) against a float64 convolution
     (ConvBnReLU.forward, reference models/module.py:254-261, BN folded) and against the direct kernel: full and ragged
@@ -867,7 +868,7 @@ def test_prob_softmax_regress_fused(hip, D, h, w):  # fp32; the bf16x3 twin is h
     assert float((vw1 - vw0).abs().max()) < 1e-5 and float((pd1 - pd0).abs().max() / 500.0) < 1e-5
 
 
-@pytest.mark.parametrize("D,h,w", [(64, 24, 40), (192, 5, 70), (192, 32, 48), (384, 9, 33)])
+@pytest.mark.parametrize("D,h,w", [(64, 24, 40), (192, 5, 70), (192, 32, 48), (384, 9, 33), (512, 6, 35)])
 def test_prob_softmax_regress_winograd(hip, D, h, w):
     """adamvs_prob_softmax_regress_wino -- `prob` in the F(2x2, 3x3) form with every lane's softmax partial in its epilogue and a
     merge kernel behind it, the score volume never stored (what the fp32 stage runs at these widths; reference adamvs.py:238,
@@ -1049,7 +1050,8 @@ def test_end_to_end_with_a_view_behind_the_planes(hip, precision):
 
 # --------------------------------------------------------------------------- any number of hypotheses / views (adamvs.py:198-228, :464, :501)
 @pytest.mark.parametrize("D,precision", [(40, "fp32"), (80, "fp32"), (160, "fp32"), (384, "fp32"), (272, "fp32"), (24, "fp32"),
-                                         (160, "bf16x3"), (384, "bf16x3"), (288, "bf16x3")])
+                                         (160, "bf16x3"), (384, "bf16x3"), (288, "bf16x3"),
+                                         (512, "fp32"), (400, "fp32"), (512, "bf16x3"), (448, "bf16x3")])
 def test_stage_one_at_any_hypothesis_count(hip, O, D, precision):
     """CostRegNet2D(in_channels) is built for any D in the reference; here D hypotheses run at the next width the kernels are
     built for (zero filters, zero similarity channels, -1e30 pad scores: csrc/costreg2d.hip::costreg_width).  Stage 1 with

@@ -364,9 +364,9 @@ def test_cost_reg_width_table_and_padded_packing():
     from ada_mvs_amd.models.adamvs import CostRegNet2D
     lib = _lib.load()
     for prec, code in (("fp32", 0), ("bf16x3", 1)):
-        for d in list(range(1, 400, 7)) + [16, 32, 48, 64, 96, 128, 192, 256, 384]:
+        for d in list(range(1, 530, 7)) + [16, 32, 48, 64, 96, 128, 192, 256, 384, 385, 512, 513]:
             want = lib.adamvs_cost_reg_width(d, code)
-            if d <= 384:
+            if d <= 512:
                 assert packing.reg_width(d, prec) == want and want >= d, (d, prec)
             else:
                 assert want == 0
@@ -384,3 +384,62 @@ def test_cost_reg_width_table_and_padded_packing():
         conv0_bias = blob[9 * dr * dr:lw]
         assert bool((conv0_bias[d:] == 0).all())
     assert lib.adamvs_cost_reg_net_2d_weight_floats(40, 0) == 0      # not a width
+
+
+def test_gru_prescaled_fields_follow_the_header():
+    """include/adamvs_hip.h, "PRE-SCALED FIELDS" of adamvs_fuse_weights: recomputed here from the header's text (element
+    addresses of the fragment layouts, the factors, the gates1 row order), not through packing.py's helpers."""
+    import math
+    L2E = math.log2(math.e)
+    m = Infer_AdaMVSNet(16, [16, 8, 4], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=3)
+    pre = "DepthNet.1.reg_fuse."
+    header_rows = [0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15]
+    for q in range(4):
+        for e in range(4):
+            assert header_rows[4 * q + e] == (2 * q + e if e < 2 else 8 + 2 * q + e - 2)
+
+    # ---- bf16x3: split-bf16 fragments [cout tile][hi|lo][k/32][lane][8], k = tap * cin_total + cin
+    blob, off = packing.pack_slice_reg_net(sd, pre, "bf16x3")
+
+    def bx3_elem(field, nt_total, K, tile, lane, kb, j):
+        nkb = (K + 31) // 32
+        frag = blob[off[field]:off[field] + nt_total * 2 * nkb * 64 * 4].view(torch.bfloat16).reshape(nt_total, 2, nkb, 64, 8)
+        return float(frag[tile, 0, kb, lane, j]) + float(frag[tile, 1, kb, lane, j])
+
+    for field, key, nt, s, rows in (("gates1", "conv_gru1.conv_gates.0", 1, -L2E, header_rows), ("cand1", "conv_gru1.convc.0", 1, 2 * L2E, None),
+                                    ("gates2", "conv_gru2.conv_gates.0", 2, -L2E, None), ("cand2", "conv_gru2.convc.0", 1, 2 * L2E, None)):
+        w, b = sd[pre + key + ".weight"].double(), sd[pre + key + ".bias"].double()
+        cout, cin = w.shape[0], w.shape[1]
+        for tile, lane, kb, j in ((0, 5, 0, 3), (nt - 1, 38, 2, 7), (0, 63, (9 * cin) // 32 - 1, 0), (nt - 1, 16 + 9, 1, 4)):
+            row = 16 * tile + (lane & 15)
+            k = 32 * kb + 8 * (lane >> 4) + j
+            tap, ci = k // cin, k % cin
+            src = rows[row] if rows else row
+            want = s * float(w[src, ci, tap // 3, tap % 3]) if src < cout and tap < 9 else 0.0
+            got = bx3_elem(field, nt, 9 * cin, tile, lane, kb, j)
+            assert abs(got - want) <= 2 ** -15 * max(abs(want), 1e-6) + 1e-12, (field, tile, lane, kb, j, got, want)
+        bias = blob[off[field + "_b"]:off[field + "_b"] + 16 * nt]
+        for row in range(16 * nt):
+            src = rows[row] if rows else row
+            want = s * float(b[src]) if src < cout else 0.0
+            assert abs(float(bias[row]) - want) <= 1e-6 * max(abs(want), 1.0), (field, row)
+
+    # ---- fp32: direct fields unscaled, *_w = G (s g) G^T as [cout tile][i][j][cin/4][64]
+    blob, off = packing.pack_slice_reg_net(sd, pre, "fp32")
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    for field, key, s in (("gates1_w", "conv_gru1.conv_gates.0", -L2E), ("gates2_w", "conv_gru2.conv_gates.0", -L2E),
+                          ("cand2_w", "conv_gru2.convc.0", 2 * L2E), ("cand1_w", "conv_gru1.convc.0", 2 * L2E)):
+        w = sd[pre + key + ".weight"].double()
+        cout, cin = w.shape[0], w.shape[1]
+        nt, KC = (cout + 15) // 16, cin // 4
+        frag = blob[off[field]:off[field] + nt * 16 * KC * 64].reshape(nt, 4, 4, KC, 64)
+        for tile, i, j, kc, lane in ((0, 0, 0, 0, 0), (nt - 1, 3, 1, KC - 1, 63), (0, 2, 2, 1, 21), (nt - 1, 1, 3, 0, 40)):
+            co, ci = 16 * tile + (lane & 15), 4 * kc + (lane >> 4)
+            want = float((G @ (s * w[co, ci]) @ G.t())[i, j]) if co < cout else 0.0
+            assert abs(float(frag[tile, i, j, kc, lane]) - want) <= 1e-6 * max(abs(want), 1e-3), (field, tile, i, j, kc, lane)
+    # the direct fp32 gate fragments [tile][tap][cin/4][64] are the unscaled reference weights, and so is their bias
+    wg = sd[pre + "conv_gru2.conv_gates.0.weight"]
+    frag = blob[off["gates2"]:off["gates2"] + 2 * 9 * 8 * 64].reshape(2, 9, 8, 64)
+    assert float(frag[1, 4, 3, 37]) == float(wg[16 + (37 & 15), 4 * 3 + (37 >> 4), 1, 1])
+    assert torch.equal(blob[off["gates2_b"]:off["gates2_b"] + 32], sd[pre + "conv_gru2.conv_gates.0.bias"].float())
