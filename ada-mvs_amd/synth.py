@@ -35,9 +35,19 @@ def _is_transposed(module):
     return isinstance(module, torch.nn.ConvTranspose2d)
 
 
-def seeded_state_dict(model, seed=0):
+# Gains on the two logits layers (`reg.prob`: the scores of the stage-1 softmax, reference adamvs.py:481; `reg_fuse.upconv2d`:
+# reg_cost, the argument of the UNSTABILISED exp of adamvs.py:516).
+#   "default"  3 / 3: the recipe of SURVEY.md 8c -- soft probability volumes (pair confidence 0.4 - 1.0, |reg_cost| <= 13)
+#   "sharp"    30 / 15: what a trained network's dynamic range looks like -- stage-1 softmaxes near one-hot (mean pair confidence
+#              0.98), reg_cost up to +-60 (exp ~ 1e26; the running sums A = sum depth * exp reach 1e29 of fp32's 3e38)
+#   "overflow" 30 / 75: reg_cost beyond 88.7 at part of the image: exp = inf, and the reference returns inf / NaN maps there
+LOGIT_GAINS = {"default": (3.0, 3.0), "sharp": (30.0, 15.0), "overflow": (30.0, 75.0)}
+
+
+def seeded_state_dict(model, seed=0, recipe="default"):
     """He-normal convs, randomised BN statistics, gain 3 on the two logits
     layers: gives non-degenerate probability volumes with random weights.
+    recipe: LOGIT_GAINS above (the same draws, other gains on the two logits layers).
 
     `model` is any nn.Module carrying the reference's key names
     (reference models/adamvs.py:537-565).  Returns a new state dict.
@@ -76,9 +86,12 @@ def seeded_state_dict(model, seed=0):
                 _rng(pre + "weight", seed).uniform(0.5, 1.5, n).astype(np.float32))
             sd[pre + "bias"] = torch.from_numpy(
                 (_rng(pre + "bias", seed).standard_normal(n) * 0.1).astype(np.float32))
+    g_prob, g_up = LOGIT_GAINS[recipe]
     for key in list(sd):
-        if key.endswith("upconv2d.weight") or key.endswith("reg.prob.weight"):
-            sd[key] = sd[key] * 3.0
+        if key.endswith("reg.prob.weight"):
+            sd[key] = sd[key] * g_prob
+        elif key.endswith("upconv2d.weight"):
+            sd[key] = sd[key] * g_up
     missing = set(model.state_dict().keys()) - set(sd.keys())
     if missing:
         raise RuntimeError("seeded_state_dict: keys without a recipe: %s" % sorted(missing)[:5])

@@ -1048,6 +1048,41 @@ def test_end_to_end_with_a_view_behind_the_planes(hip, precision):
         assert rel_l1(out["stage1"]["pair_result"][i], g["s1_pairdepth%d" % i]) < tol
 
 
+# --------------------------------------------------------------------------- a trained network's dynamic range (adamvs.py:481, 516-531)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name,recipe", [("e2e_tiny_sharp", "sharp"), ("e2e_tiny_sharp64", "sharp"), ("e2e_tiny_overflow", "overflow")])
+def test_end_to_end_on_a_trained_networks_dynamic_range(hip, name, recipe, precision):
+    """Fixtures: runs of the reference on synth.LOGIT_GAINS "sharp" / "overflow" weights (tools/gen_golden.py::end_to_end_sharp).
+    Near one-hot stage-1 softmaxes through the zero-padded 48-channel tiling with -1e30 pad scores (D1 = 40) and through the
+    F(2x2, 3x3) `prob` with per-lane online-softmax partials + k_softmax_merge (D1 = 64); reg_cost up to +-60 through the
+    unstabilised exp of the running soft-argmin; and a single stage in which that exp overflows: where the reference returns
+    inf / NaN (adamvs.py:529-531) so must the kernels, pixel for pixel (two pixels of slack for scores within rounding of the
+    overflow threshold)."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    from test_oracle_golden import finite_rel_l1, nonfinite_mismatch
+    g = load_golden(name)
+    nd = [int(v) for v in g["ndepths"]]
+    cfg = dict(views=3, H=64, W=96, ndepths=nd, num_depth=nd[0])
+    m = Infer_AdaMVSNet(nd[0], nd, synth.DEPTH_INTERVALS_RATIO[:len(nd)], False, [8, 8, 8], precision=precision)
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0, recipe=recipe))
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0)
+    with torch.no_grad():
+        out = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+    tol = E2E_TOL if precision == "fp32" else 5e-4
+    for s in range(1, len(nd) + 1):
+        for key, gk in (("depth", "s%d_depth" % s), ("photometric_confidence", "s%d_conf" % s)):
+            got, ref = out["stage%d" % s][key].cpu(), g[gk]
+            if recipe == "overflow":
+                assert nonfinite_mismatch(got, ref) <= 2, (name, key, nonfinite_mismatch(got, ref))
+            else:
+                assert bool(torch.isfinite(got).all())
+            assert finite_rel_l1(got, ref) < tol, (name, s, key, finite_rel_l1(got, ref))
+    for i in range(2):
+        assert rel_l1(out["stage1"]["pair_confidence"][i], g["s1_pairconf%d" % i]) < tol
+        assert rel_l1(out["stage1"]["pair_result"][i], g["s1_pairdepth%d" % i]) < tol
+
+
 # --------------------------------------------------------------------------- any number of hypotheses / views (adamvs.py:198-228, :464, :501)
 @pytest.mark.parametrize("D,precision", [(40, "fp32"), (80, "fp32"), (160, "fp32"), (384, "fp32"), (272, "fp32"), (24, "fp32"),
                                          (160, "bf16x3"), (384, "bf16x3"), (288, "bf16x3"),

@@ -172,3 +172,49 @@ def test_end_to_end_with_a_view_behind_the_planes():
     for i in range(2):
         assert rel_l1(out["stage1"]["pair_confidence"][i], g["s1_pairconf%d" % i]) < 5e-5
         assert rel_l1(out["stage1"]["pair_result"][i], g["s1_pairdepth%d" % i]) < 5e-5
+
+
+SHARP_CASES = (("e2e_tiny_sharp", "sharp"), ("e2e_tiny_sharp64", "sharp"), ("e2e_tiny_overflow", "overflow"))
+
+
+def finite_rel_l1(x, ref):
+    """relative L1 over the pixels where the reference is finite (the rest is compared as a pattern)"""
+    x, ref = x.detach().double().cpu(), ref.detach().double().cpu()
+    ok = torch.isfinite(ref)
+    return float((x[ok] - ref[ok]).abs().mean() / ref[ok].abs().mean().clamp_min(1e-30))
+
+
+def nonfinite_mismatch(x, ref):
+    """pixels whose class (finite / +inf / -inf / NaN) differs from the reference's"""
+    def cls(t):
+        t = t.detach().cpu()
+        return torch.isnan(t).int() * 3 + torch.isposinf(t).int() * 1 + torch.isneginf(t).int() * 2
+    return int((cls(x) != cls(ref)).sum())
+
+
+def test_end_to_end_on_a_trained_networks_dynamic_range():
+    """synth.LOGIT_GAINS "sharp" / "overflow" (runs of the reference: tools/gen_golden.py::end_to_end_sharp): stage-1 softmaxes near
+    one-hot, reg_cost up to +-60 through the UNSTABILISED exp of adamvs.py:516, and one single-stage case in which that exp
+    overflows -- the reference returns inf / NaN there (adamvs.py:529-531: inf / inf), and so must the restatement."""
+    for name, recipe in SHARP_CASES:
+        g = load_golden(name)
+        nd = [int(v) for v in g["ndepths"]]
+        cfg = dict(views=3, H=64, W=96, ndepths=nd, num_depth=nd[0])
+        m = Infer_AdaMVSNet(nd[0], nd, synth.DEPTH_INTERVALS_RATIO[:len(nd)], False, [8, 8, 8])
+        sd = synth.seeded_state_dict(m, seed=0, recipe=recipe)
+        imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0)
+        out = O.infer_adamvs_forward(imgs, proj, dv, sd, nd[0], nd, synth.DEPTH_INTERVALS_RATIO[:len(nd)])
+        assert float(g["reg_cost_max"].max()) > (88.0 if recipe == "overflow" else 35.0), name      # the fixture bites
+        assert float(g["s1_pairconf0"].mean()) > 0.95
+        for s in range(1, len(nd) + 1):
+            for key, gk in (("depth", "s%d_depth" % s), ("photometric_confidence", "s%d_conf" % s)):
+                got, ref = out["stage%d" % s][key], g[gk]
+                if recipe == "overflow":
+                    assert 0.01 < float((~torch.isfinite(ref)).float().mean()) < 0.5, name
+                    assert nonfinite_mismatch(got, ref) <= 2, (name, key)
+                else:
+                    assert bool(torch.isfinite(ref).all())
+                assert finite_rel_l1(got, ref) < 5e-5, (name, s, key)
+        for i in range(2):
+            assert rel_l1(out["stage1"]["pair_confidence"][i], g["s1_pairconf%d" % i]) < 5e-5
+            assert rel_l1(out["stage1"]["pair_result"][i], g["s1_pairdepth%d" % i]) < 5e-5

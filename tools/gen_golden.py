@@ -211,8 +211,53 @@ def end_to_end_behind():
     save("e2e_tiny_behind", **arrays)
 
 
+SHARP_CASES = (        # (fixture, ndepths, recipe): synth.tile_inputs(dict(views=3, H=64, W=96, ...), batch=1, seed=0)
+    ("e2e_tiny_sharp", [40, 8, 4], "sharp"),           # D1 = 40: CostRegNet2D zero-padded to the 48-channel tiling, -1e30 pad scores
+    ("e2e_tiny_sharp64", [64, 8, 4], "sharp"),         # D1 = 64: the F(2x2, 3x3) `prob` with per-lane softmax partials + merge
+    ("e2e_tiny_overflow", [64], "overflow"),           # one stage: exp(reg_cost) = inf at part of the image (adamvs.py:516-531)
+)
+
+
+@torch.no_grad()
+def end_to_end_sharp():
+    """The reference on weights with a trained network's dynamic range (synth.LOGIT_GAINS): near one-hot stage-1 softmaxes,
+    reg_cost up to +-60, and one case in which the unstabilised exp of adamvs.py:516 overflows: inf / NaN maps, recorded as
+    the reference returns them."""
+    for name, nd, recipe in SHARP_CASES:
+        cfg = dict(views=3, H=64, W=96, ndepths=nd, num_depth=nd[0])
+        m = ref_adamvs.Infer_AdaMVSNet(num_depth=nd[0], ndepths=nd, depth_intervals_ratio=synth.DEPTH_INTERVALS_RATIO[:len(nd)],
+                                       share_cr=False, cr_base_chs=[8, 8, 8])
+        m.load_state_dict(synth.seeded_state_dict(m, seed=0, recipe=recipe))
+        m.eval()
+        lo, hi = [1e30] * 3, [-1e30] * 3
+        for i, dn in enumerate(m.DepthNet):          # the range of reg_cost per stage, recorded with the fixture
+            def hook(mod, inp, out, i=i):
+                r = out[0][torch.isfinite(out[0])]
+                if r.numel():
+                    lo[i], hi[i] = min(lo[i], float(r.min())), max(hi[i], float(r.max()))
+            dn.reg_fuse.register_forward_hook(hook)
+        imgs, proj, dv = synth.tile_inputs(cfg, batch=1, seed=0)
+        r = m(imgs, proj, dv)
+        arrays = {"ndepths": np.asarray(nd), "reg_cost_min": np.asarray(lo[:len(nd)]), "reg_cost_max": np.asarray(hi[:len(nd)])}
+        for s in range(1, len(nd) + 1):
+            arrays["s%d_depth" % s] = r["stage%d" % s]["depth"]
+            arrays["s%d_conf" % s] = r["stage%d" % s]["photometric_confidence"]
+        for i in range(2):
+            arrays["s1_pairconf%d" % i] = r["stage1"]["pair_confidence"][i]
+            arrays["s1_pairdepth%d" % i] = r["stage1"]["pair_result"][i]
+        finite = all(bool(torch.isfinite(v).all()) for v in arrays.values() if torch.is_tensor(v))
+        assert finite == (recipe != "overflow"), (name, finite)
+        print("%-20s reg_cost per stage: %s .. %s; mean pair confidence %.3f; non-finite share of the final depth map %.4f" % (
+            name, ["%.1f" % v for v in lo[:len(nd)]], ["%.1f" % v for v in hi[:len(nd)]], float(arrays["s1_pairconf0"].mean()),
+            float((~torch.isfinite(r["depth"])).float().mean())))
+        save(name, **arrays)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--only-sharp" in sys.argv:
+        end_to_end_sharp()
+        sys.exit(0)
     if "--only-two-ranges" in sys.argv:
         two_ranges()
         sys.exit(0)
@@ -225,3 +270,4 @@ if __name__ == "__main__":
     end_to_end("cfg1", with_inputs=False)
     two_ranges()
     end_to_end_behind()
+    end_to_end_sharp()
