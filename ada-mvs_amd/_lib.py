@@ -75,7 +75,6 @@ SIGNATURES = {
     "adamvs_cost_reg_net_2d": (c_i, [c_f, c_f, c_sz, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_conv3x3_dd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_conv3x3_dd_wino": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
-    "adamvs_conv3x3_dd_wino24": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_softmax_max_regress": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_prob_softmax_regress": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_prob_softmax_regress_wino_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
@@ -111,7 +110,7 @@ SIGNATURES = {
     "adamvs_soft_argmin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 PLANES_EXPLICIT, PLANES_UNIFORM, PLANES_WINDOW = 0, 1, 2
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libadamvs_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = ["api.hip", "geometry.hip", "planesweep.hip", "sweep.hip", "costreg2d.hip", "costreg2d_wino.hip", "costreg2d_wino24.hip", "costreg2d_bf16x3.hip", "slice_red.hip", "slice_red_bf16x3.hip", "recurrence.hip", "featnet.hip", "msred.hip"]
+SOURCES = ["api.hip", "geometry.hip", "planesweep.hip", "sweep.hip", "costreg2d.hip", "costreg2d_wino.hip", "costreg2d_bf16x3.hip", "slice_red.hip", "slice_red_bf16x3.hip", "recurrence.hip", "featnet.hip", "msred.hip"]
 ARCH = "gfx950"
 # Per-source flags.  slice_red.hip: the IR load/store vectorizer fuses the three horizontally adjacent taps of an
 # MFMA B-fragment into one ds_read_b96 at a 4-byte-aligned address; gfx950 executes those with "unaligned" stalls

@@ -120,9 +120,6 @@ bool wino_softmax_fused();
 size_t wino_softmax_part_floats(int N, int D, int h, int w);
 int launch_conv_wino_softmax(const float* in, const float* wpk, const float* bias, float* part, const PlaneSrc& planes, float* vw, float* pd,
                              int N, int B, int D, int n_planes, int h, int w, hipStream_t st);
-// the same layer in the form F(2x4, 3x3) (costreg2d_wino24.hip): an op-level entry point and a measurement, not part of the network path
-int launch_conv_wino24(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
-                       int relu, hipStream_t st);
 int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
                      int relu, hipStream_t st);
 

@@ -345,16 +345,6 @@ def conv3x3_dd_wino(x_cl, wino_layer, bias, skip, N, D, h, w, relu, out=None):
     return out
 
 
-def conv3x3_dd_wino24(x_cl, wino_layer, bias, skip, N, D, h, w, relu, out=None):
-    """A stride-1 CostRegNet2D layer in the F(2x4, 3x3) form; wino_layer from packing.pack_reg_layer_wino24."""
-    if out is None:
-        out = torch.empty(N, h * w, D, device=x_cl.device, dtype=torch.float32)
-    null = ctypes.c_void_p(0)
-    check(_lib.load().adamvs_conv3x3_dd_wino24(_p(_dev(x_cl, "x")), _p(wino_layer), _p(bias), _p(skip) if skip is not None else null,
-                                               _p(out), N, D, h, w, int(relu), _stream()), "conv3x3_dd_wino24")
-    return out
-
-
 def conv3x3_dd(x_cl, wpk_layer, bias, skip, N, D, hi, wi, mode, relu, out=None, precision=0, in2=None):
     """One CostRegNet2D layer on channel-last maps (mode 0 stride 1, 1 stride 2, 2 transposed stride 2).
     skip: added to the output after the ReLU; in2: added to the input (the layer convolves x_cl + in2; fp32 only)."""

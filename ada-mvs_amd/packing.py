@@ -145,23 +145,6 @@ def pack_reg_layer_wino(w, scale):
     return u.reshape(4, 4, d // 16, 16, d // 4, 4).permute(4, 0, 2, 5, 3, 1).contiguous().reshape(-1)
 
 
-WINO_G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
-                        [0, 0, 1]], dtype=torch.float64)
-
-
-def pack_reg_layer_wino24(w, scale):
-    """A stride-1 CostRegNet2D layer for the F(2x4, 3x3) kernel (csrc/costreg2d_wino24.hip): U = G w G4^T, patch rows i by F(2, 3),
-    patch columns j by F(4, 3), formed in double precision and rounded once; A fragments [D/4][4 = i][D/16][64][4 = j 0..3]
-    followed by [D/4][4][D/16][64][2 = j 4, 5] (include/adamvs_hip.h)."""
-    w = (w.detach().to(torch.float64).cpu() * scale.detach().to(torch.float64).cpu().reshape(-1, 1, 1, 1))   # [co][ci][3][3]
-    d = w.shape[0]
-    assert w.shape[1] == d and d % 16 == 0
-    u = torch.einsum("ik,ockl,jl->ijoc", WINO_G, w, WINO_G4).to(torch.float32)                              # [i 4][j 6][co][ci]
-    # (i, j, tile, co16, kc, k4) -> (kc, i, tile, k4, co16, j): lane = k4*16 + co16
-    f = u.reshape(4, 6, d // 16, 16, d // 4, 4).permute(4, 0, 2, 5, 3, 1).contiguous()
-    return torch.cat([f[..., :4].reshape(-1), f[..., 4:].reshape(-1)])
-
-
 def pack_reg_layer_bf16x3(w, scale, shift, transposed):
     """One CostRegNet2D layer for the split-bf16 kernels: 9*D*D floats worth of bf16 fragments
     [hi|lo][tap][cin/32][cout/16][lane][8] (include/adamvs_hip.h) + [D] fp32 bias; same size as the fp32 packing."""

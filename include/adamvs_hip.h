@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 13
+#define ADAMVS_ABI_VERSION 14
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -127,15 +127,6 @@ int adamvs_conv3x3_dd(const float* in, const float* in2, const float* wpk, const
  * bias, relu as above. */
 int adamvs_conv3x3_dd_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
                            int h, int w, int relu, void* stream);
-
-/* The same layer in the form F(2x4, 3x3): rows of the 4 x 6 input patch by F(2, 3) as above, columns by F(4, 3) (G4 = [1/4 0 0;
- * -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]): 24 products per 2x4 output tile and channel pair.
- * wpk = [D/4][4][D/16][64][4] (patch columns j = 0..3) followed by [D/4][4][D/16][64][2] (j = 4, 5), U = G w G4^T, element
- * order as above.  Rounding: ~2 x that of the direct kernel (the column transform multiplies by 4, 5 and 8).  A third fewer
- * products than F(2x2, 3x3) for 3.5 % less time at cfg2's stage-1 shape: adamvs_cost_reg_net_2d does not
- * use it; the entry point is kept with its tests as the measurement (ABI 13). */
-int adamvs_conv3x3_dd_wino24(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D,
-                             int h, int w, int relu, void* stream);
 
 /* models/adamvs.py:481-486 + module.py:617-625: softmax over D, its maximum (view
  * weight) and the expectation of the hypothesis planes (pair depth).

@@ -255,33 +255,6 @@ def test_conv3x3_dd_winograd(hip, N, D, h, w, relu, skip):
     assert rel_l1(back(out), back(direct)) < 2e-6
 
 
-@pytest.mark.parametrize("N,D,h,w,relu,skip", [(1, 192, 4, 64, 1, False), (2, 192, 13, 45, 0, False), (2, 192, 7, 70, 1, True),
-                                               (1, 192, 1, 1, 1, False), (1, 64, 8, 130, 1, False), (1, 128, 13, 33, 0, True),
-                                               (1, 256, 6, 32, 0, False), (1, 384, 5, 66, 1, False), (3, 192, 24, 192, 1, False),
-                                               (12, 192, 30, 128, 1, False), (40, 64, 24, 64, 0, True)])
-def test_conv3x3_dd_winograd_2x4(hip, N, D, h, w, relu, skip):
-    """The same layer in the F(2x4, 3x3) form (csrc/costreg2d_wino24.hip: the wide levels of the hourglass) against a float64
-    convolution and the direct kernel: full and ragged blocks of 4 x 64 pixels, a map smaller than a block, every supported
-    width, more tiles than the persistent grid has workgroups (the last three cases: 324, 576, 240 x 1 tiles)."""
-    from ada_mvs_amd import packing
-    g = torch.Generator().manual_seed(N * 1000 + D + h + w)
-    x = torch.randn(N, D, h, w, generator=g)
-    wt = torch.randn(D, D, 3, 3, generator=g) / (3 * D ** 0.5)
-    scale, shift = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
-    sk = torch.randn(N, h * w, D, generator=g) if skip else None
-    ref = torch.nn.functional.conv2d(x.double(), (wt * scale.reshape(-1, 1, 1, 1)).double(), shift.double(), padding=1)
-    ref = torch.relu(ref) if relu else ref
-    if skip:
-        ref = ref + sk.double().reshape(N, h, w, D).permute(0, 3, 1, 2)
-    x_cl = dev(x.permute(0, 2, 3, 1).reshape(N, h * w, D).contiguous())
-    pk = dev(packing.pack_reg_layer(wt, scale, shift, False))
-    out = hip.conv3x3_dd_wino24(x_cl, dev(packing.pack_reg_layer_wino24(wt, scale)), dev(shift), dev(sk) if skip else None, N, D, h, w, relu)
-    direct = hip.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], dev(sk) if skip else None, N, D, h, w, 0, relu)
-    back = lambda y: y.cpu().double().reshape(N, h, w, D).permute(0, 3, 1, 2)
-    assert rel_l1(back(out), ref) < 3e-6                    # the column transform's factors 4, 5, 8: about twice F(2x2, 3x3)'s error
-    assert rel_l1(back(out), back(direct)) < 3e-6
-
-
 def test_winograd_one_and_two_workgroups_per_cu_give_the_same_bits(hip, tmp_path):
     """csrc/costreg2d_wino.hip has a 6 x 32-pixel form (one workgroup per CU) and a 4 x 32 form (two); launch_conv_wino picks by map
     size.  ADAMVS_WINO_WPS (read once per process) forces one: the same layer in two child processes, bit for bit."""

@@ -144,40 +144,6 @@ def test_winograd_packing_evaluates_the_convolution():
     assert packing.pack_cost_reg_net_2d(sd, "", "bf16x3").numel() == 11 * (9 * 64 * 64 + 64)
 
 
-def test_winograd_2x4_packing_evaluates_the_convolution():
-    """pack_reg_layer_wino24: U = G w G4^T in the two-array fragment order of include/adamvs_hip.h; Y = At2[(U . V)]A4 with
-    V = Bt2 d B4 from the PACKED arrays reproduces the 3x3 convolution (the arithmetic of csrc/costreg2d_wino24.hip, on the CPU)."""
-    D, h, w = 64, 6, 8
-    g = torch.Generator().manual_seed(6)
-    wt = torch.randn(D, D, 3, 3, generator=g, dtype=torch.float64)
-    scale = torch.rand(D, generator=g, dtype=torch.float64) + 0.5
-    x = torch.randn(1, D, h, w, generator=g, dtype=torch.float64)
-    pk = packing.pack_reg_layer_wino24(wt.float(), scale.float())
-    assert pk.numel() == 24 * D * D
-    lo = pk[:16 * D * D].reshape(D // 4, 4, D // 16, 64, 4).double()      # [kc][i][tile][lane][j 0..3]
-    hi = pk[16 * D * D:].reshape(D // 4, 4, D // 16, 64, 2).double()      # [kc][i][tile][lane][j 4, 5]
-    frag = torch.cat([lo, hi], dim=-1)
-    u = torch.zeros(4, 6, D, D, dtype=torch.float64)                        # [i][j][co][ci]
-    for lane in range(64):
-        co16, k4 = lane & 15, lane >> 4
-        u[:, :, co16::16, k4::4] = frag[:, :, :, lane, :].permute(1, 3, 2, 0)
-    Bt2 = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
-    At2 = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
-    Bt4 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
-                        [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
-    At4 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
-    xp = torch.nn.functional.pad(x[0], (1, 1, 1, 1))
-    out = torch.zeros(D, h, w, dtype=torch.float64)
-    for ty in range(h // 2):
-        for tx in range(w // 4):
-            d = xp[:, 2 * ty:2 * ty + 4, 4 * tx:4 * tx + 6]                 # [ci][4][6]
-            v = torch.einsum("ik,ckl,jl->ijc", Bt2, d, Bt4)
-            m = torch.einsum("ijoc,ijc->ijo", u, v)
-            out[:, 2 * ty:2 * ty + 2, 4 * tx:4 * tx + 4] = torch.einsum("ai,ijo,bj->oab", At2, m, At4)
-    ref = torch.nn.functional.conv2d(x, wt * scale.reshape(-1, 1, 1, 1), padding=1)[0]
-    assert float((out - ref).abs().max() / ref.abs().max()) < 2e-6         # U is rounded to fp32 once
-
-
 def test_packed_network_sizes_match_the_header():
     m = Infer_AdaMVSNet(48, [48, 32, 8], [4, 2, 1], False, [8, 8, 8])
     sd = synth.seeded_state_dict(m, 0)

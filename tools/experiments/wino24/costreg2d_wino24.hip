@@ -14,7 +14,7 @@
 // (32 B per CU and clock).  With four rows of six positions the wave keeps 6 x MT 4 x NT 2 = 48 accumulator tiles -- the
 // 192 registers of the F(2x2, 3x3) kernel -- and the same 48 MFMAs per k-step, for 4 x 64 instead of 6 x 32 output pixels.
 // Rounding: the column transform has the factors 4, 5, 8 and 1/24: 9e-7 relative L1 against a float64 convolution at
-// D = 192 where the direct kernel has 6e-7 and F(2x2, 3x3) 4e-7 (tools/wino_bench.py, tests/test_hip_parity.py::test_conv3x3_dd_winograd_2x4).
+// D = 192 where the direct kernel has 6e-7 and F(2x2, 3x3) 4e-7 (tools/wino_bench.py, tools/experiments/wino24/wino24.py --check-gpu).
 //
 // OUTCOME (round 4): a third fewer MFMAs, 3.5 % less time.  512 maps of 96 x 192 pixels at D = 192: 23.3 ms against 24.1 for
 // F(2x2, 3x3) -- 57 % of the fp32 matrix rate against 73 %; slower on every smaller level of the hourglass (48x96: 7.4 against
@@ -334,7 +334,7 @@ static int launch_wino24_cfg(const Wino24Args& a, int N, hipStream_t st) {
 int launch_conv_wino24(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
                        int relu, hipStream_t st) {
   const Wino24Args a{in, wpk, bias, skip, out, D, h, w, relu};
-  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino24: D=%d unsupported (a multiple of 64 up to 384)", D);
+  ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino24: D=%d unsupported (a multiple of 64 up to 512)", D);
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino24: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
   return launch_wino24_cfg<4, 2>(a, N, st);
 }

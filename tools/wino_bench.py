@@ -18,6 +18,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ada_mvs_amd  # noqa: E402,F401
 from ada_mvs_amd import hip_ops, packing  # noqa: E402
 
+# the F(2x4, 3x3) form lives outside the product library (tools/experiments/wino24: `wino24.py --build` first); without it the
+# third column is skipped
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments", "wino24"))
+try:
+    import wino24  # noqa: E402
+    HAVE24 = os.path.exists(wino24.LIB)
+except Exception:          # noqa: BLE001
+    wino24, HAVE24 = None, False
+
 dev = "cuda"
 
 
@@ -35,7 +44,7 @@ def accuracy(N, D, h, w, relu=1, skip=False):
     pk = packing.pack_reg_layer(wt, scale, b, False).to(dev)
     yd = hip_ops.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], sk, N, D, h, w, 0, relu)
     yw = hip_ops.conv3x3_dd_wino(x_cl, packing.pack_reg_layer_wino(wt, scale).to(dev), b.to(dev), sk, N, D, h, w, relu)
-    y4 = hip_ops.conv3x3_dd_wino24(x_cl, packing.pack_reg_layer_wino24(wt, scale).to(dev), b.to(dev), sk, N, D, h, w, relu)
+    y4 = wino24.conv3x3_dd_wino24(x_cl, wino24.pack_reg_layer_wino24(wt, scale).to(dev), b.to(dev), sk, N, D, h, w, relu) if HAVE24 else yw
     torch.cuda.synchronize()
     back = lambda y: y.cpu().double().reshape(N, h, w, D).permute(0, 3, 1, 2)
     rel = lambda y: (back(y) - ref).abs().mean().item() / ref.abs().mean().item()
@@ -49,12 +58,14 @@ def timing(N, D, h, w, reps=5):
     b = torch.randn(D) * 0.1
     pk = packing.pack_reg_layer(wt, torch.ones(D), b, False).to(dev)
     pw, bias = packing.pack_reg_layer_wino(wt, torch.ones(D)).to(dev), b.to(dev)
-    pw4 = packing.pack_reg_layer_wino24(wt, torch.ones(D)).to(dev)
+    pw4 = wino24.pack_reg_layer_wino24(wt, torch.ones(D)).to(dev) if HAVE24 else None
     out = torch.empty(N, h * w, D, device=dev)
     flops = 2.0 * 9 * D * D * h * w * N
     for name, fn, executed in (("direct", lambda: hip_ops.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], None, N, D, h, w, 0, 1, out=out), 1.0),
                                ("F(2x2,3x3)", lambda: hip_ops.conv3x3_dd_wino(x_cl, pw, bias, None, N, D, h, w, 1, out=out), 16.0 / 36.0),
-                               ("F(2x4,3x3)", lambda: hip_ops.conv3x3_dd_wino24(x_cl, pw4, bias, None, N, D, h, w, 1, out=out), 24.0 / 72.0)):
+                               ("F(2x4,3x3)", (lambda: wino24.conv3x3_dd_wino24(x_cl, pw4, bias, None, N, D, h, w, 1, out=out)) if HAVE24 else None, 24.0 / 72.0)):
+        if fn is None:
+            continue
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
