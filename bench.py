@@ -169,7 +169,7 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 # softmax / max / regression run in the epilogue of the last layer (csrc/costreg_softmax.h), as in the stage
                 fused_sm = os.environ.get("ADAMVS_FUSE_SOFTMAX", "1") != "0"
                 score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w, prec,
-                                              softmax=(planes_t, S, B) if fused_sm else None)
+                                              softmax=(planes_t, S, B, cur) if fused_sm else None)
                 vw_pd = score if fused_sm else mark("s%d.softmax_max_regress" % (s + 1),
                                                     lambda: hip_ops.softmax_max_regress(score, planes_t, S, B, D, h, w))
                 outs[0].copy_(vw_pd[0])
@@ -223,15 +223,20 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=
         in2, pending = pending, (sk if give else None)
         if mode == 0 and wino:          # the stride-1 layers in the F(2x2, 3x3) form, as adamvs_cost_reg_net_2d issues them
             ww = wpk[len(COSTREG_PLAN) * LW:][WINO_SLOT[name] * 16 * D * D:(WINO_SLOT[name] + 1) * 16 * D * D]
+            if name == "prob" and softmax is not None:
+                planes_t, S, B, dv = softmax
+                if os.environ.get("ADAMVS_WINO_SOFTMAX", "1") != "0" and dv.dim() == 2:
+                    # what the step runs: the SM instantiation (per-lane softmax partials in the epilogue, no score volume)
+                    # and k_softmax_merge behind it, timed together
+                    return mark("s%d.costreg.prob+softmax.mode0" % stage,
+                                lambda: hip_ops.prob_softmax_regress_wino(xin, ww, wl[9 * D * D:], dv, S, B, D, hi, wi))
+                score = mark("s%d.costreg.prob.mode0" % stage, lambda: hip_ops.conv3x3_dd_wino(xin, ww, wl[9 * D * D:], None, N, D, hi, wi, relu))
+                return mark("s%d.costreg.softmax.launch" % stage, lambda: hip_ops.softmax_max_regress(score, planes_t, S, B, D, hi, wi))
             acts[name] = (mark("s%d.costreg.%s.mode0" % (stage, name),
                                lambda: hip_ops.conv3x3_dd_wino(xin, ww, wl[9 * D * D:], None, N, D, hi, wi, relu)), hi, wi)
-            if name == "prob" and softmax is not None:          # the scores go through k_softmax_regress (its own launch)
-                planes_t, S, B = softmax
-                return mark("s%d.costreg.softmax.launch" % stage,
-                            lambda: hip_ops.softmax_max_regress(acts["prob"][0], planes_t, S, B, D, hi, wi))
             continue
         if name == "prob" and softmax is not None:
-            planes_t, S, B = softmax
+            planes_t, S, B, _ = softmax
             return mark("s%d.costreg.prob+softmax.mode0" % stage,
                         lambda: hip_ops.prob_softmax_regress(xin, wl, wl[9 * D * D:], planes_t, S, B, D, hi, wi, precision=precision))
         out = mark("s%d.costreg.%s.mode%d" % (stage, name, mode),
@@ -713,6 +718,10 @@ def parity_of(tile0, ref, c, depth_interval):
             "tolerance": 1e-3, "tile": 0, "against": "oracle/adamvs_oracle.py (cpu_baseline run)"}
 
 
+def wino_note(work, args):
+    return winograd_active(work[0]["D"], args.precision)
+
+
 def roofline_of(wl, args, ms_per_step):
     """roofline + phase tables of the headline workload: HIP-event timing of the stage run phase by phase through the C ABI."""
     result = {}
@@ -729,10 +738,9 @@ def roofline_of(wl, args, ms_per_step):
     layers = {k.split(".costreg.")[1]: round(v, 4) for k, v in avg.items() if ".costreg." in k}
     if layers:
         result["cost_reg_layers_ms"] = layers          # one launch each: <layer>.mode<0 s1 | 1 s2 | 2 transposed>
-        if "softmax.launch" in layers and os.environ.get("ADAMVS_WINO_SOFTMAX", "1") != "0":
-            result["cost_reg_layers_note"] = ("prob.mode0 and softmax.launch are the two ops timed one by one; the step runs them as one "
-                                              "(adamvs_prob_softmax_regress_wino: softmax partials in the layer's epilogue + a merge kernel, "
-                                              "no score volume), which the cost_reg_net_2d phase time contains")
+        if "prob+softmax.mode0" in layers and wino_note(work, args):
+            result["cost_reg_layers_note"] = ("prob+softmax.mode0 = adamvs_prob_softmax_regress_wino, as the step runs it: k_conv_wino<..., SM> "
+                                              "(softmax partials in the layer's epilogue, no score volume) + k_softmax_merge, timed together")
     dom = max(phases, key=phases.get)
     st = work[int(dom[1]) - 1]
     kind = dom.split(".", 1)[1]
@@ -749,8 +757,11 @@ def roofline_of(wl, args, ms_per_step):
         def on_dominant_kernel(layer):
             # the fp32 path sends stride-1 layers of at most 2048 blocks of 8 x 16 pixels to the 2-row kernel
             # k_conv_dd_rows2 (csrc/costreg2d.hip: small_grid_rows2); those launches are not the dominant kernel's
-            if layer == "prob+softmax":          # the last layer's own instantiation (softmax epilogue): timed, not part of this kernel's launches
-                return False
+            if layer == "prob+softmax":
+                # F(2x2, 3x3): `prob` is the SM instantiation of the same kernel family (softmax partials in its epilogue) with
+                # k_softmax_merge (0.4 ms) behind it -- timed together and counted: the fraction is what the step runs, slightly
+                # pessimistic.  Direct kernels: the last layer's own instantiation, not part of this kernel's launches.
+                return wino
             if split or wino:
                 return True
             e = os.environ.get("ADAMVS_CONV_ROWS2", "")
