@@ -22,6 +22,7 @@ struct FuseWeights {          // mirrors adamvs_fuse_weights in include/adamvs_h
   const float* gates1_w; const float* gates2_w; const float* cand2_w; const float* cand1_w;
 };
 int gru_wino_mask();          // which GRU convolutions run in the F(2x2, 3x3) form in one-role launches (slice_red.hip)
+int gru_fused_mask();         // which ConvGRU levels run as one launch with the F(2x2, 3x3) gates inside (slice_roles_fwino.h)
 
 struct StepBuffers {          // all channel-last
   float* h1; float* rh1; float* u1;              // [B][hw][8]

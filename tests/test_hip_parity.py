@@ -1268,3 +1268,67 @@ def test_minimal_filtering_roles_on_ragged_stage_sizes(hip, O, monkeypatch, recu
     for key in ("depth", "photometric_confidence"):
         assert got[key].shape == ref[key].shape
         assert rel_l1(got[key], ref[key]) < E2E_TOL, (key, stage, h, w, recur)
+
+
+# --------------------------------------------------------------------------- level 1 as one launch: F(2x2, 3x3) gates inside, strip walk
+@pytest.mark.parametrize("seg", ["", "1", "2", "5"])
+@pytest.mark.parametrize("stage,h,w,B", [(1, 22, 38, 2), (2, 26, 50, 2), (0, 8, 40, 2), (1, 4, 6, 1), (2, 70, 34, 3), (2, 96, 64, 5)])
+def test_fused_level_one_with_minimal_filtering_gates(hip, O, monkeypatch, tmp_path, seg, stage, h, w, B):
+    """Gru1WinoFusedRole (csrc/slice_roles_fwino.h; reference models/module.py:24-52): gates in the F(2x2, 3x3) form on the tile and
+    a ring, r * h and u in LDS, candidate in the two-row form, a workgroup walking `seg` vertically adjacent tiles and handing each
+    tile's last gate rows to the next -- on maps no tile divides (8 x 30 tiles: ragged rows, ragged columns, a map smaller than a
+    tile), segments of 1 (no hand-over), 2, 5 tiles and the launcher's own choice, more work items than workgroups.  Against the CPU
+    oracle, and bit for bit against the two kernels it replaces (the same chains in the same order)."""
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    V, D = 3, 34
+    m = Infer_AdaMVSNet(48, [48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    sd = synth.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    net = m.DepthNet[stage]
+    C = (32, 16, 8)[stage]
+    feats = [synth.smooth_features(B, C, h, w, seed=60 + v) for v in range(V)]
+    proj = synth.rig_projections(V, 4 * h, 4 * w, batch=B)["stage1"]
+    g = torch.Generator().manual_seed(9)
+    near = 420.0 + 20.0 * torch.rand(B, 1, h, w, generator=g)
+    D_ = 48 if stage == 0 else D
+    planes = (near + 4.0 * torch.arange(D_, dtype=torch.float32).view(1, D_, 1, 1)).contiguous()
+    prev = None if stage == 0 else [torch.rand(B, 1, h // 2, w // 2, generator=g) for _ in range(V - 1)]
+    monkeypatch.setenv("ADAMVS_RECUR_MODE", "0")
+    monkeypatch.setenv("ADAMVS_GRU_WINO", "7")
+
+    def run(fused):
+        monkeypatch.setenv("ADAMVS_GRU_FUSED", fused)
+        with torch.no_grad():
+            return net([dev(f) for f in feats], dev(proj), dev(planes), D_, None if prev is None else [dev(c) for c in prev])
+    if seg:          # ADAMVS_GRU1_SEG is read once per process: a child for the forced segment lengths
+        import subprocess
+        code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import ada_mvs_amd; from ada_mvs_amd import hip_ops, synth\n"
+                "from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet\n"
+                "B, h, w, stage, V = %d, %d, %d, %d, 3\n"
+                "m = Infer_AdaMVSNet(48, [48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8]); m.load_state_dict(synth.seeded_state_dict(m, seed=0)); m = m.cuda().eval()\n"
+                "net = m.DepthNet[stage]; fuse = net.reg_fuse.packed(torch.device('cuda:0'))\n"
+                "g = torch.Generator().manual_seed(4)\n"
+                "c1 = torch.randn(B, h * w, net.reg_fuse.in_channels, generator=g).cuda(); s1 = torch.randn(B, h * w, 8, generator=g).cuda() * 0.5\n"
+                "s2 = torch.randn(B, (h // 2) * (w // 2), 16, generator=g).cuda() * 0.5\n"
+                "r = hip_ops.slice_reg_step(c1, s1, s2, fuse, B, net.reg_fuse.in_channels, h, w, net.in_up, 0)\n"
+                "torch.cuda.synchronize(); torch.save([t.cpu() for t in (r, s1, s2)], sys.argv[1])\n" % (ROOT, os.path.join(ROOT, "tests"), B, h, w, stage))
+        outs = []
+        for fused, s_ in (("0", ""), ("1", seg)):
+            f = str(tmp_path / ("o%s.pt" % fused))
+            env = dict(os.environ, ADAMVS_GRU_FUSED=fused, ADAMVS_GRU_WINO="7")
+            if s_:
+                env["ADAMVS_GRU1_SEG"] = s_
+            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, cwd=ROOT)
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs.append(torch.load(f))
+        for a_, b_ in zip(*outs):
+            assert torch.equal(a_, b_) and bool(torch.isfinite(a_).all())
+        return
+    got, two = run("1"), run("0")
+    with torch.no_grad():
+        ref = O.infer_depth_stage(feats, proj, planes, sd, "DepthNet.%d." % stage, net.in_up, prev)
+    for key in ("depth", "photometric_confidence"):
+        assert got[key].shape == ref[key].shape
+        assert rel_l1(got[key], ref[key]) < E2E_TOL, (key, stage, h, w)
+        assert torch.equal(got[key], two[key]), key

@@ -492,7 +492,10 @@ def test_end_to_end_at_the_benchmark_shape_against_oracle(recipe):
     except OSError:
         pass
     for k, (e32, e64, o) in rows.items():
-        if k.endswith("depth"):
+        if k.endswith("depth") and recipe == "default":
             assert e32 < 1e-3 and e64 < 1e-3, (k, e32, e64)  # the bar, against the reference's fp32 and against exact arithmetic
+        # ("sharp": the reference's OWN fp32 arithmetic is 1.4e-3 / 4.2e-3 from float64 on the stage-2 / 3 depth maps and 0.19 on the last
+        #  confidence map -- measured in round 5, profiles/r05_parity_msrednet_full_size_sharp.json: the network, not the recipe, is
+        #  ill-conditioned, the more so the larger the logits; what can be held there is the relative statement below)
         assert e64 <= 1.05 * o, (k, e64, o)                  # no farther from exact arithmetic than the reference's fp32 evaluation is
         assert e32 < 2.0 * o + 1e-4, (k, e32, o)             # and from the reference no farther than two such distances
