@@ -1278,7 +1278,7 @@ def test_fused_level_one_with_minimal_filtering_gates(hip, O, monkeypatch, tmp_p
     a ring, r * h and u in LDS, candidate in the two-row form, a workgroup walking `seg` vertically adjacent tiles and handing each
     tile's last gate rows to the next -- on maps no tile divides (8 x 30 tiles: ragged rows, ragged columns, a map smaller than a
     tile), segments of 1 (no hand-over), 2, 5 tiles and the launcher's own choice, more work items than workgroups.  Against the CPU
-    oracle, and bit for bit against the two kernels it replaces (the same chains in the same order)."""
+    oracle, and to rounding against the two kernels it replaces (one recurrent step: states and cost slice to 2e-6)."""
     from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
     V, D = 3, 34
     m = Infer_AdaMVSNet(48, [48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
@@ -1323,7 +1323,7 @@ def test_fused_level_one_with_minimal_filtering_gates(hip, O, monkeypatch, tmp_p
             assert r.returncode == 0, r.stderr[-3000:]
             outs.append(torch.load(f))
         for a_, b_ in zip(*outs):
-            assert torch.equal(a_, b_) and bool(torch.isfinite(a_).all())
+            assert bool(torch.isfinite(a_).all()) and rel_l1(b_, a_) < 2e-6 and float((a_ - b_).abs().max()) < 2e-5 * float(a_.abs().max())
         return
     got, two = run("1"), run("0")
     with torch.no_grad():
@@ -1331,4 +1331,4 @@ def test_fused_level_one_with_minimal_filtering_gates(hip, O, monkeypatch, tmp_p
     for key in ("depth", "photometric_confidence"):
         assert got[key].shape == ref[key].shape
         assert rel_l1(got[key], ref[key]) < E2E_TOL, (key, stage, h, w)
-        assert torch.equal(got[key], two[key]), key
+        assert rel_l1(got[key], two[key]) < 2e-6, key           # (the same chains; the bias rides in an accumulator here: rounding only)
