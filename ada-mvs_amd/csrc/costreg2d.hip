@@ -533,6 +533,159 @@ __device__ __forceinline__ void conv_dd_t2_fused(const ConvDDArgs& a, float* lds
     }
 }
 
+// Stride-2 layer (conv1, conv3, conv5 of the hourglass: reference models/adamvs.py:206-211, 229-232) with the minimal-filtering
+// form of its polyphase decomposition along x: two neighbouring outputs of a row share the input column between them,
+//     out[2m]     = W0 c[4m]   + W1 c[4m+1] + W2 c[4m+2]
+//     out[2m + 1] = W0 c[4m+2] + W1 c[4m+3] + W2 c[4m+4]            (c = the window row, W = the three taps of one kernel row)
+// and the two-tap filter (W0, W2) over the even columns costs three products per two outputs instead of four:
+//     A0 = W1 c[4m+1] + W0 (c[4m] - c[4m+2]);  A1 = W1 c[4m+3] + W2 (c[4m+4] - c[4m+2]);  A2 = (W0 + W2) c[4m+2]
+//     out[2m] = A0 + A2,  out[2m + 1] = A1 + A2
+// -- five MFMAs per (kernel row, 4 input channels, channel tile, output row) for 32 output pixels where the direct form issues six
+// (15 / 18 of the layer's products; the same along y would give 25 / 36 but needs nine accumulator sets).  The columns of an MFMA are
+// 16 output PAIRS; a lane reads its five window values as one 16-byte and one 4-byte LDS read (row pitch 68: aligned), forms the
+// two differences (2 vector instructions per 15 MFMAs) and W0 + W2 once per chunk from the fragments it streams anyway (9 adds):
+// the blob keeps its nine taps.  Block = 3 output rows x 32 columns x all channels: three accumulator sets of 3 x 3 tiles = 108
+// registers, two waves per SIMD as in conv_dd_body; one k-step per chunk, chunks double-buffered the same way.
+constexpr int S2P_ROWS = 3;      // output rows per block (4: 144 accumulator registers next to 63 of fragments: spills; the hourglass's 48 / 24 / 12 rows divide by 3)
+template <int MT, int WM>
+__device__ __forceinline__ void conv_dd_s2_pairs(const ConvDDArgs& a, float* lds, int n, int by, int bx) {
+  static_assert(WM == 4, "every wave takes all rows of the block");
+  constexpr int BR = S2P_ROWS, LR = 2 * BR + 1, WCOLS = 65, LC = 68, PLANE = ((LR * LC + 31) / 32) * 32 + 16;
+  constexpr int NITEMS = LR * WCOLS, NITA = (NITEMS + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wm = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave = channel slice
+  const int p = lane & 15, q = lane >> 4;
+  const int D = a.D, KCT = D / 4, NTILES = D / 16;
+  const int r0 = by * BR, c0 = bx * 32;
+  const int iy0 = 2 * r0 - 1, ix0 = 2 * c0 - 1;
+
+  const buf_rsrc rx = make_rsrc((const char*)a.in + (((long)n * a.hi + iy0) * a.wi + ix0) * (long)D * 4);
+  unsigned xoff[NITA], xlds[NITA];
+#pragma unroll
+  for (int it = 0; it < NITA; ++it) {
+    const int i = min(tid + it * 256, NITEMS - 1);           // surplus lanes repeat the last item
+    const int r = i / WCOLS, c = i % WCOLS;
+    const bool ok = (unsigned)(iy0 + r) < (unsigned)a.hi && (unsigned)(ix0 + c) < (unsigned)a.wi;
+    xoff[it] = ok ? (unsigned)(((r * a.wi + c) * D) * 4) : BUF_OOB;
+    xlds[it] = (unsigned)((r * LC + c) * 4);
+    pin(xoff[it]); pin(xlds[it]);
+  }
+  const buf_rsrc rw = make_rsrc(a.wpk);
+  unsigned woff = (unsigned)(lane * 4);
+  pin(woff);
+  unsigned xb = (unsigned)((q * PLANE + 4 * p) * 4);           // the lane's k-row and first window column of its pair
+  pin(xb);
+
+  f32x4 acc[3][MT][BR];                                        // A0 | A1 | A2
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < BR; ++r) acc[t][mt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_w = [&](float (&wf)[9][MT], int ch) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned frag = (unsigned)((t * KCT + ch / 4) * NTILES + wm * MT + mt) * 256u;   // uniform
+        wf[t][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, frag, 0));
+      }
+  };
+  auto load_x = [&](f32x4 (&st)[NITA], int ch) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it)
+      st[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[it], (unsigned)ch * 4u, 0));
+  };
+  auto store_x = [&](const f32x4 (&st)[NITA]) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+      float* dl = (float*)((char*)lds + xlds[it]);
+      dl[0] = st[it].x; dl[PLANE] = st[it].y; dl[2 * PLANE] = st[it].z; dl[3 * PLANE] = st[it].w;
+    }
+  };
+  auto mfma_chunk = [&](const float (&wf)[9][MT]) {
+    float w02[3][MT];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) w02[ky][mt] = wf[ky * 3 + 0][mt] + wf[ky * 3 + 2][mt];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int r = 0; r < BR; ++r) {
+        const char* row = (const char*)lds + xb + ((2 * r + ky) * LC) * 4;
+        const f32x4 c = *(const f32x4*)row;
+        const float c4 = *(const float*)(row + 16);
+        const float d0 = c.x - c.z, d1 = c4 - c.z;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[0][mt][r] = mfma16(wf[ky * 3 + 1][mt], c.y, acc[0][mt][r]);
+          acc[0][mt][r] = mfma16(wf[ky * 3 + 0][mt], d0, acc[0][mt][r]);
+          acc[1][mt][r] = mfma16(wf[ky * 3 + 1][mt], c.w, acc[1][mt][r]);
+          acc[1][mt][r] = mfma16(wf[ky * 3 + 2][mt], d1, acc[1][mt][r]);
+          acc[2][mt][r] = mfma16(w02[ky][mt], c.z, acc[2][mt][r]);
+        }
+      }
+  };
+
+  float wfA[9][MT], wfB[9][MT];
+  f32x4 xs[NITA];
+  load_w(wfA, 0);
+  load_x(xs, 0);
+  for (int ch = 0; ch < D; ch += 8) {            // two chunks of 4 input channels per trip (D / 4 is even for every supported D)
+    wait_vmem_all();
+    __syncthreads();                    // previous chunk's readers are done
+    store_x(xs);
+    __syncthreads();
+    load_w(wfB, ch + 4);
+    load_x(xs, ch + 4);
+    mfma_chunk(wfA);
+
+    wait_vmem_all();
+    __syncthreads();
+    store_x(xs);
+    __syncthreads();
+    if (ch + 8 < D) {
+      load_w(wfA, ch + 8);
+      load_x(xs, ch + 8);
+    }
+    mfma_chunk(wfB);
+  }
+  // epilogue: lane owns channels co4 .. co4 + 3 of the output pair (c0 + 2 p, c0 + 2 p + 1) of every row
+#pragma unroll
+  for (int r = 0; r < BR; ++r) {
+    const int oy = r0 + r, ox = c0 + 2 * p;
+    if (oy >= a.ho || ox >= a.wo) continue;
+    const size_t opix = ((size_t)n * a.ho + oy) * a.wo + ox;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co4 = (wm * MT + mt) * 16 + 4 * q;
+      const f32x4 b = *(const f32x4*)(a.bias + co4);
+      f32x4 v0 = (acc[0][mt][r] + acc[2][mt][r]) + b, v1 = (acc[1][mt][r] + acc[2][mt][r]) + b;
+      if (a.relu) {
+        v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+        v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+      }
+      *(f32x4*)(a.out + opix * D + co4) = v0;
+      if (ox + 1 < a.wo) *(f32x4*)(a.out + (opix + 1) * D + co4) = v1;
+    }
+  }
+}
+
+// grid: (ceil(wo/32), ceil(ho/S2P_ROWS), N); block 256
+template <int MT, int WM>
+__global__ __launch_bounds__(256, 2) void k_conv_dd_s2p(ConvDDArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * ((((2 * S2P_ROWS + 1) * 68 + 31) / 32) * 32 + 16)];
+  conv_dd_s2_pairs<MT, WM>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
+}
+
+// ADAMVS_S2_PAIRS=0: the stride-2 layers on the direct kernel, as in rounds 1-4 (A/B)
+static bool s2_pairs() {
+  static const bool on = [] { const char* e = getenv("ADAMVS_S2_PAIRS"); return !(e && *e == '0'); }();
+  return on;
+}
+
 // grid: (ceil(cols/16), ceil(rows/BR), N); block 256; OCC = waves per SIMD the register budget is held to
 template <int MT, int WM, int KB, int BR, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_conv_dd_t2_fused(ConvDDArgs a) {
@@ -617,6 +770,8 @@ static int launch_conv_dd_cfg(const ConvDDArgs& a_, int N, int mode, hipStream_t
     hipLaunchKernelGGL((k_conv_dd_rows2<MT, (WM >= 2 ? WM : 2), CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 2), N), dim3(256), 0, st, a);
   else if (mode == CONV_S1)
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S1, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
+  else if (mode == CONV_S2 && MT == 3 && WM == 4 && !a.skip && !a.in2 && s2_pairs())      // D = 192 (and 384 as two launches): 15 / 18 of the products
+    hipLaunchKernelGGL((k_conv_dd_s2p<MT, (WM == 4 ? 4 : 4)>), dim3(cdiv(a.wo, 32), cdiv(a.ho, S2P_ROWS), N), dim3(256), 0, st, a);
   else if (mode == CONV_S2)
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
   else if (WM >= 2 && t2_fused((long)cdiv(a.wi, 16) * cdiv(a.hi, 8) * N))      // small grids: 2-row blocks, all classes per chunk

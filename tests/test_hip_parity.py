@@ -1332,3 +1332,30 @@ def test_fused_level_one_with_minimal_filtering_gates(hip, O, monkeypatch, tmp_p
         assert got[key].shape == ref[key].shape
         assert rel_l1(got[key], ref[key]) < E2E_TOL, (key, stage, h, w)
         assert rel_l1(got[key], two[key]) < 2e-6, key           # (the same chains; the bias rides in an accumulator here: rounding only)
+
+
+# --------------------------------------------------------------------------- stride-2 layers, minimal filtering along x (adamvs.py:206-211)
+@pytest.mark.parametrize("N,D,h,w,relu", [(2, 192, 24, 64, 1), (1, 192, 14, 66, 1), (3, 192, 10, 38, 0), (1, 192, 2, 2, 1), (1, 384, 12, 70, 1),
+                                          (40, 192, 24, 48, 1)])
+def test_stride_two_layer_in_the_pair_form(hip, monkeypatch, N, D, h, w, relu):
+    """k_conv_dd_s2p (csrc/costreg2d.hip: output pairs of a row share their middle input column; five products per pair, kernel row
+    and channel pair instead of six) against a float64 convolution and against the direct stride-2 kernel: output widths that are
+    no multiple of 32 (33, 19, 35: a ragged pair at the right edge, an odd width), row counts no multiple of the block's 3 (7, 5, 1),
+    a 1 x 1 output, D = 384 (two launches), 40 maps.  ADAMVS_CONV_ROWS2=0 keeps these small maps off the 2-row kernel, which the
+    launcher would otherwise choose for them."""
+    from ada_mvs_amd import packing
+    monkeypatch.setenv("ADAMVS_CONV_ROWS2", "0")
+    g = torch.Generator().manual_seed(N * 100 + D + h + w)
+    x = torch.randn(N, D, h, w, generator=g)
+    wt = torch.randn(D, D, 3, 3, generator=g) / (3 * D ** 0.5)
+    scale, shift = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double(), (wt * scale.reshape(-1, 1, 1, 1)).double(), shift.double(), stride=2, padding=1)
+    ref = torch.relu(ref) if relu else ref
+    ho, wo = ref.shape[-2:]
+    x_cl = dev(x.permute(0, 2, 3, 1).reshape(N, h * w, D).contiguous())
+    pk = dev(packing.pack_reg_layer(wt, scale, shift, False))
+    out = hip.conv3x3_dd(x_cl, pk[:9 * D * D], pk[9 * D * D:], None, N, D, h, w, 1, relu)
+    torch.cuda.synchronize()
+    got = out.cpu().double().reshape(N, ho, wo, D).permute(0, 3, 1, 2)
+    assert rel_l1(got, ref) < 2e-6, rel_l1(got, ref)
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
