@@ -770,7 +770,9 @@ static int launch_conv_dd_cfg(const ConvDDArgs& a_, int N, int mode, hipStream_t
     hipLaunchKernelGGL((k_conv_dd_rows2<MT, (WM >= 2 ? WM : 2), CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 2), N), dim3(256), 0, st, a);
   else if (mode == CONV_S1)
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S1, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);
-  else if (mode == CONV_S2 && MT == 3 && WM == 4 && !a.skip && !a.in2 && s2_pairs())      // D = 192 (and 384 as two launches): 15 / 18 of the products
+  // D = 192 (and 384 as two launches): 15 / 18 of the products.  Blocks are 32 output columns wide: taken where a row divides into
+  // them (cfg2 at 128 tiles: conv1, 48 x 96 outputs, 11.47 -> 10.10 ms; conv3, 24 x 48 -- a block and a half per row -- 2.88 -> 3.31)
+  else if (mode == CONV_S2 && MT == 3 && WM == 4 && !a.skip && !a.in2 && (a.wo % 32 == 0 || a.wo >= 256) && s2_pairs())
     hipLaunchKernelGGL((k_conv_dd_s2p<MT, (WM == 4 ? 4 : 4)>), dim3(cdiv(a.wo, 32), cdiv(a.ho, S2P_ROWS), N), dim3(256), 0, st, a);
   else if (mode == CONV_S2)
     hipLaunchKernelGGL((k_conv_dd<MT, WM, CONV_S2, KB>), dim3(cdiv(a.wo, 16), cdiv(a.ho, 8), N), dim3(256), 0, st, a);

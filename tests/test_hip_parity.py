@@ -1335,13 +1335,13 @@ def test_fused_level_one_with_minimal_filtering_gates(hip, O, monkeypatch, tmp_p
 
 
 # --------------------------------------------------------------------------- stride-2 layers, minimal filtering along x (adamvs.py:206-211)
-@pytest.mark.parametrize("N,D,h,w,relu", [(2, 192, 24, 64, 1), (1, 192, 14, 66, 1), (3, 192, 10, 38, 0), (1, 192, 2, 2, 1), (1, 384, 12, 70, 1),
-                                          (40, 192, 24, 48, 1)])
+@pytest.mark.parametrize("N,D,h,w,relu", [(2, 192, 24, 64, 1), (1, 192, 14, 128, 1), (3, 192, 10, 64, 0), (1, 192, 2, 64, 1), (1, 384, 12, 128, 1),
+                                          (40, 192, 24, 64, 1), (1, 192, 6, 520, 1), (2, 192, 14, 66, 1)])
 def test_stride_two_layer_in_the_pair_form(hip, monkeypatch, N, D, h, w, relu):
     """k_conv_dd_s2p (csrc/costreg2d.hip: output pairs of a row share their middle input column; five products per pair, kernel row
-    and channel pair instead of six) against a float64 convolution and against the direct stride-2 kernel: output widths that are
-    no multiple of 32 (33, 19, 35: a ragged pair at the right edge, an odd width), row counts no multiple of the block's 3 (7, 5, 1),
-    a 1 x 1 output, D = 384 (two launches), 40 maps.  ADAMVS_CONV_ROWS2=0 keeps these small maps off the 2-row kernel, which the
+    and channel pair instead of six) against a float64 convolution : output widths of one, two and four blocks (the launcher takes
+    this form where 32-column blocks divide a row, or from 256 columns: 260 = eight blocks and a ragged one with an odd pair), row counts
+    no multiple of the block's 3 (7, 5, 1), D = 384 (two launches), 40 maps; the last case (33 columns) stays on the direct kernel.  ADAMVS_CONV_ROWS2=0 keeps these small maps off the 2-row kernel, which the
     launcher would otherwise choose for them."""
     from ada_mvs_amd import packing
     monkeypatch.setenv("ADAMVS_CONV_ROWS2", "0")
