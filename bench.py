@@ -545,7 +545,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=list(synth.CONFIGS))
-    ap.add_argument("--batch", type=int, default=128, help="reference tiles per GPU per step (weak scaling: fixed per GPU)")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="reference tiles per GPU per step (weak scaling: fixed per GPU).  256 since round 5: ~104 GB of the 288 GB "
+                         "(measured 607.8 / 612.4 / 615.5 / 621.6 maps/s at 96 / 128 / 192 / 256 on one box)")
     ap.add_argument("--tiles-total", type=int, default=0,
                     help="strong scaling: this many tiles per step over ALL ranks (tile t on rank t mod N), e.g. 32 with "
                          "--workload cfg3 = BASELINE.json configs[3] as stated; overrides --batch")

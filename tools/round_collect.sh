@@ -4,11 +4,11 @@ r=$1
 cd "$(dirname "$0")/.."
 g=gpurun_out/${r}z
 cp ${g}_bench_default.json profiles/${r}_bench_default.json
-cp ${g}_cfg2_b128_kernel_stats.csv profiles/${r}_kernel_stats_cfg2_b128_fp32.csv
-cp ${g}_cfg2_b128_traffic.json profiles/${r}_traffic_cfg2_b128_fp32.json
-cp ${g}_cfg2_b128_traffic.txt profiles/${r}_hbm_traffic_pmc_cfg2_b128_fp32.txt
-cp ${g}_cfg2_b128_sq_counters.txt profiles/${r}_sq_counters_cfg2_b128_fp32.txt
-grep "MFMA pipe busy" ${g}_pmc_cfg2.log > profiles/${r}_mfma_busy_cfg2_b128_fp32.txt
+cp ${g}_cfg2_b256_kernel_stats.csv profiles/${r}_kernel_stats_cfg2_b256_fp32.csv
+cp ${g}_cfg2_b256_traffic.json profiles/${r}_traffic_cfg2_b256_fp32.json
+cp ${g}_cfg2_b256_traffic.txt profiles/${r}_hbm_traffic_pmc_cfg2_b256_fp32.txt
+cp ${g}_cfg2_b256_sq_counters.txt profiles/${r}_sq_counters_cfg2_b256_fp32.txt
+grep "MFMA pipe busy" ${g}_pmc_cfg2.log > profiles/${r}_mfma_busy_cfg2_b256_fp32.txt
 for p in fp32 bf16x3; do
   cp ${g}_cfg3_${p}_b32_kernel_stats.csv profiles/${r}_kernel_stats_cfg3_b32_${p}.csv
   cp ${g}_cfg3_${p}_b32_traffic.json profiles/${r}_traffic_cfg3_b32_${p}.json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The measurement set of a round, on the GPU box:   tools/round_final.sh r03 [quick]
 #   gpurun_out/<r>z_*: GPU test tail, the default bench line (headline + cascade key), kernel stats / stamped traffic / SQ
-#   counters of cfg2 (128 tiles) and cfg3 (32 tiles, both precisions), one bench line per other configuration.
+#   counters of cfg2 (256 tiles: the default batch since round 5) and cfg3 (32 tiles, both precisions), one bench line per other configuration.
 # tools/round_collect.sh <r> copies them to their tracked names under profiles/.   "quick": skip the long tail of bench lines.
 r=$1; quick=$2
 cd "$(dirname "$0")/.."
@@ -9,9 +9,9 @@ mkdir -p gpurun_out
 g=gpurun_out/${r}z
 python -m pytest tests -m gpu -q 2>&1 | tail -4 > ${g}_gpu_tests.txt; cat ${g}_gpu_tests.txt
 # cfg2 (the headline): kernel stats, stamped traffic, SQ counters, then the default bench line that quotes the traffic
-WORKLOAD=cfg2 TILES=128 tools/profile_round.sh ${r}z_cfg2_b128 --workload cfg2 --batch 128 --no-cascade > ${g}_profile_cfg2.log 2>&1
-cp ${g}_cfg2_b128_traffic.json profiles/${r}_traffic_cfg2_b128_fp32.json
-tools/bench_pmc.sh ${r}z_cfg2_b128 --workload cfg2 --batch 128 --no-cascade > ${g}_pmc_cfg2.log 2>&1
+WORKLOAD=cfg2 TILES=256 tools/profile_round.sh ${r}z_cfg2_b256 --workload cfg2 --batch 256 --no-cascade > ${g}_profile_cfg2.log 2>&1
+cp ${g}_cfg2_b256_traffic.json profiles/${r}_traffic_cfg2_b256_fp32.json
+tools/bench_pmc.sh ${r}z_cfg2_b256 --workload cfg2 --batch 256 --no-cascade > ${g}_pmc_cfg2.log 2>&1
 python bench.py > ${g}_bench_default.json 2> ${g}_bench_default.err
 python tools/show_bench.py ${g}_bench_default.json
 # cfg3 at 32 tiles per step, both precisions
