@@ -453,6 +453,187 @@ __global__ __launch_bounds__(256, 3) void k_conv1_ksplit(const float* __restrict
   }
 }
 
+// The same convolution (C = 32) with the minimal-filtering form F(2, 3) ALONG x on top of the two-row form along y (round 5).
+// Two neighbouring outputs of a row need four products per kernel row and channel instead of six:
+//     d = the four window columns under an output pair;  v = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+//     U = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2) of the kernel row's three taps;  m_j = U_j v_j
+//     out[2m] = m0 + m1 + m2,  out[2m + 1] = m1 - m2 - m3
+// so a two-row pass (rows 0-7 of the MFMA tile: the 8 channels of output row y with kernel row rr, rows 8-15: of row y + 1 with
+// kernel row rr - 1) issues 4 MFMAs per input row, 4 input channels and 32 output pixels where k_conv1_ksplit issues 6: 2 MFMAs per
+// pixel instead of 3 (the direct one-row form: 4.5).  The columns of an MFMA are 16 output PAIRS; a lane reads its four window values
+// as two 8-byte LDS reads and forms v with four vector instructions per 4 MFMAs.  U is formed from the streamed two-row fragments when
+// the kernel starts (three adds and two multiplies per fragment triple): the blob keeps its twelve (rr, kx) fragments.
+// Tile 8 x 32; the contraction is split over two wave pairs: wave (kh, rp2) owns input channels 16 kh .. + 15 (64 registers of U) and
+// the row pairs 2 rp2, 2 rp2 + 1, reduces its sixteen sums to the four outputs per row pair BEFORE the partial sums meet in LDS
+// (the output transform is linear), finishes row pair 2 rp2 + kh and hands the other to its partner: fixed order (channels 0-15 first).
+template <int C>
+__global__ __launch_bounds__(256, 2) void k_conv1_f23(const float* __restrict__ src, const float* __restrict__ wpk,
+                                                   float* __restrict__ c1, int h, int w, TileGrid tg) {
+  static_assert(C == 32, "two halves of four k-chunks");
+  typedef float f32x2c __attribute__((ext_vector_type(2)));
+  constexpr int KC = C / 4, G = C / 4, KH = KC / 2, TR = 8, TC = 32, LR = TR + 2, LC = TC + 2, NPIX = LR * LC;
+  constexpr int PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
+  static_assert((PLANE % 2) == 0 && (GP % 2) == 0 && (LC % 2) == 0, "8-byte aligned patch reads");
+  constexpr int NL = (NPIX * G + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];           // tile [G][GP], then partials [4 waves][2][64] float4
+  f32x4* red = (f32x4*)(lds + G * GP);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+  const int p = lane & 15, q = lane >> 4;
+  const int kh = wave & 1, rp2 = wave >> 1;
+  const f32x2c pm = {1.0f, -1.0f};
+
+  float uf[4][4][KH];                                                   // [rr][j][kc]
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int kc = 0; kc < KH; ++kc) {
+      const float g0 = wpk[((rr * 3 + 0) * KC + kh * KH + kc) * 64 + lane], g1 = wpk[((rr * 3 + 1) * KC + kh * KH + kc) * 64 + lane];
+      const float g2 = wpk[((rr * 3 + 2) * KC + kh * KH + kc) * 64 + lane];
+      uf[rr][0][kc] = g0;
+      uf[rr][1][kc] = 0.5f * ((g0 + g2) + g1);
+      uf[rr][2][kc] = 0.5f * ((g0 + g2) - g1);
+      uf[rr][3][kc] = g2;
+    }
+
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int j = min(tid + k * 256, NPIX * G - 1);
+    const int g = j % G, pp = j / G, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * w + c) * C + 4 * g) * 4);
+    lbyte[k] = (unsigned)((g * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]);
+  }
+  // the lane's patch of the wave's first row pair in the wave's first k-chunk: + k-chunk, row pair, input row as immediates
+  unsigned xb = (unsigned)((kh * KH * GP + q * PLANE + (4 * rp2) * LC + 2 * p) * 4);
+  pin(xb);
+  const int mine = 2 * rp2 + kh;                                       // the row pair this wave finishes
+  const int orow = 2 * mine + (q >> 1);                                // lane's output pixels (orow, 2 p), (orow, 2 p + 1), channels 4 (q & 1)..
+  unsigned ooff = (unsigned)(((orow * w + 2 * p) * 8 + 4 * (q & 1)) * 4);
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int n, int tx, int ty) {
+    const int ix0 = tx * TC - 1, iy0 = ty * TR - 1;
+    const buf_rsrc rs = make_rsrc((const char*)src + (((long)n * h + iy0) * w + ix0) * (C * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= h && ix0 + LC <= w) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(rs, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        stage[k] = buf_load4(rs, ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? goff[k] : BUF_OOB);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);               // in flight during the MFMA chains
+    }
+    f32x4 m[2][4];                                  // [the wave's row pair][j]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int kc = 0; kc < KH; ++kc)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const char* at = (const char*)lds + xb + (kc * GP + (2 * a + rr) * LC) * 4;
+          const f32x2c d01 = *(const f32x2c*)at, d23 = *(const f32x2c*)(at + 8);
+          const f32x2c v03 = d01 - d23;                              // (d0 - d2, d1 - d3)
+          // (v1, v2) = (d2 + d1, d2 - d1) as ONE packed FMA on the pairs the reads deliver (op_sel picks d1 twice, d2 twice)
+          const f32x2c v12 = __builtin_elementwise_fma(__builtin_shufflevector(d01, d01, 1, 1), pm, __builtin_shufflevector(d23, d23, 0, 0));
+          m[a][0] = mfma16(uf[rr][0][kc], v03.x, m[a][0]);
+          m[a][1] = mfma16(uf[rr][1][kc], v12.x, m[a][1]);
+          m[a][2] = mfma16(uf[rr][2][kc], v12.y, m[a][2]);
+          m[a][3] = mfma16(uf[rr][3][kc], v03.y, m[a][3]);
+        }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) drain(m[a][j]);
+    // the two outputs of every pair, for both row pairs; the one the partner finishes goes to LDS
+    f32x4 y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      y[a][0] = (m[a][0] + m[a][1]) + m[a][2];
+      y[a][1] = (m[a][1] - m[a][2]) - m[a][3];
+    }
+    red[(wave * 2 + 0) * 64 + lane] = kh ? y[0][0] : y[1][0];      // wave kh = 0 finishes its row pair 0 and hands over row pair 1; kh = 1 the reverse
+    red[(wave * 2 + 1) * 64 + lane] = kh ? y[0][1] : y[1][1];
+
+    wait_vmem_all();
+    __syncthreads();                                // partials visible; every wave is done reading the tile
+    if (more) store_tile(stage);
+
+    const f32x4 p0 = red[((wave ^ 1) * 2 + 0) * 64 + lane], p1 = red[((wave ^ 1) * 2 + 1) * 64 + lane];
+    f32x4 o0 = kh ? p0 + y[1][0] : y[0][0] + p0;    // fixed order: channels 0-15 (kh = 0), then 16-31
+    f32x4 o1 = kh ? p1 + y[1][1] : y[0][1] + p1;
+    const int y0 = ty * TR, x0 = tx * TC;
+    const buf_rsrc ro = make_rsrc((char*)c1 + (((long)n * h + y0) * w + x0) * 32);
+    unsigned oa = ooff, ob = ooff + 32;
+    if (!(y0 + TR <= h && x0 + TC <= w)) {
+      const bool rowok = y0 + orow < h;
+      oa = (rowok && x0 + 2 * p < w) ? ooff : BUF_OOB;
+      ob = (rowok && x0 + 2 * p + 1 < w) ? ooff + 32 : BUF_OOB;
+    }
+    o0.x = fmaxf(o0.x, 0.f); o0.y = fmaxf(o0.y, 0.f); o0.z = fmaxf(o0.z, 0.f); o0.w = fmaxf(o0.w, 0.f);
+    o1.x = fmaxf(o1.x, 0.f); o1.y = fmaxf(o1.y, 0.f); o1.z = fmaxf(o1.z, 0.f); o1.w = fmaxf(o1.w, 0.f);
+    buf_store4(ro, oa, o0);
+    buf_store4(ro, ob, o1);
+    if (!more) break;
+    __syncthreads();                                // next tile visible; partials consumed
+    t = tn; n = nn; tx = txn; ty = tyn;
+  }
+}
+
+// ADAMVS_CONV1_F23=0: conv1 at C = 32 on k_conv1_ksplit, as in rounds 1-4 (A/B)
+static bool conv1_f23() {
+  static const bool on = [] { const char* e = getenv("ADAMVS_CONV1_F23"); return !(e && *e == '0'); }();
+  return on;
+}
+
+static int launch_conv1_f23_32(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
+  constexpr int C = 32;
+  constexpr size_t lds = ((size_t)(C / 4) * group_pitch(plane_pitch16(10 * 34), C / 4) + 4 * 2 * 64 * 4) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "default dynamic LDS limit");
+  auto kern = k_conv1_f23<C>;
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(w_, 32), cdiv(h, 8), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, cost, w, c1, h, w_, tg);
+  ADAMVS_CHECK_LAUNCH("conv1 (F(2,3) along x)");
+  return 0;
+}
+
 static int launch_conv1_ksplit32(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
   constexpr int C = 32;
   constexpr size_t lds = ((size_t)(C / 4) * group_pitch(plane_pitch16(10 * 18), C / 4) + 12 * 64 * 4) * sizeof(float);
@@ -531,7 +712,7 @@ bool conv_pair_epilogue_partials(int B, int h, int w) { return gn_epilogue_parti
 
 int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int precision, hipStream_t st) {
   if (precision == PRECISION_BF16X3) return launch_conv1_bf16x3(cost, w, c1, N, C, h, w_, st);
-  if (C == 32) return launch_conv1_ksplit32(cost, w, c1, N, h, w_, st);
+  if (C == 32) return conv1_f23() ? launch_conv1_f23_32(cost, w, c1, N, h, w_, st) : launch_conv1_ksplit32(cost, w, c1, N, h, w_, st);
   if (C == 16) return launch_conv1_c<16>(cost, w, c1, N, h, w_, st);
   if (C == 8) return launch_conv1_c<8>(cost, w, c1, N, h, w_, st);
   return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
