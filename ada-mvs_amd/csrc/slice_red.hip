@@ -614,10 +614,152 @@ __global__ __launch_bounds__(256, 2) void k_conv1_f23(const float* __restrict__ 
   }
 }
 
-// ADAMVS_CONV1_F23=0: conv1 at C = 32 on k_conv1_ksplit, as in rounds 1-4 (A/B)
-static bool conv1_f23() {
-  static const bool on = [] { const char* e = getenv("ADAMVS_CONV1_F23"); return !(e && *e == '0'); }();
-  return on;
+// The same form for the narrow inputs of stages 2 and 3 (C = 16, 8): no split of the contraction -- wave k owns row pair k of an
+// 8 x 32 tile with all of U in registers (4 rr x 4 j x C/4: 64 / 32), four sums, the output transform in registers.
+template <int C>
+__global__ __launch_bounds__(256) void k_conv1_f23_rows(const float* __restrict__ src, const float* __restrict__ wpk,
+                                                       float* __restrict__ c1, int h, int w, TileGrid tg) {
+  typedef float f32x2c __attribute__((ext_vector_type(2)));
+  constexpr int KC = C / 4, G = C / 4, TR = 8, TC = 32, LR = TR + 2, LC = TC + 2, NPIX = LR * LC;
+  constexpr int PLANE = plane_pitch16(NPIX), GP = (group_pitch(PLANE, G) + 1) & ~1;
+  static_assert((PLANE % 2) == 0 && (GP % 2) == 0 && (LC % 2) == 0, "8-byte aligned patch reads");
+  constexpr int NL = (NPIX * G + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];           // tile [G][GP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = row pair
+  const int p = lane & 15, q = lane >> 4;
+  const f32x2c pm = {1.0f, -1.0f};
+
+  float uf[4][4][KC];                                                   // [rr][j][kc]
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const float g0 = wpk[((rr * 3 + 0) * KC + kc) * 64 + lane], g1 = wpk[((rr * 3 + 1) * KC + kc) * 64 + lane];
+      const float g2 = wpk[((rr * 3 + 2) * KC + kc) * 64 + lane];
+      uf[rr][0][kc] = g0;
+      uf[rr][1][kc] = 0.5f * ((g0 + g2) + g1);
+      uf[rr][2][kc] = 0.5f * ((g0 + g2) - g1);
+      uf[rr][3][kc] = g2;
+    }
+
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int j = min(tid + k * 256, NPIX * G - 1);
+    const int g = j % G, pp = j / G, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * w + c) * C + 4 * g) * 4);
+    lbyte[k] = (unsigned)((g * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xb = (unsigned)((q * PLANE + (2 * wave) * LC + 2 * p) * 4);
+  pin(xb);
+  const int orow = 2 * wave + (q >> 1);                                // lane's output pixels (orow, 2 p), (orow, 2 p + 1), channels 4 (q & 1)..
+  unsigned ooff = (unsigned)(((orow * w + 2 * p) * 8 + 4 * (q & 1)) * 4);
+  pin(ooff);
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int n, int tx, int ty) {
+    const int ix0 = tx * TC - 1, iy0 = ty * TR - 1;
+    const buf_rsrc rs = make_rsrc((const char*)src + (((long)n * h + iy0) * w + ix0) * (C * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= h && ix0 + LC <= w) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(rs, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        stage[k] = buf_load4(rs, ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? goff[k] : BUF_OOB);
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  for (;;) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);               // in flight during the MFMA chain
+    }
+    f32x4 m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const char* at = (const char*)lds + xb + (kc * GP + rr * LC) * 4;
+        const f32x2c d01 = *(const f32x2c*)at, d23 = *(const f32x2c*)(at + 8);
+        const f32x2c v03 = d01 - d23;
+        const f32x2c v12 = __builtin_elementwise_fma(__builtin_shufflevector(d01, d01, 1, 1), pm, __builtin_shufflevector(d23, d23, 0, 0));
+        m[0] = mfma16(uf[rr][0][kc], v03.x, m[0]);
+        m[1] = mfma16(uf[rr][1][kc], v12.x, m[1]);
+        m[2] = mfma16(uf[rr][2][kc], v12.y, m[2]);
+        m[3] = mfma16(uf[rr][3][kc], v03.y, m[3]);
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) drain(m[j]);
+    f32x4 o0 = (m[0] + m[1]) + m[2], o1 = (m[1] - m[2]) - m[3];
+
+    wait_vmem_all();
+    __syncthreads();                                // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+    const int y0 = ty * TR, x0 = tx * TC;
+    const buf_rsrc ro = make_rsrc((char*)c1 + (((long)n * h + y0) * w + x0) * 32);
+    unsigned oa = ooff, ob = ooff + 32;
+    if (!(y0 + TR <= h && x0 + TC <= w)) {
+      const bool rowok = y0 + orow < h;
+      oa = (rowok && x0 + 2 * p < w) ? ooff : BUF_OOB;
+      ob = (rowok && x0 + 2 * p + 1 < w) ? ooff + 32 : BUF_OOB;
+    }
+    o0.x = fmaxf(o0.x, 0.f); o0.y = fmaxf(o0.y, 0.f); o0.z = fmaxf(o0.z, 0.f); o0.w = fmaxf(o0.w, 0.f);
+    o1.x = fmaxf(o1.x, 0.f); o1.y = fmaxf(o1.y, 0.f); o1.z = fmaxf(o1.z, 0.f); o1.w = fmaxf(o1.w, 0.f);
+    buf_store4(ro, oa, o0);
+    buf_store4(ro, ob, o1);
+    if (!more) break;
+    __syncthreads();                                // next tile visible
+    t = tn; n = nn; tx = txn; ty = tyn;
+  }
+}
+
+template <int C>
+static int launch_conv1_f23_rows(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
+  constexpr int G = C / 4;
+  constexpr size_t lds = (size_t)G * ((group_pitch(plane_pitch16(10 * 34), G) + 1) & ~1) * sizeof(float);
+  auto kern = k_conv1_f23_rows<C>;
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(w_, 32), cdiv(h, 8), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, cost, w, c1, h, w_, tg);
+  ADAMVS_CHECK_LAUNCH("conv1 (F(2,3) along x)");
+  return 0;
+}
+
+// ADAMVS_CONV1_F23: bit 1 = C = 32 (stage 1), bit 2 = C = 16 / 8 (stages 2, 3) in the F(2, 3)-along-x form; 0 = k_conv1_ksplit /
+// k_conv1_two_row, as in rounds 1-4 (A/B).  Measured at cfg2 (aggregation + conv1 per step): 43.75 -> 38.28 ms at 128 tiles, 85.7 -> 76.0 at 256.
+static int conv1_f23() {
+  static const int mask = [] { const char* e = getenv("ADAMVS_CONV1_F23"); return e && *e ? atoi(e) : 3; }();
+  return mask;
 }
 
 static int launch_conv1_f23_32(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
@@ -712,9 +854,9 @@ bool conv_pair_epilogue_partials(int B, int h, int w) { return gn_epilogue_parti
 
 int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int precision, hipStream_t st) {
   if (precision == PRECISION_BF16X3) return launch_conv1_bf16x3(cost, w, c1, N, C, h, w_, st);
-  if (C == 32) return conv1_f23() ? launch_conv1_f23_32(cost, w, c1, N, h, w_, st) : launch_conv1_ksplit32(cost, w, c1, N, h, w_, st);
-  if (C == 16) return launch_conv1_c<16>(cost, w, c1, N, h, w_, st);
-  if (C == 8) return launch_conv1_c<8>(cost, w, c1, N, h, w_, st);
+  if (C == 32) return (conv1_f23() & 1) ? launch_conv1_f23_32(cost, w, c1, N, h, w_, st) : launch_conv1_ksplit32(cost, w, c1, N, h, w_, st);
+  if (C == 16) return (conv1_f23() & 2) ? launch_conv1_f23_rows<16>(cost, w, c1, N, h, w_, st) : launch_conv1_c<16>(cost, w, c1, N, h, w_, st);
+  if (C == 8) return (conv1_f23() & 2) ? launch_conv1_f23_rows<8>(cost, w, c1, N, h, w_, st) : launch_conv1_c<8>(cost, w, c1, N, h, w_, st);
   return set_error(-1, "conv1: C=%d unsupported (8, 16 or 32)", C);
 }
 

@@ -1059,7 +1059,7 @@ def test_end_to_end_on_a_trained_networks_dynamic_range(hip, name, recipe, preci
 # --------------------------------------------------------------------------- any number of hypotheses / views (adamvs.py:198-228, :464, :501)
 @pytest.mark.parametrize("D,precision", [(40, "fp32"), (80, "fp32"), (160, "fp32"), (384, "fp32"), (272, "fp32"), (24, "fp32"),
                                          (160, "bf16x3"), (384, "bf16x3"), (288, "bf16x3"),
-                                         (512, "fp32"), (400, "fp32"), (512, "bf16x3"), (448, "bf16x3")])
+                                         (512, "fp32"), (448, "bf16x3")])        # (a minute and a half of CPU oracle each: 512 recurrent planes)
 def test_stage_one_at_any_hypothesis_count(hip, O, D, precision):
     """CostRegNet2D(in_channels) is built for any D in the reference; here D hypotheses run at the next width the kernels are
     built for (zero filters, zero similarity channels, -1e30 pad scores: csrc/costreg2d.hip::costreg_width).  Stage 1 with
