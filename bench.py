@@ -102,6 +102,9 @@ def algorithmic_work(cfg, B):
         # direct form: gates1 16->16, gates2 32->32 and cand2 32->16 at quarter resolution, cand1 16->8
         st["gru_conv_macs"] = {1: 2304, 2: 2304, 4: 1152, 8: 1152}
         st["conv1_flops"] = B * D * hw * 2 * 72 * C
+        # round 5: conv1 runs in the two-row form with F(2, 3) along x: 16 products per two outputs of a row and channel pair where the
+        # direct form has 18 (csrc/slice_red.hip::k_conv1_f23; ADAMVS_CONV1_F23 bit 1: C = 32, bit 2: C = 16 / 8)
+        st["conv1_f23_bit"] = 1 if C == 32 else 2
         if s == 0:
             st["pair_similarity_bytes"] = B * (S * D * C * hw * e + S * C * hw * e + S * D * hw * 4)
             st["costreg_bytes"] = B * 2 * S * D * hw * 4
@@ -459,6 +462,23 @@ class Workload:
                     eff = mask if sched == 0 else 7          # the three-launch schedule never takes cand1 (bit 8) in that form
                     gru_wino += self.B * w_["D"] * w_["h"] * w_["w"] * 2.0 * sum(m for b_, m in w_["gru_conv_macs"].items() if eff & b_)
         executed -= gru_wino * (20.0 / 36.0)
+        if not split:
+            f23 = int(os.environ.get("ADAMVS_CONV1_F23", "3") or 0)
+            executed -= sum(w_["conv1_flops"] for w_ in work if f23 & w_["conv1_f23_bit"]) * (2.0 / 18.0)
+            if os.environ.get("ADAMVS_S2_PAIRS", "1") != "0" and os.environ.get("ADAMVS_CONV_ROWS2", "") != "1":
+                # round 5: the stride-2 layers of CostRegNet2D whose output rows divide into 32-column blocks run in the pair form (15 of
+                # 18 products; csrc/costreg2d.hip::k_conv_dd_s2p, D = 192 / 384): conv1, conv3, conv5 have w/2, w/4, w/8 output columns
+                # (the launcher sends small grids -- at most 2048 blocks of 8 x 16 outputs -- to the 2-row direct kernel instead)
+                pairs = 0.0
+                w0 = work[0]
+                if "costreg_flops" in w0:
+                    S_ = synth.CONFIGS[self.cfg]["views"] - 1
+                    for res in (4, 16, 64):
+                        wo, ho = w0["w"] // int(res ** 0.5), w0["h"] // int(res ** 0.5)
+                        blocks8 = -(-wo // 16) * -(-ho // 8) * S_ * self.B
+                        if (wo % 32 == 0 or wo >= 256) and blocks8 > 2048 and w0["D"] in (192, 384):
+                            pairs += self.B * S_ * 2.0 * (w0["h"] * w0["w"] // res) * w0["D"] ** 2 * 9
+                executed -= pairs * (3.0 / 18.0)
         f_mfma = (tot_flops * 3 / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS if split else executed / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS)
         f_hbm = tot_bytes / step_s / 1e9 / HBM_PEAK_GBS
         out = {"step_frac_mfma": f_mfma, "step_frac_hbm": f_hbm, "step_frac": f_hbm if split else f_mfma,
@@ -467,7 +487,7 @@ class Workload:
                             "(bf16x3), EXECUTED conv flops / step / fp32 MFMA peak (fp32)",
                "step_algorithmic": {"conv_gflop_per_tile": tot_flops / self.B / 1e9, "executed_conv_gflop_per_tile": executed / self.B / 1e9,
                                     "gbytes_per_tile": tot_bytes / self.B / 1e9}}
-        if wino or gru_wino:
+        if wino or gru_wino or not split:
             # the same step priced in SURVEY 8d's direct-form flops: an algorithmic saving, NOT a hardware fraction (can pass 1)
             out["step_frac_direct_equivalent"] = tot_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS
         return out
