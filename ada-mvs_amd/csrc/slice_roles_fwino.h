@@ -3,22 +3,32 @@
 // minimal-filtering form F(2x2, 3x3) INSIDE it, and the tiles of a column strip walked top to bottom so that the gate rows two
 // vertically adjacent tiles share are computed once.
 //
-// Why (round 5).  As two launches -- gates1 in the F(2x2, 3x3) form, the candidate in the two-row direct form -- level 1 moves
+// STATUS (round 5): correct (tests/test_hip_parity.py::test_fused_level_one_with_minimal_filtering_gates), measured, and SLOWER
+// than the two kernels it replaces at every size tried -- 180-189 us per hypothesis against 171 at cfg2 / 128 tiles -- so it runs
+// only under ADAMVS_GRU_FUSED=1.  DESIGN.md section 4 ("The fused level-1 kernel") has the three mappings that were built and
+// their timing builds; this file is the second one.
+//
+// Why it was built.  As two launches -- gates1 in the F(2x2, 3x3) form, the candidate in the two-row direct form -- level 1 moves
 // 370 B per pixel and step: x and h with their halo twice, r * h and u out and back, h a third time for the blend; the
 // candidate kernel alone runs at 6.5 TB/s of fabric traffic.  Round 4's fused level (slice_roles_fused.h) moved 173 B but paid for
 // it with the direct-form gates on the tile plus a one-pixel ring: 4.6 MFMAs per pixel against 3.75, and lost.  Here
-//   * the gates cost 16 instead of 36 products per 2 x 2 outputs (ConvWinoRole's mapping: the four waves are the four rows of the
-//     transformed 4 x 4 patch, the transformed filters stay in registers, the patch rows meet through LDS once per tile row), and
+//   * the gates cost 16 instead of 36 products per 2 x 2 outputs: tile rows 1 .. 4 of the 10 x 32 gate region are ONE WAVE each,
+//     with all sixteen positions of the transformed filters in registers (64), whole transformed patches formed by the wave and the
+//     output transform At M A in registers -- no exchange and no barrier inside the gate phase; tile row 0 is needed by a segment's
+//     first tile only and runs in ConvWinoRole's mapping (waves = patch rows, one exchange through LDS);
 //   * the ring is paid in ONE direction only: a workgroup takes a segment of `seg` vertically adjacent tiles of a strip; the
 //     bottom tile row of a tile's gate region (region rows 8, 9 = the next tile's rows 0, 1) is kept -- r * h of those two rows and
 //     u of the second move up inside LDS -- so every tile after the first of its segment computes four tile rows of gates, not
 //     five: 160 (+ 16 for a segment's first tile) MFMAs per wave and 8 x 30 tile against 150 for the two kernels; with direct gates and
-//     a full ring it was 276.
+//     a full ring it was 276;
+//   * the candidate's 48 fragment values per lane wait in LDS (they do not fit next to 64 filter and 64 accumulator registers).
 // x and h are read once (halo 2; the rows a tile shares with the one above were read by the same workgroup a tile ago: L2),
 // r * h and u never leave the chip, h' is written once: ~110 B per pixel and step.
 //
-// The arithmetic is that of the two kernels it replaces -- the same transformed filters, the same MFMA chains in the same order,
-// the same epilogue expressions -- so its maps equal theirs bit for bit (tests/test_hip_parity.py).
+// What it costs: 238 registers and 72 KB of LDS per workgroup = two waves per SIMD, where the separate kernels run four or five;
+// its time is its matrix time plus everything else with no overlap between the two, and bytes are not what bounds it (a build
+// without window loads is 2 % faster).  The arithmetic is that of the two kernels (same transformed filters, same chains; the gate
+// bias rides in accumulator position (1, 1)): maps agree to rounding (asserted <= 2e-6 per step).
 #pragma once
 #include <type_traits>
 
