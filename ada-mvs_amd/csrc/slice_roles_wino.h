@@ -28,6 +28,17 @@
 namespace adamvs {
 
 typedef float f32x2w __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+
+// Round 5 (A/B: tools/build_variant.py <name> -DWINO_GRU_IL=0): the bias in accumulator position (1, 1) for every role, and for the
+// level-1 gates the reset / update rows interleaved (see `IL` below)
+#ifndef WINO_GRU_IL
+#define WINO_GRU_IL 1
+#endif
+// Round 5 (A/B: -DWINO_GRU_RPR2=0): two tile rows per exchange round in the level-2 candidate (ConvWinoRole::RPR)
+#ifndef WINO_GRU_RPR2
+#define WINO_GRU_RPR2 1
+#endif
 
 // wpk: U fragments [NT][4 patch rows i][4 patch columns j][KC][64 lanes], lane l = U[i][j][cout = 16 nt + (l & 15)][cin = 4 kc + (l >> 4)]
 // (packing.pack_small_conv_wino); the other fields of SmallConvArgs as for ConvSmallRole with the same EPI.
@@ -40,9 +51,13 @@ struct ConvWinoRole {
   static constexpr int PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
   static_assert((PLANE % 2) == 0 && (GP % 2) == 0 && (LC % 2) == 0, "8-byte aligned patch reads");
   static constexpr int NA = (NPIX * GA + 255) / 256, NB = (NPIX * GB + 255) / 256, NL = NA + NB;
-  static constexpr int Z0 = (G * GP + 3) & ~3;                         // floats: the exchange, two buffers of [4 waves][2 b][NT][64 lanes] float4
+  static constexpr int Z0 = (G * GP + 3) & ~3;                         // floats: the exchange, two buffers of [RPR rows][4 waves][2 b][NT][64 lanes] float4
   static constexpr int ZBUF = 4 * 2 * NT * 64 * 4;
-  static constexpr size_t LDS_BYTES = (size_t)(Z0 + 2 * ZBUF) * sizeof(float);
+  // tile rows per exchange round.  2 for the level-2 candidate (round 5): half the barriers and eight independent sums per wave; its
+  // window (47 KB) + 32 KB of exchange still fit twice on a CU.  The level-1 gates (20 + 16 KB: four workgroups per CU) and the
+  // level-2 gates (NT = 2: 47 + 32 KB) would lose a workgroup per CU to it and keep 1.
+  static constexpr int RPR = (WINO_GRU_RPR2 && EPI == EPI_CAND && NT == 1 && KC == 8) ? 2 : 1;
+  static constexpr size_t LDS_BYTES = (size_t)(Z0 + 2 * RPR * ZBUF) * sizeof(float);
   static constexpr int TILE_W = TC, TILE_H = TR;
   static int tiles_x(const Args& a) { return cdiv(a.wo, TC); }
   static int tiles_y(const Args& a) { return cdiv(a.ho, TR); }
@@ -51,19 +66,32 @@ struct ConvWinoRole {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = patch row i
   const int p = lane & 15, q = lane >> 4;
 
+  // IL (the 16-row gate convolution of level 1, round 5): the gate rows as the lanes want them -- MFMA row 4 q + e = reset-gate channel
+  // 2 q + e (e = 0, 1) | update-gate channel 2 q + e - 2 (e = 2, 3) -- so that every lane ends with two reset and two update values of
+  // the same channels and no half of the wave sits out the r * h branch; a row permutation of A is a lane permutation of its
+  // fragments, applied here: the blob keeps the reference's row order.
+  constexpr bool IL = WINO_GRU_IL && EPI == EPI_GATES && NT == 1 && HC == 8;
+  const int row_of_lane = IL ? ((lane & 2) ? 8 + 2 * ((lane & 15) >> 2) + (lane & 1) : 2 * ((lane & 15) >> 2) + (lane & 1)) : (lane & 15);
+  const int src_lane = (lane & 48) | row_of_lane;
   float uf[NT][4][KC];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) uf[nt][j][kc] = a.wpk[((((nt * 4 + wave) * 4 + j) * KC) + kc) * 64 + lane];
+      for (int kc = 0; kc < KC; ++kc) uf[nt][j][kc] = a.wpk[((((nt * 4 + wave) * 4 + j) * KC) + kc) * 64 + src_lane];
   // The transformed filters carry the factor that makes the accumulator v_exp_f32's argument (-log2 e for the gates, 2 log2 e for the
-  // candidate: packing.pack_small_conv_wino); the bias, shared with the direct kernels, is scaled here, once per launch.
+  // candidate: packing.pack_small_conv_wino); the bias, shared with the direct kernels, is scaled here, once per launch.  It rides in
+  // accumulator position (1, 1) (round 5): At E A is all ones for the unit element E11, so the sum that wave 1 starts from the bias
+  // carries it into all four outputs of a tile (costreg2d_wino.hip does the same) and the epilogue adds nothing.
   constexpr float PRE = EPI == EPI_GATES ? -1.4426950408889634f : 2.8853900817779268f;
   f32x4 bias[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bias[nt] = *(const f32x4*)(a.bias + nt * 16 + 4 * q) * PRE;
+  for (int nt = 0; nt < NT; ++nt) {
+    const f32x4 b = IL ? f32x4{a.bias[2 * q], a.bias[2 * q + 1], a.bias[8 + 2 * q], a.bias[8 + 2 * q + 1]} : *(const f32x4*)(a.bias + nt * 16 + 4 * q);
+    bias[nt] = WINO_GRU_IL ? (wave == 1 ? b * PRE : f32x4{0.f, 0.f, 0.f, 0.f}) : b * PRE;
+    if (WINO_GRU_IL) drain(bias[nt]);             // (kept in registers: the select is made once)
+  }
 
   // ---- window fill: as ConvSmallRole (two sources, planar groups)
   unsigned goff[NL], lbyte[NL];
@@ -91,8 +119,11 @@ struct ConvWinoRole {
   const int CO = HC;                                                   // channels per pixel of both destinations
   unsigned ooff = (unsigned)(((oa * a.wo + 2 * p + ob) * CO + 4 * q) * 4);      // + 2 t rows; GATES: r*h and u share it (co4 or co4 - HC)
   pin(ooff);
-  // GATES: the state channels 4 q .. of the wave's pixel, in the window (pixel (2 t + oa + 1, 2 p + ob + 1))
-  const unsigned hbyte = (unsigned)(((GA + min(q, GB - 1)) * GP + (oa + 1) * LC + 2 * p + ob + 1) * 4);
+  // GATES: the state channels 4 q .. of the wave's pixel, in the window (pixel (2 t + oa + 1, 2 p + ob + 1)); IL: channels 2 q, 2 q + 1
+  const unsigned hbyte = IL ? (unsigned)(((GA + (q >> 1)) * GP + 2 * (q & 1) * PLANE + (oa + 1) * LC + 2 * p + ob + 1) * 4)
+                            : (unsigned)(((GA + min(q, GB - 1)) * GP + (oa + 1) * LC + 2 * p + ob + 1) * 4);
+  unsigned ooff2 = (unsigned)(((oa * a.wo + 2 * p + ob) * CO + 2 * q) * 4);     // IL: the lane's channel pair of both destinations
+  if (IL) pin(ooff2);
   float* zl = lds + Z0;
 
   auto load_tile = [&](f32x4 (&stage)[NL], int b, int tx, int ty) {
@@ -164,55 +195,75 @@ struct ConvWinoRole {
     }
 
 #pragma unroll
-    for (int tr4 = 0; tr4 < 4; ++tr4) {                                // tile row: output rows 2 tr4, 2 tr4 + 1
-      unsigned oo = ooff + (unsigned)(2 * tr4 * a.wo * CO * 4);
-      if (!full && !(oy0 + 2 * tr4 + oa < a.ho && ox0 + 2 * p + ob < a.wo)) oo = BUF_OOB;
-      f32x4 m[NT][4];
+    for (int rd = 0; rd < 4 / RPR; ++rd) {                             // exchange round: tile rows rd * RPR .. (output rows 2 tr4, 2 tr4 + 1 each)
+      f32x4 m[RPR][NT][4];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int rr = 0; rr < RPR; ++rr)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[nt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const int off = (kc * GP + 2 * tr4 * LC) * 4;
-        const f32x2w a01 = *(const f32x2w*)((const char*)lds + pa + off), a23 = *(const f32x2w*)((const char*)lds + pa + off + 8);
-        const f32x2w b01 = *(const f32x2w*)((const char*)lds + pb + off), b23 = *(const f32x2w*)((const char*)lds + pb + off + 8);
-        // T = A + sgn B as two packed FMAs on the pairs the LDS reads deliver; (v0, v3) = T01 - T23 as one packed subtraction
-        // (written on the vector types: as scalars the compiler packs half of them and pays for it in register moves)
-        const f32x2w t01 = __builtin_elementwise_fma(sgn2, b01, a01), t23 = __builtin_elementwise_fma(sgn2, b23, a23);
-        const f32x2w v03 = t01 - t23;
-        float v0 = v03.x, v3 = v03.y, v1 = t01.y + t23.x, v2 = t23.x - t01.y;
-        if (WINO_GRU_EXP & 4) { v0 = a01.x; v1 = a01.y; v2 = b23.x; v3 = b23.y; }
+          for (int j = 0; j < 4; ++j) m[rr][nt][j] = (WINO_GRU_IL && j == 1) ? bias[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int rr = 0; rr < RPR; ++rr) {
+          const int tr4 = rd * RPR + rr;
+          const int off = (kc * GP + 2 * tr4 * LC) * 4;
+          const f32x2w a01 = *(const f32x2w*)((const char*)lds + pa + off), a23 = *(const f32x2w*)((const char*)lds + pa + off + 8);
+          const f32x2w b01 = *(const f32x2w*)((const char*)lds + pb + off), b23 = *(const f32x2w*)((const char*)lds + pb + off + 8);
+          // T = A + sgn B as two packed FMAs on the pairs the LDS reads deliver; (v0, v3) = T01 - T23 as one packed subtraction
+          // (written on the vector types: as scalars the compiler packs half of them and pays for it in register moves)
+          const f32x2w t01 = __builtin_elementwise_fma(sgn2, b01, a01), t23 = __builtin_elementwise_fma(sgn2, b23, a23);
+          const f32x2w v03 = t01 - t23;
+          float v0 = v03.x, v3 = v03.y, v1 = t01.y + t23.x, v2 = t23.x - t01.y;
+          if (WINO_GRU_EXP & 4) { v0 = a01.x; v1 = a01.y; v2 = b23.x; v3 = b23.y; }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            m[rr][nt][0] = mfma16(uf[nt][0][kc], v0, m[rr][nt][0]);
+            m[rr][nt][1] = mfma16(uf[nt][1][kc], v1, m[rr][nt][1]);
+            m[rr][nt][2] = mfma16(uf[nt][2][kc], v2, m[rr][nt][2]);
+            m[rr][nt][3] = mfma16(uf[nt][3][kc], v3, m[rr][nt][3]);
+          }
+        }
+#pragma unroll
+      for (int rr = 0; rr < RPR; ++rr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) drain(m[rr][nt][j]);
+      // Z_i[b] = sum_j M[i][j] At[b][j] into the exchange buffer of this round
+      f32x4* zb = (f32x4*)(zl + (rd & 1) * (RPR * ZBUF));
+#pragma unroll
+      for (int rr = 0; rr < RPR; ++rr)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          m[nt][0] = mfma16(uf[nt][0][kc], v0, m[nt][0]);
-          m[nt][1] = mfma16(uf[nt][1][kc], v1, m[nt][1]);
-          m[nt][2] = mfma16(uf[nt][2][kc], v2, m[nt][2]);
-          m[nt][3] = mfma16(uf[nt][3][kc], v3, m[nt][3]);
+          if (WINO_GRU_EXP & 8) break;
+          zb[rr * (ZBUF / 4) + ((wave * 2 + 0) * NT + nt) * 64 + lane] = (m[rr][nt][0] + m[rr][nt][1]) + m[rr][nt][2];
+          zb[rr * (ZBUF / 4) + ((wave * 2 + 1) * NT + nt) * 64 + lane] = (m[rr][nt][1] - m[rr][nt][2]) - m[rr][nt][3];
         }
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) drain(m[nt][j]);
-      // Z_i[b] = sum_j M[i][j] At[b][j] into the exchange buffer of this round
-      f32x4* zb = (f32x4*)(zl + (tr4 & 1) * ZBUF);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (WINO_GRU_EXP & 8) break;
-        zb[((wave * 2 + 0) * NT + nt) * 64 + lane] = (m[nt][0] + m[nt][1]) + m[nt][2];
-        zb[((wave * 2 + 1) * NT + nt) * 64 + lane] = (m[nt][1] - m[nt][2]) - m[nt][3];
-      }
       if (!(WINO_GRU_EXP & (1 | 8))) __syncthreads();                  // one barrier per round: the buffers alternate
 #pragma unroll
+      for (int rr = 0; rr < RPR; ++rr) {
+      const int tr4 = rd * RPR + rr;
+      unsigned oo = ooff + (unsigned)(2 * tr4 * a.wo * CO * 4);
+      if (!full && !(oy0 + 2 * tr4 + oa < a.ho && ox0 + 2 * p + ob < a.wo)) oo = BUF_OOB;
+#pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        f32x4 z0 = zb[(((oa + 0) * 2 + ob) * NT + nt) * 64 + lane];
-        f32x4 z1 = zb[(((oa + 1) * 2 + ob) * NT + nt) * 64 + lane];
-        f32x4 z2 = zb[(((oa + 2) * 2 + ob) * NT + nt) * 64 + lane];
-        if (WINO_GRU_EXP & 8) { z0 = (m[nt][0] + m[nt][1]) + m[nt][2]; z1 = z0; z2 = (m[nt][1] - m[nt][2]) - m[nt][3]; }
-        const f32x4 v = (z0 + os * (z1 + z2)) + bias[nt];
+        f32x4 z0 = zb[rr * (ZBUF / 4) + (((oa + 0) * 2 + ob) * NT + nt) * 64 + lane];
+        f32x4 z1 = zb[rr * (ZBUF / 4) + (((oa + 1) * 2 + ob) * NT + nt) * 64 + lane];
+        f32x4 z2 = zb[rr * (ZBUF / 4) + (((oa + 2) * 2 + ob) * NT + nt) * 64 + lane];
+        if (WINO_GRU_EXP & 8) { z0 = (m[rr][nt][0] + m[rr][nt][1]) + m[rr][nt][2]; z1 = z0; z2 = (m[rr][nt][1] - m[rr][nt][2]) - m[rr][nt][3]; }
+        const f32x4 v = WINO_GRU_IL ? z0 + os * (z1 + z2) : (z0 + os * (z1 + z2)) + bias[nt];
         const int co4 = nt * 16 + 4 * q;
-        if (EPI == EPI_GATES) {
+        if (IL) {                                                      // (r[2q], r[2q+1], u[2q], u[2q+1]) of the lane's pixel
+          const f32x4 sg = (WINO_GRU_EXP & 2) ? v : f32x4{sigmoid_pre(v.x), sigmoid_pre(v.y), sigmoid_pre(v.z), sigmoid_pre(v.w)};
+          const float* hl = (const float*)((const char*)lds + hbyte + 2 * tr4 * LC * 4);
+          const float h0 = hl[0], h1 = hl[PLANE];
+          unsigned o2 = ooff2 + (unsigned)(2 * tr4 * a.wo * CO * 4);
+          if (oo == BUF_OOB) o2 = BUF_OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2w{__float_as_uint(sg.x * h0), __float_as_uint(sg.y * h1)}, r0, o2, 0, 0);   // r * h (module.py:35-41)
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2w{__float_as_uint(sg.z), __float_as_uint(sg.w)}, r1, o2, 0, 0);             // u
+        } else if (EPI == EPI_GATES) {
           const f32x4 sg = (WINO_GRU_EXP & 2) ? v : f32x4{sigmoid_pre(v.x), sigmoid_pre(v.y), sigmoid_pre(v.z), sigmoid_pre(v.w)};
           if (co4 < HC) {                                              // reset-gate rows -> r * h (module.py:35-41)
             const float* hl = (const float*)((const char*)lds + hbyte + 2 * tr4 * LC * 4);
@@ -226,6 +277,7 @@ struct ConvWinoRole {
           const f32x4 u4 = pre_u[EPI == EPI_CAND ? tr4 : 0][nt], h4 = pre_h[EPI == EPI_CAND ? tr4 : 0][nt];
           buf_store4(r0, oo == BUF_OOB ? BUF_OOB : oo + nt * 64, gru_blend(u4, h4, cnd));
         }
+      }
       }
     }
 
