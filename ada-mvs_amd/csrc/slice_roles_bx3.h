@@ -15,11 +15,53 @@ __device__ __forceinline__ f32x4 mfma_bx(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// hi = bf16(x) (round to nearest even), lo = bf16(x - hi).  Written on pairs -- one v_cvt_pk_bf16_f32, the two halves widened back
+// with a shift and a mask, one packed subtraction, one v_cvt_pk_bf16_f32: 10 vector instructions per four values (the element-wise
+// form compiled to 17: the conversions of the first pair once per element and once packed).
+__device__ __forceinline__ void split4(f32x4 v, bf16x4& h, bf16x4& l) {
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  u32x2v hp, lp;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const f32x2v x = e ? f32x2v{v.z, v.w} : f32x2v{v.x, v.y};
+    const unsigned hh = __builtin_bit_cast(unsigned, bf16x2v{(__bf16)x.x, (__bf16)x.y});
+    const f32x2v d = x - f32x2v{__uint_as_float(hh << 16), __uint_as_float(hh & 0xffff0000u)};
+    const unsigned ll = __builtin_bit_cast(unsigned, bf16x2v{(__bf16)d.x, (__bf16)d.y});
+    if (e) { hp.y = hh; lp.y = ll; } else { hp.x = hh; lp.x = ll; }
+  }
+  h = __builtin_bit_cast(bf16x4, hp);
+  l = __builtin_bit_cast(bf16x4, lp);
+}
 __device__ __forceinline__ void split_store(__bf16* hi, __bf16* lo, f32x4 v) {
-  bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-  bf16x4 l = {(__bf16)(v.x - (float)h.x), (__bf16)(v.y - (float)h.y), (__bf16)(v.z - (float)h.z), (__bf16)(v.w - (float)h.w)};
+  bf16x4 h, l;
+  split4(v, h, l);
   *(bf16x4*)hi = h;
   *(bf16x4*)lo = l;
+}
+
+// SPLIT MAPS (round 5).  Every map of the recurrence that a convolution of this mode reads through a window -- c1, the two states,
+// c2 -- is split into its bf16 halves ONCE, by the kernel that produces it, instead of by every consumer for every pixel of its
+// window (halo included: 1.7 x the tile for the level-1 kernel, whose fill spent 134 of its 435 vector instructions per tile on it):
+//     [pixel][hi C bf16 | lo C bf16]      4 C bytes per pixel, like the fp32 map whose place it takes
+// hi = bf16(x), lo = bf16(x - hi): the same function the fill applied, so the LDS tiles -- and every result -- keep their bits.
+// c1 and c2 exist only in this form; a state is kept twice: fp32 (the blend u h + (1 - u) c of the lane's own pixel and the
+// decoder read it; updated in place -- nobody else reads it) and split (what the next step's windows copy; two buffers in turn).
+// A window fill is then a copy: 16-byte loads, 16-byte LDS stores, no vector arithmetic.  -DBX3_PRESPLIT=0: the fills split (A/B).
+#ifndef BX3_PRESPLIT
+#define BX3_PRESPLIT 0
+#endif
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+// the lane's four channels co4 .. co4 + 3 of one pixel: hi at `off` (= pixel * 4 C + 2 co4), lo `half` (= 2 C) bytes further
+__device__ __forceinline__ void buf_store_split4(buf_rsrc r, unsigned off, unsigned half, f32x4 v) {
+  bf16x4 h, l;
+#ifdef BX3_EXP_NOSPLITSTORE
+  return;
+#endif
+  split4(v, h, l);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, h), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, l), r, off, half, 0);
 }
 
 // The fused GRU kernels of this mode take their gate / candidate weights and biases PRE-SCALED on the host
@@ -59,10 +101,13 @@ struct SmallConvArgsBx {
 // multiplies in full fp32 and therefore comes from global memory with the other epilogue operands.
 // Tile = 4 rows x 16 columns, one run per wave; the two-row conv1 takes 8 x 16 (a run = 2 output rows).
 // NPOS = 9 taps, or 12 (rr,kx) positions for the two-row conv1.
-template <int CA, int CB, int NT, int STRIDE, int EPI>
+// SIN: srcA is a split map (the fill copies); SOUT: the output is written as one (RELU / TWO_ROW epilogues).
+template <int CA, int CB, int NT, int STRIDE, int EPI, bool SIN = false, bool SOUT = false>
 struct ConvSmallBx3Role {
   typedef SmallConvArgsBx Args;
   static constexpr bool TWO = (EPI == BXE_TWO_ROW);
+  static_assert(!SIN || (CB == 0 && CA % 8 == 0), "a split source: one input, 16-byte pieces");
+  static_assert(!SOUT || EPI == BXE_RELU || EPI == BXE_TWO_ROW, "split output: the plain epilogues");
   static constexpr int CIN = CA + CB, GA = CA / 4, GB = CB / 4, HC = CB;
   static constexpr int NPOS = TWO ? 12 : 9;
   static constexpr int NKB = (NPOS * CIN + 31) / 32;
@@ -110,6 +155,8 @@ struct ConvSmallBx3Role {
     const int g = j % gs, pp = j / gs, r = pp / LC, c = pp % LC;
     goff[k] = (unsigned)(((r * a.wi + c) * cs + 4 * g) * 4);
     lbyte[k] = (unsigned)((pp * PP + (isA ? 0 : CA) + 4 * g) * 2);
+    constexpr int GH = GA >= 2 ? GA / 2 : 1;         // 16-byte pieces per half of a split pixel
+    if (SIN) lbyte[k] = (unsigned)((pp * PP + 8 * (g % GH)) * 2 + (g / GH) * LO);                 // piece g of the pixel: 8 channels of hi or lo
     rc[k] = r | (c << 16);
     pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
   }
@@ -130,7 +177,8 @@ struct ConvSmallBx3Role {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int co4 = TWO ? 4 * (q & 1) : nt * 16 + 4 * q;
-    const unsigned at = (unsigned)(((orow * a.wo + p) * CO + (EPI == BXE_GATES && co4 >= HC ? co4 - HC : co4)) * 4);
+    unsigned at = (unsigned)(((orow * a.wo + p) * CO + (EPI == BXE_GATES && co4 >= HC ? co4 - HC : co4)) * 4);
+    if (SOUT) at -= (unsigned)(2 * co4);             // the hi half of the pixel's split record
     const bool to0 = TWO ? true : (EPI == BXE_RELU ? co4 < a.cout : co4 < HC);
     const bool to1 = EPI == BXE_GATES && co4 >= HC && co4 < 2 * HC;
     ooff[nt] = to0 ? at : BUF_OOB;
@@ -159,7 +207,8 @@ struct ConvSmallBx3Role {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       __bf16* hi = (__bf16*)((char*)ldsb + lbyte[k]);
-      split_store(hi, (__bf16*)((char*)hi + LO), stage[k]);
+      if (SIN) *(f32x4*)hi = stage[k];
+      else split_store(hi, (__bf16*)((char*)hi + LO), stage[k]);
     }
   };
 
@@ -245,7 +294,8 @@ struct ConvSmallBx3Role {
       f32x4 v = acc[nt] + bias[nt];
       if (EPI == BXE_RELU || EPI == BXE_TWO_ROW) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        buf_store4(r0, oo[nt], v);
+        if (SOUT) buf_store_split4(r0, oo[nt], (unsigned)(2 * CO), v);
+        else buf_store4(r0, oo[nt], v);
       } else if (EPI == BXE_GATES) {
         f32x4 sg = {sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
         if (nt * 16 < HC) buf_store4(r0, oo[nt], sg * pre_h[nt]);              // reset-gate rows -> r * h
@@ -277,12 +327,14 @@ struct ConvSmallBx3Role {
 //   candidate at inner pixel (ir, ic) = window (ir+2, ic+2): 8 rows x 2 runs (columns 30, 31 of a row are surplus)
 // Wave k owns runs k, k+4, ... of both convolutions (its B-fragment offsets differ by compile-time constants).
 struct Gru1Args {
-  const float* x;        // c1 [B][h*w][8]
+  const float* x;        // c1 [B][h*w][8] (a split map under BX3_PRESPLIT)
   const float* hin;      // state in  [B][h*w][8]
-  float* hout;           // state out [B][h*w][8] (a different buffer)
+  float* hout;           // state out [B][h*w][8] (a different buffer; BX3_PRESPLIT: may be hin -- only the lane's own pixel is read)
   const bf16x8* wg; const float* bg;    // gates1 A fragments [1][hi|lo][5][64], bias [16]
   const bf16x8* wc; const float* bc;    // cand1  A fragments [1][hi|lo][5][64], bias [16]
   int h, w;
+  const float* hsin;     // BX3_PRESPLIT: the state as a split map, in / out (two different buffers)
+  float* hsout;
 };
 
 struct Gru1FusedBx3Role {
@@ -321,7 +373,7 @@ struct Gru1FusedBx3Role {
     int j = min(tid + k * 256, NITEM - 1);
     const int g = j & 1, pp = j >> 1, r = pp / WC, c = pp % WC;
     goff[k] = (unsigned)(((r * a.w + c) * 8 + 4 * g) * 4);
-    lbyte[k] = (unsigned)(pp * PB + 8 * g);
+    lbyte[k] = BX3_PRESPLIT ? (unsigned)(pp * PB + g * LO) : (unsigned)(pp * PB + 8 * g);      // piece g: the hi / the lo half of the pixel
     rc[k] = r | (c << 16);
     pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
   }
@@ -353,7 +405,7 @@ struct Gru1FusedBx3Role {
     const int ix0 = tx * TC - 2, iy0 = ty * TR - 2;
     const long pix0 = ((long)b * a.h + iy0) * a.w + ix0;
     const buf_rsrc rx = make_rsrc((const char*)a.x + pix0 * 32);
-    const buf_rsrc rh = make_rsrc((const char*)a.hin + pix0 * 32);
+    const buf_rsrc rh = make_rsrc((const char*)(BX3_PRESPLIT ? a.hsin : a.hin) + pix0 * 32);
     if (iy0 >= 0 && ix0 >= 0 && iy0 + WR <= a.h && ix0 + WC <= a.w) {
 #pragma unroll
       for (int k = 0; k < NS; ++k) { sx[k] = buf_load4(rx, goff[k]); sh[k] = buf_load4(rh, goff[k]); }
@@ -371,8 +423,13 @@ struct Gru1FusedBx3Role {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       __bf16* hi = (__bf16*)(lds + lbyte[k]);
-      split_store(hi, (__bf16*)((char*)hi + LO), sx[k]);
-      split_store(hi + 8, (__bf16*)((char*)hi + LO) + 8, sh[k]);
+      if (BX3_PRESPLIT) {
+        *(f32x4*)hi = sx[k];
+        *(f32x4*)(hi + 8) = sh[k];
+      } else {
+        split_store(hi, (__bf16*)((char*)hi + LO), sx[k]);
+        split_store(hi + 8, (__bf16*)((char*)hi + LO) + 8, sh[k]);
+      }
     }
   };
 
@@ -390,6 +447,7 @@ struct Gru1FusedBx3Role {
     const long opix0 = ((long)b * a.h + oy0) * a.w + ox0;
     const buf_rsrc rin = make_rsrc((const char*)a.hin + opix0 * 32);
     const buf_rsrc rout = make_rsrc((char*)a.hout + opix0 * 32);
+    const buf_rsrc rsout = make_rsrc((char*)a.hsout + opix0 * 32);
     const bool full = oy0 + TR <= a.h && ox0 + TC <= a.w;
     unsigned oo[NC];
 #pragma unroll
@@ -470,7 +528,9 @@ struct Gru1FusedBx3Role {
     for (int j = 0; j < NC; ++j) {
       const f32x4 v = ac[j];
       const f32x4 cnd = {tanh_pre(v.x), tanh_pre(v.y), tanh_pre(v.z), tanh_pre(v.w)};
-      buf_store4(rout, oo[j], gru_blend(u4[j], pre_h[j], cnd));
+      const f32x4 hn = gru_blend(u4[j], pre_h[j], cnd);
+      buf_store4(rout, oo[j], hn);
+      if (BX3_PRESPLIT) buf_store_split4(rsout, oo[j] == BUF_OOB ? BUF_OOB : oo[j] - 8 * q, 16, hn);
     }
     if (!more) break;
     __syncthreads();                   // next tile visible
@@ -493,12 +553,14 @@ struct Gru1FusedBx3Role {
 //   LDS: window [hi|lo][12*18 pixels][c2 16 | h 16 | pad 16] bf16; u [10*16 region pixels][16] fp32;
 //        r*h [hi|lo][10 rows x 18 (16 + 2 never-written columns that only the two surplus lanes of a run read)][16] bf16.
 struct Gru2Args {
-  const float* x;        // conv2 output [B][h*w][16]     (h, w: the level-2 size)
+  const float* x;        // conv2 output [B][h*w][16]     (h, w: the level-2 size; a split map under BX3_PRESPLIT)
   const float* hin;      // state in  [B][h*w][16]
-  float* hout;           // state out [B][h*w][16] (a different buffer)
+  float* hout;           // state out [B][h*w][16] (a different buffer; BX3_PRESPLIT: may be hin)
   const bf16x8* wg; const float* bg;    // gates2 A fragments [2][hi|lo][9][64], bias [32]
   const bf16x8* wc; const float* bc;    // cand2  A fragments [1][hi|lo][9][64], bias [16]
   int h, w;
+  const float* hsin;     // BX3_PRESPLIT: the state as a split map, in / out (two different buffers)
+  float* hsout;
 };
 
 struct Gru2FusedBx3Role {
@@ -539,7 +601,7 @@ struct Gru2FusedBx3Role {
     int j = min(tid + k * 256, NITEM - 1);
     const int g = j & 3, pp = j >> 2, r = pp / WC, c = pp % WC;
     goff[k] = (unsigned)(((r * a.w + c) * 16 + 4 * g) * 4);
-    lbyte[k] = (unsigned)(pp * PB + 8 * g);
+    lbyte[k] = BX3_PRESPLIT ? (unsigned)(pp * PB + 16 * (g & 1) + (g >> 1) * LO) : (unsigned)(pp * PB + 8 * g);   // piece g: 8 channels of hi (g < 2) or lo
     pin(goff[k]); pin(lbyte[k]);
   }
   // B fragments: k-block = tap, lane q: channels 8q .. 8q+7 of cat(c2, state).  Gate run 0 of the wave reads the window;
@@ -562,7 +624,7 @@ struct Gru2FusedBx3Role {
     const int ix0 = tx * TC - 2, iy0 = ty * TR - 2;
     const long pix0 = ((long)b * a.h + iy0) * a.w + ix0;
     const buf_rsrc rx = make_rsrc((const char*)a.x + pix0 * 64);
-    const buf_rsrc rh = make_rsrc((const char*)a.hin + pix0 * 64);
+    const buf_rsrc rh = make_rsrc((const char*)(BX3_PRESPLIT ? a.hsin : a.hin) + pix0 * 64);
     if (iy0 >= 0 && ix0 >= 0 && iy0 + WR <= a.h && ix0 + WC <= a.w) {
 #pragma unroll
       for (int k = 0; k < NS; ++k) { sx[k] = buf_load4(rx, goff[k]); sh[k] = buf_load4(rh, goff[k]); }
@@ -581,8 +643,13 @@ struct Gru2FusedBx3Role {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       __bf16* hi = (__bf16*)(lds + lbyte[k]);
-      split_store(hi, (__bf16*)((char*)hi + LO), sx[k]);
-      split_store(hi + 16, (__bf16*)((char*)hi + LO) + 16, sh[k]);
+      if (BX3_PRESPLIT) {
+        *(f32x4*)hi = sx[k];
+        *(f32x4*)(hi + 16) = sh[k];
+      } else {
+        split_store(hi, (__bf16*)((char*)hi + LO), sx[k]);
+        split_store(hi + 16, (__bf16*)((char*)hi + LO) + 16, sh[k]);
+      }
     }
   };
 
@@ -600,6 +667,7 @@ struct Gru2FusedBx3Role {
     const long opix0 = ((long)b * a.h + oy0) * a.w + ox0;
     const buf_rsrc rin = make_rsrc((const char*)a.hin + opix0 * 64);
     const buf_rsrc rout = make_rsrc((char*)a.hout + opix0 * 64);
+    const buf_rsrc rsout = make_rsrc((char*)a.hsout + opix0 * 64);
     const bool full = oy0 + TR <= a.h && ox0 + TC <= a.w;
     unsigned oo[NC];
 #pragma unroll
@@ -676,7 +744,9 @@ struct Gru2FusedBx3Role {
     for (int j = 0; j < NC; ++j) {
       const f32x4 v = ac[j];
       const f32x4 cnd = {tanh_pre(v.x), tanh_pre(v.y), tanh_pre(v.z), tanh_pre(v.w)};
-      buf_store4(rout, oo[j], gru_blend(u4[j], pre_h[j], cnd));
+      const f32x4 hn = gru_blend(u4[j], pre_h[j], cnd);
+      buf_store4(rout, oo[j], hn);
+      if (BX3_PRESPLIT) buf_store_split4(rsout, oo[j] == BUF_OOB ? BUF_OOB : oo[j] - 8 * q, 32, hn);
     }
     if (!more) break;
     __syncthreads();                   // every wave is done with the tile

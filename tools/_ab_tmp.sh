@@ -1,4 +1,6 @@
 mkdir -p gpurun_out
-timeout 500 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "minimal_filtering or gru_convolutions or slice_reg or fused_level_one" > gpurun_out/rpr_tests.log 2>&1; tail -2 gpurun_out/rpr_tests.log
-timeout 200 tools/step_prof.sh rpr1 2>&1 | grep -E "wino|conv1|tail|ms" | head -12
-ADAMVS_LIB_PATH=ada-mvs_amd/libadamvs_hip.rpr0.so timeout 200 tools/step_prof.sh rpr0 2>&1 | grep -E "wino|conv1|ms" | head -12
+timeout 300 python tools/wino_bench.py --time-only > gpurun_out/wino_fill1.txt 2>&1
+ADAMVS_LIB_PATH=ada-mvs_amd/libadamvs_hip.fill0.so timeout 300 python tools/wino_bench.py --time-only > gpurun_out/wino_fill0.txt 2>&1
+timeout 300 python tools/wino_bench.py --time-only > gpurun_out/wino_fill1b.txt 2>&1
+grep "F(2x2" gpurun_out/wino_fill1.txt gpurun_out/wino_fill0.txt gpurun_out/wino_fill1b.txt
+timeout 600 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "wino or winograd or cost_reg" 2>&1 | tail -2
