@@ -52,6 +52,15 @@ __device__ __forceinline__ void split_store(__bf16* hi, __bf16* lo, f32x4 v) {
 #ifndef BX3_PRESPLIT
 #define BX3_PRESPLIT 0
 #endif
+// Timing builds of Gru1FusedBx3Role only (tools/build_variant.py <name> -DBX3_EXP=<bits>; results are wrong): 1 no MFMAs (the fragment
+// reads stay), 2 the B fragments of a tile read once (run 0's serve every run), 4 no transcendentals, 8 no window (loads and LDS stores).
+#ifndef BX3_EXP
+#define BX3_EXP 0
+#endif
+#ifndef BX3_CAND_TWO_ROW
+#define BX3_CAND_TWO_ROW 1
+#endif
+__device__ __forceinline__ void keep(const bf16x8& v) { asm volatile("" ::"v"(v)); }
 typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
 // the lane's four channels co4 .. co4 + 3 of one pixel: hi at `off` (= pixel * 4 C + 2 co4), lo `half` (= 2 C) bytes further
 __device__ __forceinline__ void buf_store_split4(buf_rsrc r, unsigned off, unsigned half, f32x4 v) {
@@ -344,7 +353,14 @@ struct Gru1FusedBx3Role {
                                                        // non-contiguous 16-lane groups a 32-byte pitch is conflict-free here, 48 is 2-way
   static constexpr int LO = NPIXW * PB;                // lo image
   static constexpr int U0 = 2 * LO;                    // u tile
-  static constexpr int NKB = 5, NG = 5, NC = 4;        // k-blocks (9 taps x 16 channels), gate / candidate runs per wave
+  static constexpr int NKB = 5, NG = 5;                // gates: k-blocks (9 taps x 16 channels), runs per wave
+  // The candidate convolution has 8 output channels -- half an MFMA tile -- and runs in the TWO-ROW form (round 5; the form of conv1
+  // and of the fp32 cand1): MFMA rows 0-7 are inner row R, rows 8-15 inner row R + 1, k = (window row rr 0..3, kx, channel) = 192 =
+  // 6 k-blocks for the PAIR of rows where two one-row runs took 10 -- 18 MFMAs and 12 fragment reads instead of 30 and 20 -- and
+  // all four lane groups carry outputs (row R + (q >> 1), channels 4 (q & 1) ..): half the transcendentals per lane.
+  // -DBX3_CAND_TWO_ROW=0: one-row runs (cand1 then packed by pack_small_conv_bf16x3; A/B).
+  static constexpr bool C2R = BX3_CAND_TWO_ROW != 0;
+  static constexpr int NKC = C2R ? 6 : 5, NC = C2R ? 2 : 4;      // candidate: k-blocks, runs per wave
   static constexpr int NITEM = NPIXW * 2, NS = (NITEM + 255) / 256;      // 4-channel groups per source, loads per thread
   static constexpr size_t LDS_BYTES = (size_t)2 * 12 * 34 * 32 + 10 * 32 * 32;
   static constexpr int TILE_W = TC, TILE_H = TR;
@@ -357,14 +373,13 @@ struct Gru1FusedBx3Role {
   const int p = lane & 15, q = lane >> 4;
   const int rr0 = wave >> 1, c0w = (wave & 1) * 16;    // first run of the wave: region row / first column
 
-  bf16x8 gh[NKB], gl[NKB], ch[NKB], cl[NKB];
+  bf16x8 gh[NKB], gl[NKB], ch[NKC], cl[NKC];
 #pragma unroll
-  for (int kb = 0; kb < NKB; ++kb) {
-    gh[kb] = a.wg[(0 * NKB + kb) * 64 + lane]; gl[kb] = a.wg[(1 * NKB + kb) * 64 + lane];
-    ch[kb] = a.wc[(0 * NKB + kb) * 64 + lane]; cl[kb] = a.wc[(1 * NKB + kb) * 64 + lane];
-  }
+  for (int kb = 0; kb < NKB; ++kb) { gh[kb] = a.wg[(0 * NKB + kb) * 64 + lane]; gl[kb] = a.wg[(1 * NKB + kb) * 64 + lane]; }
+#pragma unroll
+  for (int kb = 0; kb < NKC; ++kb) { ch[kb] = a.wc[(0 * NKC + kb) * 64 + lane]; cl[kb] = a.wc[(1 * NKC + kb) * 64 + lane]; }
   const f32x4 bias_g = *(const f32x4*)(a.bg + 4 * q);
-  const f32x4 bias_c = *(const f32x4*)(a.bc + 4 * q);
+  const f32x4 bias_c = *(const f32x4*)(a.bc + 4 * (C2R ? (q & 1) : q));
 
   unsigned goff[NS], lbyte[NS];
   int rc[NS];
@@ -394,12 +409,26 @@ struct Gru1FusedBx3Role {
   // the gate epilogue was the largest share of the kernel's 3.4 vector instructions per MFMA.)
   const unsigned hbyte = (unsigned)(((rr0 + 1) * WC + c0w + p + 1) * PB + (8 + 2 * q) * 2);
   const unsigned ubyte_w = (unsigned)(U0 + ((rr0 * 32 + c0w + p) * 8 + 2 * q) * 4);
-  // candidate epilogue: lanes q < 2, inner pixel (rr0 + 2j, c0w + p): u of region (ir+1, ic+1)
-  const unsigned ubyte_r = (unsigned)(U0 + (((rr0 + 1) * 32 + c0w + p + 1) * 8 + 4 * (q & 1)) * 4);
-  const bool lane_out = q < 2 && c0w + p < TC;
-  unsigned ooff = lane_out ? (unsigned)(((rr0 * a.w + c0w + p) * 8 + 4 * q) * 4) : BUF_OOB;
-  const unsigned orow2 = (unsigned)(a.w * 64);         // two rows of the state maps, bytes
+  // candidate epilogue, inner pixel (crow + CSTEP j, c0w + p), channels 4 (q & 1) ..: u of region (ir+1, ic+1).
+  // One-row runs: lanes q < 2, rows rr0 + 2 j.  Two-row: every lane, rows 2 (wave >> 1) + (q >> 1) + 4 j.
+  constexpr int CSTEP = C2R ? 4 : 2;
+  const int crow0 = C2R ? 2 * rr0 : rr0, crow = C2R ? crow0 + (q >> 1) : rr0;
+  const unsigned ubyte_r = (unsigned)(U0 + (((crow + 1) * 32 + c0w + p + 1) * 8 + 4 * (q & 1)) * 4);
+  const bool lane_out = (C2R || q < 2) && c0w + p < TC;
+  unsigned ooff = lane_out ? (unsigned)(((crow * a.w + c0w + p) * 8 + 4 * (q & 1)) * 4) : BUF_OOB;
+  const unsigned orow2 = (unsigned)(a.w * 32 * CSTEP); // CSTEP rows of the state maps, bytes
   pin(ooff);
+  unsigned xoffc[NKC];                                 // candidate run 0 of the wave
+#pragma unroll
+  for (int kb = 0; kb < NKC; ++kb) {
+    if (C2R) {                                         // k-block = (window row rr, kx) pairs: inner row R reads window rows R + 1 + rr
+      const int kk = 32 * kb + 8 * q, pos = kk / 16, ch0 = kk % 16;
+      xoffc[kb] = (unsigned)((((crow0 + 1 + pos / 3) * WC + c0w + p + 1 + pos % 3) * PB) + ch0 * 2);
+    } else {
+      xoffc[kb] = xoff[kb] + (WC + 1) * PB;
+    }
+    pin(xoffc[kb]);
+  }
 
   auto load_tile = [&](f32x4 (&sx)[NS], f32x4 (&sh)[NS], int b, int tx, int ty) {
     const int ix0 = tx * TC - 2, iy0 = ty * TR - 2;
@@ -453,7 +482,7 @@ struct Gru1FusedBx3Role {
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       oo[j] = ooff + j * orow2;
-      if (!full && !(oy0 + rr0 + 2 * j < a.h && ox0 + c0w + p < a.w)) oo[j] = BUF_OOB;
+      if (!full && !(oy0 + crow + CSTEP * j < a.h && ox0 + c0w + p < a.w)) oo[j] = BUF_OOB;
     }
     f32x4 pre_h[NC];
 #pragma unroll
@@ -463,7 +492,7 @@ struct Gru1FusedBx3Role {
     int bn = 0, txn = 0, tyn = 0;
     if (more) {
       tile_coords(tg, tn, bn, txn, tyn);
-      load_tile(sx, sh, bn, txn, tyn);
+      if (!(BX3_EXP & 8)) load_tile(sx, sh, bn, txn, tyn);
     }
 
     // ---- gates on cat(x, h)
@@ -473,9 +502,10 @@ struct Gru1FusedBx3Role {
       ag[j] = bias_g;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
-        const char* at = lds + xoff[kb] + j * (2 * WC * PB);
+        const char* at = lds + xoff[kb] + ((BX3_EXP & 2) ? 0 : j) * (2 * WC * PB);
         const bf16x8 bh = *(const bf16x8*)at;
         const bf16x8 bl = *(const bf16x8*)(at + LO);
+        if (BX3_EXP & 1) { keep(bh); keep(bl); continue; }
         ag[j] = mfma_bx(gh[kb], bh, ag[j]);
         ag[j] = mfma_bx(gh[kb], bl, ag[j]);
         ag[j] = mfma_bx(gl[kb], bh, ag[j]);
@@ -487,7 +517,7 @@ struct Gru1FusedBx3Role {
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const f32x4 v = ag[j];
-      const f32x4 sg = {sigmoid_pre(v.x), sigmoid_pre(v.y), sigmoid_pre(v.z), sigmoid_pre(v.w)};      // r(2q), r(2q+1), u(2q), u(2q+1)
+      const f32x4 sg = (BX3_EXP & 4) ? v : f32x4{sigmoid_pre(v.x), sigmoid_pre(v.y), sigmoid_pre(v.z), sigmoid_pre(v.w)};      // r(2q), r(2q+1), u(2q), u(2q+1)
       __bf16* hi = (__bf16*)(lds + hbyte + j * (2 * WC * PB));
       __bf16* lo = (__bf16*)((char*)hi + LO);
       const bf16x2 h2 = *(const bf16x2*)hi, l2 = *(const bf16x2*)lo;
@@ -506,10 +536,11 @@ struct Gru1FusedBx3Role {
     for (int j = 0; j < NC; ++j) {
       ac[j] = bias_c;
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const char* at = lds + xoff[kb] + (WC + 1) * PB + j * (2 * WC * PB);
+      for (int kb = 0; kb < NKC; ++kb) {
+        const char* at = lds + xoffc[kb] + ((BX3_EXP & 2) ? 0 : j) * (CSTEP * WC * PB);
         const bf16x8 bh = *(const bf16x8*)at;
         const bf16x8 bl = *(const bf16x8*)(at + LO);
+        if (BX3_EXP & 1) { keep(bh); keep(bl); continue; }
         ac[j] = mfma_bx(ch[kb], bh, ac[j]);
         ac[j] = mfma_bx(ch[kb], bl, ac[j]);
         ac[j] = mfma_bx(cl[kb], bh, ac[j]);
@@ -519,18 +550,18 @@ struct Gru1FusedBx3Role {
     for (int j = 0; j < NC; ++j) drain(ac[j]);
     f32x4 u4[NC];
 #pragma unroll
-    for (int j = 0; j < NC; ++j) u4[j] = *(const f32x4*)(lds + ubyte_r + j * (2 * 32 * 32));
+    for (int j = 0; j < NC; ++j) u4[j] = *(const f32x4*)(lds + ubyte_r + j * (CSTEP * 32 * 32));
 
     wait_vmem_all();                   // the one wait point of the tile
     __syncthreads();                   // every wave is done with the tile
-    if (more) store_tile(sx, sh);
+    if (more && !(BX3_EXP & 8)) store_tile(sx, sh);
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const f32x4 v = ac[j];
-      const f32x4 cnd = {tanh_pre(v.x), tanh_pre(v.y), tanh_pre(v.z), tanh_pre(v.w)};
+      const f32x4 cnd = (BX3_EXP & 4) ? v : f32x4{tanh_pre(v.x), tanh_pre(v.y), tanh_pre(v.z), tanh_pre(v.w)};
       const f32x4 hn = gru_blend(u4[j], pre_h[j], cnd);
       buf_store4(rout, oo[j], hn);
-      if (BX3_PRESPLIT) buf_store_split4(rsout, oo[j] == BUF_OOB ? BUF_OOB : oo[j] - 8 * q, 16, hn);
+      if (BX3_PRESPLIT) buf_store_split4(rsout, oo[j] == BUF_OOB ? BUF_OOB : oo[j] - 8 * (q & 1), 16, hn);
     }
     if (!more) break;
     __syncthreads();                   // next tile visible

@@ -6,6 +6,8 @@ of one tap), eval-mode BatchNorm is folded into the CostRegNet2D weights.
 Layouts are specified in include/adamvs_hip.h.  Pure tensor shuffling on the
 CPU; no arithmetic of the hot path happens here.
 """
+import os
+
 import torch
 
 BN_EPS = 1e-5
@@ -249,8 +251,10 @@ def pack_slice_reg_net(sd, pre, precision="fp32"):
         "conv1": pack_c1(sd[pre + "conv1.conv.weight"]),
         "gates1": pack_small(wg1),
         "gates1_b": pad_bias(bg1, 16),
-        # fp32: 8 outputs fill half an MFMA tile, so the kernel takes them in the two-row form of conv1
-        "cand1": (pack_conv1_two_row if precision == "fp32" else pack_small)(scaled("conv_gru1.convc.0.weight", cs)),
+        # 8 outputs fill half an MFMA tile, so the kernels take them in the two-row form of conv1 (bf16x3: since ABI 15;
+        # ADAMVS_BX3_CAND_TWO_ROW=0 packs the one-row form for a library built with -DBX3_CAND_TWO_ROW=0: A/B runs only)
+        "cand1": (pack_c1 if precision == "fp32" or os.environ.get("ADAMVS_BX3_CAND_TWO_ROW", "1") != "0" else pack_small)(
+            scaled("conv_gru1.convc.0.weight", cs)),
         "cand1_b": pad_bias(scaled("conv_gru1.convc.0.bias", cs), 16),
         "conv2": pack_small(sd[pre + "conv2.conv.weight"]),
         "gates2": pack_small(scaled("conv_gru2.conv_gates.0.weight", gs)),

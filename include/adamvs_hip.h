@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 14
+#define ADAMVS_ABI_VERSION 15
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
@@ -166,7 +166,8 @@ int adamvs_prob_softmax_regress_wino(const float* in, const float* wpk, const fl
  *
  * With precision ADAMVS_PRECISION_BF16X3 the conv1 / gates / cand / conv2 fields point to split-bf16 fragments
  * instead: the contraction index is flattened, k = pos*cin_total + cin (pos = tap ky*3+kx, or rr*3+kx for the
- * two-row conv1), zero-padded to a multiple of 32; layout [cout tile][hi|lo][k/32][lane][8 bf16], element j of
+ * two-row conv1 and -- since ABI 15 -- the two-row cand1: 12 positions x 16 channels = 6 k-blocks, rows as in the fp32 two-row
+ * form above), zero-padded to a multiple of 32; layout [cout tile][hi|lo][k/32][lane][8 bf16], element j of
  * lane l = W[16*tile + (l&15)][k = 32*kb + 8*(l>>4) + j].  upconv1 / final_w / the biases keep the fp32 form.
  *
  * PRE-SCALED FIELDS (since ABI 13; nothing in the struct's size or layout shows it, so a caller that packs its own blob must

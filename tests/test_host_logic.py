@@ -162,7 +162,8 @@ def test_packed_network_sizes_match_the_header():
     assert frag[1, 2, 3, 1, 8 + 5] == wc[5, 13, 0, 2]                 # rows 8-15: output row y+1, ky = rr - 1
     assert frag[3, 0, 0, 0, 2] == 0 and frag[0, 0, 0, 0, 8 + 2] == 0  # no tap for (row y, rr = 3) and (row y+1, rr = 0)
     flat_b, off_b = packing.pack_slice_reg_net(sd, "DepthNet.0.reg_fuse.", "bf16x3")
-    assert off_b["cand1_b"] - off_b["cand1"] != 12 * 4 * 64           # the split-bf16 kernel keeps its own k-flattened form
+    # split bf16 (ABI 15): cand1 two-row as well, k = (rr * 3 + kx) * 16 + cin = 192 = 6 k-blocks of [hi|lo][64 lanes][8 bf16]
+    assert off_b["cand1_b"] - off_b["cand1"] == 2 * 6 * 64 * 8 // 2
     # last layer: tap-major (a channel pair of one tap is one 64-bit scalar operand of the packed FMA), bias at [72]
     w_up = sd["DepthNet.0.reg_fuse.upconv2d.weight"]                  # ConvTranspose2d: [8][1][3][3]
     fw = flat[off["final_w"]:off["final_w"] + 73]
@@ -373,18 +374,26 @@ def test_gru_prescaled_fields_follow_the_header():
         frag = blob[off[field]:off[field] + nt_total * 2 * nkb * 64 * 4].view(torch.bfloat16).reshape(nt_total, 2, nkb, 64, 8)
         return float(frag[tile, 0, kb, lane, j]) + float(frag[tile, 1, kb, lane, j])
 
-    for field, key, nt, s, rows in (("gates1", "conv_gru1.conv_gates.0", 1, -L2E, header_rows), ("cand1", "conv_gru1.convc.0", 1, 2 * L2E, None),
+    for field, key, nt, s, rows in (("gates1", "conv_gru1.conv_gates.0", 1, -L2E, header_rows), ("cand1", "conv_gru1.convc.0", 1, 2 * L2E, "two-row"),
                                     ("gates2", "conv_gru2.conv_gates.0", 2, -L2E, None), ("cand2", "conv_gru2.convc.0", 1, 2 * L2E, None)):
         w, b = sd[pre + key + ".weight"].double(), sd[pre + key + ".bias"].double()
         cout, cin = w.shape[0], w.shape[1]
-        for tile, lane, kb, j in ((0, 5, 0, 3), (nt - 1, 38, 2, 7), (0, 63, (9 * cin) // 32 - 1, 0), (nt - 1, 16 + 9, 1, 4)):
+        two_row = rows == "two-row"                    # cand1 (ABI 15): positions (rr, kx), rows 0-7 output row y, 8-15 row y + 1
+        npos = 12 if two_row else 9
+        for tile, lane, kb, j in ((0, 5, 0, 3), (nt - 1, 38, 2, 7), (0, 63, (npos * cin) // 32 - 1, 0), (nt - 1, 16 + 9, 1, 4), (0, 12, 4, 2)):
             row = 16 * tile + (lane & 15)
             k = 32 * kb + 8 * (lane >> 4) + j
             tap, ci = k // cin, k % cin
-            src = rows[row] if rows else row
-            want = s * float(w[src, ci, tap // 3, tap % 3]) if src < cout and tap < 9 else 0.0
-            got = bx3_elem(field, nt, 9 * cin, tile, lane, kb, j)
+            if two_row:
+                rr, kx = tap // 3, tap % 3
+                src, ky = (row, rr) if row < 8 else (row - 8, rr - 1)
+                want = s * float(w[src, ci, ky, kx]) if 0 <= ky <= 2 else 0.0
+            else:
+                src = rows[row] if rows else row
+                want = s * float(w[src, ci, tap // 3, tap % 3]) if src < cout and tap < 9 else 0.0
+            got = bx3_elem(field, nt, npos * cin, tile, lane, kb, j)
             assert abs(got - want) <= 2 ** -15 * max(abs(want), 1e-6) + 1e-12, (field, tile, lane, kb, j, got, want)
+        rows = None if two_row else rows
         bias = blob[off[field + "_b"]:off[field + "_b"] + 16 * nt]
         for row in range(16 * nt):
             src = rows[row] if rows else row
