@@ -57,6 +57,9 @@ __device__ __forceinline__ void split_store(__bf16* hi, __bf16* lo, f32x4 v) {
 #ifndef BX3_EXP
 #define BX3_EXP 0
 #endif
+#ifndef BX3_GATE_REUSE
+#define BX3_GATE_REUSE 1
+#endif
 #ifndef BX3_CAND_TWO_ROW
 #define BX3_CAND_TWO_ROW 1
 #endif
@@ -496,15 +499,21 @@ struct Gru1FusedBx3Role {
     }
 
     // ---- gates on cat(x, h)
+    // A wave's runs are two rows apart, so k-block 3 of run j -- taps (2, 0) and (2, 1) -- IS k-block 0 of run j + 1 -- taps (0, 0)
+    // and (0, 1) two rows further down: kept in registers, 42 instead of 50 fragment reads (the reads are the largest single term of
+    // this kernel: with run 0's fragments serving every run it takes 81 instead of 125 us)
     f32x4 ag[NG];
+    bf16x8 ph, pl;
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       ag[j] = bias_g;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         const char* at = lds + xoff[kb] + ((BX3_EXP & 2) ? 0 : j) * (2 * WC * PB);
-        const bf16x8 bh = *(const bf16x8*)at;
-        const bf16x8 bl = *(const bf16x8*)(at + LO);
+        const bool reuse = BX3_GATE_REUSE && kb == 0 && j > 0;
+        const bf16x8 bh = reuse ? ph : *(const bf16x8*)at;
+        const bf16x8 bl = reuse ? pl : *(const bf16x8*)(at + LO);
+        if (BX3_GATE_REUSE && kb == 3) { ph = bh; pl = bl; }
         if (BX3_EXP & 1) { keep(bh); keep(bl); continue; }
         ag[j] = mfma_bx(gh[kb], bh, ag[j]);
         ag[j] = mfma_bx(gh[kb], bl, ag[j]);
@@ -709,8 +718,8 @@ struct Gru2FusedBx3Role {
 
     // ---- the wave's gate rows on cat(c2, h): region rows rr0, rr0 + 2, ...; r*h (from the split state of the window:
     //      what the candidate convolution multiplies is a split value anyway) and u go to their own buffers
-#pragma unroll 1                       // (unrolled, the scheduler interleaves the five chains: spills)
-    for (int j = 0; j < NG; ++j) {
+#pragma unroll 1                       // (unrolled, the scheduler interleaves the five chains: spills.  Keeping the taps (2, kx) of a
+    for (int j = 0; j < NG; ++j) {     //  run in registers as the taps (0, kx) of the next, as level 1 does: 24 registers, spills, 82 -> 91 us)
       f32x4 ag = *(const f32x4*)(lds + bgbyte);
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
