@@ -57,6 +57,12 @@ __device__ __forceinline__ void split_store(__bf16* hi, __bf16* lo, f32x4 v) {
 #ifndef BX3_EXP
 #define BX3_EXP 0
 #endif
+#ifndef BX3_AHEAD
+#define BX3_AHEAD 2
+#endif
+#ifndef BX3_AHEAD2
+#define BX3_AHEAD2 1
+#endif
 #ifndef BX3_GATE_REUSE
 #define BX3_GATE_REUSE 1
 #endif
@@ -502,22 +508,33 @@ struct Gru1FusedBx3Role {
     // A wave's runs are two rows apart, so k-block 3 of run j -- taps (2, 0) and (2, 1) -- IS k-block 0 of run j + 1 -- taps (0, 0)
     // and (0, 1) two rows further down: kept in registers, 42 instead of 50 fragment reads (the reads are the largest single term of
     // this kernel: with run 0's fragments serving every run it takes 81 instead of 125 us)
+    // The fragment reads run BX3_AHEAD k-blocks ahead of the MFMAs that consume them, across the runs (the compiler's own schedule
+    // waited for every k-block's two reads right after issuing them: with two waves per SIMD the LDS latency was exposed 25 times per
+    // tile -- the "fragments read once" timing build of DESIGN.md was mostly this).  One flat sequence of steps s = (run, k-block);
+    // everything is unrolled, so the fragment arrays are names for registers, and a reused k-block is the same registers again.
     f32x4 ag[NG];
-    bf16x8 ph, pl;
-#pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      ag[j] = bias_g;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
+    {
+      constexpr int NSTEP = NG * NKB, AH = BX3_AHEAD;
+      bf16x8 fh[NSTEP], fl[NSTEP];
+      auto rd = [&](int s) {
+        const int j = s / NKB, kb = s % NKB;
+        if (BX3_GATE_REUSE && kb == 0 && j > 0) { fh[s] = fh[s - 2]; fl[s] = fl[s - 2]; return; }      // = (run j - 1, k-block 3)
         const char* at = lds + xoff[kb] + ((BX3_EXP & 2) ? 0 : j) * (2 * WC * PB);
-        const bool reuse = BX3_GATE_REUSE && kb == 0 && j > 0;
-        const bf16x8 bh = reuse ? ph : *(const bf16x8*)at;
-        const bf16x8 bl = reuse ? pl : *(const bf16x8*)(at + LO);
-        if (BX3_GATE_REUSE && kb == 3) { ph = bh; pl = bl; }
-        if (BX3_EXP & 1) { keep(bh); keep(bl); continue; }
-        ag[j] = mfma_bx(gh[kb], bh, ag[j]);
-        ag[j] = mfma_bx(gh[kb], bl, ag[j]);
-        ag[j] = mfma_bx(gl[kb], bh, ag[j]);
+        fh[s] = *(const bf16x8*)at;
+        fl[s] = *(const bf16x8*)(at + LO);
+      };
+#pragma unroll
+      for (int s = 0; s < AH; ++s) rd(s);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const int j = s / NKB, kb = s % NKB;
+        if (s + AH < NSTEP) rd(s + AH);
+        if (AH) __builtin_amdgcn_sched_barrier(0);     // (the scheduler would sink the reads back to their uses)
+        if (kb == 0) ag[j] = bias_g;
+        if (BX3_EXP & 1) { keep(fh[s]); keep(fl[s]); continue; }
+        ag[j] = mfma_bx(gh[kb], fh[s], ag[j]);
+        ag[j] = mfma_bx(gh[kb], fl[s], ag[j]);
+        ag[j] = mfma_bx(gl[kb], fh[s], ag[j]);
       }
     }
 #pragma unroll
@@ -541,18 +558,27 @@ struct Gru1FusedBx3Role {
 
     // ---- candidate on cat(x, r*h)
     f32x4 ac[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      ac[j] = bias_c;
-#pragma unroll
-      for (int kb = 0; kb < NKC; ++kb) {
+    {
+      constexpr int NSTEP = NC * NKC, AH = BX3_AHEAD;
+      bf16x8 fh[NSTEP], fl[NSTEP];
+      auto rd = [&](int s) {
+        const int j = s / NKC, kb = s % NKC;
         const char* at = lds + xoffc[kb] + ((BX3_EXP & 2) ? 0 : j) * (CSTEP * WC * PB);
-        const bf16x8 bh = *(const bf16x8*)at;
-        const bf16x8 bl = *(const bf16x8*)(at + LO);
-        if (BX3_EXP & 1) { keep(bh); keep(bl); continue; }
-        ac[j] = mfma_bx(ch[kb], bh, ac[j]);
-        ac[j] = mfma_bx(ch[kb], bl, ac[j]);
-        ac[j] = mfma_bx(cl[kb], bh, ac[j]);
+        fh[s] = *(const bf16x8*)at;
+        fl[s] = *(const bf16x8*)(at + LO);
+      };
+#pragma unroll
+      for (int s = 0; s < AH; ++s) rd(s);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const int j = s / NKC, kb = s % NKC;
+        if (s + AH < NSTEP) rd(s + AH);
+        if (AH) __builtin_amdgcn_sched_barrier(0);
+        if (kb == 0) ac[j] = bias_c;
+        if (BX3_EXP & 1) { keep(fh[s]); keep(fl[s]); continue; }
+        ac[j] = mfma_bx(ch[kb], fh[s], ac[j]);
+        ac[j] = mfma_bx(ch[kb], fl[s], ac[j]);
+        ac[j] = mfma_bx(cl[kb], fh[s], ac[j]);
       }
     }
 #pragma unroll
@@ -721,14 +747,24 @@ struct Gru2FusedBx3Role {
 #pragma unroll 1                       // (unrolled, the scheduler interleaves the five chains: spills.  Keeping the taps (2, kx) of a
     for (int j = 0; j < NG; ++j) {     //  run in registers as the taps (0, kx) of the next, as level 1 does: 24 registers, spills, 82 -> 91 us)
       f32x4 ag = *(const f32x4*)(lds + bgbyte);
+      {                                // fragment reads BX3_AHEAD2 k-blocks ahead of their MFMAs, inside the run (as level 1 does across runs)
+        constexpr int AH = BX3_AHEAD2;
+        bf16x8 fh[NKB], fl[NKB];
+        auto rd = [&](int kb) {
+          const char* at = lds + xg + ((kb / 3) * WC + kb % 3) * PB + j * (2 * WC * PB);
+          fh[kb] = *(const bf16x8*)at;
+          fl[kb] = *(const bf16x8*)(at + LO);
+        };
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const char* at = lds + xg + ((kb / 3) * WC + kb % 3) * PB + j * (2 * WC * PB);
-        const bf16x8 bh = *(const bf16x8*)at;
-        const bf16x8 bl = *(const bf16x8*)(at + LO);
-        ag = mfma_bx(gh[kb], bh, ag);
-        ag = mfma_bx(gh[kb], bl, ag);
-        ag = mfma_bx(gl[kb], bh, ag);
+        for (int kb = 0; kb < AH; ++kb) rd(kb);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          if (kb + AH < NKB) rd(kb + AH);
+          if (AH) __builtin_amdgcn_sched_barrier(0);
+          ag = mfma_bx(gh[kb], fh[kb], ag);
+          ag = mfma_bx(gh[kb], fl[kb], ag);
+          ag = mfma_bx(gl[kb], fh[kb], ag);
+        }
       }
       drain(ag);
       const f32x4 sg = {sigmoid_pre(ag.x), sigmoid_pre(ag.y), sigmoid_pre(ag.z), sigmoid_pre(ag.w)};
