@@ -251,7 +251,7 @@ static const FusedCosts& fused_costs() {
   return c;
 }
 static RoleCosts parse_role_costs() {
-  RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 5.0f, 13.8f, 3.2f, 12.0f, 5.0f, 0.6f, 0.8f, 0.42f};       // (dec: 8 x 30 tiles since round 4)
+  RoleCosts c = {2.85f, 4.07f, 2.39f, 9.98f, 5.53f, 5.0f, 11.3f, 3.2f, 12.0f, 5.0f, 0.6f, 0.8f, 0.42f};       // (dec: 8 x 30 tiles since round 4; k1bx 13.8 until the two-row candidate of round 5)
   if (const char* e = getenv("ADAMVS_RECUR_COSTS")) {
     float v[13];
     bool ok = sscanf(e, "%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9, v + 10,

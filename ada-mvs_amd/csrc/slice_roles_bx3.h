@@ -53,7 +53,8 @@ __device__ __forceinline__ void split_store(__bf16* hi, __bf16* lo, f32x4 v) {
 #define BX3_PRESPLIT 0
 #endif
 // Timing builds of Gru1FusedBx3Role only (tools/build_variant.py <name> -DBX3_EXP=<bits>; results are wrong): 1 no MFMAs (the fragment
-// reads stay), 2 the B fragments of a tile read once (run 0's serve every run), 4 no transcendentals, 8 no window (loads and LDS stores).
+// reads stay), 2 the B fragments of a tile read once (run 0's serve every run -- NOT a measure of the reads: with identical operands the
+// compiler folds the runs' MFMA chains too), 4 no transcendentals, 8 no window (loads and LDS stores).
 #ifndef BX3_EXP
 #define BX3_EXP 0
 #endif
@@ -506,11 +507,10 @@ struct Gru1FusedBx3Role {
 
     // ---- gates on cat(x, h)
     // A wave's runs are two rows apart, so k-block 3 of run j -- taps (2, 0) and (2, 1) -- IS k-block 0 of run j + 1 -- taps (0, 0)
-    // and (0, 1) two rows further down: kept in registers, 42 instead of 50 fragment reads (the reads are the largest single term of
-    // this kernel: with run 0's fragments serving every run it takes 81 instead of 125 us)
+    // and (0, 1) two rows further down: kept in registers, 42 instead of 50 fragment reads
     // The fragment reads run BX3_AHEAD k-blocks ahead of the MFMAs that consume them, across the runs (the compiler's own schedule
     // waited for every k-block's two reads right after issuing them: with two waves per SIMD the LDS latency was exposed 25 times per
-    // tile -- the "fragments read once" timing build of DESIGN.md was mostly this).  One flat sequence of steps s = (run, k-block);
+    // tile: 1 - 4 % of the kernel).  One flat sequence of steps s = (run, k-block);
     // everything is unrolled, so the fragment arrays are names for registers, and a reused k-block is the same registers again.
     f32x4 ag[NG];
     {
