@@ -77,9 +77,15 @@ __device__ __forceinline__ f32x4 up_sample4(const float* map, int n, int hm, int
   return top * (1.f - ly) + bot * ly;
 }
 
-template <int CA, int CB, int NT, int MODE, int EPI>
+// PAIR8 (transposed layers with at most 8 output channels, round 5): a parity class fills rows 0-7 of an MFMA tile, so two classes
+// that read the same input pixel share one -- tile 1 = (class 00 | class 01), tile 2 = (10 | 11): input offset (0,0) feeds both tiles,
+// (0,1) the second halves of both, (1,0) and (1,1) tile 2 -- 6 MFMAs per k-chunk instead of 9, and every lane group carries outputs
+// (lanes q < 2 the first class of a tile, q >= 2 the second).  The paired fragments are formed per lane at kernel start from the
+// class-by-class fragments k_fconv is packed with: rows 8-15 take rows 0-7 of the partner's fragment (one ds_bpermute each).
+template <int CA, int CB, int NT, int MODE, int EPI, bool PAIR8 = false>
 __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
   using GM = FGeom<MODE>;
+  static_assert(!PAIR8 || GM::T, "PAIR8: the transposed mode");
   constexpr int CIN = CA + CB, KC = CIN / 4, G = CIN / 4, GA = CA / 4, GB = CB / 4;
   constexpr int TR = 4, TC = 16, STR = GM::STR, NTAPS = GM::NTAPS;
   constexpr int LR = GM::rows(TR), LC = GM::cols(TC), NPIX = LR * LC;
@@ -100,7 +106,28 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
       for (int kc = 0; kc < KC; ++kc) wf[nt][t][kc] = a.wpk[((nt * NTAPS + t) * KC + kc) * 64 + lane];
   f32x4 bias[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bias[nt] = *(const f32x4*)(a.bias + nt * 16 + 4 * q);
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = *(const f32x4*)(a.bias + nt * 16 + 4 * (PAIR8 ? (q & 1) : q));
+  // PAIR8: pw[tile][input offset ty * 2 + tx][kc]; class taps in wf: 00: 0 | 01: 1 (0,0), 2 (0,1) | 10: 3 (0,0), 4 (1,0) |
+  // 11: 5 (0,0), 6 (0,1), 7 (1,0), 8 (1,1)   (index = cbase[cls] + ty * (1 + px) + tx, as in the class-by-class chain below)
+  float pw[2][4][KC];
+  if constexpr (PAIR8) {
+    const bool upper = (lane & 15) >= 8;
+    const int from = (lane - 8) << 2;        // ds_bpermute byte address of lane - 8 (same k-row, output row - 8)
+    auto pair = [&](float lo, float hi) {   // rows 0-7 from `lo` (its rows 8-15 are zero), rows 8-15 <- rows 0-7 of `hi`
+      const float h = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, hi)));
+      return upper ? h : lo;
+    };
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      pw[0][0][kc] = pair(wf[0][0][kc], wf[0][1][kc]);      // (0,0): class 00 | class 01
+      pw[0][1][kc] = pair(0.f, wf[0][2][kc]);               // (0,1):          | class 01
+      pw[0][2][kc] = 0.f; pw[0][3][kc] = 0.f;
+      pw[1][0][kc] = pair(wf[0][3][kc], wf[0][5][kc]);      // (0,0): class 10 | class 11
+      pw[1][1][kc] = pair(0.f, wf[0][6][kc]);               // (0,1):          | class 11
+      pw[1][2][kc] = pair(wf[0][4][kc], wf[0][7][kc]);      // (1,0): class 10 | class 11
+      pw[1][3][kc] = pair(0.f, wf[0][8][kc]);               // (1,1):          | class 11
+    }
+  }
 
   // ---- per-lane constants
   unsigned goff[NL], lbyte[NL];
@@ -129,8 +156,8 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
   unsigned ooff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int co4 = nt * 16 + 4 * q;
-    const int py = GM::T ? 2 * row : row, px = GM::T ? 2 * p : p;
+    const int co4 = PAIR8 ? 4 * (q & 1) : nt * 16 + 4 * q;
+    const int py = GM::T ? 2 * row : row, px = GM::T ? 2 * p + (PAIR8 ? (q >> 1) : 0) : p;       // PAIR8: lanes q >= 2 hold the px = 1 class of their tile
     ooff[nt] = co4 < a.cout ? (unsigned)(((py * Wo + px) * a.ctot + a.co0 + co4) * 4) : BUF_OOB;
     pin(ooff[nt]);
   }
@@ -208,7 +235,10 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
           const float bv = *(const float*)((const char*)lds + xbyte[kc] + (ty9 * LC + tx9) * 4);
-          if (GM::T) {                 // input pixel (i+ty9, j+tx9) feeds the classes with py >= ty9, px >= tx9
+          if constexpr (PAIR8) {
+            if (ty9 == 0 && tx9 < 2) acc[0] = mfma16(pw[0][tx9][kc], bv, acc[0]);
+            acc[1] = mfma16(pw[1][ty9 * 2 + tx9][kc], bv, acc[1]);
+          } else if (GM::T) {          // input pixel (i+ty9, j+tx9) feeds the classes with py >= ty9, px >= tx9
 #pragma unroll
             for (int cls = 0; cls < 4; ++cls) {
               const int py = cls >> 1, px = cls & 1;
@@ -225,7 +255,14 @@ __global__ __launch_bounds__(256) void k_fconv(FConvArgs a, TileGrid tg) {
     __syncthreads();                   // every wave is done reading the tile
     if (more) store_tile(stage);
 
-    if (GM::T) {
+    if constexpr (PAIR8) {             // tile t: output row 2 row + t, column 2p + (q >> 1) (in ooff), channels 4 (q & 1) ..
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        f32x4 v = acc[tl] + bias[0];
+        if (EPI & FE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        buf_store4(ro, (valid && ooff[0] != BUF_OOB) ? ooff[0] + (unsigned)(tl * Wo * a.ctot * 4) : BUF_OOB, v);
+      }
+    } else if (GM::T) {
 #pragma unroll
       for (int cls = 0; cls < 4; ++cls) {
         f32x4 v = acc[cls] + bias[0];
@@ -429,9 +466,202 @@ static int launch_pair_two_row(const float* srcA, const float* srcB, const adamv
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The stride-1 3 x 3 layers in the minimal-filtering form F(2, 3) ALONG X (round 5; the form of conv1 of the recurrent net,
+// slice_red.hip::k_conv1_f23): a lane owns the output pixels (row, 2p) and (row, 2p + 1); per kernel row ky and input channel it
+// reads the four pixels 2p .. 2p + 3 (two 8-byte LDS reads), forms (d0 - d2, d1 + d2, d2 - d1, d1 - d3) and feeds four MFMAs with
+// U = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2) -- 12 products per two pixels and channel pair instead of 18, two LDS reads
+// instead of six, on tiles of 4 x 32 pixels instead of 4 x 16 (half the barriers per pixel).  U is formed per lane from the nine
+// tap fragments of the layer as they are packed for k_fconv (every tap fragment holds the same (cout, cin) element in a lane):
+// no second weight format.  y(2p) = m0 + m1 + m2, y(2p + 1) = m1 - m2 - m3.  These layers sat at 63 - 76 % of the fp32 matrix rate
+// on k_fconv (conv1.1 / 1.2, conv2.1 / 2.2, deconv1.conv: 2.9 of FeatureNet0's 9.8 ms per 160 images).
+template <int CA, int CB, int NT, int EPI>
+__global__ __launch_bounds__(256) void k_fconv_f23(FConvArgs a, TileGrid tg) {
+  static_assert(!(EPI & (FE_CONTEXT | FE_ADD_UP)), "plain epilogues");
+  constexpr int CIN = CA + CB, KC = CIN / 4, G = CIN / 4, GA = CA / 4, GB = CB / 4;
+  constexpr int TR = 4, TC = 32, LR = TR + 2, LC = TC + 2, NPIX = LR * LC;
+  constexpr int PLANE = plane_pitch16(NPIX), GP = group_pitch(PLANE, G);
+  static_assert((PLANE % 2) == 0 && (GP % 2) == 0 && (LC % 2) == 0, "8-byte aligned pair reads");
+  constexpr int NA = (NPIX * GA + 255) / 256, NB = (NPIX * GB + 255) / 256, NL = NA + NB;
+  extern __shared__ float lds[];         // [G][GP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+  const int row = wave;                  // the wave's run: row `wave` of the 4 x 32 tile
+
+  float uf[NT][3][4][KC];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const float g0 = a.wpk[((nt * 9 + ky * 3 + 0) * KC + kc) * 64 + lane], g1 = a.wpk[((nt * 9 + ky * 3 + 1) * KC + kc) * 64 + lane],
+                    g2 = a.wpk[((nt * 9 + ky * 3 + 2) * KC + kc) * 64 + lane];
+        uf[nt][ky][0][kc] = g0;
+        uf[nt][ky][1][kc] = 0.5f * ((g0 + g2) + g1);
+        uf[nt][ky][2][kc] = 0.5f * ((g0 + g2) - g1);
+        uf[nt][ky][3][kc] = g2;
+      }
+  f32x4 bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = *(const f32x4*)(a.bias + nt * 16 + 4 * q);
+
+  // ---- per-lane constants
+  unsigned goff[NL], lbyte[NL];
+  int rc[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const bool isA = k < NA;
+    const int gs = isA ? GA : GB, cs = isA ? CA : CB;
+    int j = tid + (isA ? k : k - NA) * 256;
+    j = min(j, NPIX * gs - 1);           // surplus lanes repeat the last item
+    const int g = j % gs, pp = j / gs, r = pp / LC, c = pp % LC;
+    goff[k] = (unsigned)(((r * a.wi + c) * cs + 4 * g) * 4);
+    lbyte[k] = (unsigned)((((isA ? 0 : GA) + g) * GP + r * LC + c) * 4);
+    rc[k] = r | (c << 16);
+    pin(goff[k]); pin(lbyte[k]); pin(rc[k]);
+  }
+  unsigned xbyte[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    xbyte[kc] = (unsigned)((kc * GP + q * PLANE + row * LC + 2 * p) * 4);
+    pin(xbyte[kc]);
+  }
+  unsigned ooff[NT];                     // the lane's pixel (row, 2p), channels co0 + 16 nt + 4q ..; (row, 2p + 1) is ctot floats further
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co4 = nt * 16 + 4 * q;
+    ooff[nt] = co4 < a.cout ? (unsigned)(((row * a.wo + 2 * p) * a.ctot + a.co0 + co4) * 4) : BUF_OOB;
+    pin(ooff[nt]);
+  }
+
+  auto load_tile = [&](f32x4 (&stage)[NL], int n, int tx, int ty) {
+    const int ix0 = tx * TC - 1, iy0 = ty * TR - 1;
+    const long pix0 = ((long)n * a.hi + iy0) * a.wi + ix0;
+    const buf_rsrc ra = make_rsrc((const char*)a.srcA + pix0 * (CA * 4));
+    const buf_rsrc rb = make_rsrc((const char*)a.srcB + pix0 * (CB * 4));
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + LR <= a.hi && ix0 + LC <= a.wi) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stage[k] = buf_load4(k < NA ? ra : rb, goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int iy = iy0 + (rc[k] & 0xffff), ix = ix0 + (rc[k] >> 16);
+        const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        stage[k] = buf_load4(k < NA ? ra : rb, ok ? goff[k] : BUF_OOB);              // zero padding
+      }
+    }
+  };
+  auto store_tile = [&](const f32x4 (&stage)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float* dl = (float*)((char*)lds + lbyte[k]);
+      f32x4 v = stage[k];
+      dl[0] = v.x; dl[PLANE] = v.y; dl[2 * PLANE] = v.z; dl[3 * PLANE] = v.w;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= tg.ntiles) return;
+  int n, tx, ty;
+  tile_coords(tg, t, n, tx, ty);
+  f32x4 stage[NL];
+  load_tile(stage, n, tx, ty);
+  wait_vmem_all();
+  store_tile(stage);
+  __syncthreads();
+  typedef float f32x2f __attribute__((ext_vector_type(2)));
+  for (;;) {
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const long opix0 = ((long)n * a.ho + oy0) * a.wo + ox0;
+    const buf_rsrc ro = make_rsrc((char*)a.out + opix0 * ((long)a.ctot * 4));
+    const bool valid0 = oy0 + row < a.ho && ox0 + 2 * p < a.wo, valid1 = oy0 + row < a.ho && ox0 + 2 * p + 1 < a.wo;
+    const int tn = t + gridDim.x;
+    const bool more = tn < tg.ntiles;
+    int nn = 0, txn = 0, tyn = 0;
+    if (more) {
+      tile_coords(tg, tn, nn, txn, tyn);
+      load_tile(stage, nn, txn, tyn);
+    }
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[nt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const char* at = (const char*)lds + xbyte[kc] + ky * LC * 4;
+        const f32x2f d01 = *(const f32x2f*)at, d23 = *(const f32x2f*)(at + 8);
+        // (v0, v3) = d01 - d23 and (v1, v2) = (d2 + d1, d2 - d1) as two packed instructions (written on the vector types: as scalars
+        // the compiler emits four)
+        const f32x2f v03 = d01 - d23;
+        const f32x2f v12 = __builtin_elementwise_fma(__builtin_shufflevector(d01, d01, 1, 1), f32x2f{1.0f, -1.0f}, __builtin_shufflevector(d23, d23, 0, 0));
+        const float v0 = v03.x, v1 = v12.x, v2 = v12.y, v3 = v03.y;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[nt][0] = mfma16(uf[nt][ky][0][kc], v0, acc[nt][0]);
+          acc[nt][1] = mfma16(uf[nt][ky][1][kc], v1, acc[nt][1]);
+          acc[nt][2] = mfma16(uf[nt][ky][2][kc], v2, acc[nt][2]);
+          acc[nt][3] = mfma16(uf[nt][ky][3][kc], v3, acc[nt][3]);
+        }
+      }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) drain(acc[nt][j]);
+
+    wait_vmem_all();
+    __syncthreads();                   // every wave is done reading the tile
+    if (more) store_tile(stage);
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 y0 = ((acc[nt][0] + acc[nt][1]) + acc[nt][2]) + bias[nt];
+      f32x4 y1 = ((acc[nt][1] - acc[nt][2]) - acc[nt][3]) + bias[nt];
+      if (EPI & FE_RELU) {
+        y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
+        y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
+      }
+      buf_store4(ro, valid0 ? ooff[nt] : BUF_OOB, y0);
+      buf_store4(ro, (valid1 && ooff[nt] != BUF_OOB) ? ooff[nt] + (unsigned)(a.ctot * 4) : BUF_OOB, y1);
+    }
+    if (!more) break;
+    __syncthreads();                   // next tile visible
+    t = tn; n = nn; tx = txn; ty = tyn;
+  }
+}
+
+// ADAMVS_FCONV_F23=0: the stride-1 3 x 3 layers on k_fconv, as in rounds 2 - 4 (A/B)
+static bool fconv_f23() {
+  static const bool on = [] { const char* e = getenv("ADAMVS_FCONV_F23"); return !(e && *e == '0'); }();
+  return on;
+}
+
+template <int CA, int CB, int NT, int EPI>
+static int launch_fconv_f23(const FConvArgs& a, int N, hipStream_t st, const char* name) {
+  constexpr int G = (CA + CB) / 4, NPIX = 6 * 34;
+  constexpr size_t lds = (size_t)G * group_pitch(plane_pitch16(NPIX), G) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
+  auto kern = k_fconv_f23<CA, CB, NT, EPI>;
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
+  TileGrid tg;
+  if (int rc = make_tile_grid(tg, cdiv(a.wo, 32), cdiv(a.ho, 4), N)) return rc;
+  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tg);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "feature_net0 %s (F(2,3) along x): %s", name, hipGetErrorString(e));
+  return 0;
+}
+
 template <int CA, int CB, int NT, int MODE, int EPI>
 static int launch_fconv(const FConvArgs& a_in, int N, hipStream_t st, const char* name) {
   using GM = FGeom<MODE>;
+  if constexpr (MODE == FM_K3 && !(EPI & (FE_CONTEXT | FE_ADD_UP))) {
+    if (fconv_f23()) return launch_fconv_f23<CA, CB, NT, EPI>(a_in, N, st, name);
+  }
   FConvArgs a = a_in;
   if (EPI & FE_CONTEXT) {
     a.syA = (float)a.hA / (float)a.ho; a.sxA = (float)a.wA / (float)a.wo;
@@ -441,10 +671,20 @@ static int launch_fconv(const FConvArgs& a_in, int N, hipStream_t st, const char
   constexpr int PLANE = (GM::STR == 1) ? plane_pitch16(NPIX) : (NPIX | 1);
   constexpr size_t lds = (size_t)G * group_pitch(PLANE, G) * sizeof(float);
   static_assert(lds <= 64 * 1024, "tile exceeds the default dynamic LDS limit");
-  auto kern = k_fconv<CA, CB, NT, MODE, EPI>;
-  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
   TileGrid tg;
   if (int rc = make_tile_grid(tg, cdiv(a.wo, 16), cdiv(a.ho, 4), N)) return rc;
+  if constexpr (GM::T && NT == 1) {
+    if (a.cout <= 8 && fconv_f23()) {      // (the same switch: ADAMVS_FCONV_F23=0 = rounds 2 - 4)
+      auto kp = k_fconv<CA, CB, NT, MODE, EPI, true>;
+      static const int cap8 = resident_blocks(kp, 256, lds);
+      hipLaunchKernelGGL(kp, dim3(tg.ntiles < cap8 ? tg.ntiles : cap8), dim3(256), lds, st, a, tg);
+      hipError_t e8 = hipGetLastError();
+      if (e8 != hipSuccess) return set_error((int)e8, "feature_net0 %s (paired classes): %s", name, hipGetErrorString(e8));
+      return 0;
+    }
+  }
+  auto kern = k_fconv<CA, CB, NT, MODE, EPI>;
+  static const int capacity = resident_blocks(kern, 256, lds);      // once per instantiation, thread-safely (magic static)
   const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, tg);
   hipError_t e = hipGetLastError();

@@ -609,6 +609,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   phase 2  last layer on the vector units.  Transposed (IN_UP): one thread per s pixel produces its 2 x 2
 //            output quad from s[i..i+1][j..j+1] (72 FMAs, weights as scalar operands), two 8-byte stores.
 //            Flat: one thread per pixel, 3 x 3 x 8 FMAs.
+// Round 5 (A/B: -DDEC_PAIR=0): PAIRED parity classes in phase 1.  upconv1 has 8 output channels: a parity class fills rows 0-7 of an
+// MFMA tile.  The classes (py = 0, px) and (py = 1, px) of one h2 base row li read the same h2 pixels, so they share a tile -- rows
+// 0-7 = s row 2 li - 1 (tap ky = 1), rows 8-15 = s row 2 li (ky = 2 from row li, ky = 0 from row li + 1): per base row and k-chunk
+// 2 MFMAs for px = 0 and 4 for px = 1 instead of 3 and 6, every lane group carries outputs (half the epilogue per lane), and the
+// paired fragments are formed per lane at kernel start from the fragments the kernel is packed with (rows 8-15 of a tap's fragment
+// are zero: they take rows 0-7 of the partner's, one ds_bpermute each).  Six base rows cover the ten s rows (the outer halves of
+// rows 0 and 5 fall outside the region and are dropped): 12 tile runs, three per wave -- (li = wave, px = 1), (li = wave, px = 0)
+// and one of (4 | 5, px = 1 | 0) -- 40 / 32 MFMAs per wave instead of 40 - 52.
+#ifndef DEC_PAIR
+#define DEC_PAIR 1
+#endif
 template <bool IN_UP>
 struct DecoderRole {
   typedef DecoderArgs Args;
@@ -616,7 +627,7 @@ struct DecoderRole {
   static constexpr int SR = TRI + 2, SC = 32, SPX = 12; // s region, channel-last, 8 channels + 4 floats of padding per
                                                   // pixel: 16-byte lane accesses at a 48-byte stride are conflict-free
   static constexpr int HR = TRI / 2 + 2, HCOLS = 17, HPLANE = plane_pitch16(HR * HCOLS);     // h2 region, 16 planes in 4 groups
-  static constexpr int NRUN = 5;                                            // runs per wave: (class j, row wave) j = 0..3; (class wave, row 4)
+  static constexpr int NRUN = DEC_PAIR ? 3 : 5;                             // runs per wave.  5: (class j, row wave) j = 0..3; (class wave, row 4)
   static_assert(TRI == 8 && TRI * TCI <= 256, "five s-row pairs, one thread per inner pixel in phase 2");
   static constexpr int HGP = group_pitch(HPLANE, 4);
   static constexpr int NH = (HR * HCOLS * 4 + 255) / 256;                   // h2 load instructions per tile
@@ -633,7 +644,26 @@ struct DecoderRole {
   const int h = a.h, w = a.w, h2 = h >> 1, w2 = w >> 1;
   float wf[1][9][4];
   load_wfrag<1, 4>(wf, a.wup1, lane);
-  const f32x4 bup = *(const f32x4*)(a.bup1 + 4 * q);
+  const f32x4 bup = *(const f32x4*)(a.bup1 + 4 * (DEC_PAIR ? (q & 1) : q));
+  // paired fragments [input offset][kc]: P1 = px 1 classes (01 | 11) at (0,0), (0,1), (1,0), (1,1); P0 = px 0 classes (00 | 10) at (0,0), (1,0)
+  float P1[4][4], P0[2][4];
+  if (DEC_PAIR) {
+    const bool upper = (lane & 15) >= 8;
+    const int from = (lane - 8) << 2;                                       // ds_bpermute address of lane - 8: same k-row, output row - 8
+    auto pair = [&](float lo, float hi) {
+      const float hv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, hi)));
+      return upper ? hv : lo;
+    };
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      P1[0][kc] = pair(wf[0][1 * 3 + 2][kc], wf[0][2 * 3 + 2][kc]);
+      P1[1][kc] = pair(wf[0][1 * 3 + 0][kc], wf[0][2 * 3 + 0][kc]);
+      P1[2][kc] = pair(0.f, wf[0][0 * 3 + 2][kc]);
+      P1[3][kc] = pair(0.f, wf[0][0 * 3 + 0][kc]);
+      P0[0][kc] = pair(wf[0][1 * 3 + 1][kc], wf[0][2 * 3 + 1][kc]);
+      P0[1][kc] = pair(0.f, wf[0][0 * 3 + 1][kc]);
+    }
+  }
 
   // ---- per-lane constants
   unsigned h2off[NH], h2lds[NH];
@@ -648,10 +678,23 @@ struct DecoderRole {
     pin(h2off[k]); pin(h2lds[k]); pin(h2rc[k]);
   }
   // run j < 4 of this wave = parity class j (py = j >> 1, px = j & 1), row k = wave of that class; run 4 = class `wave`, row 4
-  unsigned xbyte[NRUN], h1off[NRUN], sbyte[NRUN];
+  unsigned xbyte[NRUN], xbyte1[NRUN], h1off[NRUN], sbyte[NRUN];
   int src[NRUN];       // s-region row | column << 16 of the lane's pixel
+  unsigned rmask = 0;  // DEC_PAIR: bit j = the lane's s row of run j lies inside the region
 #pragma unroll
   for (int j = 0; j < NRUN; ++j) {
+    if (DEC_PAIR) {
+      const int li = j < 2 ? wave : 4 + (wave & 1), px = j == 0 ? 1 : (j == 1 ? 0 : (wave < 2 ? 1 : 0));
+      const int lj = px ? p : p + 1, r = 2 * li - 1 + (q >> 1), c = px ? 2 * p : 2 * p + 1;
+      const bool rv = (unsigned)r < (unsigned)SR;
+      xbyte[j] = (unsigned)((q * HPLANE + li * HCOLS + lj) * 4);
+      xbyte1[j] = xbyte[j] + (li + 1 < HR ? HCOLS * 4 : 0);                  // the taps of h2 row li + 1 (base row 5: dropped half, row 5 again)
+      h1off[j] = rv ? (unsigned)(((r * w + c) * 8 + 4 * (q & 1)) * 4) : BUF_OOB;
+      sbyte[j] = (unsigned)((((rv ? r : 0) * SC + c) * SPX + 4 * (q & 1)) * 4);
+      src[j] = (rv ? r : 0) | (c << 16);
+      rmask |= rv ? (1u << j) : 0u;
+      pin(xbyte1[j]);
+    } else {
     const int cls = j < 4 ? j : wave, py = cls >> 1, px = cls & 1, k = j < 4 ? wave : 4;
     const int r = py ? 2 * k : 2 * k + 1, c = px ? 2 * p : 2 * p + 1;
     const int li = py ? k : k + 1, lj = px ? p : p + 1;
@@ -659,8 +702,10 @@ struct DecoderRole {
     h1off[j] = q < 2 ? (unsigned)(((r * w + c) * 8 + 4 * q) * 4) : BUF_OOB;       // rows 8-15 of the tile are padding
     sbyte[j] = (unsigned)(((r * SC + c) * SPX + 4 * (q & 1)) * 4);
     src[j] = r | (c << 16);
+    }
     pin(xbyte[j]); pin(h1off[j]); pin(sbyte[j]); pin(src[j]);
   }
+  pin(rmask);
   // phase 2: thread -> inner pixel (i, j)
   const bool worker = tid < TRI * TCI;
   const int pi = min(tid, TRI * TCI - 1) / TCI, pj = min(tid, TRI * TCI - 1) % TCI;
@@ -699,7 +744,7 @@ struct DecoderRole {
 #pragma unroll
     for (int j = 0; j < NRUN; ++j) {
       const int ys = ys0 + (src[j] & 0xffff), xs = xs0 + (src[j] >> 16);
-      const bool ok = (unsigned)ys < (unsigned)h && (unsigned)xs < (unsigned)w;
+      const bool ok = ((unsigned)ys < (unsigned)h && (unsigned)xs < (unsigned)w) || (DEC_PAIR && !((rmask >> j) & 1u));     // (a dropped half: nothing to zero)
       hreg[j] = buf_load4(r1, ok ? h1off[j] : BUF_OOB);
       in |= ok ? (1u << j) : 0u;
     }
@@ -735,6 +780,36 @@ struct DecoderRole {
 
     // ---- phase 1
     f32x4 sv[NRUN];
+#if DEC_PAIR
+    {
+      auto chain1 = [&](unsigned x0, unsigned x1) {      // px = 1 tile: h2 pixels (li, lj), (li, lj + 1), (li + 1, lj), (li + 1, lj + 1)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          const char* b0 = (const char*)lh2 + x0 + kc * HGP * 4;
+          const char* b1 = (const char*)lh2 + x1 + kc * HGP * 4;
+          acc = mfma16(P1[0][kc], *(const float*)b0, acc);
+          acc = mfma16(P1[1][kc], *(const float*)(b0 + 4), acc);
+          acc = mfma16(P1[2][kc], *(const float*)b1, acc);
+          acc = mfma16(P1[3][kc], *(const float*)(b1 + 4), acc);
+        }
+        return acc;
+      };
+      auto chain0 = [&](unsigned x0, unsigned x1) {      // px = 0 tile: (li, lj), (li + 1, lj)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          acc = mfma16(P0[0][kc], *(const float*)((const char*)lh2 + x0 + kc * HGP * 4), acc);
+          acc = mfma16(P0[1][kc], *(const float*)((const char*)lh2 + x1 + kc * HGP * 4), acc);
+        }
+        return acc;
+      };
+      sv[0] = chain1(xbyte[0], xbyte1[0]);
+      sv[1] = chain0(xbyte[1], xbyte1[1]);
+      if (wave < 2) sv[2] = chain1(xbyte[2], xbyte1[2]);                  // uniform
+      else sv[2] = chain0(xbyte[2], xbyte1[2]);
+    }
+#else
     sv[0] = upconv1_class<0, 0, HGP, HCOLS>(wf, lh2, xbyte[0]);
     sv[1] = upconv1_class<0, 1, HGP, HCOLS>(wf, lh2, xbyte[1]);
     sv[2] = upconv1_class<1, 0, HGP, HCOLS>(wf, lh2, xbyte[2]);
@@ -745,10 +820,11 @@ struct DecoderRole {
       case 2: sv[4] = upconv1_class<1, 0, HGP, HCOLS>(wf, lh2, xbyte[4]); break;
       default: sv[4] = upconv1_class<1, 1, HGP, HCOLS>(wf, lh2, xbyte[4]); break;
     }
+#endif
 #pragma unroll
     for (int j = 0; j < NRUN; ++j) drain(sv[j]);
     const bool all_in = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(inside != ALL_IN) == 0) != 0;
-    if (q < 2) {
+    if (DEC_PAIR || q < 2) {
 #pragma unroll
       for (int j = 0; j < NRUN; ++j) {
         f32x4 v = sv[j] + bup + hreg[j];                                  // adamvs.py:420-421
@@ -761,7 +837,8 @@ struct DecoderRole {
           if (!((inside >> j) & 1u)) sv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int j = 0; j < NRUN; ++j) *(f32x4*)((char*)ls + sbyte[j]) = sv[j];
+      for (int j = 0; j < NRUN; ++j)
+        if (!DEC_PAIR || ((rmask >> j) & 1u)) *(f32x4*)((char*)ls + sbyte[j]) = sv[j];
     }
     unsigned inside_n = ALL_IN;
     if (more) inside_n = load_h1(hreg, bn, txn, tyn);                     // hreg is free again
