@@ -523,6 +523,9 @@ __global__ void k_soft_argmin_chunk(const float* __restrict__ vol, int vol_D, Pl
   const PlaneLine p10 = plane_line(planes, b, (size_t)y1 * w + x0, D, hw), p11 = plane_line(planes, b, (size_t)y1 * w + x1, D, hw);
   float E = 0.f, M = 0.f, A = 0.f;
   if (!first) { E = acc[i]; M = acc[total + i]; A = acc[2 * total + i]; }
+  // eight planes per trip: their loads are issued together (one load in flight per thread ran this kernel at 2.9 TB/s); the sums keep
+  // their order
+#pragma unroll 8
   for (int d = 0; d < nd; ++d) {
     float pr = __expf(v[(size_t)d * HW]);
     float dep;
