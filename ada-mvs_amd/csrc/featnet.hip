@@ -476,7 +476,7 @@ static int launch_pair_two_row(const float* srcA, const float* srcB, const adamv
 // no second weight format.  y(2p) = m0 + m1 + m2, y(2p + 1) = m1 - m2 - m3.  These layers sat at 63 - 76 % of the fp32 matrix rate
 // on k_fconv (conv1.1 / 1.2, conv2.1 / 2.2, deconv1.conv: 2.9 of FeatureNet0's 9.8 ms per 160 images).
 template <int CA, int CB, int NT, int EPI>
-__global__ __launch_bounds__(256) void k_fconv_f23(FConvArgs a, TileGrid tg) {
+__global__ __launch_bounds__(256, (CA + CB == 16 && NT == 1) ? 4 : 1) void k_fconv_f23(FConvArgs a, TileGrid tg) {      // (16 channels: 132 registers uncapped -- three waves per SIMD; 128: four)
   static_assert(!(EPI & (FE_CONTEXT | FE_ADD_UP)), "plain epilogues");
   constexpr int CIN = CA + CB, KC = CIN / 4, G = CIN / 4, GA = CA / 4, GB = CB / 4;
   constexpr int TR = 4, TC = 32, LR = TR + 2, LC = TC + 2, NPIX = LR * LC;
@@ -743,7 +743,7 @@ static int launch_out8_context(const FConvArgs& a_in, int N, hipStream_t st) {
 // are 16 and 64 times smaller than the feature map, so this is a plain streaming kernel.
 //   w1 [C/2][C] (scale folded), b1 [C/2], w2 [C][C/2];  outA [N][(h/4)(w/4)][C], outB [N][(h/8)(w/8)][C]
 template <int C>
-__global__ __launch_bounds__(256) void k_context(const float* __restrict__ feat, adamvs_context_weights wa,
+__global__ __launch_bounds__(256, C == 8 ? 4 : 1) void k_context(const float* __restrict__ feat, adamvs_context_weights wa,
                                                  adamvs_context_weights wb, float* __restrict__ outA,
                                                  float* __restrict__ outB, int h, int w, size_t total) {
   constexpr int C2 = C / 2;

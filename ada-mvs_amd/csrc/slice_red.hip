@@ -44,8 +44,12 @@ __global__ __launch_bounds__(256) void k_conv_small_pro(SmallConvArgs a, TileGri
   ConvSmallRole<CA, CB, NT, 1, EPI_LINEAR, 4, 1>::run(a, tg, TileRange{0, tg.ntiles}, blockIdx.x, gridDim.x, lds, pro);
 }
 
+// DEC_WAVES workgroups per CU the decoder is built for (A/B: -DDEC_WAVES=1 = no register cap, 133 registers = three)
+#ifndef DEC_WAVES
+#define DEC_WAVES 4
+#endif
 template <bool IN_UP>
-__global__ __launch_bounds__(256) void k_decoder(DecoderArgs a, TileGrid tg) {
+__global__ __launch_bounds__(256, DEC_WAVES) void k_decoder(DecoderArgs a, TileGrid tg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   DecoderRole<IN_UP>::run(a, tg, TileRange{0, tg.ntiles}, blockIdx.x, gridDim.x, lds);
 }
