@@ -10,8 +10,12 @@ failure modes that has not, and this module is where they are handled:
   * a rank that HANGS (a collective that never completes, a GPU that stopped answering) would leave the run sitting until an
     outer timeout with no diagnostic: after `timeout` seconds every rank still alive is ended by PID -- SIGTERM, then SIGKILL after
     a grace period -- and the launcher returns 124 (the code of coreutils' `timeout`);
+  * the LAUNCHER is told to stop (SIGTERM / SIGHUP / SIGINT from an outer `timeout`, a scheduler or `gpurun`'s own limit): the
+    ranks are no process group of their own and would be orphaned inside a collective, holding the GPUs: the signal is caught,
+    every rank is ended by PID and the launcher returns 128 + signal;
   * ranks other than 0 have no stdout of interest, but their stderr is all there is when they fail: every rank's stderr goes to
-    a file of its own and its last lines are relayed on any failure.
+    a file of its own and its last lines are relayed on any failure; the files themselves are KEPT after a failed run (their
+    directory is named in the report) and removed after a good one.
 
 Never an exec: the children are fresh processes (`subprocess.Popen`), the launcher itself imports nothing that initialises the
 GPU (this module imports no torch).
@@ -22,6 +26,7 @@ import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 DEFAULT_TIMEOUT_S = 900.0
@@ -97,6 +102,15 @@ def run_ranks(cmd, world, timeout=DEFAULT_TIMEOUT_S, extra_env=None, tail_lines=
     port = free_port()
     tmp = tempfile.mkdtemp(prefix="adamvs_ranks_")
     procs, logs, files = [], [], []
+    code = 1                                                   # what `finally` sees if anything below raises
+    told = []                                                  # signals the launcher itself received
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():  # signal.signal works on the main thread only
+        for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+            try:
+                old_handlers[sig] = signal.signal(sig, lambda n, _f: told.append(n))
+            except (OSError, ValueError):
+                pass
     try:
         for r in range(world):
             path = os.path.join(tmp, "rank%d.stderr" % r)
@@ -105,7 +119,6 @@ def run_ranks(cmd, world, timeout=DEFAULT_TIMEOUT_S, extra_env=None, tail_lines=
             logs.append(path)
             procs.append(subprocess.Popen(list(cmd), env=rank_env(r, world, port, extra=extra_env),
                                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=f))
-        import threading
         out0 = []
         reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
         reader.start()
@@ -113,6 +126,13 @@ def run_ranks(cmd, world, timeout=DEFAULT_TIMEOUT_S, extra_env=None, tail_lines=
         code, how = 0, {}
         pending = list(range(world))
         while pending:
+            if told:
+                code = 128 + told[0]
+                for q in pending:
+                    how[q] = "ended by the launcher, which received signal %d" % told[0]
+                _end([procs[q] for q in pending])
+                pending = []
+                break
             for r in list(pending):
                 c = procs[r].poll()
                 if c is None:
@@ -138,8 +158,8 @@ def run_ranks(cmd, world, timeout=DEFAULT_TIMEOUT_S, extra_env=None, tail_lines=
         for f in files:
             f.close()
         if code != 0:
-            err.write("launcher: %d rank(s), exit code %d%s\n" % (
-                world, code, " (deadline of %.0f s passed: --launch-timeout)" % timeout if code == TIMEOUT_EXIT_CODE else ""))
+            err.write("launcher: %d rank(s), exit code %d%s; every rank's full stderr is kept in %s\n" % (
+                world, code, " (deadline of %.0f s passed: --launch-timeout)" % timeout if code == TIMEOUT_EXIT_CODE else "", tmp))
             for r in range(world):
                 err.write("---- rank %d (pid %d): %s; last stderr lines:\n%s\n" % (
                     r, procs[r].pid, how.get(r, "exit code %s" % procs[r].returncode), _tail(logs[r], tail_lines) or "(none)"))
@@ -157,18 +177,22 @@ def run_ranks(cmd, world, timeout=DEFAULT_TIMEOUT_S, extra_env=None, tail_lines=
                 pass
         return code, data
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+        _end([p for p in procs if p.poll() is None], grace=1.0)
+        for sig, h in old_handlers.items():
+            try:
+                signal.signal(sig, h)
+            except (OSError, ValueError):
+                pass
         for f in files:
             if not f.closed:
                 f.close()
-        for path in logs:
+        if code == 0:                                          # a failed run keeps its logs (the report names the directory)
+            for path in logs:
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
             try:
-                os.remove(path)
+                os.rmdir(tmp)
             except OSError:
                 pass
-        try:
-            os.rmdir(tmp)
-        except OSError:
-            pass

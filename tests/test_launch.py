@@ -28,6 +28,15 @@ def _pid_alive(pid):
         return False
 
 
+def _kept_logs(txt):
+    """The directory a failed run keeps its ranks' stderr in (named in the report); removed here after a look inside."""
+    import shutil
+    d = txt.split("full stderr is kept in ")[1].split("\n")[0].strip()
+    names = sorted(os.listdir(d))
+    shutil.rmtree(d, ignore_errors=True)
+    return names
+
+
 def test_all_ranks_succeed_and_rank0_stdout_is_relayed():
     out, err = io.StringIO(), io.StringIO()
     code, data = launch.run_ranks(WORKER + ["ok"], 2, timeout=120, out=out, err=err)
@@ -54,6 +63,31 @@ def test_a_rank_sleeping_outside_the_barrier_trips_the_deadline():
     assert txt.count("still running after 20 s: ended by the launcher") == 2
     assert not any(_pid_alive(p) for p in pids)
     assert '"ok"' not in out.getvalue()
+    assert _kept_logs(txt) == ["rank0.stderr", "rank1.stderr"]
+
+
+def test_a_launcher_told_to_stop_ends_its_ranks():
+    """SIGTERM to the launcher itself (an outer `timeout`, a scheduler): the ranks are ended by PID, the code is 128 + 15."""
+    prog = ("import sys, os; sys.path.insert(0, %r); import ada_mvs_amd; from ada_mvs_amd import launch;"
+            "sys.exit(launch.run_ranks([sys.executable, %r, 'hang'], 2, timeout=300)[0])" % (ROOT, WORKER[1]))
+    p = subprocess.Popen([sys.executable, "-c", prog], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # wait until both ranks exist (children of the launcher), then tell the launcher to stop
+    kids, t_end = [], time.monotonic() + 120
+    while len(kids) < 2 and time.monotonic() < t_end:
+        try:
+            with open("/proc/%d/task/%d/children" % (p.pid, p.pid)) as f:
+                kids = [int(x) for x in f.read().split()]
+        except OSError:
+            kids = []
+        time.sleep(0.2)
+    assert len(kids) == 2
+    time.sleep(1.0)
+    p.send_signal(15)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + 15
+    assert not any(_pid_alive(k) for k in kids)
+    assert "received signal 15" in err
+    _kept_logs(err)
 
 
 def test_a_failing_rank_ends_the_others_and_its_stderr_is_relayed():
@@ -63,6 +97,7 @@ def test_a_failing_rank_ends_the_others_and_its_stderr_is_relayed():
     assert code == 7 and time.monotonic() - t0 < 120
     txt = err.getvalue()
     assert "rank 1: simulated failure" in txt and "ended by the launcher after rank 1 failed" in txt
+    _kept_logs(txt)
 
 
 def test_bench_parses_launch_timeout_before_torch_and_relays_rank_failures():
@@ -70,7 +105,10 @@ def test_bench_parses_launch_timeout_before_torch_and_relays_rank_failures():
     non-zero -- not 124 -- within the deadline and says which rank said what."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["ADAMVS_DIST_BACKEND"] = "gloo"
+    # hide every device from the ranks: the failure must not depend on the host (a box with two GPUs would run real ranks)
+    env["HIP_VISIBLE_DEVICES"] = env["ROCR_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = ""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-timeout=60", "--workload", "tiny"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode not in (0, 124)
     assert "---- rank 0 (pid " in r.stderr and "---- rank 1 (pid " in r.stderr
+    _kept_logs(r.stderr)
