@@ -60,6 +60,11 @@ class StageDesc(ctypes.Structure):
 SIGNATURES = {
     "adamvs_version": (c_i, []),
     "adamvs_last_error_string": (ctypes.c_char_p, []),
+    "adamvs_option_count": (c_i, []),
+    "adamvs_option_name": (ctypes.c_char_p, [c_i]),
+    "adamvs_option_default": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),
+    "adamvs_get_option": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),
+    "adamvs_set_option": (c_i, [ctypes.c_char_p, c_i]),
     "adamvs_relative_transforms": (c_i, [c_f, c_f, c_i, c_i, c_st]),
     "adamvs_pack_features": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
     "adamvs_unpack_features": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
@@ -89,6 +94,8 @@ SIGNATURES = {
     "adamvs_gru_wino_mask": (c_i, []),
     "adamvs_depth_stage_forward": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, c_sz, ctypes.POINTER(FuseWeights),
                                          c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p, c_sz, c_st]),
+    "adamvs_bench_stage_phase": (c_i, [ctypes.POINTER(StageDesc), c_f, c_f, c_f, c_f, c_f, c_sz, ctypes.POINTER(FuseWeights),
+                                       c_f, c_f, c_f, c_f, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_feature_net0_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "adamvs_feature_net0": (c_i, [c_f, ctypes.POINTER(FeatureWeights), c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
     "adamvs_feature_net0_views": (c_i, [c_f, ctypes.POINTER(FeatureWeights), c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_void_p, c_sz, c_st]),
@@ -110,11 +117,10 @@ SIGNATURES = {
     "adamvs_soft_argmin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_st]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 PLANES_EXPLICIT, PLANES_UNIFORM, PLANES_WINDOW = 0, 1, 2
 PHASE_VIEW_WEIGHTS, PHASE_AGGREGATE, PHASE_RECURRENCE, PHASE_SOFT_ARGMIN, PHASE_ALL = 1, 2, 4, 8, 15
-PHASE_TIMING_ONLY = 16       # a proper subset of AGGREGATE|RECURRENCE|SOFT_ARGMIN at D > 32: its duration, no maps (adamvs_hip.h)
 _lib = None
 
 
@@ -150,3 +156,36 @@ def check(rc, what):
     msg = load().adamvs_last_error_string().decode("utf-8", "replace")
     kind = "invalid argument" if rc < 0 else "HIP error %d" % rc
     raise AdaMVSHipError("%s failed (%s): %s" % (what, kind, msg))
+
+
+def set_option(name, value):
+    """adamvs_set_option: one of the integers of include/adamvs_hip.h "OPTIONS" (which of two equivalent kernel forms a layer takes)."""
+    check(load().adamvs_set_option(name.encode(), int(value)), "adamvs_set_option(%s)" % name)
+
+
+def get_option(name):
+    v = c_i(0)
+    check(load().adamvs_get_option(name.encode(), ctypes.byref(v)), "adamvs_get_option(%s)" % name)
+    return v.value
+
+
+def option_names():
+    lib = load()
+    return [lib.adamvs_option_name(i).decode() for i in range(lib.adamvs_option_count())]
+
+
+class options:
+    """`with _lib.options(winograd=0, gru_wino=0): ...` -- set for the block, restored afterwards (tests, A/B timing)."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.saved = {k: get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.saved.items():
+            set_option(k, v)

@@ -58,6 +58,12 @@ def _compile(src, extra):
 
 
 def build(force=False, extra_flags=(), verbose=True):
+    """extra_flags: remarks and temporaries only (-R..., -save-temps...).  Anything that changes the generated code (-D, -O, -m)
+    would land in the PRODUCT's object directory and library, and the next plain build() would call that "up to date":
+    variants belong to tools/build_variant.py, which builds into _build_<name>/ and libadamvs_hip.<name>.so."""
+    bad = [f for f in extra_flags if not (f.startswith("-R") or f.startswith("-save-temps"))]
+    if bad:
+        raise ValueError("build(extra_flags=%r): only -R* / -save-temps* here; build variants with tools/build_variant.py" % (bad,))
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):

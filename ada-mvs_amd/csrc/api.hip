@@ -1,6 +1,10 @@
 // C-ABI glue: error plumbing, the one-step op and the whole-stage driver
 // (InferDepthNet0.forward, reference models/adamvs.py:433-533).
 #include <stdarg.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
 
 #include "../../include/adamvs_hip.h"
 #include "common.h"
@@ -19,6 +23,42 @@ int set_error(int code, const char* fmt, ...) {
 }
 
 static_assert(sizeof(FuseWeights) == sizeof(adamvs_fuse_weights), "adamvs_fuse_weights layout");
+
+// ---- run-time options (options.h; documented in include/adamvs_hip.h "OPTIONS")
+struct OptionEntry { const char* name; int def; };
+static const OptionEntry g_option_table[OPT_COUNT] = {
+#define ADAMVS_OPTION_ROW(e, n, d) {n, d},
+    ADAMVS_OPTION_LIST(ADAMVS_OPTION_ROW)
+#undef ADAMVS_OPTION_ROW
+};
+static std::atomic<int> g_option_value[OPT_COUNT];
+static std::once_flag g_option_once;
+// defaults, then ADAMVS_<NAME> from the environment: the library's one read of the process environment besides the two cost
+// tables of recurrence.hip (tuning), made once
+static void option_init() {
+  std::call_once(g_option_once, [] {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+      int v = g_option_table[i].def;
+      char key[64] = "ADAMVS_";
+      size_t n = strlen(key);
+      for (const char* c = g_option_table[i].name; *c && n + 1 < sizeof(key); ++c) key[n++] = (*c >= 'a' && *c <= 'z') ? (char)(*c - 32) : *c;
+      key[n] = 0;
+      if (const char* e = getenv(key))
+        if (*e) v = atoi(e);
+      g_option_value[i].store(v, std::memory_order_relaxed);
+    }
+  });
+}
+int opt(Option o) {
+  option_init();
+  return g_option_value[o].load(std::memory_order_relaxed);
+}
+static int option_index(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (!strcmp(name, g_option_table[i].name)) return i;
+  return -1;
+}
 
 static size_t align_up(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats: 256-byte slots
 
@@ -92,6 +132,28 @@ static int check_desc(const adamvs_stage_desc* d) {
 using namespace adamvs;
 
 extern "C" int adamvs_version(void) { return ADAMVS_ABI_VERSION; }
+
+extern "C" int adamvs_option_count(void) { return OPT_COUNT; }
+extern "C" const char* adamvs_option_name(int index) { return index >= 0 && index < OPT_COUNT ? g_option_table[index].name : nullptr; }
+extern "C" int adamvs_option_default(const char* name, int* value) {
+  const int i = option_index(name);
+  ADAMVS_CHECK_ARG(i >= 0 && value, "option_default: unknown option '%s' (include/adamvs_hip.h, OPTIONS)", name ? name : "(null)");
+  *value = g_option_table[i].def;
+  return 0;
+}
+extern "C" int adamvs_get_option(const char* name, int* value) {
+  const int i = option_index(name);
+  ADAMVS_CHECK_ARG(i >= 0 && value, "get_option: unknown option '%s' (include/adamvs_hip.h, OPTIONS)", name ? name : "(null)");
+  *value = opt((Option)i);
+  return 0;
+}
+extern "C" int adamvs_set_option(const char* name, int value) {
+  const int i = option_index(name);
+  ADAMVS_CHECK_ARG(i >= 0, "set_option: unknown option '%s' (include/adamvs_hip.h, OPTIONS)", name ? name : "(null)");
+  option_init();
+  g_option_value[i].store(value, std::memory_order_relaxed);
+  return 0;
+}
 extern "C" const char* adamvs_last_error_string(void) { return g_last_error; }
 
 extern "C" size_t adamvs_slice_reg_step_scratch_bytes(int B, int h, int w) {
@@ -143,13 +205,13 @@ extern "C" size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* de
   return carve(*desc).total * sizeof(float);
 }
 
-extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt,
-                                          const float* planes, const float* prev_conf, const float* w_reg, size_t w_reg_floats,
-                                          const adamvs_fuse_weights* w_fuse, float* view_weight, float* pair_depth,
-                                          float* depth, float* confidence, int phases, void* workspace,
-                                          size_t workspace_bytes, void* stream) {
+static int stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt, const float* planes,
+                         const float* prev_conf, const float* w_reg, size_t w_reg_floats, const adamvs_fuse_weights* w_fuse,
+                         float* view_weight, float* pair_depth, float* depth, float* confidence, int phases, void* workspace,
+                         size_t workspace_bytes, void* stream, bool timing_only) {
   int rc = check_desc(desc);
   if (rc) return rc;
+  ADAMVS_CHECK_ARG(phases >= 0 && phases <= ADAMVS_PHASE_ALL, "stage: phases=%d (a subset of ADAMVS_PHASE_ALL = 15)", phases);
   const adamvs_stage_desc& s = *desc;
   ADAMVS_CHECK_ARG(feat && rt && planes && w_fuse && view_weight && depth && confidence && workspace, "stage: null pointer");
   ADAMVS_CHECK_ARG(!s.first_stage || (w_reg && pair_depth), "stage: first stage needs w_reg and pair_depth");
@@ -188,17 +250,17 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
   // -- per chunk of hypotheses: weighted aggregation + conv1 (state-independent), the recurrence, soft-argmin accumulation.
   // With the three bits set they are interleaved chunk by chunk and the recurrence runs as a pipeline across chunk
   // boundaries.  The workspace holds ONE chunk of conv1 outputs and two of cost slices, so with more than one chunk a
-  // proper subset of the three cannot hand its results to a later call: refused, unless the caller states that it wants
-  // the phase's duration only (ADAMVS_PHASE_TIMING_ONLY, bench.py's phase-by-phase timing), in which case the selected
-  // phase runs alone over all chunks on whatever the buffers hold.
+  // proper subset of the three cannot hand its results to a later call: refused by adamvs_depth_stage_forward.  The measurement
+  // entry point adamvs_bench_stage_phase (bench.py's phase-by-phase timing) runs the selected phase alone over all chunks on
+  // whatever the buffers hold: its duration is the phase's, it promises no maps.
   const bool do_agg = phases & ADAMVS_PHASE_AGGREGATE, do_rec = phases & ADAMVS_PHASE_RECURRENCE, do_arg = phases & ADAMVS_PHASE_SOFT_ARGMIN;
   if (!do_agg && !do_rec && !do_arg) return 0;
   const size_t hw = (size_t)s.h * s.w, hw4 = (size_t)(s.h / 2) * (s.w / 2);
   const int dc = c.dc, nchunks = (s.D + dc - 1) / dc;
-  ADAMVS_CHECK_ARG(nchunks == 1 || (do_agg && do_rec && do_arg) || (phases & ADAMVS_PHASE_TIMING_ONLY),
+  ADAMVS_CHECK_ARG(nchunks == 1 || (do_agg && do_rec && do_arg) || timing_only,
                    "stage: phases=%d selects a proper subset of AGGREGATE|RECURRENCE|SOFT_ARGMIN, but D=%d runs in %d chunks of %d "
-                   "hypotheses and the workspace keeps one: pass all three in one call (or add ADAMVS_PHASE_TIMING_ONLY "
-                   "for the duration alone, no maps)", phases, s.D, nchunks, dc);
+                   "hypotheses and the workspace keeps one: pass all three in one call (adamvs_bench_stage_phase times one "
+                   "phase alone, no maps)", phases, s.D, nchunks, dc);
   const size_t c1_stride = (size_t)s.B * hw * 8;
   GruStateRing rb{{ws + c.h1[0], ws + c.h1[1], ws + c.h1[2], ws + c.h1[3]}, ws + c.rh1, ws + c.u1, {ws + c.c2[0], ws + c.c2[1]},
                   {ws + c.h2[0], ws + c.h2[1]}, ws + c.rh2, ws + c.u2};
@@ -257,4 +319,23 @@ extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const f
     if (do_arg && (rc = argmin_chunk(nchunks - 1))) return rc;
   }
   return 0;
+}
+
+extern "C" int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat, const float* rt,
+                                          const float* planes, const float* prev_conf, const float* w_reg, size_t w_reg_floats,
+                                          const adamvs_fuse_weights* w_fuse, float* view_weight, float* pair_depth,
+                                          float* depth, float* confidence, int phases, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  return stage_forward(desc, feat, rt, planes, prev_conf, w_reg, w_reg_floats, w_fuse, view_weight, pair_depth, depth, confidence,
+                       phases, workspace, workspace_bytes, stream, false);
+}
+
+// MEASUREMENT ONLY (bench.py's phase table): the selected phases of a stage for their duration; depth / confidence are not valid
+extern "C" int adamvs_bench_stage_phase(const adamvs_stage_desc* desc, const float* feat, const float* rt,
+                                        const float* planes, const float* prev_conf, const float* w_reg, size_t w_reg_floats,
+                                        const adamvs_fuse_weights* w_fuse, float* view_weight, float* pair_depth,
+                                        float* depth, float* confidence, int phases, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  return stage_forward(desc, feat, rt, planes, prev_conf, w_reg, w_reg_floats, w_fuse, view_weight, pair_depth, depth, confidence,
+                       phases, workspace, workspace_bytes, stream, true);
 }

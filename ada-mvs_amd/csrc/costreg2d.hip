@@ -680,11 +680,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_dd_s2p(ConvDDArgs a) {
   conv_dd_s2_pairs<MT, WM>(a, lds, blockIdx.z, blockIdx.y, blockIdx.x);
 }
 
-// ADAMVS_S2_PAIRS=0: the stride-2 layers on the direct kernel, as in rounds 1-4 (A/B)
-static bool s2_pairs() {
-  static const bool on = [] { const char* e = getenv("ADAMVS_S2_PAIRS"); return !(e && *e == '0'); }();
-  return on;
-}
+// option s2_pairs = 0: the stride-2 layers on the direct kernel, as in rounds 1-4 (A/B)
+static bool s2_pairs() { return opt(OPT_S2_PAIRS) != 0; }
 
 // grid: (ceil(cols/16), ceil(rows/BR), N); block 256; OCC = waves per SIMD the register budget is held to
 template <int MT, int WM, int KB, int BR, int OCC>
@@ -717,10 +714,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_dd_rows2(ConvDDArgs a) {
 }
 
 // Measured (cfg3, 4 / 32 tiles per step): 64 blocks of 8 rows 0.185 -> 0.073 ms, 144: 0.193 -> 0.139, 576: 0.49 -> 0.38, 512: 0.33 -> 0.25,
-// 1152: 0.80 -> 0.72; at 4608 blocks it is a wash and beyond it loses (10.9 -> 11.2 ms).  ADAMVS_CONV_ROWS2=0 / 1 forces.
+// 1152: 0.80 -> 0.72; at 4608 blocks it is a wash and beyond it loses (10.9 -> 11.2 ms).  Option conv_rows2 = 0 / 1 forces.
 static bool small_grid_rows2(long blocks8) {
-  const char* e = getenv("ADAMVS_CONV_ROWS2");
-  if (e && *e) return atoi(e) != 0;
+  const int forced = opt(OPT_CONV_ROWS2);
+  if (forced >= 0) return forced != 0;
   return blocks8 <= 2048;
 }
 
@@ -730,25 +727,19 @@ static bool small_grid_rows2(long blocks8) {
 // Which transposed kernel: measured (tools/r02_t2_ab.sh), the fused form wins while the class-by-class grid is small --
 // 64 ... 2048 blocks: 0.246 -> 0.080 ms, 0.267 -> 0.169, 0.646 -> 0.509, 1.57 -> 1.31 -- and loses on the large layers
 // (4608 blocks: 3.61 -> 3.92 ms; 18432: 14.1 -> 15.4), where the 4-tap class alone already gives the class-by-class
-// kernel 96 MFMAs per barrier pair.  ADAMVS_T2_FUSED=0 / 1 forces one of them (A/B timing).
+// kernel 96 MFMAs per barrier pair.  Option t2_fused = 0 / 1 forces one of them (A/B timing).
 static bool t2_fused(long blocks_class_by_class) {
-  const char* e = getenv("ADAMVS_T2_FUSED");
-  if (e && *e) return atoi(e) != 0;
+  const int forced = opt(OPT_T2_FUSED);
+  if (forced >= 0) return forced != 0;
   return blocks_class_by_class <= 2048;
 }
 
-// ADAMVS_T2_KB8=0: one k-step per chunk in the transposed kernel at D = 192, as in rounds 1-2 (A/B).  Two k-steps halve
+// option t2_kb8 = 0: one k-step per chunk in the transposed kernel at D = 192, as in rounds 1-2 (A/B).  Two k-steps halve
 // the barrier pairs per class (a class has at most four taps, so the fragments still fit two waves per SIMD):
 // measured conv11 of cfg2 14.2 -> 13.8 ms, with the epilogue freed of the skip operand 14.5 -> 12.3.
-static bool t2_kb8() {
-  static const bool on = [] { const char* e = getenv("ADAMVS_T2_KB8"); return !(e && *e == '0'); }();      // once, thread-safely
-  return on;
-}
-// ADAMVS_COSTREG_DEFER_SKIPS=0: the skip additions in the producing layer's epilogue, as in rounds 1-2 (A/B)
-static bool costreg_deferred_skips() {
-  static const bool on = [] { const char* e = getenv("ADAMVS_COSTREG_DEFER_SKIPS"); return !(e && *e == '0'); }();
-  return on;
-}
+static bool t2_kb8() { return opt(OPT_T2_KB8) != 0; }
+// option costreg_defer_skips = 0: the skip additions in the producing layer's epilogue, as in rounds 1-2 (A/B)
+static bool costreg_deferred_skips() { return opt(OPT_COSTREG_DEFER_SKIPS) != 0; }
 
 template <int MT, int WM>
 static int launch_conv_dd_cfg(const ConvDDArgs& a_, int N, int mode, hipStream_t st) {
@@ -985,10 +976,7 @@ __global__ __launch_bounds__(DUAL ? 512 : 256) void k_conv_dd_resident(ConvDDArg
   }
 }
 
-static int small_grid_limit() {          // workgroups up to which the resident form is used (0 disables it)
-  static const int limit = [] { const char* e = getenv("ADAMVS_CONV_SMALL_GRID"); return e ? atoi(e) : 1024; }();   // once, thread-safely
-  return limit;
-}
+static int small_grid_limit() { return opt(OPT_CONV_SMALL_GRID); }      // workgroups up to which the resident form is used (0 disables it)
 
 template <int D, int NTR>
 static int launch_conv_dd_resident_rows(const ConvDDArgs& a, int N, hipStream_t st, const GruPro& pro = GruPro{}) {
@@ -1024,10 +1012,7 @@ static int launch_conv_dd_resident(const ConvDDArgs& a, int N, hipStream_t st) {
   return -1;
 }
 
-static bool conv256_split() {
-  static const bool on = [] { const char* e = getenv("ADAMVS_CONV256_SPLIT"); return !(e && *e == '0'); }();
-  return on;
-}
+static bool conv256_split() { return opt(OPT_CONV256_SPLIT) != 0; }
 
 static int launch_conv_dd_z(const ConvDDArgs& a, int N, int mode, hipStream_t st);
 
@@ -1276,15 +1261,13 @@ __global__ __launch_bounds__(256) void k_softmax_regress(const float* __restrict
 // sm_vw != null: the `prob` layer reduces its scores over D in its epilogue (costreg_softmax.h) and writes the view
 // weights / pair depths of softmax_max_regress directly (score is not written); the caller skips launch_softmax_regress.
 bool cost_reg_softmax_fusable(int D, int precision, const PlaneSrc& planes) {
-  static const bool on = [] { const char* e = getenv("ADAMVS_FUSE_SOFTMAX"); return !(e && *e == '0'); }();
   (void)planes; (void)precision;      // any plane source, both precisions: one code path, so generated == materialised bit for bit
-  return on && D >= 16;
+  return opt(OPT_FUSE_SOFTMAX) != 0 && D >= 16;
 }
 
-// ADAMVS_WINOGRAD=0: the stride-1 layers on the direct kernel, as in rounds 1-2 (A/B)
+// option winograd = 0: the stride-1 layers on the direct kernel, as in rounds 1-2 (A/B)
 bool cost_reg_winograd(int D, int precision) {
-  static const bool on = [] { const char* e = getenv("ADAMVS_WINOGRAD"); return !(e && *e == '0'); }();
-  return on && precision == PRECISION_FP32 && wino_depth_supported(D);
+  return opt(OPT_WINOGRAD) != 0 && precision == PRECISION_FP32 && wino_depth_supported(D);
 }
 
 int launch_cost_reg_net_2d(const float* x, const float* wpk, float* ws, float* score, int N, int D, int h, int w,

@@ -399,8 +399,8 @@ int launch_conv_wino(const float* in, const float* wpk, const float* bias, const
   // one-workgroup form cover a 12-row map without a ragged tile row.  With the XCD-aware tile order, D = 192 (tools/wino_bench.py):
   // 512 maps of 96x192 / 48x96 / 24x48 / 12x24 pixels 23.2 / 5.79 / 1.90 / 0.57 ms against 24.0 / 5.99 / 2.00 / 0.51 - 0.56;
   // 64 maps of 96x192 2.87 against 3.01, 16 maps (cfg4's share of four tiles) 0.74 against 0.76.
-  // ADAMVS_WINO_WPS=1 / 2 forces one form (A/B); both give the same bits.
-  static const int forced = [] { const char* e = getenv("ADAMVS_WINO_WPS"); return e ? atoi(e) : 0; }();
+  // Option wino_wps = 1 / 2 forces one form (A/B); both give the same bits.
+  const int forced = opt(OPT_WINO_WPS);
   const bool two = forced ? forced == 2 : h * w >= 1024;
   return two ? launch_wino_cfg<4, 2, 2>(a, N, st) : launch_wino_cfg<4, 3, 1>(a, N, st);
 }
@@ -437,11 +437,8 @@ __global__ __launch_bounds__(256) void k_softmax_merge(const f32x4* __restrict__
   }
 }
 
-// ADAMVS_WINO_SOFTMAX=0: the scores of `prob` through the score volume to k_softmax_regress, as in rounds 3-4 (A/B)
-bool wino_softmax_fused() {
-  static const bool on = [] { const char* e = getenv("ADAMVS_WINO_SOFTMAX"); return !(e && *e == '0'); }();
-  return on;
-}
+// option wino_softmax = 0: the scores of `prob` through the score volume to k_softmax_regress, as in rounds 3-4 (A/B)
+bool wino_softmax_fused() { return opt(OPT_WINO_SOFTMAX) != 0; }
 
 size_t wino_softmax_part_floats(int N, int D, int h, int w) { return (size_t)N * h * w * (D / 16) * 4; }
 
@@ -454,7 +451,7 @@ int launch_conv_wino_softmax(const float* in, const float* wpk, const float* bia
   ADAMVS_CHECK_ARG(planes.mode == PLANES_UNIFORM && a.sm_D > 1, "conv_wino_softmax: planes uniform per tile, at least two (mode %d, %d planes)", planes.mode, a.sm_D);
   ADAMVS_CHECK_ARG(wino_depth_supported(D), "conv_wino_softmax: D=%d unsupported (a multiple of 64 up to 512)", D);
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino_softmax: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
-  static const int forced = [] { const char* e = getenv("ADAMVS_WINO_WPS"); return e ? atoi(e) : 0; }();
+  const int forced = opt(OPT_WINO_WPS);
   const bool two = forced ? forced == 2 : h * w >= 1024;
   if (int rc = two ? launch_wino_cfg<4, 2, 2, true>(a, N, st) : launch_wino_cfg<4, 3, 1, true>(a, N, st)) return rc;
   const size_t npix = (size_t)N * h * w;

@@ -634,11 +634,8 @@ __global__ __launch_bounds__(256, (CA + CB == 16 && NT == 1) ? 4 : 1) void k_fco
   }
 }
 
-// ADAMVS_FCONV_F23=0: the stride-1 3 x 3 layers on k_fconv, as in rounds 2 - 4 (A/B)
-static bool fconv_f23() {
-  static const bool on = [] { const char* e = getenv("ADAMVS_FCONV_F23"); return !(e && *e == '0'); }();
-  return on;
-}
+// option fconv_f23 = 0: the stride-1 3 x 3 layers on k_fconv, as in rounds 2 - 4 (A/B)
+static bool fconv_f23() { return opt(OPT_FCONV_F23) != 0; }
 
 template <int CA, int CB, int NT, int EPI>
 static int launch_fconv_f23(const FConvArgs& a, int N, hipStream_t st, const char* name) {

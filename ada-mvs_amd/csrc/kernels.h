@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "options.h"
 #include "planes.h"
 
 namespace adamvs {
@@ -22,7 +23,6 @@ struct FuseWeights {          // mirrors adamvs_fuse_weights in include/adamvs_h
   const float* gates1_w; const float* gates2_w; const float* cand2_w; const float* cand1_w;
 };
 int gru_wino_mask();          // which GRU convolutions run in the F(2x2, 3x3) form in one-role launches (slice_red.hip)
-int gru_fused_mask();         // which ConvGRU levels run as one launch with the F(2x2, 3x3) gates inside (slice_roles_fwino.h)
 
 struct StepBuffers {          // all channel-last
   float* h1; float* rh1; float* u1;              // [B][hw][8]
@@ -88,9 +88,9 @@ bool conv_pair_epilogue_partials(int B, int h, int w);       // whether launch_c
 // (*gn_parts > 0), plain otherwise (*gn_parts = 0): MS-REDNet's deep levels
 // Folding pays while a stage is bound by its dependent launches: one or two tiles per step (measured at cfg3's shape: 51.3 ->
 // 53.8 maps/s at one tile; 92.2 -> 88.7 at four and 115.4 -> 111.6 at sixteen, where the window halo's recomputed sigmoid /
-// tanh and the per-workgroup reductions cost more than the launches they replace).  ADAMVS_RED_FOLD_APPLIES=0 / 1 forces.
+// tanh and the per-workgroup reductions cost more than the launches they replace).  Option red_fold_applies = 0 / 1 forces.
 inline bool gru_fold_enabled(int samples) {
-  static const int forced = [] { const char* e = getenv("ADAMVS_RED_FOLD_APPLIES"); return e && *e ? atoi(e) : -1; }();
+  const int forced = opt(OPT_RED_FOLD_APPLIES);
   return forced >= 0 ? forced != 0 : samples <= 2;
 }
 bool can_fold_gru_applies(int N, int D, int h, int w);

@@ -225,7 +225,6 @@ typedef ConvWinoRole<16, 16, 2, EPI_GATES> Gates2W;
 typedef ConvWinoRole<16, 16, 1, EPI_CAND> Cand2W;
 typedef Gru1FusedRole<4, 2> Gru1S;      // fp32, both levels fused: 4 x 30 / 4 x 14 tiles for stages with few tiles per CU
 typedef Gru2FusedRole<4> Gru2S;
-typedef Gru1FusedRole<8, 2> Gru1L;      // 8 x 30: the large-batch tile
 typedef Gru1FusedBx3Role Gru1Bx;
 typedef ConvSmallBx3Role<8, 0, 1, 2, BXE_RELU, BX3_PRESPLIT != 0, BX3_PRESPLIT != 0> Conv2Bx;      // split maps in and out
 typedef Gru2FusedBx3Role Gru2Bx;
@@ -269,14 +268,14 @@ static const RoleCosts& role_costs() {
   return c;
 }
 
-// ADAMVS_RECUR_MODE: 0 = six launches per step, states updated in place; 1 / 2 / 3 / 5 = software-pipelined slots, schedule
-// 1 / 2 / 3 / 5 (recurrence_lags; 5: bf16x3 only); unset = by size.  Measured on MI355X (profiles/r02_recurrence_schedules.txt): sharing launches does
+// option recur_mode: 0 = six launches per step, states updated in place; 1 / 3 / 5 = software-pipelined slots, schedule
+// 1 / 3 / 5 (recurrence_lags); -1 (the default) = by size.  Measured on MI355X (profiles/r02_recurrence_schedules.txt): sharing launches does
 // not make the roles faster -- a slot takes the sum of its roles' standalone times, the decoder more -- so what the
 // pipeline buys is three launch latencies per hypothesis, which pays while a step is latency-bound (few tiles per CU:
 // cfg4's 4 tiles per GPU 24.3 -> 22.0 ms) and costs 2-3 % once every role fills the chip several times over.
 int recurrence_mode(int precision, long pixels) {
-  const char* e = getenv("ADAMVS_RECUR_MODE");
-  if (e && *e) return atoi(e);
+  const int forced = opt(OPT_RECUR_MODE);
+  if (forced == 0 || forced == 1 || forced == 3 || forced == 5) return forced;
   // B * h * w of the stage.  Measured (profiles/r02_recurrence_schedules.txt): fp32 -- two launches per hypothesis win up
   // to ~200k pixels (cfg4's 4 tiles per GPU at stage 1: 7.8 -> 5.9 -> 5.1 ms), three up to ~800k, six beyond;
   // bf16x3 (both GRU levels are one kernel each: four launches per hypothesis, two, or one) -- one up to ~300k pixels
@@ -288,8 +287,8 @@ int recurrence_mode(int precision, long pixels) {
   // round 4, fp32 with both ConvGRU levels one kernel each (slice_roles_fused.h): ONE launch per hypothesis pays on the
   // smallest stages only -- cfg4's share at stage 1 (74k pixels) 5.01 -> 4.79 ms; at 295k 4.44 -> 5.28, at 1.18M 1.72 -> 2.50:
   // the fused tiles execute 36 % more MFMAs and the stage is not latency- but throughput-bound as soon as every CU has a few tiles.
-  // Schedule 6 (level 1 fused on 8 x 30 tiles, a launch per role) loses at every size: cfg3 at 32 tiles 23.4 / 26.5 / 13.2 ms
-  // per stage -> 25.4 / 27.8 / 13.4; cfg2 at 128 tiles 79.6 -> 86.5.  Kept behind ADAMVS_RECUR_MODE=6 as the measurement.
+  // (Level 1 fused on 8 x 30 tiles with a launch per role -- schedule 6 of round 4 -- lost at every size: cfg3 at 32 tiles 23.4 / 26.5 /
+  // 13.2 ms per stage -> 25.4 / 27.8 / 13.4; cfg2 at 128 tiles 79.6 -> 86.5.  Removed in round 6; docs/history/tried_without_gain.md.)
   // With the gate convolutions in the F(2x2, 3x3) form (slice_roles_wino.h) in both: cfg3 at 32 tiles, stage 1 (590k pixels)
   // 22.2 ms with three launches per hypothesis, 22.7 with six (direct kernels: 23.3 / 23.9); at 2.36M 27.3 against 22.4.
   return pixels <= 100000 ? 5 : (pixels <= 200000 ? 3 : (pixels <= 800000 ? 1 : 0));
@@ -302,17 +301,13 @@ template <class R> static RoleUse<R> none() { return RoleUse<R>{nullptr, 0.f, 0.
 
 // How far level-2's candidate and the decoder run behind level 1 (in hypotheses) under a schedule.
 //   schedule 1 (the default)         A: gates1(t) | conv2(t-1)    B: cand1(t) | gates2(t-1)              C: cand2(t-1) | decoder(t-2)
-//   schedule 2 (fp32 only)           A: gates1(t) | conv2(t-1)    B: cand1(t) | cand2(t-2) | decoder(t-3)   C: gates2(t-1)
 //   schedule 3                       A: gates1(t) | conv2+gates2(t-1)   B: cand1(t) | cand2(t-1) | decoder(t-2)
 //                                    two dependent launches per hypothesis (Conv2Gates2Role fuses conv2 into the gate kernel);
 //                                    bf16x3: the fused level-1 kernel takes the place of gates1 and cand1, its tiles dealt to both
-// Schedule 2 keeps the one role that needs 234 registers (gates2: two 16-row output tiles of 32 input channels, 144
-// registers of weights) in a launch of its own, so that the roles sharing a launch all run at three to five waves per
-// SIMD; in schedule 1 cand1 runs at gates2's two.
+// (Schedule 2 of round 2 -- gates2, the one role that needs 234 registers, in a launch of its own -- was never chosen by size and
+// was removed in round 6.)
 //   schedule 5 (both levels one kernel each)   gru1(t) | conv2(t-1) | gru2(t-2) | decoder(t-3): ONE launch per hypothesis
-//   schedule 6 (fp32, level 1 fused)           gru1(t); conv2(t-1); gates2(t-1); cand2(t-1); decoder(t-2): one role per launch
 RecurLags recurrence_lags(int schedule, int precision) {
-  if (schedule == 2 && precision == PRECISION_FP32) return RecurLags{2, 3};
   if (schedule == 5) return RecurLags{2, 3};       // one launch: gru2 two, the decoder three behind
   return RecurLags{1, 2};
 }
@@ -397,22 +392,6 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
   SmallConvArgs v2{H1(s2), nullptr, fw.conv2, nullptr, C2(s2), nullptr, h, w, h2, w2, 16, nullptr};
   SmallConvArgs g2{C2(s2), H2(s2 - 1), fw.gates2, fw.gates2_b, rb.rh2, rb.u2, h2, w2, h2, w2, 32, nullptr};
   SmallConvArgs c2{C2(sc), rb.rh2, fw.cand2, fw.cand2_b, H2(sc), rb.u2, h2, w2, h2, w2, 16, H2(sc - 1)};
-  if (schedule == 6) {
-    // level 1 as one kernel on the large tile, every role a launch of its own (large stages: sharing launches buys nothing)
-    Gru1F32Args f1{c1_t, H1(t - 1), H1(t), fw.gates1, fw.gates1_b, fw.cand1, fw.cand1_b, h, w};
-    if (l1 && (rc = launch_slot<Gru1L, NopRole, NopRole>(use<Gru1L>(&f1, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: gru1 (fp32, fused)"))) return rc;
-    if (l2) {
-      if ((rc = launch_slot<Conv2, NopRole, NopRole>(use<Conv2>(&v2, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: conv2"))) return rc;
-      if ((rc = launch_slot<Gates2, NopRole, NopRole>(use<Gates2>(&g2, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: gates2"))) return rc;
-    }
-    if (lc && (rc = launch_slot<Cand2, NopRole, NopRole>(use<Cand2>(&c2, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: cand2"))) return rc;
-    if (dec) {
-      if (in_up) rc = launch_slot<DecoderRole<true>, NopRole, NopRole>(use<DecoderRole<true>>(&da, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: decoder");
-      else rc = launch_slot<DecoderRole<false>, NopRole, NopRole>(use<DecoderRole<false>>(&da, 1.f), none<NopRole>(), none<NopRole>(), B, st, "recurrence: decoder");
-      if (rc) return rc;
-    }
-    return 0;
-  }
   if (schedule == 3) {
     Conv2Gates2Args vg{H1(s2), H2(s2 - 1), fw.conv2, fw.gates2, fw.gates2_b, C2(s2), rb.rh2, rb.u2, h, w, h2, w2};
     if (l1 || l2)
@@ -460,21 +439,6 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
     if ((rc = launch_slot<Gates1, Conv2, NopRole>(l1 ? use<Gates1>(&g1, k.g1) : none<Gates1>(), l2 ? use<Conv2>(&v2, k.v2) : none<Conv2>(),
                                                   none<NopRole>(), B, st, "recurrence slot A")))
       return rc;
-  if (lag.c2 == 2) {                          // schedule 2
-    if (l1 || lc || dec) {
-      if (in_up)
-        rc = launch_slot<Cand1, Cand2, DecoderRole<true>>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
-                                                          dec ? use<DecoderRole<true>>(&da, k.dec) : none<DecoderRole<true>>(), B, st,
-                                                          "recurrence slot B");
-      else
-        rc = launch_slot<Cand1, Cand2, DecoderRole<false>>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), lc ? use<Cand2>(&c2, k.c2) : none<Cand2>(),
-                                                           dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st,
-                                                           "recurrence slot B");
-      if (rc) return rc;
-    }
-    if (l2) return launch_slot<Gates2, NopRole, NopRole>(use<Gates2>(&g2, k.g2), none<NopRole>(), none<NopRole>(), B, st, "recurrence slot C");
-    return 0;
-  }
   if (l1 || l2)
     if ((rc = launch_slot<Cand1, Gates2, NopRole>(l1 ? use<Cand1>(&c1, k.c1) : none<Cand1>(), l2 ? use<Gates2>(&g2, k.g2) : none<Gates2>(),
                                                   none<NopRole>(), B, st, "recurrence slot B")))

@@ -13,15 +13,8 @@
 #include "persistent.h"
 #include "slice_roles.h"
 #include "slice_roles_wino.h"
-#include "slice_roles_fwino.h"
 
 namespace adamvs {
-
-// Level 1 as one launch with the F(2x2, 3x3) gates inside and the strip walk (slice_roles_fwino.h)
-__global__ __launch_bounds__(256, 2) void k_gru1_wfused(Gru1WArgs a, TileGrid tg) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  Gru1WinoFusedRole::run(a, tg, TileRange{0, tg.ntiles}, blockIdx.x, gridDim.x, lds);
-}
 
 // A GRU convolution in the F(2x2, 3x3) form (slice_roles_wino.h), one role per launch
 template <int CA, int CB, int NT, int EPI>
@@ -144,53 +137,11 @@ static int launch_small_wino(const SmallConvArgs& a, int B, hipStream_t st, cons
   return 0;
 }
 
-// ADAMVS_GRU_FUSED: bit 1 = level 1 of the fp32 recurrence as ONE launch per hypothesis (Gru1WinoFusedRole) wherever its roles have
-// launches of their own (stages that run one role per launch).  Read per call: the tests switch it.
-int gru_fused_mask() {
-  const char* e = getenv("ADAMVS_GRU_FUSED");
-  return e && *e ? atoi(e) : 0;
-}
-
-// Tiles per strip segment: a segment's first tile computes five tile rows of gates, the others four, so long segments save work and
-// short ones balance the persistent grid -- the choice that minimises (items per workgroup, rounded up) x (tile rows per item).
-static int strip_segment(int nrows, int tiles_x, int B, int capacity) {
-  static const int forced = [] { const char* e = getenv("ADAMVS_GRU1_SEG"); return e && *e ? atoi(e) : 0; }();
-  if (forced > 0) return forced < nrows ? forced : nrows;
-  int best = 1;
-  long best_cost = -1;
-  for (int s = 1; s <= nrows; ++s) {
-    const long items = (long)tiles_x * cdiv(nrows, s) * B;
-    const long cost = ((items + capacity - 1) / capacity) * (4L * s + 1);
-    if (best_cost < 0 || cost <= best_cost) { best = s; best_cost = cost; }
-  }
-  return best;
-}
-
-static int launch_gru1_wfused(Gru1WArgs a, int B, hipStream_t st) {
-  typedef Gru1WinoFusedRole Role;
-  constexpr size_t lds = Role::LDS_BYTES;
-  static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  static const int capacity = [&] {                      // once, thread-safely (magic static)
-    (void)hipFuncSetAttribute((const void*)k_gru1_wfused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    return resident_blocks(k_gru1_wfused, 256, lds);
-  }();
-  a.seg = strip_segment(Role::rows_of_tiles(a), Role::tiles_x(a), B, capacity);
-  TileGrid tg;
-  if (int rc = make_tile_grid(tg, Role::tiles_x(a), Role::tiles_y(a), B)) return rc;
-  const int grid = tg.ntiles < capacity ? tg.ntiles : capacity;
-  hipLaunchKernelGGL(k_gru1_wfused, dim3(grid), dim3(256), lds, st, a, tg);
-  ADAMVS_CHECK_LAUNCH("gru1 (fused, F(2x2,3x3) gates)");
-  return 0;
-}
-
-// ADAMVS_GRU_WINO: bit mask of the GRU convolutions that run in the F(2x2, 3x3) form when a role has a launch of its own
+// option gru_wino: bit mask of the GRU convolutions that run in the F(2x2, 3x3) form when a role has a launch of its own
 // (1 gates1, 2 gates2, 4 cand2, 8 cand1; default 7; 0 = the direct kernels, which the pipelined schedules use: their maps
-// equal the direct kernels' bit for bit, the F(2x2, 3x3) ones to ~1e-7).  Read per call: the tests switch it.
+// equal the direct kernels' bit for bit, the F(2x2, 3x3) ones to ~1e-7).
 // Measured at cfg2, 128 tiles (recurrence per step, ms): none 79.8; gates1 74.9; gates2 74.2; cand2 78.6; all three 68.3.
-int gru_wino_mask() {
-  const char* e = getenv("ADAMVS_GRU_WINO");
-  return e && *e ? atoi(e) : 7;
-}
+int gru_wino_mask() { return opt(OPT_GRU_WINO); }
 
 // Tile = 4 rows x 16 columns: the smallest halo (6 x 18 input pixels for 64 outputs) of the one-run-per-wave shapes.
 template <int CA, int CB, int NT, int STRIDE, int EPI>
@@ -759,12 +710,9 @@ static int launch_conv1_f23_rows(const float* cost, const float* w, float* c1, i
   return 0;
 }
 
-// ADAMVS_CONV1_F23: bit 1 = C = 32 (stage 1), bit 2 = C = 16 / 8 (stages 2, 3) in the F(2, 3)-along-x form; 0 = k_conv1_ksplit /
+// option conv1_f23: bit 1 = C = 32 (stage 1), bit 2 = C = 16 / 8 (stages 2, 3) in the F(2, 3)-along-x form; 0 = k_conv1_ksplit /
 // k_conv1_two_row, as in rounds 1-4 (A/B).  Measured at cfg2 (aggregation + conv1 per step): 43.75 -> 38.28 ms at 128 tiles, 85.7 -> 76.0 at 256.
-static int conv1_f23() {
-  static const int mask = [] { const char* e = getenv("ADAMVS_CONV1_F23"); return e && *e ? atoi(e) : 3; }();
-  return mask;
-}
+static int conv1_f23() { return opt(OPT_CONV1_F23); }
 
 static int launch_conv1_f23_32(const float* cost, const float* w, float* c1, int N, int h, int w_, hipStream_t st) {
   constexpr int C = 32;
@@ -873,15 +821,7 @@ int launch_slice_step(const float* c1, const FuseWeights& fw, const StepBuffers&
   if (precision == PRECISION_BF16X3) {
     if ((rc = launch_gru_convs_bf16x3(c1, fw, sb, B, h, w, d, &h1, &h2s, st))) return rc;
   } else {
-  if ((gru_fused_mask() & 1) && fw.gates1_w) {
-    // level 1 as one launch; its state alternates between the h1 and rh1 buffers (step d reads the one step d - 1 wrote; chunks
-    // hold an even number of hypotheses, so d's parity is the hypothesis index's)
-    float* hin = (d & 1) ? sb.rh1 : sb.h1;
-    float* hout = (d & 1) ? sb.h1 : sb.rh1;
-    Gru1WArgs g{c1, hin, hout, fw.gates1_w, fw.gates1_b, fw.cand1, fw.cand1_b, h, w, 1};
-    if ((rc = launch_gru1_wfused(g, B, st))) return rc;
-    h1 = hout;
-  } else {  // GRU level 1: gates on cat(c1, h1), candidate on cat(c1, r*h1)
+  {  // GRU level 1: gates on cat(c1, h1), candidate on cat(c1, r*h1)
     SmallConvArgs g{c1, sb.h1, fw.gates1, fw.gates1_b, sb.rh1, sb.u1, h, w, h, w, 16};
     if ((gru_wino_mask() & 1) && fw.gates1_w) {
       g.wpk = fw.gates1_w;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_sweep_aggregate(const float* __restrict
 
 // ---------------------------------------------------------------------------
 // The weighted aggregation of the hot path (MODE 0 above), restructured around what the plane loop of k_sweep_aggregate
-// spends its time on (round 3; the kernel above stays for the variance mode and as the A/B reference, ADAMVS_SWEEP=0):
+// spends its time on (round 3; the kernel above stays for the variance mode and for feature maps of 2 GiB and more per view):
 //  * projections are handed around inside a quad with DPP moves (VALU, no LDS crossbar, no lgkmcnt wait) instead of five
 //    ds_bpermute per view and plane: lane q of a quad projects views q, q + 4 (both quads of a C = 32 pixel hold all
 //    views; with C = 8 a quad holds two pixels and lane q of a pair projects views q, q + 2, ...);
@@ -370,17 +370,11 @@ int launch_sweep_variance(const float* feat, const float* rt, const float* plane
   return set_error(-1, "sweep_variance: C=%d unsupported (8, 16 or 32)", C);
 }
 
-// ADAMVS_SWEEP=0: the round-2 kernel (A/B); default: k_sweep_blend
-static bool sweep_blend_enabled() {
-  static const bool on = [] { const char* e = getenv("ADAMVS_SWEEP"); return !(e && *e == '0'); }();
-  return on;
-}
-
 template <int C>
 static int launch_sweep_c(const float* feat, const float* rt, PlaneSrc planes, const float* vw, float* sim, int B, int S,
                           int D, int d0, int d1, int h, int w, int eps_num, hipStream_t st) {
   dim3 grid(cdiv(h * w, 256 / (C / 4)), 1, B);
-  if (sweep_blend_enabled() && (size_t)B * h * w * C * 4 < 0x7fffffffu) {      // 32-bit lane offsets inside one view / one plane
+  if ((size_t)B * h * w * C * 4 < 0x7fffffffu) {      // 32-bit lane offsets inside one view / one plane; larger batches: the kernel above
     const bool gen = planes.mode != PLANES_EXPLICIT;
     for (int vbase = 0; vbase < S; vbase += 8) {        // groups of 8 views; the later ones accumulate
       if (S - vbase <= 4) {
@@ -395,7 +389,7 @@ static int launch_sweep_c(const float* feat, const float* rt, PlaneSrc planes, c
     }
     return 0;
   }
-  if (S > 8) return set_error(-1, "aggregate_conv1: S=%d source views need the blend sweep (ADAMVS_SWEEP=0 and maps of 2 GiB per view take at most 8)", S);
+  if (S > 8) return set_error(-1, "aggregate_conv1: S=%d source views need the blend sweep (maps of 2 GiB per view take at most 8)", S);
   if (S <= 4)
     hipLaunchKernelGGL((k_sweep_aggregate<C, 4>), grid, dim3(256), 0, st, feat, rt, planes, vw, sim, B, S, D, d0, d1, h, w, eps_num);
   else

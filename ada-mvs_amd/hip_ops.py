@@ -358,9 +358,11 @@ def conv3x3_dd(x_cl, wpk_layer, bias, skip, N, D, hi, wi, mode, relu, out=None, 
     return out
 
 
-def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspace=None, phases=_lib.PHASE_ALL, outputs=None):
+def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspace=None, phases=_lib.PHASE_ALL, outputs=None,
+                        timing_only=False):
     """InferDepthNet0.forward (adamvs.py:433-533).  Returns (view_weight [S,B,h,w], pair_depth or None,
-    depth [B,Ho,Wo], confidence [B,Ho,Wo])."""
+    depth [B,Ho,Wo], confidence [B,Ho,Wo]).  timing_only: adamvs_bench_stage_phase -- the selected phases for their duration,
+    no maps promised (bench.py's phase table)."""
     dev = feat.device
     B, S, h, w = desc.B, desc.S, desc.h, desc.w
     Ho, Wo = (2 * h, 2 * w) if desc.in_up else (h, w)
@@ -375,7 +377,8 @@ def depth_stage_forward(desc, feat, rt, planes, prev_conf, w_reg, fuse, workspac
         depth = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
         conf = torch.empty(B, Ho, Wo, device=dev, dtype=torch.float32)
     null = ctypes.c_void_p(0)
-    check(_lib.load().adamvs_depth_stage_forward(
+    entry = _lib.load().adamvs_bench_stage_phase if timing_only else _lib.load().adamvs_depth_stage_forward
+    check(entry(
         ctypes.byref(desc), _p(_dev(feat, "feat")), _p(_dev(rt, "rt")), _p(_dev(planes, "planes")),
         _p(_dev(prev_conf, "prev_conf")) if prev_conf is not None else null,
         _p(w_reg) if w_reg is not None else null, w_reg.numel() if w_reg is not None else 0, fuse.ptr(),

@@ -213,7 +213,7 @@ class InferDepthNet0(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def run(self, feat_cl, B, C, h, w, rt, depth_values, prev_conf, group=0, twin=False, planes=None, num_depth=None,
-            workspaces=None, phases=None, outputs=None):
+            workspaces=None, phases=None, outputs=None, timing_only=False):
         """feat_cl [V*B, h*w, C] view-major channel-last; rt [B,S,12]; depth_values [B,D,h,w] -- or None with
         planes = hip_ops.plane_source(...) and num_depth: the hypothesis planes are then generated inside the kernels;
         prev_conf None (stage 1) or [S,B,hp,wp].  -> (view_weight [S,B,h,w], pair_depth|None, depth, conf).
@@ -250,7 +250,7 @@ class InferDepthNet0(nn.Module):
         if phases is None:
             return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev), ws)
         return hip_ops.depth_stage_forward(desc, feat_cl, rt, depth_values, prev_conf, w_reg, self.reg_fuse.packed(dev), ws,
-                                           phases=phases, outputs=outputs)
+                                           phases=phases, outputs=outputs, timing_only=timing_only)
 
     def forward(self, features, proj_matrices, depth_values, num_depth, confidence_map=None):
         assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"

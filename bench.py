@@ -103,7 +103,7 @@ def algorithmic_work(cfg, B):
         st["gru_conv_macs"] = {1: 2304, 2: 2304, 4: 1152, 8: 1152}
         st["conv1_flops"] = B * D * hw * 2 * 72 * C
         # round 5: conv1 runs in the two-row form with F(2, 3) along x: 16 products per two outputs of a row and channel pair where the
-        # direct form has 18 (csrc/slice_red.hip::k_conv1_f23; ADAMVS_CONV1_F23 bit 1: C = 32, bit 2: C = 16 / 8)
+        # direct form has 18 (csrc/slice_red.hip::k_conv1_f23; option conv1_f23 bit 1: C = 32, bit 2: C = 16 / 8)
         st["conv1_f23_bit"] = 1 if C == 32 else 2
         if s == 0:
             st["pair_similarity_bytes"] = B * (S * D * C * hw * e + S * C * hw * e + S * D * hw * 4)
@@ -159,8 +159,9 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
             fuse = net.reg_fuse.packed(dev)
             ws = model._stage_workspace[(dev, 0)]
 
-            def phase(mask):
-                return hip_ops.depth_stage_forward(desc, feats_cl[s], rt, planes, conf, w_reg, fuse, ws, phases=mask, outputs=outs)
+            def phase(mask, timing_only=False):
+                return hip_ops.depth_stage_forward(desc, feats_cl[s], rt, planes, conf, w_reg, fuse, ws, phases=mask, outputs=outs,
+                                                   timing_only=timing_only)
 
             if first:
                 # pass A split further, op by op; CostRegNet2D layer by layer so that every launch of its
@@ -170,7 +171,7 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 sim = mark("s%d.pair_similarity" % (s + 1), lambda: hip_ops.pair_similarity(feats_cl[s], rt, planes_t, B, S, C, D, h, w))
                 prec = _lib.PRECISIONS[net.reg.effective_precision()]
                 # softmax / max / regression run in the epilogue of the last layer (csrc/costreg_softmax.h), as in the stage
-                fused_sm = os.environ.get("ADAMVS_FUSE_SOFTMAX", "1") != "0"
+                fused_sm = _lib.get_option("fuse_softmax") != 0
                 score = timed_cost_reg_layers(mark, s + 1, sim, w_reg, S * B, D, h, w, prec,
                                               softmax=(planes_t, S, B, cur) if fused_sm else None)
                 vw_pd = score if fused_sm else mark("s%d.softmax_max_regress" % (s + 1),
@@ -181,9 +182,9 @@ def timed_phases(model, feats_cl, shapes, proj, dv, interval, steps):
                 mark("s%d.view_weight_resample" % (s + 1), lambda: phase(_lib.PHASE_VIEW_WEIGHTS))
             # the three phases below are interleaved chunk by chunk in a real run; called one by one each runs alone over
             # all chunks (its own duration, no maps), so the maps that feed the next stage come from one untimed full call
-            mark("s%d.aggregate_conv1" % (s + 1), lambda: phase(_lib.PHASE_AGGREGATE | _lib.PHASE_TIMING_ONLY))
-            mark("s%d.recurrence" % (s + 1), lambda: phase(_lib.PHASE_RECURRENCE | _lib.PHASE_TIMING_ONLY))
-            mark("s%d.soft_argmin" % (s + 1), lambda: phase(_lib.PHASE_SOFT_ARGMIN | _lib.PHASE_TIMING_ONLY))
+            mark("s%d.aggregate_conv1" % (s + 1), lambda: phase(_lib.PHASE_AGGREGATE, True))
+            mark("s%d.recurrence" % (s + 1), lambda: phase(_lib.PHASE_RECURRENCE, True))
+            mark("s%d.soft_argmin" % (s + 1), lambda: phase(_lib.PHASE_SOFT_ARGMIN, True))
             phase(_lib.PHASE_AGGREGATE | _lib.PHASE_RECURRENCE | _lib.PHASE_SOFT_ARGMIN)
             depth, conf = outs[2], outs[0]
     torch.cuda.synchronize()
@@ -205,7 +206,7 @@ WINO_SLOT = {"conv0": 0, "conv2": 1, "conv4": 2, "conv6": 3, "prob": 4}
 def winograd_active(D, precision):
     """csrc/costreg2d.hip::cost_reg_winograd: fp32, a supported width, not switched off."""
     from ada_mvs_amd import packing
-    return precision in (0, "fp32") and D in packing.WINO_WIDTHS and os.environ.get("ADAMVS_WINOGRAD", "1") != "0"
+    return precision in (0, "fp32") and D in packing.WINO_WIDTHS and _lib.get_option("winograd") != 0
 
 
 def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=None):
@@ -215,7 +216,7 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=
     acts = {"x": (x, h, w)}
     # fp32: conv7's and conv9's skip additions run in the CONSUMING transposed layer (in2), as adamvs_cost_reg_net_2d issues
     # them (csrc/costreg2d.hip); conv11's, and all of them in bf16x3, in the producing layer's epilogue (skip)
-    defer = precision == 0 and os.environ.get("ADAMVS_COSTREG_DEFER_SKIPS", "1") != "0"
+    defer = precision == 0 and _lib.get_option("costreg_defer_skips") != 0
     wino = winograd_active(D, precision)
     pending = None                       # the addend the next layer has to add to its input
     for i, (name, mode, relu, src, skip) in enumerate(COSTREG_PLAN):
@@ -228,7 +229,7 @@ def timed_cost_reg_layers(mark, stage, x, wpk, N, D, h, w, precision=0, softmax=
             ww = wpk[len(COSTREG_PLAN) * LW:][WINO_SLOT[name] * 16 * D * D:(WINO_SLOT[name] + 1) * 16 * D * D]
             if name == "prob" and softmax is not None:
                 planes_t, S, B, dv = softmax
-                if os.environ.get("ADAMVS_WINO_SOFTMAX", "1") != "0" and dv.dim() == 2:
+                if _lib.get_option("wino_softmax") != 0 and dv.dim() == 2:
                     # what the step runs: the SM instantiation (per-lane softmax partials in the epilogue, no score volume)
                     # and k_softmax_merge behind it, timed together
                     return mark("s%d.costreg.prob+softmax.mode0" % stage,
@@ -463,9 +464,9 @@ class Workload:
                     gru_wino += self.B * w_["D"] * w_["h"] * w_["w"] * 2.0 * sum(m for b_, m in w_["gru_conv_macs"].items() if eff & b_)
         executed -= gru_wino * (20.0 / 36.0)
         if not split:
-            f23 = int(os.environ.get("ADAMVS_CONV1_F23", "3") or 0)
+            f23 = _lib.get_option("conv1_f23")
             executed -= sum(w_["conv1_flops"] for w_ in work if f23 & w_["conv1_f23_bit"]) * (2.0 / 18.0)
-            if os.environ.get("ADAMVS_S2_PAIRS", "1") != "0" and os.environ.get("ADAMVS_CONV_ROWS2", "") != "1":
+            if _lib.get_option("s2_pairs") != 0 and _lib.get_option("conv_rows2") != 1:
                 # round 5: the stride-2 layers of CostRegNet2D whose output rows divide into 32-column blocks run in the pair form (15 of
                 # 18 products; csrc/costreg2d.hip::k_conv_dd_s2p, D = 192 / 384): conv1, conv3, conv5 have w/2, w/4, w/8 output columns
                 # (the launcher sends small grids -- at most 2048 blocks of 8 x 16 outputs -- to the 2-row direct kernel instead)
@@ -786,9 +787,9 @@ def roofline_of(wl, args, ms_per_step):
                 return wino
             if split or wino:
                 return True
-            e = os.environ.get("ADAMVS_CONV_ROWS2", "")
-            if e:
-                return int(e) == 0
+            e = _lib.get_option("conv_rows2")
+            if e >= 0:
+                return e == 0
             r = res[layer]
             return -(-(st["w"] // r) // 16) * -(-(st["h"] // r) // 8) * N > 2048
 

@@ -13,7 +13,8 @@
  *     so every call can be captured into a hipGraph;
  *   - return 0 on success, <0 for an argument/shape error, >0 a hipError_t;
  *     adamvs_last_error_string() describes the last failure on this thread;
- *   - re-entrant; the only global state is the thread-local error string.
+ *   - re-entrant; the only global state is the thread-local error string and the option table below (process-wide
+ *     integers that select between equivalent kernel forms; read on every call, written only by adamvs_set_option).
  *
  * Layouts ("channel-last"): feature maps [view][B][h*w][C], GRU states
  * [B][h*w][ch], cost-regularisation activations [N][h*w][D]; hypothesis planes
@@ -27,10 +28,48 @@
 extern "C" {
 #endif
 
-#define ADAMVS_ABI_VERSION 15
+#define ADAMVS_ABI_VERSION 16
 
 int adamvs_version(void);
 const char* adamvs_last_error_string(void);
+
+/* ---- OPTIONS ---------------------------------------------------------------
+ * Integers that choose between kernel forms of the SAME layer (every form is held to the same oracle; forms differ in the
+ * order of their fp32 sums at most) and a few tuning limits.  adamvs_set_option takes effect at the next call of any entry
+ * point, for every caller of the process (two callers that need different forms set the option before their calls; the
+ * table is atomic integers, not locked state).  When the table is first touched each option is seeded from the environment
+ * variable ADAMVS_<NAME IN CAPITALS> if that is set (A/B timing of an unmodified caller); nothing else in the compute path
+ * reads the environment (two tuning tables of the recurrence's grid split: ADAMVS_RECUR_COSTS, ADAMVS_RECUR_COSTS_FUSED).
+ *
+ *   name                  default  meaning
+ *   winograd                 1     CostRegNet2D (models/adamvs.py:229-238), fp32, widths that are multiples of 64: the five stride-1
+ *                                  layers in the minimal-filtering form F(2x2, 3x3) (16 of 36 products); 0: direct kernels
+ *   wino_softmax             1     ... its `prob` layer carries the softmax partials, no score volume (stage path); 0: score volume
+ *   wino_wps                 0     ... 1 / 2: one / two workgroups per CU for every map size (same bits); 0: by map size
+ *   fuse_softmax             1     direct `prob` kernel: softmax / max / depth regression in its epilogue; 0: k_softmax_regress
+ *   s2_pairs                 1     CostRegNet2D: large stride-2 layers in the pair form along x (15 of 18 products); 0: direct
+ *   conv_rows2              -1     CostRegNet2D: 2-row blocks for small grids: 0 never, 1 always, -1 by grid size
+ *   t2_fused                -1     transposed layers, the four parity classes in one launch: 0 / 1 / -1 by grid size
+ *   t2_kb8                   1     transposed layers at D = 192: two k-steps per chunk; 0: one
+ *   costreg_defer_skips      1     the hourglass's skip additions formed by the consuming layer; 0: in the producer's epilogue
+ *   conv256_split            1     D = 256 direct layers as two launches of 128 output channels; 0: one
+ *   conv_small_grid       1024     MS-REDNet (models/msrednet.py): workgroups up to which a layer takes the resident form; 0: never
+ *   red_fold_applies        -1     MS-REDNet: the GRU's element-wise applies folded into the next layer's prologue: 0 / 1 / -1 by batch
+ *   conv1_f23                3     conv1 of SliceCostRegNetRED (adamvs.py:417) in the F(2, 3)-along-x form: bit 1 C = 32, bit 2 C = 16 / 8
+ *   fconv_f23                1     FeatureNet0's stride-1 3x3 layers in the F(2, 3)-along-x form; 0: k_fconv
+ *   gru_wino                 7     fp32 ConvGRU convolutions (module.py:24-52) in the F(2x2, 3x3) form where a role has a launch of
+ *                                  its own and in the three-launch schedule: 1 gates1, 2 gates2, 4 cand2, 8 cand1; 0: direct kernels
+ *                                  (the software-pipelined schedules 3 and 5 always use the direct / fused roles)
+ *   recur_mode              -1     launches per hypothesis of the recurrence: 0 one role per launch (six; bf16x3: four), 1 three,
+ *                                  3 two, 5 one (both levels one kernel each); -1: by stage size (adamvs_recurrence_schedule)
+ *   sweep_fused              1     aggregation + conv1 (adamvs.py:495-512, :417) as ONE kernel, the similarity of a plane never
+ *                                  leaving the CU, for the shapes it is built for; 0: the sweep and conv1 as two kernels
+ */
+int adamvs_option_count(void);
+const char* adamvs_option_name(int index);                   /* 0 <= index < adamvs_option_count(); NULL outside */
+int adamvs_option_default(const char* name, int* value);     /* -1: unknown name */
+int adamvs_get_option(const char* name, int* value);
+int adamvs_set_option(const char* name, int value);
 
 /* ---- geometry ----------------------------------------------------------- */
 
@@ -301,9 +340,9 @@ typedef struct adamvs_stage_desc {
 size_t adamvs_depth_stage_workspace_bytes(const adamvs_stage_desc* desc);
 
 /* How a stage of B*h*w pixels runs its recurrence (for accounting: bench.py prices executed flops): the schedule
- * (0: one role per launch, sequential; 1, 2, 3, 5, 6: software-pipelined, see ADAMVS_RECUR_MODE in INTEGRATION.md) and, for
+ * (0: one role per launch, sequential; 1, 3, 5: software-pipelined, see option recur_mode) and, for
  * schedule 0 in fp32, the bit mask of the GRU convolutions that run in the minimal-filtering form F(2x2, 3x3)
- * (1 gates1, 2 gates2, 4 cand2, 8 cand1: 16 of the 36 products of the direct form; ADAMVS_GRU_WINO overrides, default 7). */
+ * (1 gates1, 2 gates2, 4 cand2, 8 cand1: 16 of the 36 products of the direct form; option gru_wino, default 7). */
 int adamvs_recurrence_schedule(int precision_fuse, long long pixels);
 int adamvs_gru_wino_mask(void);
 
@@ -311,15 +350,12 @@ int adamvs_gru_wino_mask(void);
  * tensors, which a later call reads back.  AGGREGATE, RECURRENCE and SOFT_ARGMIN form one chain over chunks of 32
  * hypotheses (the workspace holds one chunk of conv1 outputs and two of cost slices, nothing of it grows with D), so
  * for D > 32 they produce maps only when all three are in ONE call: a call with a proper subset of them returns an
- * argument error (-1) unless ADAMVS_PHASE_TIMING_ONLY is set, which runs the selected phase alone over all chunks on
- * whatever the workspace holds -- its duration is the phase's, depth / confidence are NOT valid (bench.py's
- * phase-by-phase timing).  For D <= 32 (one chunk) every subset is valid without the bit, in order. */
+ * argument error (-1).  For D <= 32 (one chunk) every subset is valid, in order. */
 #define ADAMVS_PHASE_VIEW_WEIGHTS 1  /* pass A (pair similarity, CostRegNet2D, softmax) or resample of prev_conf */
 #define ADAMVS_PHASE_AGGREGATE    2  /* weighted aggregation + conv1 */
 #define ADAMVS_PHASE_RECURRENCE   4  /* D sequential ConvGRU encoder-decoder steps */
 #define ADAMVS_PHASE_SOFT_ARGMIN  8  /* depth / confidence from the regularised slices */
 #define ADAMVS_PHASE_ALL         15
-#define ADAMVS_PHASE_TIMING_ONLY 16  /* allow a proper subset of AGGREGATE|RECURRENCE|SOFT_ARGMIN at D > 32: timing, no maps */
 
 /* feat [V=S+1][B][h*w][C]; rt [B][S][12]; planes: see adamvs_stage_desc.plane_mode;
  * prev_conf [S][B][prev_h*prev_w] (previous stage's view weights; ignored when first_stage);
@@ -332,6 +368,15 @@ int adamvs_depth_stage_forward(const adamvs_stage_desc* desc, const float* feat,
                                const float* prev_conf, const float* w_reg, size_t w_reg_floats, const adamvs_fuse_weights* w_fuse,
                                float* view_weight, float* pair_depth, float* depth, float* confidence,
                                int phases, void* workspace, size_t workspace_bytes, void* stream);
+
+/* MEASUREMENT ONLY -- not part of the inference path.  The same arguments; runs the selected phases of a stage alone over all
+ * chunks on whatever the workspace holds, also where adamvs_depth_stage_forward refuses (a proper subset of
+ * AGGREGATE|RECURRENCE|SOFT_ARGMIN at D > 32): the call's duration is the phase's, depth / confidence are NOT valid
+ * afterwards.  bench.py's phase-by-phase table uses it, after the timed region. */
+int adamvs_bench_stage_phase(const adamvs_stage_desc* desc, const float* feat, const float* rt, const float* planes,
+                             const float* prev_conf, const float* w_reg, size_t w_reg_floats, const adamvs_fuse_weights* w_fuse,
+                             float* view_weight, float* pair_depth, float* depth, float* confidence,
+                             int phases, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- MS-REDNet inference (models/msrednet.py:330-436) ------------------------
  * The sibling model of predict_whu.py --model msrednet.  Its 3x3 convolutions run on adamvs_conv3x3_dd with the

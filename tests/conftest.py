@@ -30,3 +30,20 @@ def rel_l1(x, ref):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture
+def set_option():
+    """`set_option(name, value)`: adamvs_set_option for the duration of one test (include/adamvs_hip.h "OPTIONS": which of two
+    equivalent kernel forms a layer takes); every option touched is restored afterwards."""
+    import ada_mvs_amd  # noqa: F401
+    from ada_mvs_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = _lib.get_option(name)
+        _lib.set_option(name, value)
+    yield set_
+    for name, value in saved.items():
+        _lib.set_option(name, value)

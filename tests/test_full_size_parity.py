@@ -137,13 +137,10 @@ def test_cfg4_rank_share_against_oracle(precision):
         assert torch.equal(one["photometric_confidence"][0], out["photometric_confidence"][2])
     else:
         assert rel_l1(one["depth"][0], out["depth"][2]) < 1e-6 and rel_l1(one["photometric_confidence"][0], out["photometric_confidence"][2]) < 2e-5
-        os.environ["ADAMVS_GRU_WINO"] = "0"
-        try:
-            with torch.no_grad():
-                batch = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
-                one = m(imgs[2:3].cuda(), {k: v[2:3].cuda() for k, v in proj.items()}, dv[2:3].cuda())
-        finally:
-            del os.environ["ADAMVS_GRU_WINO"]
+        from ada_mvs_amd import _lib
+        with _lib.options(gru_wino=0), torch.no_grad():
+            batch = m(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+            one = m(imgs[2:3].cuda(), {k: v[2:3].cuda() for k, v in proj.items()}, dv[2:3].cuda())
         assert torch.equal(one["depth"][0], batch["depth"][2])
         assert torch.equal(one["photometric_confidence"][0], batch["photometric_confidence"][2])
 

@@ -255,37 +255,45 @@ def test_conv3x3_dd_winograd(hip, N, D, h, w, relu, skip):
     assert rel_l1(back(out), back(direct)) < 2e-6
 
 
-def test_winograd_one_and_two_workgroups_per_cu_give_the_same_bits(hip, tmp_path):
+def test_winograd_one_and_two_workgroups_per_cu_give_the_same_bits(hip, set_option):
     """csrc/costreg2d_wino.hip has a 6 x 32-pixel form (one workgroup per CU) and a 4 x 32 form (two); launch_conv_wino picks by map
-    size.  ADAMVS_WINO_WPS (read once per process) forces one: the same layer in two child processes, bit for bit."""
-    import subprocess
-    code = ("import sys, torch; sys.path.insert(0, %r); import ada_mvs_amd; from ada_mvs_amd import hip_ops, packing\n"
-            "g = torch.Generator().manual_seed(3); N, D, h, w = 3, 192, 26, 70\n"
-            "x = torch.randn(N, h * w, D, generator=g).cuda(); wt = torch.randn(D, D, 3, 3, generator=g) / 72\n"
-            "y = hip_ops.conv3x3_dd_wino(x, packing.pack_reg_layer_wino(wt, torch.ones(D)).cuda(), torch.zeros(D).cuda(), None, N, D, h, w, 1)\n"
-            "torch.save(y.cpu(), sys.argv[1])\n" % ROOT)
+    size.  Option wino_wps forces one: the same layer through both, bit for bit."""
+    from ada_mvs_amd import packing
+    g = torch.Generator().manual_seed(3)
+    N, D, h, w = 3, 192, 26, 70
+    x = dev(torch.randn(N, h * w, D, generator=g))
+    wt = torch.randn(D, D, 3, 3, generator=g) / 72
     outs = []
-    for wps in ("1", "2"):
-        f = str(tmp_path / ("y%s.pt" % wps))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, ADAMVS_WINO_WPS=wps), capture_output=True, text=True, cwd=ROOT)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(torch.load(f))
+    for wps in (1, 2):
+        set_option("wino_wps", wps)
+        outs.append(hip.conv3x3_dd_wino(x, dev(packing.pack_reg_layer_wino(wt, torch.ones(D))), dev(torch.zeros(D)), None, N, D, h, w, 1).cpu())
     assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
 
 
-@pytest.mark.parametrize("switch", ["ADAMVS_WINOGRAD", "ADAMVS_WINO_SOFTMAX"])
-def test_cost_reg_net_2d_direct_kernels_in_a_child_process(hip, switch):
-    """The A/B switches of CostRegNet2D (read once per process).  ADAMVS_WINOGRAD=0: its stride-1 layers on the direct kernel at
-    the widths the F(2x2, 3x3) kernel otherwise takes, the softmax epilogue of the direct `prob` layer included.
-    ADAMVS_WINO_SOFTMAX=0: the F(2x2, 3x3) `prob` layer writes its scores and k_softmax_regress reads them, as before round 4's
-    partials + merge (test_piecewise_phase_masks runs stage 1 at D = 192 through it)."""
-    import subprocess
-    env = dict(os.environ, **{switch: "0"})
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                        "test_cost_reg_net_2d_widths or test_prob_softmax_regress_fused or test_generated_planes_equal_materialised_planes "
-                        "or test_piecewise_phase_masks"],
-                       env=env, capture_output=True, text=True, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("switch", ["winograd", "wino_softmax"])
+def test_cost_reg_net_2d_direct_kernels_behind_their_options(hip, O, set_option, switch):
+    """The A/B options of CostRegNet2D.  winograd = 0: its stride-1 layers on the direct kernel at the widths the F(2x2, 3x3) kernel
+    otherwise takes, the softmax epilogue of the direct `prob` layer included.  wino_softmax = 0: the F(2x2, 3x3) `prob` layer writes
+    its scores and k_softmax_regress reads them, as before round 4's partials + merge (test_piecewise_phase_masks runs stage 1 at
+    D = 192 through it).  The tests named below run again under the option."""
+    set_option(switch, 0)
+    import inspect
+    me = sys.modules[__name__]
+    ran = 0
+    for name in ("test_cost_reg_net_2d_widths", "test_prob_softmax_regress_fused", "test_generated_planes_equal_materialised_planes",
+                 "test_piecewise_phase_masks"):
+        fn = getattr(me, name)
+        marks = [mk for mk in getattr(fn, "pytestmark", []) if mk.name == "parametrize"]
+        names = inspect.signature(fn).parameters
+        cases = [{}]
+        for mk in marks:
+            keys = [k.strip() for k in mk.args[0].split(",")]
+            cases = [dict(c, **dict(zip(keys, v if len(keys) > 1 else (v,)))) for c in cases for v in mk.args[1]]
+        for c in cases:
+            fixtures = {"hip": hip, "O": O}
+            fn(**{k: (c[k] if k in c else fixtures[k]) for k in names})
+            ran += 1
+    assert ran >= 8
 
 
 @pytest.mark.parametrize("D,h,w", [(32, 16, 24), (64, 8, 16), (192, 8, 16), (256, 8, 8)])
@@ -617,11 +625,11 @@ def test_train_test_twin_golden(hip):
 # --------------------------------------------------------------------------- software-pipelined recurrence
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("cfg,batch", [("tiny", 3), ("cfg1", 2)])
-def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, monkeypatch, cfg, batch, precision):
+def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, set_option, cfg, batch, precision):
     """The stage driver skews the steps (level 1 of hypothesis t, level 2 of t-1 / t-2 and the decoder of t-2 / t-3 share
     launches, state rings of 4 / 2 buffers, hypotheses in chunks of 32 across which the pipeline keeps running): the
     arithmetic per tile is that of the one-role kernels, so the maps of both schedules must equal, bit for bit, those
-    of ADAMVS_RECUR_MODE=0 (six dependent launches per hypothesis, states updated in place).  cfg1 has 48 hypotheses
+    of option recur_mode = 0 (six dependent launches per hypothesis, states updated in place).  cfg1 has 48 hypotheses
     at stage 1: two chunks."""
     from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
     c = synth.CONFIGS[cfg]
@@ -630,14 +638,14 @@ def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, monkeypatch, c
     m = m.cuda().eval()
     imgs, proj, dv = synth.tile_inputs(cfg, batch=batch, seed=21)
     args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
-    monkeypatch.setenv("ADAMVS_GRU_WINO", "0")       # mode 0 on the direct kernels too (its F(2x2, 3x3) form: the test below)
+    set_option("gru_wino", 0)       # mode 0 on the direct kernels too (its F(2x2, 3x3) form: the test below)
     outs = {}
-    for mode in ("0", "1", "2", "3", "5", "6"):      # 5: one launch per hypothesis (both levels fused); 6: fp32, level 1 fused, a launch per role
-        monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
+    for mode in ("0", "1", "3", "5"):      # 5: one launch per hypothesis (both levels fused)
+        set_option("recur_mode", int(mode))
         with torch.no_grad():
             outs[mode] = m(*args)
         torch.cuda.synchronize()
-    for mode in ("1", "2", "3", "5", "6"):
+    for mode in ("1", "3", "5"):
         for s in ("stage1", "stage2", "stage3"):
             for key in ("depth", "photometric_confidence"):
                 assert torch.equal(outs["0"][s][key], outs[mode][s][key]), (mode, s, key)
@@ -645,7 +653,7 @@ def test_pipelined_recurrence_is_bit_identical_to_sequential(hip, monkeypatch, c
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("stage,h,w", [(1, 22, 38), (2, 26, 50), (1, 4, 6)])
-def test_pipelined_recurrence_on_ragged_stage_sizes(hip, O, monkeypatch, precision, stage, h, w):
+def test_pipelined_recurrence_on_ragged_stage_sizes(hip, O, set_option, precision, stage, h, w):
     """One cascade stage (InferDepthNet0.forward, reference adamvs.py:433-533) on maps no tile size of any role divides
     (level-2 maps 11 x 19, 13 x 25, 2 x 3; the end-to-end model only meets multiples of 8) and 40 hypotheses = one
     full chunk of 32 plus a ragged one.  Every schedule of the recurrence -- the two-launch one runs conv2 inside the
@@ -664,14 +672,14 @@ def test_pipelined_recurrence_on_ragged_stage_sizes(hip, O, monkeypatch, precisi
     near = 420.0 + 20.0 * torch.rand(B, 1, h, w, generator=g)
     planes = (near + 4.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).contiguous()
     prev = [torch.rand(B, 1, h // 2, w // 2, generator=g) for _ in range(V - 1)]
-    monkeypatch.setenv("ADAMVS_GRU_WINO", "0")       # mode 0 on the direct kernels too
+    set_option("gru_wino", 0)       # mode 0 on the direct kernels too
     outs = {}
-    for mode in ("0", "1", "2", "3", "5", "6"):      # 5: one launch per hypothesis (both levels fused); 6: fp32, level 1 fused
-        monkeypatch.setenv("ADAMVS_RECUR_MODE", mode)
+    for mode in ("0", "1", "3", "5"):      # 5: one launch per hypothesis (both levels fused)
+        set_option("recur_mode", int(mode))
         with torch.no_grad():
             outs[mode] = net([dev(f) for f in feats], dev(proj), dev(planes), D, [dev(c) for c in prev])
         torch.cuda.synchronize()
-    for mode in ("1", "2", "3", "5", "6"):
+    for mode in ("1", "3", "5"):
         for key in ("depth", "photometric_confidence"):
             assert torch.equal(outs["0"][key], outs[mode][key]), (mode, key)
     with torch.no_grad():
@@ -773,7 +781,7 @@ def test_piecewise_phase_masks(hip, D, stage):
     """adamvs_depth_stage_forward's phase mask (include/adamvs_hip.h): VIEW_WEIGHTS in a call of its own followed by
     AGGREGATE | RECURRENCE | SOFT_ARGMIN in one call equals PHASE_ALL bit for bit at any D.  The workspace keeps ONE chunk of
     32 hypotheses, so with D > 32 a proper subset of the last three is refused (it cannot hand results to a later call)
-    unless ADAMVS_PHASE_TIMING_ONLY is set, which runs it for its duration alone; with D <= 32 the phases may run one by
+    (the measurement entry point adamvs_bench_stage_phase runs it for its duration alone); with D <= 32 the phases may run one by
     one and still produce the maps."""
     from ada_mvs_amd import _lib
     from ada_mvs_amd._lib import AdaMVSHipError
@@ -810,9 +818,9 @@ def test_piecewise_phase_masks(hip, D, stage):
         for sub in (_lib.PHASE_AGGREGATE, _lib.PHASE_RECURRENCE, _lib.PHASE_SOFT_ARGMIN, _lib.PHASE_AGGREGATE | _lib.PHASE_RECURRENCE,
                     _lib.PHASE_VIEW_WEIGHTS | _lib.PHASE_SOFT_ARGMIN):
             if D > 32:
-                with pytest.raises(AdaMVSHipError, match="TIMING_ONLY"):
+                with pytest.raises(AdaMVSHipError, match="adamvs_bench_stage_phase"):
                     net.run(feat_cl, B, C, h, w, rt, planes, prev, phases=sub, outputs=outputs())
-                net.run(feat_cl, B, C, h, w, rt, planes, prev, phases=sub | _lib.PHASE_TIMING_ONLY, outputs=outputs())    # runs; no maps promised
+                net.run(feat_cl, B, C, h, w, rt, planes, prev, phases=sub, outputs=outputs(), timing_only=True)    # runs; no maps promised
         if D <= 32:            # one chunk: the phases one by one, in order, still make the maps
             o = outputs()
             for ph in (_lib.PHASE_VIEW_WEIGHTS, _lib.PHASE_AGGREGATE, _lib.PHASE_RECURRENCE, _lib.PHASE_SOFT_ARGMIN):
@@ -1198,9 +1206,9 @@ def test_conv_layers_on_more_images_than_one_grid_takes(hip, precision):
 
 @pytest.mark.parametrize("recur,mask", [("0", "1"), ("0", "2"), ("0", "4"), ("0", "8"), ("0", "15"), ("1", "7")])
 @pytest.mark.parametrize("cfg,batch", [("tiny", 3), ("cfg1", 2)])
-def test_gru_convolutions_in_the_minimal_filtering_form(hip, monkeypatch, cfg, batch, recur, mask):
-    """With one role per launch (ADAMVS_RECUR_MODE=0: what large stages run) the gate convolutions of both ConvGRU levels and
-    the level-2 candidate run in the form F(2x2, 3x3) (csrc/slice_roles_wino.h; ADAMVS_GRU_WINO selects which, default 7):
+def test_gru_convolutions_in_the_minimal_filtering_form(hip, set_option, cfg, batch, recur, mask):
+    """With one role per launch (option recur_mode = 0: what large stages run) the gate convolutions of both ConvGRU levels and
+    the level-2 candidate run in the form F(2x2, 3x3) (csrc/slice_roles_wino.h; option gru_wino selects which, default 7):
     16 instead of 36 products, fp32 throughout, so the maps agree with the direct kernels' to rounding (asserted: 2e-5 through
     the whole cascade; measured ~1e-6) and with the reference's fixture where there is one.  Image sizes that are no multiple
     of the 8 x 32 tile (tiny: 16 x 24 at stage 1) exercise the edge paths."""
@@ -1211,10 +1219,10 @@ def test_gru_convolutions_in_the_minimal_filtering_form(hip, monkeypatch, cfg, b
     m = m.cuda().eval()
     imgs, proj, dv = synth.tile_inputs(cfg, batch=batch, seed=21)
     args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
-    monkeypatch.setenv("ADAMVS_RECUR_MODE", recur)      # 1: three launches per hypothesis, the same roles sharing launches (mask 7 only)
+    set_option("recur_mode", int(recur))      # 1: three launches per hypothesis, the same roles sharing launches (mask 7 only)
     outs = {}
     for mk in ("0", mask):
-        monkeypatch.setenv("ADAMVS_GRU_WINO", mk)
+        set_option("gru_wino", int(mk))
         with torch.no_grad():
             outs[mk] = m(*args)
         torch.cuda.synchronize()
@@ -1226,11 +1234,11 @@ def test_gru_convolutions_in_the_minimal_filtering_form(hip, monkeypatch, cfg, b
     assert differs, "the switch did not select another kernel"
 
 
-def test_drop_in_forward_with_one_role_per_launch(hip, monkeypatch):
+def test_drop_in_forward_with_one_role_per_launch(hip, set_option):
     """The reference's fixtures through the schedule large stages run (one role per launch, GRU convolutions in the F(2x2, 3x3)
     form): the small shapes of the fixtures would otherwise only meet the pipelined schedules."""
-    monkeypatch.setenv("ADAMVS_RECUR_MODE", "0")
-    monkeypatch.setenv("ADAMVS_GRU_WINO", "15")
+    set_option("recur_mode", 0)
+    set_option("gru_wino", 15)
     for cfg in ("tiny", "cfg1"):
         g = load_golden("e2e_" + cfg)
         m, _ = _model(cfg)
@@ -1242,7 +1250,7 @@ def test_drop_in_forward_with_one_role_per_launch(hip, monkeypatch):
 
 @pytest.mark.parametrize("recur", ["0", "1"])
 @pytest.mark.parametrize("stage,h,w", [(1, 22, 38), (2, 26, 50), (0, 8, 40), (1, 4, 6), (2, 70, 34)])
-def test_minimal_filtering_roles_on_ragged_stage_sizes(hip, O, monkeypatch, recur, stage, h, w):
+def test_minimal_filtering_roles_on_ragged_stage_sizes(hip, O, set_option, recur, stage, h, w):
     """The F(2x2, 3x3) roles (8 x 32 tiles of 2 x 2 output tiles) on maps no tile divides -- level-2 maps of 11 x 19, 13 x 25, 2 x 3,
     35 x 17 pixels: odd sizes cut through the 2 x 2 tiles --, as their own launches and sharing launches, against the CPU oracle."""
     from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
@@ -1260,8 +1268,8 @@ def test_minimal_filtering_roles_on_ragged_stage_sizes(hip, O, monkeypatch, recu
     D_ = 48 if stage == 0 else D
     planes = (near + 4.0 * torch.arange(D_, dtype=torch.float32).view(1, D_, 1, 1)).contiguous()
     prev = None if stage == 0 else [torch.rand(B, 1, h // 2, w // 2, generator=g) for _ in range(V - 1)]
-    monkeypatch.setenv("ADAMVS_RECUR_MODE", recur)
-    monkeypatch.setenv("ADAMVS_GRU_WINO", "7")
+    set_option("recur_mode", int(recur))
+    set_option("gru_wino", 7)
     with torch.no_grad():
         got = net([dev(f) for f in feats], dev(proj), dev(planes), D_, None if prev is None else [dev(c) for c in prev])
         ref = O.infer_depth_stage(feats, proj, planes, sd, "DepthNet.%d." % stage, net.in_up, prev)
@@ -1270,81 +1278,17 @@ def test_minimal_filtering_roles_on_ragged_stage_sizes(hip, O, monkeypatch, recu
         assert rel_l1(got[key], ref[key]) < E2E_TOL, (key, stage, h, w, recur)
 
 
-# --------------------------------------------------------------------------- level 1 as one launch: F(2x2, 3x3) gates inside, strip walk
-@pytest.mark.parametrize("seg", ["", "1", "2", "5"])
-@pytest.mark.parametrize("stage,h,w,B", [(1, 22, 38, 2), (2, 26, 50, 2), (0, 8, 40, 2), (1, 4, 6, 1), (2, 70, 34, 3), (2, 96, 64, 5)])
-def test_fused_level_one_with_minimal_filtering_gates(hip, O, monkeypatch, tmp_path, seg, stage, h, w, B):
-    """Gru1WinoFusedRole (csrc/slice_roles_fwino.h; reference models/module.py:24-52): gates in the F(2x2, 3x3) form on the tile and
-    a ring, r * h and u in LDS, candidate in the two-row form, a workgroup walking `seg` vertically adjacent tiles and handing each
-    tile's last gate rows to the next -- on maps no tile divides (8 x 30 tiles: ragged rows, ragged columns, a map smaller than a
-    tile), segments of 1 (no hand-over), 2, 5 tiles and the launcher's own choice, more work items than workgroups.  Against the CPU
-    oracle, and to rounding against the two kernels it replaces (one recurrent step: states and cost slice to 2e-6)."""
-    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
-    V, D = 3, 34
-    m = Infer_AdaMVSNet(48, [48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
-    sd = synth.seeded_state_dict(m, seed=0)
-    m.load_state_dict(sd)
-    m = m.cuda().eval()
-    net = m.DepthNet[stage]
-    C = (32, 16, 8)[stage]
-    feats = [synth.smooth_features(B, C, h, w, seed=60 + v) for v in range(V)]
-    proj = synth.rig_projections(V, 4 * h, 4 * w, batch=B)["stage1"]
-    g = torch.Generator().manual_seed(9)
-    near = 420.0 + 20.0 * torch.rand(B, 1, h, w, generator=g)
-    D_ = 48 if stage == 0 else D
-    planes = (near + 4.0 * torch.arange(D_, dtype=torch.float32).view(1, D_, 1, 1)).contiguous()
-    prev = None if stage == 0 else [torch.rand(B, 1, h // 2, w // 2, generator=g) for _ in range(V - 1)]
-    monkeypatch.setenv("ADAMVS_RECUR_MODE", "0")
-    monkeypatch.setenv("ADAMVS_GRU_WINO", "7")
-
-    def run(fused):
-        monkeypatch.setenv("ADAMVS_GRU_FUSED", fused)
-        with torch.no_grad():
-            return net([dev(f) for f in feats], dev(proj), dev(planes), D_, None if prev is None else [dev(c) for c in prev])
-    if seg:          # ADAMVS_GRU1_SEG is read once per process: a child for the forced segment lengths
-        import subprocess
-        code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import ada_mvs_amd; from ada_mvs_amd import hip_ops, synth\n"
-                "from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet\n"
-                "B, h, w, stage, V = %d, %d, %d, %d, 3\n"
-                "m = Infer_AdaMVSNet(48, [48, 32, 8], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8]); m.load_state_dict(synth.seeded_state_dict(m, seed=0)); m = m.cuda().eval()\n"
-                "net = m.DepthNet[stage]; fuse = net.reg_fuse.packed(torch.device('cuda:0'))\n"
-                "g = torch.Generator().manual_seed(4)\n"
-                "c1 = torch.randn(B, h * w, net.reg_fuse.in_channels, generator=g).cuda(); s1 = torch.randn(B, h * w, 8, generator=g).cuda() * 0.5\n"
-                "s2 = torch.randn(B, (h // 2) * (w // 2), 16, generator=g).cuda() * 0.5\n"
-                "r = hip_ops.slice_reg_step(c1, s1, s2, fuse, B, net.reg_fuse.in_channels, h, w, net.in_up, 0)\n"
-                "torch.cuda.synchronize(); torch.save([t.cpu() for t in (r, s1, s2)], sys.argv[1])\n" % (ROOT, os.path.join(ROOT, "tests"), B, h, w, stage))
-        outs = []
-        for fused, s_ in (("0", ""), ("1", seg)):
-            f = str(tmp_path / ("o%s.pt" % fused))
-            env = dict(os.environ, ADAMVS_GRU_FUSED=fused, ADAMVS_GRU_WINO="7")
-            if s_:
-                env["ADAMVS_GRU1_SEG"] = s_
-            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, cwd=ROOT)
-            assert r.returncode == 0, r.stderr[-3000:]
-            outs.append(torch.load(f))
-        for a_, b_ in zip(*outs):
-            assert bool(torch.isfinite(a_).all()) and rel_l1(b_, a_) < 2e-6 and float((a_ - b_).abs().max()) < 2e-5 * float(a_.abs().max())
-        return
-    got, two = run("1"), run("0")
-    with torch.no_grad():
-        ref = O.infer_depth_stage(feats, proj, planes, sd, "DepthNet.%d." % stage, net.in_up, prev)
-    for key in ("depth", "photometric_confidence"):
-        assert got[key].shape == ref[key].shape
-        assert rel_l1(got[key], ref[key]) < E2E_TOL, (key, stage, h, w)
-        assert rel_l1(got[key], two[key]) < 2e-6, key           # (the same chains; the bias rides in an accumulator here: rounding only)
-
-
 # --------------------------------------------------------------------------- stride-2 layers, minimal filtering along x (adamvs.py:206-211)
 @pytest.mark.parametrize("N,D,h,w,relu", [(2, 192, 24, 64, 1), (1, 192, 14, 128, 1), (3, 192, 10, 64, 0), (1, 192, 2, 64, 1), (1, 384, 12, 128, 1),
                                           (40, 192, 24, 64, 1), (1, 192, 6, 520, 1), (2, 192, 14, 66, 1)])
-def test_stride_two_layer_in_the_pair_form(hip, monkeypatch, N, D, h, w, relu):
+def test_stride_two_layer_in_the_pair_form(hip, set_option, N, D, h, w, relu):
     """k_conv_dd_s2p (csrc/costreg2d.hip: output pairs of a row share their middle input column; five products per pair, kernel row
     and channel pair instead of six) against a float64 convolution : output widths of one, two and four blocks (the launcher takes
     this form where 32-column blocks divide a row, or from 256 columns: 260 = eight blocks and a ragged one with an odd pair), row counts
-    no multiple of the block's 3 (7, 5, 1), D = 384 (two launches), 40 maps; the last case (33 columns) stays on the direct kernel.  ADAMVS_CONV_ROWS2=0 keeps these small maps off the 2-row kernel, which the
+    no multiple of the block's 3 (7, 5, 1), D = 384 (two launches), 40 maps; the last case (33 columns) stays on the direct kernel.  Option conv_rows2 = 0 keeps these small maps off the 2-row kernel, which the
     launcher would otherwise choose for them."""
     from ada_mvs_amd import packing
-    monkeypatch.setenv("ADAMVS_CONV_ROWS2", "0")
+    set_option("conv_rows2", 0)
     g = torch.Generator().manual_seed(N * 100 + D + h + w)
     x = torch.randn(N, D, h, w, generator=g)
     wt = torch.randn(D, D, 3, 3, generator=g) / (3 * D ** 0.5)

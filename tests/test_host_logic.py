@@ -27,6 +27,32 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.StageDesc) == 14 * ctypes.sizeof(ctypes.c_int) + ctypes.sizeof(ctypes.c_float)      # 14 ints + half_span
 
 
+def test_every_option_is_documented_in_the_header_with_its_default():
+    """The option table (csrc/options.h) against the OPTIONS section of include/adamvs_hip.h: same names, same defaults, in both
+    directions; set / get round trip; an unknown name is an argument error; the compute path has one place that reads the
+    environment for them (the seeding loop) plus the recurrence's two tuning tables."""
+    hdr = open(os.path.join(ROOT, "include", "adamvs_hip.h")).read()
+    sec = hdr[hdr.index("---- OPTIONS"):hdr.index("int adamvs_option_count")]
+    documented = {m.group(1): int(m.group(2)) for m in re.finditer(r"^ \*   ([a-z0-9_]+)\s+(-?\d+)\s{2,}\S", sec, re.M)}
+    lib = _lib.load()
+    table = {}
+    for name in _lib.option_names():
+        v = ctypes.c_int(0)
+        assert lib.adamvs_option_default(name.encode(), ctypes.byref(v)) == 0
+        table[name] = v.value
+    assert lib.adamvs_option_name(lib.adamvs_option_count()) is None
+    assert documented == table, (set(documented) ^ set(table), {k: (documented[k], table[k]) for k in documented if k in table and documented[k] != table[k]})
+    with _lib.options(gru_wino=5, recur_mode=3):
+        assert _lib.get_option("gru_wino") == 5 and lib.adamvs_gru_wino_mask() == 5
+        assert lib.adamvs_recurrence_schedule(0, 10 ** 9) == 3
+    assert _lib.get_option("gru_wino") == table["gru_wino"] and lib.adamvs_recurrence_schedule(0, 10 ** 9) == 0
+    with pytest.raises(_lib.AdaMVSHipError, match="unknown option 'no_such'"):
+        _lib.set_option("no_such", 1)
+    csrc = os.path.join(ROOT, "ada-mvs_amd", "csrc")
+    sites = sum(open(os.path.join(csrc, f)).read().count("getenv(") for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    assert sites <= 3, sites
+
+
 def test_argument_errors_surface_as_exceptions_without_a_gpu():
     lib = _lib.load()
     null = ctypes.c_void_p(0)

@@ -297,7 +297,8 @@ def test_unfolded_recurrence_paths_in_a_child_process(fold, small_grid):
     """At one or two samples the GRU levels run with their elementwise kernels folded into the convolutions (two dependent
     launches per plane, csrc/msred.hip); the four-launch form (epilogue partial sums, one launch for both gate
     convolutions) serves larger batches, and the seven-launch form (k_gn_partial, plain convolutions) maps whose partial sums
-    would not fit.  The switches are read once per process: a child process runs the end-to-end and slice-step cases with
+    would not fit.  A child process, its options seeded from the environment (ADAMVS_<NAME>, read once when the option table is
+    first touched: include/adamvs_hip.h "OPTIONS"), runs the end-to-end and slice-step cases with
     folding off, and with the small-grid kernels off as well (ADAMVS_CONV_SMALL_GRID=0: every convolution on the generic
     kernel, every reduction a launch of its own)."""
     import subprocess
