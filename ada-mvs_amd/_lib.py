@@ -53,7 +53,8 @@ class FeatureFpnWeights(ctypes.Structure):
 class StageDesc(ctypes.Structure):
     """adamvs_stage_desc"""
     _fields_ = [(n, ctypes.c_int) for n in ("B", "S", "C", "h", "w", "D", "in_up", "first_stage", "prev_h", "prev_w", "precision", "precision_fuse",
-                                            "eps_in_numerator", "plane_mode")] + [("half_span", ctypes.c_float)]
+                                            "eps_in_numerator", "plane_mode")] + [("half_span", ctypes.c_float),
+                                                                                   ("half_span_dev", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/adamvs_hip.h declares

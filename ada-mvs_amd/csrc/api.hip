@@ -226,7 +226,7 @@ static int stage_forward(const adamvs_stage_desc* desc, const float* feat, const
   float* ws = (float*)workspace;
   FuseWeights fw;
   memcpy(&fw, w_fuse, sizeof(fw));
-  const PlaneSrc ps{planes, s.plane_mode, s.half_span};
+  const PlaneSrc ps{planes, s.plane_mode, s.half_span, s.plane_mode == PLANES_WINDOW ? s.half_span_dev : nullptr};
 
   // -- view weights: scored by CostRegNet2D (stage 1) or resampled from the previous stage
   if (!(phases & ADAMVS_PHASE_VIEW_WEIGHTS)) {

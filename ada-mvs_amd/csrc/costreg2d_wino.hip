@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
       const int sm_b = SM ? done.n % a.sm_B : 0, sm_last = a.sm_D - 1, dq = 4 * q;
       const float sm_lo = SM ? a.sm_planes.p[2 * sm_b] : 0.f, sm_hi = SM ? a.sm_planes.p[2 * sm_b + 1] : 0.f;
       const float sm_step = (sm_hi - sm_lo) / (float)sm_last;   // as planes.h::plane_line
-      const buf_rsrc rp = make_rsrc((char*)a.sm_part + (size_t)done.n * a.h * a.w * (size_t)D);
+      const buf_rsrc rp = make_rsrc((char*)a.sm_part + (size_t)done.n * a.h * a.w * (size_t)(64 * groups));      // 4 partials of 16 bytes per channel group
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (t) __syncthreads();                                // the previous round's readers are done
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, WPS) void k_conv_wino(WinoArgs a, TileGrid tg,
             m = mn;
           }
           // one 16-byte store per lane and round, always issued (out-of-image pixels: BUF_OOB) so that the wait below counts right
-          const unsigned pbase = (oy < a.h && ox < a.w) ? (unsigned)(((oy * a.w + ox) * (D / 16) + done.cg * 4 + q) * 16) : BUF_OOB;
+          const unsigned pbase = (oy < a.h && ox < a.w) ? (unsigned)(((oy * a.w + ox) * (4 * groups) + done.cg * 4 + q) * 16) : BUF_OOB;
           buf_store4(rp, pbase, f32x4{m, se, sd, 0.f});
         } else {
         const unsigned obase = (oy < a.h && ox < a.w)
@@ -389,6 +389,12 @@ static int launch_wino_cfg(const WinoArgs& a, int N, hipStream_t st) {
 
 bool wino_depth_supported(int D) { return D >= 64 && D <= 512 && D % 64 == 0; }       // channel groups of 64; 16-channel LDS chunks
 
+// Channel groups of 96 (MT = 6 channel tiles, NT = 2 tile rows: the same 192 accumulator registers as 4 x 3, one workgroup per CU) where
+// they divide the width -- D = 192: TWO groups per pixel block instead of three.  A raw patch row then feeds 24 MFMAs instead of 16
+// (4 packed vector instructions and 4 LDS reads per 24: fp32 MFMA and the vector ALU are the same lanes) and the window of a pixel
+// block crosses the fabric twice instead of three times.  Option wino_mt6 = 0: the 64-channel forms (A/B).
+static bool wino_wide_groups(int D, int h, int w) { return opt(OPT_WINO_MT6) != 0 && D % 96 == 0 && h * w >= 1024 && opt(OPT_WINO_WPS) == 0; }
+
 int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
                      int relu, hipStream_t st) {
   const WinoArgs a{in, wpk, bias, skip, out, D, h, w, relu, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, D};
@@ -402,6 +408,7 @@ int launch_conv_wino(const float* in, const float* wpk, const float* bias, const
   // Option wino_wps = 1 / 2 forces one form (A/B); both give the same bits.
   const int forced = opt(OPT_WINO_WPS);
   const bool two = forced ? forced == 2 : h * w >= 1024;
+  if (wino_wide_groups(D, h, w)) return launch_wino_cfg<6, 2, 1>(a, N, st);
   return two ? launch_wino_cfg<4, 2, 2>(a, N, st) : launch_wino_cfg<4, 3, 1>(a, N, st);
 }
 
@@ -453,9 +460,14 @@ int launch_conv_wino_softmax(const float* in, const float* wpk, const float* bia
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino_softmax: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
   const int forced = opt(OPT_WINO_WPS);
   const bool two = forced ? forced == 2 : h * w >= 1024;
-  if (int rc = two ? launch_wino_cfg<4, 2, 2, true>(a, N, st) : launch_wino_cfg<4, 3, 1, true>(a, N, st)) return rc;
+  const bool wide = wino_wide_groups(D, h, w);
+  if (int rc = wide ? launch_wino_cfg<6, 2, 1, true>(a, N, st)
+                    : (two ? launch_wino_cfg<4, 2, 2, true>(a, N, st) : launch_wino_cfg<4, 3, 1, true>(a, N, st)))
+    return rc;
   const size_t npix = (size_t)N * h * w;
-  hipLaunchKernelGGL(k_softmax_merge, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, st, (const f32x4*)part, vw, pd, npix, D / 16);
+  // a lane's partial covers the MT channel tiles of its workgroup: 4 partials per channel group and pixel
+  hipLaunchKernelGGL(k_softmax_merge, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, st, (const f32x4*)part, vw, pd, npix,
+                     wide ? 4 * (D / 96) : D / 16);
   ADAMVS_CHECK_LAUNCH("softmax_merge");
   return 0;
 }

@@ -6,7 +6,8 @@
 //   mode 1  uniform, get_depth_range_samples with a 2-D cur_depth (module.py:650-658): p = [B][2] = (min, max),
 //           plane d = min + d * ((max - min) / (D - 1))
 //   mode 2  window, get_cur_depth_range_samples (module.py:628-643): p = cur_depth [B][hw],
-//           lo = cur - half_span, hi = cur + half_span, plane d = lo + d * ((hi - lo) / (D - 1))
+//           lo = cur - half_span, hi = cur + half_span, plane d = lo + d * ((hi - lo) / (D - 1)); half_span from the
+//           descriptor or, when span_dev is set, from device memory
 // with the reference's fp32 operation order (a rounded product, then a rounded sum: no fused multiply-add), so a
 // generated plane equals the materialised one bit for bit.
 #pragma once
@@ -20,8 +21,10 @@ struct PlaneSrc {
   const float* p;
   int mode;
   float half_span;
+  const float* span_dev;     // window mode: when non-null the half span is read from device memory (one float) instead -- a
+                             // captured hipGraph then serves tiles of any depth range (adamvs_stage_desc.half_span_dev)
 };
-static inline PlaneSrc explicit_planes(const float* planes) { return PlaneSrc{planes, PLANES_EXPLICIT, 0.f}; }
+static inline PlaneSrc explicit_planes(const float* planes) { return PlaneSrc{planes, PLANES_EXPLICIT, 0.f, nullptr}; }
 
 // the planes of one (tile b, pixel): a strided line of the tensor, or (lo, step)
 struct PlaneLine {
@@ -50,8 +53,9 @@ __device__ __forceinline__ PlaneLine plane_line(const PlaneSrc& s, size_t b, siz
       hi = s.p[2 * b + 1];
     } else {
       const float c = s.p[b * hw + pix];
-      lo = c - s.half_span;
-      hi = c + s.half_span;
+      const float hs = s.span_dev ? *s.span_dev : s.half_span;       // uniform address: a scalar load
+      lo = c - hs;
+      hi = c + hs;
     }
     l.lo = lo;
     l.step = (hi - lo) / (float)(D - 1);          // single operations: nothing to contract

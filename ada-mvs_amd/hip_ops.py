@@ -307,13 +307,21 @@ def slice_reg_step(cost_cl, state1, state2, fuse, B, C, h, w, in_up, precision=0
 
 
 def stage_desc(B, S, C, h, w, D, in_up, first_stage, prev_hw=(0, 0), precision=0, precision_fuse=0, eps_in_numerator=0,
-               plane_mode=_lib.PLANES_EXPLICIT, half_span=0.0):
+               plane_mode=_lib.PLANES_EXPLICIT, half_span=0.0, half_span_dev=None):
+    """half_span_dev: a one-element float32 device tensor holding the half span (window planes) -- read by the kernels when they run,
+    so that a captured graph serves any depth range; the caller keeps it alive."""
     return StageDesc(B, S, C, h, w, D, int(in_up), int(first_stage), int(prev_hw[0]), int(prev_hw[1]), int(precision),
-                     int(precision_fuse), int(eps_in_numerator), int(plane_mode), float(half_span))
+                     int(precision_fuse), int(eps_in_numerator), int(plane_mode), float(half_span),
+                     ctypes.c_void_p(_dev(half_span_dev, "half_span_dev").data_ptr()) if half_span_dev is not None else None)
 
 
-def plane_source(cur_depth, ndepth, depth_interval_pixel, shape):
-    """What get_depth_range_samples (module.py:646-663) would materialise, as (plane_mode, half_span, tensor) for
+def half_span_of(ndepth, depth_interval_pixel):
+    """ndepth / 2 * depth_inteval_pixel formed in Python floats, the product rounded to fp32 where it meets the map (module.py:632)."""
+    return float(ndepth / 2.0 * float(depth_interval_pixel))
+
+
+def plane_source(cur_depth, ndepth, depth_interval_pixel, shape, span_dev=None):
+    """What get_depth_range_samples (module.py:646-663) would materialise, as (plane_mode, half_span, tensor[, span_dev]) for
     adamvs_depth_stage_forward: a 2-D cur_depth [B, >=2] gives uniform planes over [min, max] (the interval is ignored
     there, quirk Q3), a map [B,h,w] gives the per-pixel window cur -+ ndepth / 2 * depth_interval_pixel.  The planes are
     generated inside the kernels, bit-identical to depth_range_samples()."""
@@ -325,7 +333,9 @@ def plane_source(cur_depth, ndepth, depth_interval_pixel, shape):
         return _lib.PLANES_UNIFORM, 0.0, cur_depth
     if tuple(cur_depth.shape) != (B, h, w):
         raise _lib.AdaMVSHipError("cur_depth:%s, input shape:%s" % (tuple(cur_depth.shape), shape))
-    return _lib.PLANES_WINDOW, float(ndepth / 2.0 * float(depth_interval_pixel)), cur_depth
+    if span_dev is not None:           # the half span lives in device memory (graphed.py): nothing of the depth range is baked into the launch
+        return _lib.PLANES_WINDOW, 0.0, cur_depth, span_dev
+    return _lib.PLANES_WINDOW, half_span_of(ndepth, depth_interval_pixel), cur_depth
 
 
 def depth_stage_workspace_bytes(desc):

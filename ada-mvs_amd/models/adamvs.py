@@ -226,9 +226,10 @@ class InferDepthNet0(nn.Module):
         first = prev_conf is None
         prev_hw = (0, 0) if first else tuple(prev_conf.shape[-2:])
         if planes is None:
-            D, mode, half_span = depth_values.shape[1], 0, 0.0
+            D, mode, half_span, span_dev = depth_values.shape[1], 0, 0.0, None
         else:
-            (mode, half_span, depth_values), D = planes, num_depth
+            (mode, half_span, depth_values), D = planes[:3], num_depth
+            span_dev = planes[3] if len(planes) > 3 else None
         if first and D != self.reg.prob.weight.shape[0]:
             # CostRegNet2D is D -> D (reference adamvs.py:198-228, built with in_depths = ndepths[0]): the reference's conv0 fails on
             # any other plane count.  Here the network may run zero-padded to a wider tiling (packing.reg_width), so a count that
@@ -236,7 +237,8 @@ class InferDepthNet0(nn.Module):
             raise AdaMVSHipError("stage 1 was given %d hypothesis planes but its CostRegNet2D is built for %d (ndepths[0])"
                                  % (D, self.reg.prob.weight.shape[0]))
         desc = hip_ops.stage_desc(B, S, C, h, w, D, self.in_up, first, prev_hw, _PRECISIONS[self.reg.effective_precision()],
-                                  _PRECISIONS[self.reg_fuse.precision], eps_in_numerator=int(twin), plane_mode=mode, half_span=half_span)
+                                  _PRECISIONS[self.reg_fuse.precision], eps_in_numerator=int(twin), plane_mode=mode, half_span=half_span,
+                                  half_span_dev=span_dev)
         need = hip_ops.depth_stage_workspace_bytes(desc) // 4
         table = self._workspace if workspaces is None else workspaces
         key = (feat_cl.device, group)
@@ -317,11 +319,14 @@ class Infer_AdaMVSNet(nn.Module):
             net.reg.precision = net.reg_fuse.precision = precision
 
     # ---- the hot path on pre-extracted features ---------------------------------------------
-    def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval, group=0, twin=False):
+    def infer_from_features(self, feats_cl, shapes, proj_matrices, depth_values, depth_interval, group=0, twin=False, span_dev=None):
         """feats_cl[s]: [V*B, h*w, C] channel-last view-major; shapes[s] = (B, C, h, w).
         Everything below is HIP.  `group` selects the workspace: independent
         tile groups may run concurrently on different streams (the recurrence is latency-bound per group).
-        twin: semantics of the train/test model AdaMVSNet (see that class)."""
+        twin: semantics of the train/test model AdaMVSNet (see that class).
+        span_dev: float32 device tensor [num_stage] holding hip_ops.half_span_of(ndepths[s], ratio[s] * depth_interval) per stage; the
+        window planes of stages 2, 3 then read their half span from it when the kernels run and `depth_interval` is not used for
+        them -- nothing of the tile's depth range is baked into the launches (graphed.py replays one capture for every tile)."""
         outputs = {}
         depth, conf = None, None
         first_maps = None
@@ -343,7 +348,7 @@ class Infer_AdaMVSNet(nn.Module):
                 vw, pd, depth, pconf = adist.stage_with_sharded_views(net, feats_cl[s], B, C, h, w, rt, planes, self.ndepths[s], group, twin,
                                                                       self._stage_workspace, *self.view_shard)
             else:
-                planes = hip_ops.plane_source(cur, self.ndepths[s], span, [B, h, w])
+                planes = hip_ops.plane_source(cur, self.ndepths[s], span, [B, h, w], None if span_dev is None else span_dev[s:s + 1])
                 vw, pd, depth, pconf = net.run(feats_cl[s], B, C, h, w, rt, None, conf, group, twin, planes=planes, num_depth=self.ndepths[s],
                                                workspaces=self._stage_workspace)
             if twin:

@@ -51,6 +51,9 @@ def build_parser():
     # not in the reference
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"], help="arithmetic of the convolutions")
     ap.add_argument("--num_workers", type=int, default=4, help="loader processes (the reference uses 1); decoding and resizing a view takes ~1 s of CPU")
+    ap.add_argument("--graph", type=str2bool, default=True,
+                    help="--model adamvs: capture the forward of an input shape into a hipGraph once and replay it for every later sample "
+                         "of that shape (ada_mvs_amd/graphed.py); 0: launch eagerly")
     ap.add_argument("--seeded_weights", type=int, default=None,
                     help="no checkpoint: seeded random weights (ada_mvs_amd.synth), for dry runs and tests")
     return ap
@@ -133,6 +136,10 @@ def predict_depth(args):
     loader = DataLoader(dataset, args.batch_size, shuffle=False, num_workers=args.num_workers, drop_last=False,
                         multiprocessing_context=ctx)
     model = build_model(args, device)
+    forward = model
+    if args.graph and args.model == "adamvs":
+        from .graphed import GraphedForward
+        forward = GraphedForward(model)
     os.makedirs(args.output_folder, exist_ok=True)
     step, t_first = 0, time.time()
     with torch.no_grad():
@@ -140,7 +147,8 @@ def predict_depth(args):
             t0 = time.time()
             imgs = sample["imgs"].to(device)
             proj = {k: v.to(device) for k, v in sample["proj_matrices"].items()}
-            outputs = model(imgs, proj, sample["depth_values"].to(device))
+            # (the graphed forward reads depth_min / depth_max from the loader's HOST tensor: no device round trip per sample)
+            outputs = forward(imgs, proj, sample["depth_values"] if forward is not model else sample["depth_values"].to(device))
             depth = outputs["depth"].float().cpu().numpy()
             conf = outputs["photometric_confidence"].float().cpu().numpy()
             t1 = time.time()

@@ -46,6 +46,8 @@ const char* adamvs_last_error_string(void);
  *                                  layers in the minimal-filtering form F(2x2, 3x3) (16 of 36 products); 0: direct kernels
  *   wino_softmax             1     ... its `prob` layer carries the softmax partials, no score volume (stage path); 0: score volume
  *   wino_wps                 0     ... 1 / 2: one / two workgroups per CU for every map size (same bits); 0: by map size
+ *   wino_mt6                 1     ... widths that are multiples of 96, maps of >= 1024 pixels: 96 output channels per workgroup (two
+ *                                  channel groups at D = 192 instead of three; same bits); 0: groups of 64
  *   fuse_softmax             1     direct `prob` kernel: softmax / max / depth regression in its epilogue; 0: k_softmax_regress
  *   s2_pairs                 1     CostRegNet2D: large stride-2 layers in the pair form along x (15 of 18 products); 0: direct
  *   conv_rows2              -1     CostRegNet2D: 2-row blocks for small grids: 0 never, 1 always, -1 by grid size
@@ -332,6 +334,9 @@ typedef struct adamvs_stage_desc {
                              lo = cur - half_span, hi = cur + half_span, plane d = lo + d (hi - lo)/(D - 1) (module.py:628-643).
                              Generated planes equal the materialised ones bit for bit and never cross HBM. */
   float half_span;        /* ADAMVS_PLANES_WINDOW: ndepth / 2 * depth_interval_pixel (module.py:632) */
+  const float* half_span_dev; /* ADAMVS_PLANES_WINDOW, optional (NULL: half_span above): DEVICE pointer to that one float.  The value
+                             is then read by the kernels when they run, not baked into the launch: a captured hipGraph of the
+                             stage serves tiles of any depth range (ada_mvs_amd/graphed.py; predict_whu.py's loop) */
 } adamvs_stage_desc;
 #define ADAMVS_PLANES_EXPLICIT 0
 #define ADAMVS_PLANES_UNIFORM  1

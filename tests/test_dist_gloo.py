@@ -57,6 +57,32 @@ def _worker_steps(rank, world, port, n_tiles, q):
     dist.destroy_process_group()
 
 
+def _worker_every_step(rank, world, port, n_tiles, q):
+    """A predict-style caller: finish() after EVERY start(), the result consumed (cloned) per step -- next to the throughput loop
+    above, where only the last step's maps are read.  The staging buffers alternate and the receive set is reused: a step's
+    result must never carry the previous or the next step's values."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    adist.init_from_env(backend="gloo")
+    tiles = adist.tiles_of_rank(n_tiles, rank, world)
+    g = adist.MapGatherer(n_tiles, len(tiles), 4, 6, torch.device("cpu"))
+    out = torch.zeros(max(len(tiles), 1), 4, 6)[:len(tiles)]          # reused "graph output" buffers
+    per_step = []
+    for step in range(4):
+        for i, t in enumerate(tiles):
+            out[i] = 100.0 * step + t
+        g.start(out, out + 0.25)
+        out.fill_(-1.0)                                               # the caller reuses its buffers at once: start() has copied
+        depth, conf = g.finish()
+        if rank == 0:
+            per_step.append((depth.clone(), conf.clone()))
+        else:
+            assert depth is None and conf is None
+    if rank == 0:
+        q.put((torch.stack([d for d, _ in per_step]), torch.stack([c for _, c in per_step])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker_views(rank, world, port, n_views, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     adist.init_from_env(backend="gloo")
@@ -119,6 +145,17 @@ def test_map_gatherer_steps_even_and_uneven():
         for t in range(n_tiles):
             assert float(depth[t].min()) == float(depth[t].max()) == 200.0 + t
             assert float(conf[t, 0, 0]) == 200.25 + t
+
+
+def test_map_gatherer_consumed_after_every_step():
+    """finish() after every start(): each step's gathered maps are that step's, for even and uneven tile counts."""
+    for n_tiles in (4, 5):
+        depth, conf = _run(n_tiles, _worker_every_step)
+        assert depth.shape == (4, n_tiles, 4, 6)
+        for step in range(4):
+            for t in range(n_tiles):
+                assert float(depth[step, t].min()) == float(depth[step, t].max()) == 100.0 * step + t
+                assert float(conf[step, t].min()) == float(conf[step, t].max()) == 100.0 * step + t + 0.25
 
 
 def test_map_gatherer_single_process_is_identity():

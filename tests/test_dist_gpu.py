@@ -130,3 +130,25 @@ def test_bench_self_launches_its_ranks(tmp_path):
     assert [x["rank"] for x in d["devices"]] == [0, 1] and len({x["pid"] for x in d["devices"]}) == 2
     assert d["scaling"] == "strong" and d["config"]["global_tiles_per_step"] == 5 and d["value"] > 0
     assert d["roofline"] is None and d["cpu_baseline"] is None
+
+
+def test_bench_cfg4_as_stated_eight_ranks_dry_run(tmp_path):
+    """BASELINE config 4 as it is written -- `python bench.py --gpus 8 --workload cfg3 --tiles-total 32 --precision bf16x3`: 32 cascade
+    tiles dealt to 8 ranks, 4 per rank, one gather per step -- with all eight ranks on device 0 over gloo: the exact command a node with
+    eight GPUs will run has executed end to end (self-launch, tile ownership, per-rank graphs, the gather, the max-over-ranks clock,
+    one JSON line).  One device shared by eight processes: NOT a scaling point, only the code path."""
+    import json
+    env = dict(os.environ, ADAMVS_BENCH_ONE_DEVICE="1", ADAMVS_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--workload", "cfg3",
+           "--tiles-total", "32", "--precision", "bf16x3", "--launch-timeout=840"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["backend"] == "gloo" and d["launcher"] == "self"
+    assert [x["rank"] for x in d["devices"]] == list(range(8)) and len({x["pid"] for x in d["devices"]}) == 8
+    assert d["scaling"] == "strong" and d["config"]["global_tiles_per_step"] == 32 and d["config"]["tiles_per_gpu_per_step"] == "4..4"
+    assert d["value"] > 0 and d["roofline"] is None and d["cpu_baseline"] is None

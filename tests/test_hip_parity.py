@@ -1303,3 +1303,43 @@ def test_stride_two_layer_in_the_pair_form(hip, set_option, N, D, h, w, relu):
     got = out.cpu().double().reshape(N, ho, wo, D).permute(0, 3, 1, 2)
     assert rel_l1(got, ref) < 2e-6, rel_l1(got, ref)
     assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+# --------------------------------------------------------------------------- one captured graph per input shape (predict_whu.py:100-112)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_graphed_forward_equals_eager_for_every_depth_range(hip, precision):
+    """ada_mvs_amd/graphed.py: the forward of a shape captured once and replayed for every later sample of that shape -- other images,
+    other rigs and OTHER DEPTH RANGES (the half span of the window planes is read from device memory by the captured kernels,
+    adamvs_stage_desc.half_span_dev; depth_min / depth_max are read from the caller's host tensor, reference adamvs.py:569-571), two
+    shapes interleaved (each graph owns its workspace), depth_values handed over on the host and on the device.  Bit for bit the
+    eager forward."""
+    from ada_mvs_amd.graphed import GraphedForward
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    m = Infer_AdaMVSNet(16, [16, 8, 4], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8], precision=precision)
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.cuda().eval()
+    fwd = GraphedForward(m)
+    small = dict(views=3, H=64, W=96, ndepths=[16, 8, 4], num_depth=16)
+    large = dict(views=3, H=96, W=160, ndepths=[16, 8, 4], num_depth=16)
+    cases = [(small, 1, 0, (400.0, 600.0)), (small, 1, 1, (380.0, 640.0)), (large, 2, 2, (400.0, 600.0)), (small, 1, 3, (420.0, 520.0)),
+             (large, 2, 4, (350.0, 700.0)), (small, 1, 0, (400.0, 600.0))]
+    for i, (cfg, batch, seed, (lo, hi)) in enumerate(cases):
+        imgs, proj, _ = synth.tile_inputs(cfg, batch=batch, seed=seed, baseline=8.0 + seed)
+        dv = torch.tensor([[lo, hi]] * batch, dtype=torch.float32)
+        args = (dev(imgs), {k: dev(v) for k, v in proj.items()})
+        with torch.no_grad():
+            want = m(*args, dev(dv))
+            want = {s: {k: want[s][k].clone() for k in ("depth", "photometric_confidence")} for s in ("stage1", "stage2", "stage3")}
+            got = fwd(*args, dv if i % 2 == 0 else dev(dv))
+        torch.cuda.synchronize()
+        for s in ("stage1", "stage2", "stage3"):
+            for k in ("depth", "photometric_confidence"):
+                assert torch.equal(got[s][k], want[s][k]), (i, s, k)
+        assert torch.equal(got["depth"], want["stage3"]["depth"])
+    assert fwd.captures == 2 and len(fwd.cache) == 2
+    third = dict(views=3, H=64, W=128, ndepths=[16, 8, 4], num_depth=16)      # a third shape evicts the least recently used graph
+    imgs, proj, dv = synth.tile_inputs(third, batch=1, seed=5)
+    with torch.no_grad():
+        want = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))["depth"].clone()
+        got = fwd(dev(imgs), {k: dev(v) for k, v in proj.items()}, dv)["depth"]
+    assert torch.equal(got, want) and fwd.captures == 3 and len(fwd.cache) == 2

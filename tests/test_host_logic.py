@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.adamvs_version() == _lib.ABI_VERSION
     assert ctypes.sizeof(_lib.FuseWeights) == 17 * ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_lib.StageDesc) == 14 * ctypes.sizeof(ctypes.c_int) + ctypes.sizeof(ctypes.c_float)      # 14 ints + half_span
+    assert ctypes.sizeof(_lib.StageDesc) == 72      # 14 ints + half_span (60), padded to the pointer half_span_dev (64 + 8)
 
 
 def test_every_option_is_documented_in_the_header_with_its_default():

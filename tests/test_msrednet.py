@@ -453,9 +453,10 @@ def test_end_to_end_at_the_benchmark_shape_against_oracle(recipe):
     three stages' confidence maps (depth maps: 2-5e-5), although a different thread count or form of the warp moves it by
     8e-5 ... 2e-4 only; the HIP path, with other summation orders in every convolution, is 2.6e-4 / 8.8e-4 / 3.6e-3 from the
     fp32 run and 1.7e-4 / 5.8e-4 / 2.3e-3 from float64: three evaluations of the same network, pairwise a few 1e-3 apart on the
-    last confidence map, the HIP one the closest to exact arithmetic.  The bar (1e-3 relative L1, BASELINE.json) is therefore
-    asserted where it is meaningful -- every depth map, against both oracles -- and every map must be no farther from float64
-    than the reference's own fp32 arithmetic is.
+    last confidence map, the HIP one the closest to exact arithmetic.  The bar (1e-3 relative L1, BASELINE.json) is asserted,
+    against both oracles, on every map the reference's own fp32 arithmetic holds to 1e-3 of float64 (all but the stage-3
+    confidence map on the seeded weights); the others are "reference-limited" and held to a recorded distance from float64
+    (the block at the end of the test); every map must be no farther from float64 than the reference's fp32 arithmetic is.
 
     recipe "sharp" (round 5; synth.LOGIT_GAINS: gain 15 instead of 3 on upconv2d, the layer in front of the unstabilised exp): the same
     three evaluations on weights with a trained network's dynamic range -- whether the 3.6e-3 of the last confidence map belongs to
@@ -492,11 +493,21 @@ def test_end_to_end_at_the_benchmark_shape_against_oracle(recipe):
             json.dump({k: {"hip_vs_fp32_oracle": v[0], "hip_vs_float64_oracle": v[1], "fp32_oracle_vs_float64": v[2]} for k, v in rows.items()}, f, indent=1)
     except OSError:
         pass
+    # Every map is held to an ABSOLUTE bar (round 6).  Where the reference's own fp32 arithmetic is well-conditioned -- its CPU evaluation
+    # within 1e-3 of float64 -- that bar is the north star's: 1e-3 against the fp32 oracle AND against float64.  Where it is not (the
+    # reference's fp32 run is itself further than 1e-3 from exact arithmetic: "reference-limited"), no evaluation of the network in
+    # fp32 can be held to 1e-3 of another; there the HIP path is held to a RECORDED distance from float64 (1.3 x what round 5 measured,
+    # profiles/r05_parity_msrednet_full_size*.json) and must not be farther from float64 than the reference's fp32 evaluation.
+    REFERENCE_LIMITED = {"default": {"stage3.photometric_confidence": 3.0e-3},
+                         "sharp": {"stage2.depth": 1.3e-3, "stage2.photometric_confidence": 6.8e-3, "stage3.depth": 4.3e-3,
+                                   "stage3.photometric_confidence": 0.22}}[recipe]
     for k, (e32, e64, o) in rows.items():
-        if k.endswith("depth") and recipe == "default":
-            assert e32 < 1e-3 and e64 < 1e-3, (k, e32, e64)  # the bar, against the reference's fp32 and against exact arithmetic
-        # ("sharp": the reference's OWN fp32 arithmetic is 1.4e-3 / 4.2e-3 from float64 on the stage-2 / 3 depth maps and 0.19 on the last
-        #  confidence map -- measured in round 5, profiles/r05_parity_msrednet_full_size_sharp.json: the network, not the recipe, is
-        #  ill-conditioned, the more so the larger the logits; what can be held there is the relative statement below)
-        assert e64 <= 1.05 * o, (k, e64, o)                  # no farther from exact arithmetic than the reference's fp32 evaluation is
-        assert e32 < 2.0 * o + 1e-4, (k, e32, o)             # and from the reference no farther than two such distances
+        three = "%s: hip vs fp32 oracle %.2e, hip vs float64 %.2e, fp32 oracle vs float64 %.2e" % (k, e32, e64, o)
+        if o < 1e-3:
+            assert k not in REFERENCE_LIMITED, "the reference is well-conditioned here now: hold the map to 1e-3 (" + three + ")"
+            assert e32 < 1e-3 and e64 < 1e-3, three          # the bar, against the reference's fp32 and against exact arithmetic
+        else:
+            assert k in REFERENCE_LIMITED, "reference-limited map without a recorded bound (" + three + ")"
+            assert e64 < REFERENCE_LIMITED[k], "reference-limited; " + three
+        assert e64 <= 1.05 * o, three                        # no farther from exact arithmetic than the reference's fp32 evaluation is
+        assert e32 < 2.0 * o + 1e-4, three                   # and from the reference no farther than two such distances

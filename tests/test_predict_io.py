@@ -327,6 +327,12 @@ def test_predict_end_to_end_writes_reference_layout(tmp_path, model_name):
     argv = ["--data_folder", str(src), "--output_folder", str(out), "--view_num", "3", "--numdepth", "16", "--model", model_name,
             "--ndepths", "16,8,4", "--seeded_weights", "0", "--batch_size", "2", "--num_workers", "0"]
     assert predict.main(argv) == 4
+    if model_name == "adamvs":        # the default replays one captured graph per shape (graphed.py); launched eagerly: the same bytes
+        eager = tmp_path / "eager"
+        assert predict.main(argv[:3] + [str(eager)] + argv[4:] + ["--graph", "0"]) == 4
+        for i in range(4):
+            for f in ("%03d_init.pfm" % i, "%03d_prob.pfm" % i):
+                assert open(str(out / "view0" / f), "rb").read() == open(str(eager / "view0" / f), "rb").read(), f
     ds = find_dataset_def("predict_oblique")(str(src), 3, predict.build_parser().parse_args(argv))
     cls = Infer_AdaMVSNet if model_name == "adamvs" else Infer_CascadeREDNet
     model = cls(16, [16, 8, 4], [4.0, 2.0, 1.0], False, [8, 8, 8])
