@@ -176,13 +176,8 @@ extern "C" int adamvs_slice_reg_step(const float* cost, float* state1, float* st
   StepBuffers sb{state1, s + n1, s + 2 * n1, s + 3 * n1, state2, s + 3 * n1 + n2, s + 3 * n1 + 2 * n2};
   FuseWeights fw;
   memcpy(&fw, weights, sizeof(fw));
-  const bool split = precision == PRECISION_BF16X3 && bx3_presplit();
-  int rc = launch_conv1(cost, fw.conv1, c1, B, C, h, w, precision, st, split);
+  int rc = launch_conv1(cost, fw.conv1, c1, B, C, h, w, precision, st);
   if (rc) return rc;
-  if (split) {       // the states as split maps, where step 0 of launch_gru_convs_bf16x3 reads them
-    if ((rc = launch_split_map(state1, sb.u1, (long)B * h * w, 8, st))) return rc;
-    if ((rc = launch_split_map(state2, sb.u2, (long)B * (h / 2) * (w / 2), 16, st))) return rc;
-  }
   float* h1_now = state1;
   float* h2_now = state2;
   if ((rc = launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, precision, st, &h1_now, &h2_now))) return rc;
@@ -267,14 +262,9 @@ static int stage_forward(const adamvs_stage_desc* desc, const float* feat, const
   const int mode = recurrence_mode(s.precision_fuse, (long)s.B * s.h * s.w);
   const bool pipelined = mode != 0;
   const int lag = recurrence_lags(mode, s.precision_fuse).dec;       // the decoder runs `lag` hypotheses behind level 1
-  const bool c1_split = s.precision_fuse == PRECISION_BF16X3 && bx3_presplit();
   if (do_rec) {      // zero initial states (adamvs.py:448-449): h1[-1] = ring slot 3, h2[-1] = ring slot 1 (slot 0 when sequential)
     hipError_t e = hipMemsetAsync(pipelined ? rb.h1[3] : rb.h1[0], 0, (size_t)s.B * hw * 8 * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(pipelined ? rb.h2[1] : rb.h2[0], 0, (size_t)s.B * hw4 * 16 * sizeof(float), st);
-    if (c1_split) {  // ... and their split twins (slice_roles_bx3.h): hypothesis -1 lives in u1 / u2
-      if (e == hipSuccess) e = hipMemsetAsync(rb.u1, 0, (size_t)s.B * hw * 8 * sizeof(float), st);
-      if (e == hipSuccess) e = hipMemsetAsync(rb.u2, 0, (size_t)s.B * hw4 * 16 * sizeof(float), st);
-    }
     if (e != hipSuccess) return set_error((int)e, "stage: hipMemsetAsync: %s", hipGetErrorString(e));
   }
   auto vol_of = [&](int d) { return ws + c.vol[(d / dc) & 1]; };
@@ -287,7 +277,7 @@ static int stage_forward(const adamvs_stage_desc* desc, const float* feat, const
   for (int k = 0; k < nchunks; ++k) {
     const int d0 = k * dc, d1 = d0 + dc < s.D ? d0 + dc : s.D;
     if (do_agg && (rc = launch_sweep_conv1_chunk(feat, rt, ps, view_weight, fw.conv1, ws + c.c1, ws + c.agg, s.B, s.S, s.C, s.D, d0,
-                                                 d1, s.h, s.w, s.precision_fuse, s.eps_in_numerator, st, c1_split)))
+                                                 d1, s.h, s.w, s.precision_fuse, s.eps_in_numerator, st)))
       return rc;
     if (do_rec) {
       for (int t = d0; t < d1; ++t) {

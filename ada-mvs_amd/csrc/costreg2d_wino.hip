@@ -389,12 +389,12 @@ static int launch_wino_cfg(const WinoArgs& a, int N, hipStream_t st) {
 
 bool wino_depth_supported(int D) { return D >= 64 && D <= 512 && D % 64 == 0; }       // channel groups of 64; 16-channel LDS chunks
 
-// Channel groups of 96 (MT = 6 channel tiles, NT = 2 tile rows: the same 192 accumulator registers as 4 x 3, one workgroup per CU) where
-// they divide the width -- D = 192: TWO groups per pixel block instead of three.  A raw patch row then feeds 24 MFMAs instead of 16
-// (4 packed vector instructions and 4 LDS reads per 24: fp32 MFMA and the vector ALU are the same lanes) and the window of a pixel
-// block crosses the fabric twice instead of three times.  Option wino_mt6 = 0: the 64-channel forms (A/B).
-static bool wino_wide_groups(int D, int h, int w) { return opt(OPT_WINO_MT6) != 0 && D % 96 == 0 && h * w >= 1024 && opt(OPT_WINO_WPS) == 0; }
-
+// (Round 6 measured channel groups of 96 -- MT = 6 channel tiles x NT = 2 tile rows, the same 192 accumulator registers as 4 x 3,
+// one workgroup per CU, TWO groups per pixel block at D = 192 instead of three: 4 packed vector instructions and 4 LDS reads per 24
+// MFMAs instead of 16, a third less window traffic.  It loses to the 4 x 2 form at two workgroups per CU everywhere: 512 maps of
+// 96 x 192 / 48 x 96 / 24 x 48: 24.5 / 6.15 / 2.06 ms against 22.0 / 5.79 / 1.89; cfg2's step 393.5 -> 406.3 ms.  What the second
+// wave per SIMD hides -- the transforms, the barrier -- is worth more than the vector instructions the wider group saves.
+// profiles/r06_wino_mt6_ab.txt; the kernel is generic in MT, the instantiation is not built.)
 int launch_conv_wino(const float* in, const float* wpk, const float* bias, const float* skip, float* out, int N, int D, int h, int w,
                      int relu, hipStream_t st) {
   const WinoArgs a{in, wpk, bias, skip, out, D, h, w, relu, nullptr, PlaneSrc{nullptr, 0, 0.f}, 1, D};
@@ -408,7 +408,6 @@ int launch_conv_wino(const float* in, const float* wpk, const float* bias, const
   // Option wino_wps = 1 / 2 forces one form (A/B); both give the same bits.
   const int forced = opt(OPT_WINO_WPS);
   const bool two = forced ? forced == 2 : h * w >= 1024;
-  if (wino_wide_groups(D, h, w)) return launch_wino_cfg<6, 2, 1>(a, N, st);
   return two ? launch_wino_cfg<4, 2, 2>(a, N, st) : launch_wino_cfg<4, 3, 1>(a, N, st);
 }
 
@@ -460,14 +459,10 @@ int launch_conv_wino_softmax(const float* in, const float* wpk, const float* bia
   ADAMVS_CHECK_ARG((size_t)h * w * D * 4 < 0x7fffffffu, "conv_wino_softmax: a map of %dx%dx%d floats exceeds the 2 GiB a buffer descriptor spans", h, w, D);
   const int forced = opt(OPT_WINO_WPS);
   const bool two = forced ? forced == 2 : h * w >= 1024;
-  const bool wide = wino_wide_groups(D, h, w);
-  if (int rc = wide ? launch_wino_cfg<6, 2, 1, true>(a, N, st)
-                    : (two ? launch_wino_cfg<4, 2, 2, true>(a, N, st) : launch_wino_cfg<4, 3, 1, true>(a, N, st)))
-    return rc;
+  if (int rc = two ? launch_wino_cfg<4, 2, 2, true>(a, N, st) : launch_wino_cfg<4, 3, 1, true>(a, N, st)) return rc;
   const size_t npix = (size_t)N * h * w;
-  // a lane's partial covers the MT channel tiles of its workgroup: 4 partials per channel group and pixel
-  hipLaunchKernelGGL(k_softmax_merge, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, st, (const f32x4*)part, vw, pd, npix,
-                     wide ? 4 * (D / 96) : D / 16);
+  // a lane's partial covers the MT = 4 channel tiles of its workgroup: 4 partials per channel group of 64 and pixel
+  hipLaunchKernelGGL(k_softmax_merge, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, st, (const f32x4*)part, vw, pd, npix, D / 16);
   ADAMVS_CHECK_LAUNCH("softmax_merge");
   return 0;
 }

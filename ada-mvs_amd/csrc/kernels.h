@@ -45,13 +45,10 @@ int launch_soft_argmin_chunk(const float* vol, int vol_D, PlaneSrc planes, int D
 int sweep_chunk_planes(int D);
 int launch_sweep_conv1_chunk(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,
                              float* c1_chunk, float* sim_ws, int B, int S, int C, int D, int d0, int d1, int h, int w, int precision,
-                             int eps_in_numerator, hipStream_t st, int c1_split = 0);
+                             int eps_in_numerator, hipStream_t st);
 
-// c1_split (bf16x3 only): c1 as a split map, the form the recurrence of that mode reads (slice_roles_bx3.h)
-int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, int precision, hipStream_t st, int c1_split = 0);
-int launch_conv1_bf16x3(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int split_out, hipStream_t st);
-int launch_split_map(const float* src, float* dst, long npix, int C, hipStream_t st);
-bool bx3_presplit();
+int launch_conv1(const float* cost, const float* w, float* c1, int B, int C, int h, int w_, int precision, hipStream_t st);
+int launch_conv1_bf16x3(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, hipStream_t st);
 int launch_gru_convs_bf16x3(const float* c1, const FuseWeights& fw, const StepBuffers& sb, int B, int h, int w, int d,
                             float** h1_now, float** h2_now, hipStream_t st);
 // step d of a stage; *h1_now / *h2_now (optional) receive the buffers holding the states afterwards (sb.h1 / sb.h2, or

@@ -14,7 +14,6 @@ namespace adamvs {
   X(OPT_WINOGRAD, "winograd", 1)                     /* CostRegNet2D: stride-1 layers in the F(2x2, 3x3) form (fp32, D % 64 == 0) */ \
   X(OPT_WINO_SOFTMAX, "wino_softmax", 1)             /* ... `prob` carries the softmax partials (no score volume) */                 \
   X(OPT_WINO_WPS, "wino_wps", 0)                     /* ... 1 / 2 workgroups per CU; 0 = by map size */                              \
-  X(OPT_WINO_MT6, "wino_mt6", 1)                     /* ... 96-channel groups (two per pixel block at D = 192) on large maps */        \
   X(OPT_FUSE_SOFTMAX, "fuse_softmax", 1)             /* direct `prob` kernel: softmax / max / regression in its epilogue */           \
   X(OPT_S2_PAIRS, "s2_pairs", 1)                     /* CostRegNet2D: large stride-2 layers in the pair form along x */               \
   X(OPT_CONV_ROWS2, "conv_rows2", -1)                /* CostRegNet2D: 2-row blocks on small grids; -1 = by grid size */               \

@@ -226,7 +226,7 @@ typedef ConvWinoRole<16, 16, 1, EPI_CAND> Cand2W;
 typedef Gru1FusedRole<4, 2> Gru1S;      // fp32, both levels fused: 4 x 30 / 4 x 14 tiles for stages with few tiles per CU
 typedef Gru2FusedRole<4> Gru2S;
 typedef Gru1FusedBx3Role Gru1Bx;
-typedef ConvSmallBx3Role<8, 0, 1, 2, BXE_RELU, BX3_PRESPLIT != 0, BX3_PRESPLIT != 0> Conv2Bx;      // split maps in and out
+typedef ConvSmallBx3Role<8, 0, 1, 2, BXE_RELU> Conv2Bx;
 typedef Gru2FusedBx3Role Gru2Bx;
 
 // Relative cost per tile (microseconds of a whole-chip launch per tile, measured at cfg2's stage-1 shape; only the
@@ -334,15 +334,11 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
     // both GRU levels are one kernel each: two launches per hypothesis whatever the schedule number
     //   A: gru1(t) [0,f) | conv2(t-1)        B: gru1(t) [f,1) | gru2(t-1) | decoder(t-2)
     // (the level-1 kernel has no dependant inside its step: its tiles are dealt to both launches so that they carry equal work)
-    // split twins of the states (slice_roles_bx3.h): hypothesis s in rh for even s, in u for odd s (-1: zeroed by the stage driver);
-    // a twin is read by the launches of the next hypothesis only (gru1's window, conv2), so two buffers carry the ring of four
-    auto S1 = [&](int s) { return (s & 1) ? rb.u1 : rb.rh1; };
-    auto S2 = [&](int s) { return (s & 1) ? rb.u2 : rb.rh2; };
-    Gru1Args g1{c1_t, H1(t - 1), H1(t), (const bf16x8*)fw.gates1, fw.gates1_b, (const bf16x8*)fw.cand1, fw.cand1_b, h, w, S1(t - 1), S1(t)};
-    SmallConvArgsBx v2{BX3_PRESPLIT ? S1(s2) : H1(s2), nullptr, (const bf16x8*)fw.conv2, nullptr, C2(s2), nullptr, nullptr, h, w, h2, w2, 16, nullptr};
+    Gru1Args g1{c1_t, H1(t - 1), H1(t), (const bf16x8*)fw.gates1, fw.gates1_b, (const bf16x8*)fw.cand1, fw.cand1_b, h, w};
+    SmallConvArgsBx v2{H1(s2), nullptr, (const bf16x8*)fw.conv2, nullptr, C2(s2), nullptr, nullptr, h, w, h2, w2, 16, nullptr};
     if (schedule == 5) {
       // ONE launch per hypothesis: gru1(t) | conv2(t-1) | gru2(t-2) | decoder(t-3) -- every role reads only what earlier launches wrote
-      Gru2Args g2s{C2(sc), H2(sc - 1), H2(sc), (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2, S2(sc - 1), S2(sc)};
+      Gru2Args g2s{C2(sc), H2(sc - 1), H2(sc), (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2};
       if (in_up)
         return launch_slot4<Gru1Bx, Conv2Bx, Gru2Bx, DecoderRole<true>>(
             l1 ? use<Gru1Bx>(&g1, k.k1bx) : none<Gru1Bx>(), l2 ? use<Conv2Bx>(&v2, k.v2bx) : none<Conv2Bx>(), lc ? use<Gru2Bx>(&g2s, k.g2bx) : none<Gru2Bx>(),
@@ -351,7 +347,7 @@ int launch_recur_pipeline_step(const GruStateRing& rb, const FuseWeights& fw, in
           l1 ? use<Gru1Bx>(&g1, k.k1bx) : none<Gru1Bx>(), l2 ? use<Conv2Bx>(&v2, k.v2bx) : none<Conv2Bx>(), lc ? use<Gru2Bx>(&g2s, k.g2bx) : none<Gru2Bx>(),
           dec ? use<DecoderRole<false>>(&da, k.dec) : none<DecoderRole<false>>(), B, st, "recurrence, one launch (bf16x3)");
     }
-    Gru2Args g2{C2(s2), H2(s2 - 1), H2(s2), (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2, S2(s2 - 1), S2(s2)};
+    Gru2Args g2{C2(s2), H2(s2 - 1), H2(s2), (const bf16x8*)fw.gates2, fw.gates2_b, (const bf16x8*)fw.cand2, fw.cand2_b, h2, w2};
     // per level-1 tile (8 x 30 pixels): 0.94 conv2 tiles (4 x 16 at half resolution), 0.54 gru2 tiles (8 x 14), 1 decoder tile (8 x 30)
     float f = 0.5f + ((0.54f * k.g2bx + 1.0f * k.dec) - 0.94f * k.v2bx) / (2.f * k.k1bx);
     f = !l2 ? 1.0f : (f < 0.1f ? 0.1f : (f > 1.f ? 1.f : f));

@@ -804,8 +804,8 @@ int launch_conv_pair(const float* srcA, int CA, const float* srcB, int CB, const
 
 bool conv_pair_epilogue_partials(int B, int h, int w) { return gn_epilogue_partials((long)cdiv(w, 16) * cdiv(h, 4) * 4, B); }
 
-int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int precision, hipStream_t st, int c1_split) {
-  if (precision == PRECISION_BF16X3) return launch_conv1_bf16x3(cost, w, c1, N, C, h, w_, c1_split, st);
+int launch_conv1(const float* cost, const float* w, float* c1, int N, int C, int h, int w_, int precision, hipStream_t st) {
+  if (precision == PRECISION_BF16X3) return launch_conv1_bf16x3(cost, w, c1, N, C, h, w_, st);
   if (C == 32) return (conv1_f23() & 1) ? launch_conv1_f23_32(cost, w, c1, N, h, w_, st) : launch_conv1_ksplit32(cost, w, c1, N, h, w_, st);
   if (C == 16) return (conv1_f23() & 2) ? launch_conv1_f23_rows<16>(cost, w, c1, N, h, w_, st) : launch_conv1_c<16>(cost, w, c1, N, h, w_, st);
   if (C == 8) return (conv1_f23() & 2) ? launch_conv1_f23_rows<8>(cost, w, c1, N, h, w_, st) : launch_conv1_c<8>(cost, w, c1, N, h, w_, st);

@@ -409,7 +409,7 @@ size_t sweep_workspace_floats(int B, int C, int D, int h, int w) {
 // c1_chunk [d1-d0][B][hw][8]
 int launch_sweep_conv1_chunk(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,
                              float* c1_chunk, float* sim_ws, int B, int S, int C, int D, int d0, int d1, int h, int w, int precision,
-                             int eps_num, hipStream_t st, int c1_split) {
+                             int eps_num, hipStream_t st) {
   if (S < 1) return set_error(-1, "aggregate_conv1: S=%d source views", S);
   int rc;
   if (C == 32) rc = launch_sweep_c<32>(feat, rt, planes, vw, sim_ws, B, S, D, d0, d1, h, w, eps_num, st);
@@ -418,7 +418,7 @@ int launch_sweep_conv1_chunk(const float* feat, const float* rt, PlaneSrc planes
   else return set_error(-1, "aggregate_conv1: C=%d unsupported (8, 16 or 32)", C);
   if (rc) return rc;
   // conv1 over the (d1-d0)*B similarity maps of the chunk; image n = dlocal*B + b lands in c1_chunk[dlocal][b]
-  return launch_conv1(sim_ws, w1pk, c1_chunk, (d1 - d0) * B, C, h, w, precision, st, c1_split);
+  return launch_conv1(sim_ws, w1pk, c1_chunk, (d1 - d0) * B, C, h, w, precision, st);
 }
 
 int launch_sweep_conv1(const float* feat, const float* rt, PlaneSrc planes, const float* vw, const float* w1pk,

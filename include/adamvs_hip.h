@@ -46,8 +46,6 @@ const char* adamvs_last_error_string(void);
  *                                  layers in the minimal-filtering form F(2x2, 3x3) (16 of 36 products); 0: direct kernels
  *   wino_softmax             1     ... its `prob` layer carries the softmax partials, no score volume (stage path); 0: score volume
  *   wino_wps                 0     ... 1 / 2: one / two workgroups per CU for every map size (same bits); 0: by map size
- *   wino_mt6                 1     ... widths that are multiples of 96, maps of >= 1024 pixels: 96 output channels per workgroup (two
- *                                  channel groups at D = 192 instead of three; same bits); 0: groups of 64
  *   fuse_softmax             1     direct `prob` kernel: softmax / max / depth regression in its epilogue; 0: k_softmax_regress
  *   s2_pairs                 1     CostRegNet2D: large stride-2 layers in the pair form along x (15 of 18 products); 0: direct
  *   conv_rows2              -1     CostRegNet2D: 2-row blocks for small grids: 0 never, 1 always, -1 by grid size

@@ -67,12 +67,15 @@ class Rounded:
     """Patches the oracle's network parts with operand-rounded twins for the duration of a `with` block."""
 
     def __init__(self, parts):
-        self.parts = parts                      # {"gru": fmt, "conv1": fmt, "dec": fmt, "reg": fmt}
+        self.parts = parts                      # {"gru": fmt, "conv1": fmt, "dec": fmt, "reg": fmt}; "gru@0": stage 1 only
         self.stats = {}
+        self.stage = 0
 
     def conv(self, part, x, w, b=None, stride=1, transposed=False):
-        qx, qw = _fmt(self.parts.get(part, "fp32"))
-        if part in self.parts and self.parts[part].startswith("f16"):       # range check: fp16 normal range 6.1e-5 .. 65504
+        # "gru@0": the part at stage 1 only (the stage index comes from the weight prefix of the step in flight)
+        fmt = self.parts.get("%s@%d" % (part, self.stage), self.parts.get(part, "fp32"))
+        qx, qw = _fmt(fmt)
+        if fmt.startswith("f16"):       # range check: fp16 normal range 6.1e-5 .. 65504
             a = x.abs()
             st = self.stats.setdefault(part, [0.0, 0, 0])
             st[0] = max(st[0], float(a.max()))
@@ -90,6 +93,7 @@ class Rounded:
         return u * h + (1 - u) * c
 
     def step(self, cost, s1, s2, sd, pre, in_up):
+        self.stage = int(pre.split(".")[1])
         c1 = F.relu(self.conv("conv1", cost, sd[pre + "conv1.conv.weight"]))
         s1 = self.gru(c1, s1, sd, pre + "conv_gru1.")
         c2 = F.relu(self.conv("gru", s1, sd[pre + "conv2.conv.weight"], None, 2))
@@ -103,6 +107,8 @@ class Rounded:
         return reg, s1, s2
 
     def reg2d(self, x, sd, pre):
+        self.stage = int(pre.split(".")[1])
+
         def cbr(x, p, stride=1):
             return F.relu(O._bn(self.conv("reg", x, sd[p + "conv.weight"], None, stride), sd, p + "bn."))
 
@@ -170,6 +176,14 @@ CASES = [
     ("gru+conv1+reg:f16_ws", {"gru": "f16_ws", "conv1": "f16_ws", "reg": "f16_ws"}),
     ("all:f16_ws", {"gru": "f16_ws", "conv1": "f16_ws", "dec": "f16_ws", "reg": "f16_ws"}),
     ("all:f16", {"gru": "f16", "conv1": "f16", "dec": "f16", "reg": "f16"}),
+    # one stage only: where does the last confidence map's error come from?
+    ("gru@s1:f16", {"gru@0": "f16"}),
+    ("gru@s1:f16_ws", {"gru@0": "f16_ws"}),
+    ("gru@s2:f16_ws", {"gru@1": "f16_ws"}),
+    ("gru@s3:f16_ws", {"gru@2": "f16_ws"}),
+    ("gru+conv1+dec@s1:f16_ws", {"gru@0": "f16_ws", "conv1@0": "f16_ws", "dec@0": "f16_ws"}),
+    ("gru+conv1+dec@s1:f16", {"gru@0": "f16", "conv1@0": "f16", "dec@0": "f16"}),
+    ("gru+conv1+dec@s1:bf16", {"gru@0": "bf16", "conv1@0": "bf16", "dec@0": "bf16"}),
 ]
 
 
