@@ -62,6 +62,34 @@ static int option_index(const char* name) {
 
 static size_t align_up(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats: 256-byte slots
 
+// Zero fills and device-to-device copies are KERNELS here, not the runtime's asynchronous memset / memcpy calls.  Inside a captured
+// hipGraph those become memset / memcpy nodes, and on this stack (ROCm 7.x, gfx950) a memset node between kernel nodes was observed to
+// run out of order with them: a replayed stage started its recurrence from the previous replay's states as soon as the kernels around
+// the node were short (profiles/r06_graph_memset_node.txt: the same graph is bit-exact over 28 replays with the fill as a kernel and
+// wrong from the second replay on with the memset call, whatever the kernel-argument placement).
+__global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ p, size_t n) {
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (((size_t)p & 15) == 0)
+    for (size_t i = i0; i < n4; i += stride) ((f32x4*)p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  else
+    for (size_t i = i0; i < n4 * 4; i += stride) p[i] = 0.f;
+  if (i0 < n - n4 * 4) p[n4 * 4 + i0] = 0.f;
+}
+__global__ __launch_bounds__(256) void k_copy_floats(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+static unsigned fill_grid(size_t n) { return (unsigned)(n / 1024 + 1 < 2048 ? n / 1024 + 1 : 2048); }
+hipError_t zero_floats(float* p, size_t n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_fill_zero, dim3(fill_grid(n)), dim3(256), 0, st, p, n);
+  return hipGetLastError();
+}
+hipError_t copy_floats(const float* src, float* dst, size_t n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_copy_floats, dim3(fill_grid(n)), dim3(256), 0, st, src, dst, n);
+  return hipGetLastError();
+}
+
 // Workspace of one stage.  The hypothesis axis is processed in chunks of DC = sweep_chunk_planes(D) planes (aggregation
 // -> conv1 -> recurrence -> soft-argmin accumulation per chunk, reference models/adamvs.py:495-531 runs the same
 // chain per plane), so nothing below grows with D except the stage-1 similarity / score volumes, whose hypothesis axis
@@ -182,12 +210,12 @@ extern "C" int adamvs_slice_reg_step(const float* cost, float* state1, float* st
   float* h2_now = state2;
   if ((rc = launch_slice_step(c1, fw, sb, reg_cost, B, h, w, 1, 0, in_up, precision, st, &h1_now, &h2_now))) return rc;
   if (h1_now != state1) {              // the split-bf16 GRU kernels write the new state to the other buffer
-    hipError_t e = hipMemcpyAsync(state1, h1_now, (size_t)B * h * w * 8 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return set_error((int)e, "slice_reg_step: hipMemcpyAsync: %s", hipGetErrorString(e));
+    hipError_t e = copy_floats(h1_now, state1, (size_t)B * h * w * 8, st);
+    if (e != hipSuccess) return set_error((int)e, "slice_reg_step: state copy: %s", hipGetErrorString(e));
   }
   if (h2_now != state2) {
-    hipError_t e = hipMemcpyAsync(state2, h2_now, (size_t)B * (h / 2) * (w / 2) * 16 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return set_error((int)e, "slice_reg_step: hipMemcpyAsync: %s", hipGetErrorString(e));
+    hipError_t e = copy_floats(h2_now, state2, (size_t)B * (h / 2) * (w / 2) * 16, st);
+    if (e != hipSuccess) return set_error((int)e, "slice_reg_step: state copy: %s", hipGetErrorString(e));
   }
   return 0;
 }
@@ -263,9 +291,9 @@ static int stage_forward(const adamvs_stage_desc* desc, const float* feat, const
   const bool pipelined = mode != 0;
   const int lag = recurrence_lags(mode, s.precision_fuse).dec;       // the decoder runs `lag` hypotheses behind level 1
   if (do_rec) {      // zero initial states (adamvs.py:448-449): h1[-1] = ring slot 3, h2[-1] = ring slot 1 (slot 0 when sequential)
-    hipError_t e = hipMemsetAsync(pipelined ? rb.h1[3] : rb.h1[0], 0, (size_t)s.B * hw * 8 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(pipelined ? rb.h2[1] : rb.h2[0], 0, (size_t)s.B * hw4 * 16 * sizeof(float), st);
-    if (e != hipSuccess) return set_error((int)e, "stage: hipMemsetAsync: %s", hipGetErrorString(e));
+    hipError_t e = zero_floats(pipelined ? rb.h1[3] : rb.h1[0], (size_t)s.B * hw * 8, st);
+    if (e == hipSuccess) e = zero_floats(pipelined ? rb.h2[1] : rb.h2[0], (size_t)s.B * hw4 * 16, st);
+    if (e != hipSuccess) return set_error((int)e, "stage: zero initial states: %s", hipGetErrorString(e));
   }
   auto vol_of = [&](int d) { return ws + c.vol[(d / dc) & 1]; };
   auto argmin_chunk = [&](int k) {

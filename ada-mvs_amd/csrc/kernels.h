@@ -10,6 +10,10 @@ namespace adamvs {
 
 enum { PRECISION_FP32 = 0, PRECISION_BF16X3 = 1 };
 
+// zero fill / copy as kernels (api.hip: a captured hipGraph must not contain memset / memcpy nodes)
+hipError_t zero_floats(float* p, size_t n, hipStream_t st);
+hipError_t copy_floats(const float* src, float* dst, size_t n, hipStream_t st);
+
 struct FuseWeights {          // mirrors adamvs_fuse_weights in include/adamvs_hip.h
   const float* conv1;         // [1][9][C/4][64]
   const float* gates1; const float* gates1_b;   // [1][9][4][64], [16]

@@ -347,8 +347,8 @@ int carve_recur(RecurBuffers& r, void* workspace, size_t bytes, int B, int npix,
   r.u = p;     p += al((size_t)B * npix * HC);
   r.part = (double*)p;
   // the state starts at zero; rh keeps zeros in its padding channels (only HC channels are ever written)
-  hipError_t e = hipMemsetAsync(r.state, 0, 2 * al((size_t)B * npix * W) * sizeof(float), st);
-  if (e != hipSuccess) return set_error((int)e, "red_recur: hipMemsetAsync: %s", hipGetErrorString(e));
+  hipError_t e = zero_floats(r.state, 2 * al((size_t)B * npix * W), st);
+  if (e != hipSuccess) return set_error((int)e, "red_recur: zero state: %s", hipGetErrorString(e));
   return 0;
 }
 }  // namespace

@@ -26,8 +26,7 @@ namespace adamvs {
   X(OPT_CONV1_F23, "conv1_f23", 3)                   /* conv1 in the F(2, 3)-along-x form: bit 1 C = 32, bit 2 C = 16 / 8 */          \
   X(OPT_FCONV_F23, "fconv_f23", 1)                   /* FeatureNet0: stride-1 3 x 3 layers in the F(2, 3)-along-x form */             \
   X(OPT_GRU_WINO, "gru_wino", 7)                     /* fp32 GRU convolutions in the F(2x2, 3x3) form: 1 gates1, 2 gates2, 4 cand2 */ \
-  X(OPT_RECUR_MODE, "recur_mode", -1)                /* launches per hypothesis of the recurrence: 0 / 1 / 3 / 5; -1 = by size */      \
-  X(OPT_SWEEP_FUSED, "sweep_fused", 1)               /* aggregation + conv1 in one kernel (sim never leaves the CU) where built */
+  X(OPT_RECUR_MODE, "recur_mode", -1)                /* launches per hypothesis of the recurrence: 0 / 1 / 3 / 5; -1 = by size */
 
 enum Option {
 #define ADAMVS_OPTION_ENUM(e, n, d) e,

@@ -62,8 +62,6 @@ const char* adamvs_last_error_string(void);
  *                                  (the software-pipelined schedules 3 and 5 always use the direct / fused roles)
  *   recur_mode              -1     launches per hypothesis of the recurrence: 0 one role per launch (six; bf16x3: four), 1 three,
  *                                  3 two, 5 one (both levels one kernel each); -1: by stage size (adamvs_recurrence_schedule)
- *   sweep_fused              1     aggregation + conv1 (adamvs.py:495-512, :417) as ONE kernel, the similarity of a plane never
- *                                  leaving the CU, for the shapes it is built for; 0: the sweep and conv1 as two kernels
  */
 int adamvs_option_count(void);
 const char* adamvs_option_name(int index);                   /* 0 <= index < adamvs_option_count(); NULL outside */

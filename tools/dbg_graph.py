@@ -5,6 +5,8 @@ import ada_mvs_amd
 from ada_mvs_amd import synth, hip_ops
 from ada_mvs_amd.graphed import GraphedForward
 from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
+NOEAGER = "noeager" in mode          # every eager reference run happens BEFORE the capture: nothing but replays afterwards
 m = Infer_AdaMVSNet(16, [16, 8, 4], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
 m.load_state_dict(synth.seeded_state_dict(m, seed=0)); m = m.cuda().eval()
 cfg = dict(views=3, H=64, W=96, ndepths=[16, 8, 4], num_depth=16)
@@ -14,40 +16,42 @@ def inputs(seed, baseline, lo, hi):
 def eager(a):
     with torch.no_grad():
         o = m(a[0], a[1], a[2].cuda())
-    return {s: o[s]["depth"].clone() for s in ("stage1", "stage2", "stage3")}
+    r = {s: o[s]["depth"].clone() for s in ("stage1", "stage2", "stage3")}
+    r["vw"] = torch.stack([x.clone() for x in o["stage1"]["pair_confidence"][:2]]); r["pd"] = torch.stack([x.clone() for x in o["stage1"]["pair_result"]])
+    return r
 def cmp(tag, got, want):
     torch.cuda.synchronize()
-    print(tag, {s: (bool(torch.equal(got[s]["depth"], want[s])), float(torch.isnan(got[s]["depth"]).float().mean())) for s in want}, flush=True)
+    res = {s: (bool(torch.equal(got[s]["depth"], want[s])), round(float(torch.isnan(got[s]["depth"]).float().mean()), 3)) for s in ("stage1", "stage2", "stage3")}
+    vw = torch.stack(got["stage1"]["pair_confidence"][:2]); pd = torch.stack(got["stage1"]["pair_result"])
+    res["vw"] = bool(torch.equal(vw, want["vw"])); res["pd"] = bool(torch.equal(pd, want["pd"]))
+    print(mode, tag, res, flush=True)
 fwd = GraphedForward(m)
 A = inputs(0, 8.0, 400., 600.)
+B = inputs(1, 9.0, 380., 640.)
 wA = eager(A)
+if NOEAGER: wB = eager(B)
 with torch.no_grad(): cmp("A first (capture+replay)", fwd(*A), wA)
-with torch.no_grad(): cmp("A again (replay)", fwd(*A), wA)
-wA2 = eager(A)
-with torch.no_grad(): cmp("A after an eager call", fwd(*A), wA)
-for tag, a in (("new imgs", (inputs(1, 8.0, 400., 600.)[0], A[1], A[2])), ("new proj", (A[0], inputs(0, 9.0, 400., 600.)[1], A[2])),
-               ("new dv", (A[0], A[1], torch.tensor([[380., 640.]]))), ("all new", inputs(1, 9.0, 380., 640.))):
-    w = eager(a)
-    with torch.no_grad(): cmp(tag, fwd(*a), w)
-# the hot path alone in a graph, features eager
-print("--- features outside the graph")
-g = torch.cuda.CUDAGraph()
-a = A
+if not NOEAGER: wB = eager(B)
+if mode == "sync":
+    torch.cuda.synchronize()
 with torch.no_grad():
-    simgs = a[0].clone(); sproj = {k: v.clone() for k, v in a[1].items()}; sdv = a[2].cuda().clone()
-    spans = torch.tensor(fwd._spans(a[2]), dtype=torch.float32).cuda()
-    table, shared = {}, m._stage_workspace
-    m._stage_workspace = table
-    m(simgs, sproj, sdv); torch.cuda.synchronize()
-    feats, shapes = m.extract_features(simgs)
-    with torch.cuda.graph(g):
-        out = m.infer_from_features(feats, shapes, sproj, sdv, 0.0, span_dev=spans)
-    m._stage_workspace = shared
+    o = fwd(*B)
+    if mode == "sync": torch.cuda.synchronize()
+    cmp("B (second call)", o, wB)
+    g, st, out = list(fwd.cache.values())[0]
+    torch.cuda.synchronize()
+    print(mode, "static imgs == B", bool(torch.equal(st["imgs"], B[0])), "proj", all(bool(torch.equal(st["proj"][k], B[1][k])) for k in B[1]),
+          "dv", st["dv"].cpu().tolist(), "spans", st["spans"].cpu().tolist(), fwd._spans(B[2]))
+    g.replay(); cmp("B replayed again", out, wB)
+    g.replay(); cmp("B replayed a third time", out, wB)
+    cmp("A back", fwd(*A), wA)
+    cmp("B back", fwd(*B), wB)
     for rep in range(3):
-        b = inputs(rep, 8.0 + rep, 400. - 10 * rep, 600. + 20 * rep)
-        w = eager(b)
-        simgs.copy_(b[0]); [sproj[k].copy_(v) for k, v in b[1].items()]; sdv.copy_(b[2]); spans.copy_(torch.tensor(fwd._spans(b[2]), dtype=torch.float32))
-        f2, _ = m.extract_features(simgs)
-        for x, y in zip(feats, f2): x.copy_(y)
-        g.replay()
-        cmp("hot path graph, rep %d" % rep, out, w)
+        cmp("A again %d" % rep, fwd(*A), wA)
+        if not NOEAGER: eager(B)
+        cmp("B again %d" % rep, fwd(*B), wB)
+    # the span_dev path launched eagerly (no graph) on B
+    spans = torch.tensor(fwd._spans(B[2]), dtype=torch.float32).cuda()
+    feats, shapes = m.extract_features(B[0])
+    o2 = m.infer_from_features(feats, shapes, B[1], B[2].cuda(), 0.0, span_dev=spans)
+    cmp("eager with span_dev on B", o2, wB)
