@@ -163,7 +163,6 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
     store_x(xs);
     load_w(w0h, w0l, kb, 0);
     __syncthreads();
-    if (kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);               // in flight during the MFMAs, stored at the next top
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
       // next tap's fragments are requested before this tap's MFMAs; the scheduling barriers keep the taps apart
@@ -173,6 +172,11 @@ __device__ __forceinline__ void conv_dd_bx3_body(const ConvDDArgs16& a, __bf16* 
         tap(w1h, w1l, t);
       } else {
         if (t + 1 < NTAP) load_w(w1h, w1l, kb, t + 1);
+        // The next chunk's window is requested HERE, behind tap 1's fragments (round 6): vmcnt retires in order, so a window request in
+        // front of them made the wait for tap 1's weights a wait for the window too -- one tap after it was issued; now it has two taps
+        // to arrive before a wait reaches it (stored at the next chunk's top).  -1.2 % of the kernel (timing builds:
+        // profiles/r06_bx3_costreg_timing.txt, which also show what bounds it: matrix time 1.86 ms + everything else 1.64 ms = 3.50).
+        if (t == 0 && kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);
         tap(w0h, w0l, t);
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Timing builds of k_conv_dd_bx3 (CostRegNet2D in the bf16x3 mode, reference models/adamvs.py:229-238) WITHOUT touching the product
+sources: csrc/ is copied to a scratch directory, one textual patch is applied to costreg2d_bf16x3.hip per variant, and the copy is
+built into ada-mvs_amd/libadamvs_hip.<variant>.so (results of these libraries are wrong by construction; they answer "what does
+this part of the kernel cost").
+
+    python tools/experiments/bx3_costreg_timing/build_variants.py          (CPU box: hipcc cross-compiles)
+    python tools/experiments/bx3_costreg_timing/time_variants.py           (GPU box)
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT)
+import ada_mvs_amd  # noqa: E402,F401
+from ada_mvs_amd import build as B  # noqa: E402
+
+MFMA3 = '''#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bh[r], acc[mt][r]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bl[r], acc[mt][r]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wl[mt], bh[r], acc[mt][r]);'''
+KEEP = '''#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { asm volatile("" ::"v"(wh[mt]), "v"(wl[mt])); }
+      asm volatile("" ::"v"(bh[r]), "v"(bl[r]));'''
+ONE = '''#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][r] = mfma_bf16(wh[mt], bh[r], acc[mt][r]);
+      asm volatile("" ::"v"(bl[r]));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { asm volatile("" ::"v"(wl[mt])); }'''
+
+VARIANTS = {
+    # name: [(old, new), ...]
+    "bxc_nomfma": [(MFMA3, KEEP)],                                     # everything but the matrix instructions
+    "bxc_onemfma": [(MFMA3, ONE)],                                     # one of the three products (what plain bf16 would issue)
+    "bxc_noweights": [("        if (t + 1 < NTAP) load_w(w0h, w0l, kb, t + 1);", "        if (t + 1 < NTAP && kb == 0 && t == 0) load_w(w0h, w0l, kb, t + 1);"),
+                      ("        if (t + 1 < NTAP) load_w(w1h, w1l, kb, t + 1);", "        if (t + 1 < NTAP && kb == 0 && t == 0) load_w(w1h, w1l, kb, t + 1);")],
+    "bxc_nofill": [("    if (kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);", "    if (false) load_x(xs, (kb + 1) * BX_KB);"),
+                   ("    store_x(xs);\n    load_w(w0h, w0l, kb, 0);", "    if (kb == 0) store_x(xs);\n    load_w(w0h, w0l, kb, 0);")],
+    # candidates (results stay right): the next chunk's window requested AFTER the first tap's weight request, so that the wait for tap
+    # 1's weights (vmcnt retires in order) does not include it -- it then has two taps instead of one to arrive
+    "bxc_xlate": [("    if (kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);               // in flight during the MFMAs, stored at the next top\n", ""),
+                  ("        if (t + 1 < NTAP) load_w(w1h, w1l, kb, t + 1);\n        tap(w0h, w0l, t);",
+                   "        if (t + 1 < NTAP) load_w(w1h, w1l, kb, t + 1);\n        if (t == 0 && kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);\n        tap(w0h, w0l, t);")],
+    # ... and the B fragments two rows ahead of their MFMAs instead of one
+    "bxc_xlate_b2": [("    if (kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);               // in flight during the MFMAs, stored at the next top\n", ""),
+                     ("        if (t + 1 < NTAP) load_w(w1h, w1l, kb, t + 1);\n        tap(w0h, w0l, t);",
+                      "        if (t + 1 < NTAP) load_w(w1h, w1l, kb, t + 1);\n        if (t == 0 && kb + 1 < KBT) load_x(xs, (kb + 1) * BX_KB);\n        tap(w0h, w0l, t);"),
+                     ("""      bh[0] = *(const bf16x8*)at;
+      bl[0] = *(const bf16x8*)(at + LOB);
+    }""", """      bh[0] = *(const bf16x8*)at;
+      bl[0] = *(const bf16x8*)(at + LOB);
+      if (NTR > 1) {
+        const char* at1 = (const char*)lds + boff + ((STR + ty) * LC + tx) * (BX_PIX * 2);
+        bh[1] = *(const bf16x8*)at1;
+        bl[1] = *(const bf16x8*)(at1 + LOB);
+      }
+    }"""),
+                     ("""      if (r + 1 < NTR) {
+        const char* at = (const char*)lds + boff + (((r + 1) * STR + ty) * LC + tx) * (BX_PIX * 2);
+        bh[r + 1] = *(const bf16x8*)at;
+        bl[r + 1] = *(const bf16x8*)(at + LOB);
+      }""", """      if (r + 2 < NTR) {
+        const char* at = (const char*)lds + boff + (((r + 2) * STR + ty) * LC + tx) * (BX_PIX * 2);
+        bh[r + 2] = *(const bf16x8*)at;
+        bl[r + 2] = *(const bf16x8*)(at + LOB);
+      }""")],
+    "bxc_nobarrier": [("    __syncthreads();                     // previous chunk's readers are done\n", "    if (kb == 0) __syncthreads();\n"),
+                      ("    load_w(w0h, w0l, kb, 0);\n    __syncthreads();\n", "    load_w(w0h, w0l, kb, 0);\n    if (kb == 0) __syncthreads();\n")],
+}
+
+
+def build(name, patches):
+    tmp = tempfile.mkdtemp(prefix="adamvs_" + name + "_")
+    src_dir = os.path.join(tmp, "pkg", "csrc")                  # api.hip includes ../../include/adamvs_hip.h
+    shutil.copytree(B.CSRC, src_dir, ignore=shutil.ignore_patterns("_build*"))
+    shutil.copytree(B.INCLUDE, os.path.join(tmp, "include"))
+    p = os.path.join(src_dir, "costreg2d_bf16x3.hip")
+    s = open(p).read()
+    for old, new in patches:
+        assert s.count(old) == 1, (name, old[:60], s.count(old))
+        s = s.replace(old, new)
+    open(p, "w").write(s)
+    flags = [f if f != B.CSRC else src_dir for f in B.FLAGS]
+
+    def cc(src):
+        obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+        r = subprocess.run([B._hipcc()] + flags + B.SOURCE_FLAGS.get(src, []) + ["-c", os.path.join(src_dir, src), "-o", obj], capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(r.stderr[-3000:])
+        return obj
+    with ThreadPoolExecutor(max_workers=5) as ex:
+        objs = list(ex.map(cc, B.SOURCES))
+    lib = os.path.join(B.HERE, "libadamvs_hip.%s.so" % name)
+    subprocess.run([B._hipcc(), "-shared", "-fPIC", "--offload-arch=" + B.ARCH, "-o", lib] + objs, check=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("built", lib, flush=True)
+
+
+if __name__ == "__main__":
+    for name, patches in VARIANTS.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
+        build(name, patches)
