@@ -346,6 +346,12 @@ __global__ __launch_bounds__(256) void k_sweep_blend(const float* __restrict__ f
 #undef ADAMVS_EACH_VIEW
 }
 
+// (Round 6 built this kernel with a STORE WAVE -- seven compute waves parking four planes at a time in LDS, an eighth wave of the
+// workgroup doing nothing but the global stores, so that no compute wave ever has a store in its in-order vmcnt queue.  The timing
+// builds had put the stores at 20 - 27 % of the aggregation + conv1 phase.  Bit-identical, and slower: cfg3 / bf16x3 / 32 tiles
+// 8.65 / 7.48 / 2.92 -> 9.08 / 7.64 / 2.92 ms per stage, cfg2 / 256 tiles 75.5 -> 78.9 ms: the workgroup barrier that hands a
+// buffer over couples the seven compute waves -- every reload stall of one is then a stall of all -- and an eighth of the compute
+// waves is gone.  tools/experiments/sweep_store_wave/, profiles/r06_sweep_timing.txt.)
 template <int C>
 static int launch_sweep_variance_c(const float* feat, const float* rt, PlaneSrc planes, float* out_a, int Da, float* out_b,
                                    int Db, int B, int S, int D, int h, int w, hipStream_t st) {

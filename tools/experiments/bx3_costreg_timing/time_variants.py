@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: one stride-1 CostRegNet2D layer (conv0's shape at cfg3 / 32 tiles: 128 maps of 96 x 192, D = 192) in the bf16x3 mode on the
-shipped library and on every timing build of build_variants.py, each in its own process (ADAMVS_LIB_PATH)."""
+shipped library and on every timing build of tools/experiments/timing_builds.py, each in its own process (ADAMVS_LIB_PATH)."""
 import os
 import subprocess
 import sys

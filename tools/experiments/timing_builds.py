@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Timing builds of k_conv_dd_bx3 (CostRegNet2D in the bf16x3 mode, reference models/adamvs.py:229-238) WITHOUT touching the product
-sources: csrc/ is copied to a scratch directory, one textual patch is applied to costreg2d_bf16x3.hip per variant, and the copy is
-built into ada-mvs_amd/libadamvs_hip.<variant>.so (results of these libraries are wrong by construction; they answer "what does
-this part of the kernel cost").
+"""Timing builds WITHOUT touching the product sources: csrc/ is copied to a scratch directory, the textual patches of a variant are
+applied to the copy, and the copy is built into ada-mvs_amd/libadamvs_hip.<variant>.so (most of these libraries give wrong
+results by construction; they answer "what does this part of the kernel cost").  Use one with ADAMVS_LIB_PATH=<that .so>.
 
-    python tools/experiments/bx3_costreg_timing/build_variants.py          (CPU box: hipcc cross-compiles)
-    python tools/experiments/bx3_costreg_timing/time_variants.py           (GPU box)
+    python tools/experiments/timing_builds.py [variant ...]                  (CPU box: hipcc cross-compiles; default: all)
+    python tools/experiments/bx3_costreg_timing/time_variants.py             (GPU box: the bxc_* set, k_conv_dd_bx3)
+
+bxc_*: k_conv_dd_bx3 (CostRegNet2D in the bf16x3 mode, reference models/adamvs.py:229-238); profiles/r06_bx3_costreg_timing.txt.
+swp_*: k_sweep_blend (the weighted aggregation, reference models/adamvs.py:495-512); profiles/r06_sweep_timing.txt.
 """
 import os
 import shutil
@@ -14,7 +16,7 @@ import sys
 import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ada_mvs_amd  # noqa: E402,F401
 from ada_mvs_amd import build as B  # noqa: E402
@@ -70,6 +72,31 @@ VARIANTS = {
         bh[r + 2] = *(const bf16x8*)at;
         bl[r + 2] = *(const bf16x8*)(at + LOB);
       }""")],
+    # ---- k_sweep_blend (sweep.hip), HALVES = 1
+    "swp_nostore": [("sweep.hip", """        if (accum) v += buf_load4(ro, ooff);
+        buf_store4(ro, ooff, v);
+      }
+    } else {""", """        if (accum) v += buf_load4(ro, ooff);
+        asm volatile("" ::"v"(v));
+      }
+    } else {""")],                                                                       # the flush's global stores
+    "swp_noreload": [("sweep.hip", "        if (cell != -1 && cell != cc) {                            // entered another source cell",
+                      "        if (cell != -1 && cell != cc && cc == -1) {")],            # taps loaded once per launch, never reloaded
+    "swp_nowait": [("sweep.hip", "      wait_vmem_all();\n    }\n    const int nd_ = min(PK, d1 - dg);", "    }\n    const int nd_ = min(PK, d1 - dg);")],
+    "swp_nostore_noreload": [("sweep.hip", """        if (accum) v += buf_load4(ro, ooff);
+        buf_store4(ro, ooff, v);
+      }
+    } else {""", """        if (accum) v += buf_load4(ro, ooff);
+        asm volatile("" ::"v"(v));
+      }
+    } else {"""), ("sweep.hip", "        if (cell != -1 && cell != cc) {                            // entered another source cell",
+                      "        if (cell != -1 && cell != cc && cc == -1) {")],
+    # candidate (results stay right: the compiler's own wait insertion guards every use): the explicit wait at the end of a plane only
+    # when some lane of the wave reloaded in that plane -- otherwise the flush's stores keep draining behind the next planes
+    "swp_condwait": [("sweep.hip", "        if (cell != -1 && cell != cc) {                            // entered another source cell\n          cc = cell;",
+                      "        if (cell != -1 && cell != cc) {                            // entered another source cell\n          cc = cell; reloaded = true;"),
+                     ("sweep.hip", "      // ---- phase 1: the cells of this plane, every reload issued\n", "      bool reloaded = false;\n"),
+                     ("sweep.hip", "      wait_vmem_all();\n    }\n    const int nd_ = min(PK, d1 - dg);", "      if (__builtin_amdgcn_ballot_w64(reloaded) != 0) wait_vmem_all();\n    }\n    const int nd_ = min(PK, d1 - dg);")],
     "bxc_nobarrier": [("    __syncthreads();                     // previous chunk's readers are done\n", "    if (kb == 0) __syncthreads();\n"),
                       ("    load_w(w0h, w0l, kb, 0);\n    __syncthreads();\n", "    load_w(w0h, w0l, kb, 0);\n    if (kb == 0) __syncthreads();\n")],
 }
@@ -80,12 +107,12 @@ def build(name, patches):
     src_dir = os.path.join(tmp, "pkg", "csrc")                  # api.hip includes ../../include/adamvs_hip.h
     shutil.copytree(B.CSRC, src_dir, ignore=shutil.ignore_patterns("_build*"))
     shutil.copytree(B.INCLUDE, os.path.join(tmp, "include"))
-    p = os.path.join(src_dir, "costreg2d_bf16x3.hip")
-    s = open(p).read()
-    for old, new in patches:
+    for patch in patches:
+        fname, old, new = patch if len(patch) == 3 else ("costreg2d_bf16x3.hip",) + tuple(patch)
+        p = os.path.join(src_dir, fname)
+        s = open(p).read()
         assert s.count(old) == 1, (name, old[:60], s.count(old))
-        s = s.replace(old, new)
-    open(p, "w").write(s)
+        open(p, "w").write(s.replace(old, new))
     flags = [f if f != B.CSRC else src_dir for f in B.FLAGS]
 
     def cc(src):
