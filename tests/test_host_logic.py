@@ -444,3 +444,23 @@ def test_gru_prescaled_fields_follow_the_header():
     frag = blob[off["gates2"]:off["gates2"] + 2 * 9 * 8 * 64].reshape(2, 9, 8, 64)
     assert float(frag[1, 4, 3, 37]) == float(wg[16 + (37 & 15), 4 * 3 + (37 >> 4), 1, 1])
     assert torch.equal(blob[off["gates2_b"]:off["gates2_b"] + 32], sd[pre + "conv_gru2.conv_gates.0.bias"].float())
+
+
+def test_graphed_forward_host_side():
+    """ada_mvs_amd/graphed.py without a GPU: the half spans it hands the captured kernels are the reference's Python-float products
+    (ndepth / 2 * ratio * depth_interval with depth_interval = (max - min) / num_depth from batch item 0, models/adamvs.py:569-571,
+    models/module.py:632) -- from a host tensor, a [B,2] or longer depth_values row -- and CPU images raise instead of running anything."""
+    import torch
+    from ada_mvs_amd import hip_ops, synth
+    from ada_mvs_amd.graphed import GraphedForward
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    m = Infer_AdaMVSNet(48, [48, 32, 8], [4.0, 2.0, 1.0], False, [8, 8, 8]).eval()
+    fwd = GraphedForward(m)
+    dv = torch.tensor([[425.5, 611.25], [1.0, 2.0]], dtype=torch.float32)            # item 0 only (quirk Q4)
+    interval = (float(dv[0, 1]) - float(dv[0, 0])) / 48
+    assert fwd._spans(dv) == [48 / 2.0 * (4.0 * interval), 32 / 2.0 * (2.0 * interval), 8 / 2.0 * (1.0 * interval)]
+    assert fwd._spans(dv) == [hip_ops.half_span_of(n, r * interval) for n, r in zip([48, 32, 8], [4.0, 2.0, 1.0])]
+    imgs, proj, dv1 = synth.tile_inputs("tiny", batch=1, seed=0)
+    with pytest.raises(_lib.AdaMVSHipError, match="MI355X"):
+        fwd(imgs, proj, dv1)
+    assert fwd.captures == 0 and len(fwd.cache) == 0
