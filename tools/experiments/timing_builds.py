@@ -97,6 +97,17 @@ VARIANTS = {
                       "        if (cell != -1 && cell != cc) {                            // entered another source cell\n          cc = cell; reloaded = true;"),
                      ("sweep.hip", "      // ---- phase 1: the cells of this plane, every reload issued\n", "      bool reloaded = false;\n"),
                      ("sweep.hip", "      wait_vmem_all();\n    }\n    const int nd_ = min(PK, d1 - dg);", "      if (__builtin_amdgcn_ballot_w64(reloaded) != 0) wait_vmem_all();\n    }\n    const int nd_ = min(PK, d1 - dg);")],
+    # candidate: the two workgroups of a CU at different issue priorities (the one whose LDS allocation starts at 0 gets priority 3), so
+    # that their MFMA phases cannot run in lock-step: kernel time = "everything else" + the matrix time of BOTH waves of a SIMD today
+    "bxc_prio": [("  __bf16* lhi = lds;                       // [NPIX][BX_PIX]\n",
+                  "  __bf16* lhi = lds;                       // [NPIX][BX_PIX]\n  if (__builtin_amdgcn_s_getreg((7 << 11) | 6) == 0) __builtin_amdgcn_s_setprio(3);\n")],
+    "bxc_sleep": [("  __bf16* lhi = lds;                       // [NPIX][BX_PIX]\n",
+                   "  __bf16* lhi = lds;                       // [NPIX][BX_PIX]\n  if ((blockIdx.x + blockIdx.y + blockIdx.z) & 1) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }\n")],
+    "bxc_prio2": [("  __bf16* lhi = lds;                       // [NPIX][BX_PIX]\n",
+                   "  __bf16* lhi = lds;                       // [NPIX][BX_PIX]\n  if ((blockIdx.x + blockIdx.y + blockIdx.z) & 1) __builtin_amdgcn_s_setprio(3);\n")],
+    # debug: what the two workgroups of a CU read from HW_REG_LDS_ALLOC / HW_ID (written over the first output pixels' channel 0..1)
+    "bxc_hwregs": [("  if (SOFTMAX) {                         // the last layer inside a stage: scores reduced over D here, never stored",
+                    "  if (!SOFTMAX && threadIdx.x == 0) { float* dbg = a.out + ((size_t)n * a.ho * a.wo + (size_t)(by * gridDim.x + bx)) * a.D * 0 + ((size_t)((n * gridDim.y + by) * gridDim.x + bx)) * 4; dbg[0] = (float)__builtin_amdgcn_s_getreg((15 << 11) | 6); dbg[1] = (float)__builtin_amdgcn_s_getreg((31 << 11) | 4); return; }\n  if (SOFTMAX) {                         // the last layer inside a stage: scores reduced over D here, never stored")],
     "bxc_nobarrier": [("    __syncthreads();                     // previous chunk's readers are done\n", "    if (kb == 0) __syncthreads();\n"),
                       ("    load_w(w0h, w0l, kb, 0);\n    __syncthreads();\n", "    load_w(w0h, w0l, kb, 0);\n    if (kb == 0) __syncthreads();\n")],
 }
