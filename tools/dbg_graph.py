@@ -1,3 +1,16 @@
+"""Replays of a captured forward against the eager one (GPU box): the evidence behind "a captured stage contains kernel nodes only".
+
+    python tools/dbg_graph.py <tag>                         tag = a free label printed in front of every line; "noeager" in it:
+                                                            no eager launch between the capture and the replays
+    (round 6, when the stage still zeroed its GRU states with hipMemsetAsync behind option zero_fill_kernel:
+     ADAMVS_ZERO_FILL_KERNEL=0 python tools/dbg_graph.py memset  -> wrong maps from the second replay on;
+     profiles/r06_graph_memset_node.txt holds the six runs.  The option is gone: every fill is a kernel now, and this script
+     is what to run first if a replay ever disagrees with the eager forward again.)
+
+A tiny cascade (64 x 96, 16 / 8 / 4 planes) through ada_mvs_amd.graphed.GraphedForward: capture on input set A, then B, A, B ...;
+per call: bit-identity of the three stage depth maps and of stage 1's view weights / pair depths with the eager forward, and the
+fraction of NaN pixels; at the end the span_dev path launched eagerly.
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
