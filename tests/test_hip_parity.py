@@ -1343,3 +1343,43 @@ def test_graphed_forward_equals_eager_for_every_depth_range(hip, precision):
         want = m(dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))["depth"].clone()
         got = fwd(dev(imgs), {k: dev(v) for k, v in proj.items()}, dv)["depth"]
     assert torch.equal(got, want) and fwd.captures == 3 and len(fwd.cache) == 2
+
+
+def test_a_captured_forward_contains_kernel_nodes_only(hip):
+    """A memset node inside a captured hipGraph ran out of order with the kernel nodes around it on this stack (round 6,
+    profiles/r06_graph_memset_node.txt): a replayed stage then started its recurrence from the previous replay's states.  The library
+    zeroes and copies with kernels for that reason (csrc/api.hip zero_floats / copy_floats).  Here: the forward captured the way
+    ada_mvs_amd/graphed.py captures it; the node types of the captured graph, read back through hipGraphGetNodes /
+    hipGraphNodeGetType, must be kernel nodes (and the empty nodes a capture may insert) -- no memset, no memcpy."""
+    import collections
+    import ctypes
+    from ada_mvs_amd.models.adamvs import Infer_AdaMVSNet
+    m = Infer_AdaMVSNet(16, [16, 8, 4], synth.DEPTH_INTERVALS_RATIO, False, [8, 8, 8])
+    m.load_state_dict(synth.seeded_state_dict(m, seed=0))
+    m = m.cuda().eval()
+    imgs, proj, dv = synth.tile_inputs("tiny", batch=1, seed=0)
+    args = (dev(imgs), {k: dev(v) for k, v in proj.items()}, dev(dv))
+    spans = dev(torch.tensor([1.0, 1.0, 1.0]))
+    try:
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError as e:
+        pytest.skip("CUDAGraph(keep_graph=True) unavailable: %s" % e)
+    with torch.no_grad():
+        m(*args)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            feats_cl, shapes = m.extract_features(args[0])
+            m.infer_from_features(feats_cl, shapes, args[1], args[2], 0.0, span_dev=spans)
+    rt = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))      # the runtime torch itself uses
+    raw = ctypes.c_void_p(g.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    assert rt.hipGraphGetNodes(raw, None, ctypes.byref(n)) == 0 and n.value > 50, n.value
+    nodes = (ctypes.c_void_p * n.value)()
+    assert rt.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) == 0
+    kinds = collections.Counter()
+    for node in nodes:
+        t = ctypes.c_int(-1)
+        assert rt.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(t)) == 0
+        kinds[t.value] += 1
+    KERNEL, MEMCPY, MEMSET, EMPTY = 0, 1, 2, 5          # hipGraphNodeType
+    assert kinds[KERNEL] > 50 and kinds[MEMSET] == 0 and kinds[MEMCPY] == 0 and set(kinds) <= {KERNEL, EMPTY}, dict(kinds)
