@@ -6,6 +6,8 @@
 //   lds      ... with the B fragment pair read from LDS (two ds_read_b128 per 9 MFMAs), one row ahead
 //   ldsw     ... and the A fragments reloaded from global memory (L2-resident, 6 x 16 bytes per lane per 72 MFMAs), one tap ahead
 //   bar      ... and two workgroup barriers per 648 MFMAs (the chunk structure of k_conv_dd_bx3)
+//   valu     n independent vector instructions per MFMA in the same wave (the fused GRU kernels issue 1.7 - 2.5 per MFMA):
+//            hidden under the matrix instruction, or added to it?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -95,6 +97,56 @@ __global__ __launch_bounds__(256, 2) void k_x3(float* out, int iters, const bf16
   out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y + s.z + s.w;
 }
 
+// NV independent vector instructions per MFMA in the SAME wave (v_fma_f32 on private registers; QUARTER: v_exp_f32, the quarter-rate
+// transcendental of the gate epilogues): do they hide under the 16 cycles of the matrix instruction?
+template <int NV, bool QUARTER>
+__global__ __launch_bounds__(256) void k_valu(float* out, int iters, const bf16x8* src) {
+  bf16x8 a = src[threadIdx.x & 63], b = src[64 + (threadIdx.x & 63)];
+  f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 1.0f + 0.001f * (float)(threadIdx.x + i);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 72; ++u) {
+      acc[u & 3] = mfma(a, b, acc[u & 3]);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        float& x = v[(u * NV + k) & 7];
+        if (QUARTER) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+        else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(v[(u + k + 1) & 7]));
+      }
+    }
+  }
+  f32x4 s = acc[0] + acc[1] + acc[2] + acc[3];
+  float t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t += v[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y + s.z + s.w + t;
+}
+
+// the vector instructions alone (no MFMA): their own cost per "MFMA slot"
+template <int NV, bool QUARTER>
+__global__ __launch_bounds__(256) void k_valu_only(float* out, int iters, const bf16x8* src) {
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 1.0f + 0.001f * (float)(threadIdx.x + i) + (float)((const unsigned short*)src)[threadIdx.x & 7];
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 72; ++u)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        float& x = v[(u * NV + k) & 7];
+        if (QUARTER) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+        else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(v[(u + k + 1) & 7]));
+      }
+  }
+  float t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t += v[i];
+  out[blockIdx.x * 256 + threadIdx.x] = t;
+}
+
 template <class K>
 static double run(K kern, int wps, int iters, int mfma_per_iter, float* out, const bf16x8* src, const char* name) {
   const int grid = 256 * wps;                            // workgroups of 4 waves: `wps` waves per SIMD
@@ -130,6 +182,14 @@ int main() {
     run(k_x3<1>, wps, 300, 648, out, src, "x3 order, B from LDS one row ahead");
     run(k_x3<2>, wps, 300, 648, out, src, "x3 order, B from LDS, A from L2 one tap ahead");
     run(k_x3<3>, wps, 300, 648, out, src, "... and two barriers per 648 MFMAs");
+    run(k_valu<1, false>, wps, 2000, 72, out, src, "reg, 4 acc + 1 v_fma_f32 per MFMA");
+    run(k_valu<2, false>, wps, 2000, 72, out, src, "reg, 4 acc + 2 v_fma_f32 per MFMA");
+    run(k_valu<3, false>, wps, 2000, 72, out, src, "reg, 4 acc + 3 v_fma_f32 per MFMA");
+    run(k_valu<4, false>, wps, 2000, 72, out, src, "reg, 4 acc + 4 v_fma_f32 per MFMA");
+    run(k_valu<1, true>, wps, 2000, 72, out, src, "reg, 4 acc + 1 v_exp_f32 per MFMA");
+    run(k_valu<2, true>, wps, 2000, 72, out, src, "reg, 4 acc + 2 v_exp_f32 per MFMA");
+    run(k_valu_only<3, false>, wps, 2000, 72, out, src, "(3 v_fma_f32 per slot alone, no MFMA)");
+    run(k_valu_only<2, true>, wps, 2000, 72, out, src, "(2 v_exp_f32 per slot alone, no MFMA)");
   }
   return 0;
 }
